@@ -1,0 +1,91 @@
+"""ctypes binding of libocr_hip.so (C ABI in include/ocr_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing, importing
+this module still works (so CPU-only host logic is testable) but any kernel call
+raises `OcrHipError` loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libocr_hip.so")
+
+
+class OcrHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    """ocr_conv_desc (include/ocr_hip.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "n", "h", "w", "cin", "oh", "ow", "cout", "kh", "kw", "stride",
+        "dilation", "pad_top", "pad_left", "flip_taps", "flags")]
+
+
+CONV_BIAS, CONV_RELU, CONV_STATS, CONV_ACCUM_F16 = 1, 2, 4, 8
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library; raises OcrHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OcrHipError(
+            "libocr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C tensorflow_ocr_amd/csrc` (no CPU fallback exists for the product path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ocr_status_string.restype = ctypes.c_char_p
+    lib.ocr_status_string.argtypes = [ctypes.c_int]
+    lib.ocr_abi_version.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        lib = load()
+        msg = lib.ocr_status_string(int(status)).decode()
+        raise OcrHipError("%s failed: %s (%d)" % (what or "ocr call", msg, status))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    """Call `ocr_<name>` and raise on a non-zero status."""
+    lib = load()
+    fn = getattr(lib, name)
+    fn.restype = ctypes.c_int
+    rc = fn(*args)
+    check(rc, name)
+    return rc
+
+
+def call_size(name, *args):
+    """Call a `size_t`-returning query."""
+    lib = load()
+    fn = getattr(lib, name)
+    fn.restype = ctypes.c_size_t
+    return int(fn(*args))
+
+
+def call_int(name, *args):
+    lib = load()
+    fn = getattr(lib, name)
+    fn.restype = ctypes.c_int
+    v = int(fn(*args))
+    if v < 0:
+        check(v, name)
+    return v
