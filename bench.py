@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one data-parallel TRAINING step (forward + dice loss +
+backward + gradient all-reduce + Adam/EMA) of the VGG-16 detector at 512x512, batch 32 per GPU
+(BASELINE.json configs[1]; the graph is nets/model_vgg_16.py: model_vgg + loss).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
+the implicit-GEMM conv, achieved TFLOP/s from HIP-event timing of every launch inside the timed
+steps) and, at N=1, `cpu_baseline` (the CPU oracle's train step on the host cores; baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
+TRAIN_GFLOP_PER_IMG = 516.5       # BASELINE.md §2, VGG-16 + PixelLink heads at 512x512
+
+
+def cpu_baseline(size, threads):
+    """The oracle's (CPU restatement, f32) full train step on a bounded sample: batch 1."""
+    from oracle import ocr_oracle as O
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(0)
+    p = O.init_model_vgg_params(rng)
+    images, pixel, link, mask = O.synthetic_batch(rng, 1, size)
+    times = []
+    for it in range(2):
+        t0 = time.time()
+        tp = O.to_torch_params(p)
+        px, lk, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=False)
+        L = O.dice_loss(torch.from_numpy(pixel), px, torch.from_numpy(link), lk, torch.from_numpy(mask))
+        L.backward()
+        times.append(time.time() - t0)
+    return {"value": round(1.0 / min(times), 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "1 image %dx%d, forward+loss+backward (no optimiser), best of 2, torch-CPU f32 oracle" % (size, size)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (reference: batch_size_per_gpu)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loss-scale", type=float, default=1024.0)
+    args = ap.parse_args()
+
+    from tensorflow_ocr_amd import dist, ops, synthetic
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model_vgg_16 as M
+    from tensorflow_ocr_amd.train import AdamOptimizer, TrainStep
+    import torch.distributed as td
+
+    rank, world, local = dist.init_process_group_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    g = Graph(device, loss_scale=args.loss_scale, seed=1)           # same init on every rank
+    rng = np.random.default_rng(100 + rank)                          # different data per rank
+    images, pixel, link, mask = synthetic.make_batch(rng, args.batch, args.size)
+    batch = [torch.from_numpy(a).to(device) for a in (images, pixel, link, mask)]   # resident in HBM
+
+    def forward_loss(gr, im, px, lk, mk):
+        f_score, f_geometry = M.model_vgg(im, is_training=True, graph=gr)
+        return M.loss(px, f_score, lk, f_geometry, mk, graph=gr)
+
+    step = TrainStep(g, forward_loss, lambda gr: AdamOptimizer(gr, learning_rate=1e-4), world_size=world)
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = step(*batch)
+    barrier()
+    ops.KERNEL_TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(*batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = loss.item()
+
+    # dominant kernel: the conv_igemm instantiation with the most accumulated time
+    per = {}
+    for variant, flops, e0, e1 in timing:
+        a = per.setdefault(variant, [0.0, 0.0, 0])
+        a[0] += flops
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    dom = max(per, key=lambda k: per[k][1]) if per else None
+    roof = None
+    if dom:
+        fl, sec, cnt = per[dom]
+        ach = fl / sec / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": cnt // args.steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
+                "share_of_step": round(sec / dt, 3)}
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * args.steps / dt
+        out = {
+            "metric": "images/sec training, 512x512 ICDAR, VGG-16 EAST, batch 32, 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "VGG-16 model_vgg + dice loss train step, %dx%d, batch %d per GPU, "
+                                   "f16 storage / f32 accumulate, Adam+EMA" % (args.size, args.size, args.batch),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "loss_scale": args.loss_scale},
+            "loss": round(loss_val, 5),
+            "train_tflops": round(value * TRAIN_GFLOP_PER_IMG / 1e3 * (args.size / 512.0) ** 2, 1),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,382 @@
+"""CPU restatement (oracle) of the BowieHsu/tensorflow_ocr hot path — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module,
+and only as the checker.  The product path (tensorflow_ocr_amd/) never imports it and has no
+CPU fallback.
+
+PARITY UNPINNED: the reference is Python-2 / TensorFlow-1.4 graph code that can be neither
+imported nor run here (no TF, no cv2) and ships no tests, fixtures or golden
+vectors.  This file restates the cited reference lines with the TF-1.4 op semantics listed in
+SURVEY.md §3.5 on top of PyTorch-CPU / NumPy arithmetic.  The single known-answer value the
+reference holds (example.py:13-21, softmax([1,2]) = [0.268941, 0.731059]) is checked in
+tests/test_oracle.py.
+
+Two arithmetic modes:
+  * fp32 (default): every tensor f32 — the reference's arithmetic.
+  * mixed=True: emulates the device pipeline's storage precision — conv inputs/outputs,
+    activations and activation gradients are rounded to IEEE f16 at exactly the points where the
+    HIP path stores f16 tensors (reductions, BN statistics and parameters stay f32/f64).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+torch.set_grad_enabled(True)
+
+
+# ----------------------------------------------------------------------------- rounding
+class _Q(torch.autograd.Function):
+    """forward: round to f16 storage; backward: straight through."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _QG(torch.autograd.Function):
+    """forward: identity; backward: gradient rounded to f16 storage."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.half().float()
+
+
+def q(x, mixed):
+    return _Q.apply(x) if mixed else x
+
+
+def qg(x, mixed):
+    return _QG.apply(x) if mixed else x
+
+
+# ------------------------------------------------------------------------ TF primitives
+def tf_same_pad(size, k, stride=1, rate=1):
+    """TF 'SAME': pad_total = max((ceil(n/s)-1)*s + k_eff - n, 0); before = total//2 (§3.5-2)."""
+    k_eff = (k - 1) * rate + 1
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k_eff - size, 0)
+    return out, total // 2, total - total // 2
+
+
+def conv2d(x, w_hwio, stride=1, rate=1, padding="SAME"):
+    """slim.conv2d's convolution (no bias/activation).  x NHWC, w HWIO (nets/vgg.py:14)."""
+    n, h, wd, c = x.shape
+    kh, kw, ci, co = w_hwio.shape
+    xn = x.permute(0, 3, 1, 2)
+    if padding == "SAME":
+        _, pt, pb = tf_same_pad(h, kh, stride, rate)
+        _, pl, pr = tf_same_pad(wd, kw, stride, rate)
+        xn = F.pad(xn, (pl, pr, pt, pb))
+    y = F.conv2d(xn, w_hwio.permute(3, 2, 0, 1), stride=stride, dilation=rate)
+    return y.permute(0, 2, 3, 1)
+
+
+def conv2d_same(x, w_hwio, stride, rate=1):
+    """resnet_utils.conv2d_same (nets/resnet_utils.py:77-122): explicit pad + VALID for stride>1."""
+    if stride == 1:
+        return conv2d(x, w_hwio, 1, rate, "SAME")
+    k = w_hwio.shape[0]
+    k_eff = k + (k - 1) * (rate - 1)
+    pad_total = k_eff - 1
+    pb = pad_total // 2
+    pe = pad_total - pb
+    xn = F.pad(x.permute(0, 3, 1, 2), (pb, pe, pb, pe)).permute(0, 2, 3, 1)
+    return conv2d(xn, w_hwio, stride, rate, "VALID")
+
+
+def max_pool(x, k, stride):
+    """slim.max_pool2d(padding='SAME'): -inf padding, first maximum wins the gradient."""
+    n, h, w, c = x.shape
+    oh, pt, pb = tf_same_pad(h, k, stride)
+    ow, pl, pr = tf_same_pad(w, k, stride)
+    xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb), value=float("-inf"))
+    win = xn.unfold(2, k, stride).unfold(3, k, stride)          # n,c,oh,ow,k,k
+    win = win.reshape(n, c, oh, ow, k * k)
+    idx = torch.argmax(win.detach(), dim=-1, keepdim=True)      # first max
+    return torch.gather(win, -1, idx).squeeze(-1).permute(0, 2, 3, 1)
+
+
+def resize_bilinear_x2(x):
+    """tf.image.resize_bilinear(size=2x, align_corners=False) of TF 1.4: src = dst*0.5, no
+    half-pixel centres (nets/model.py:14-15)."""
+    n, h, w, c = x.shape
+
+    def idx(sz):
+        o = torch.arange(2 * sz)
+        lo = o // 2
+        hi = torch.clamp(lo + 1, max=sz - 1)
+        frac = (o % 2).to(x.dtype) * 0.5
+        return lo, hi, frac
+    ylo, yhi, yf = idx(h)
+    xlo, xhi, xf = idx(w)
+    top = x[:, ylo]
+    bot = x[:, yhi]
+    tl, tr = top[:, :, xlo], top[:, :, xhi]
+    bl, br = bot[:, :, xlo], bot[:, :, xhi]
+    xf = xf.view(1, 1, -1, 1)
+    yf = yf.view(1, -1, 1, 1)
+    t = tl + (tr - tl) * xf
+    b = bl + (br - bl) * xf
+    return t + (b - t) * yf
+
+
+def batch_norm(x, gamma, beta, moving_mean, moving_var, training, decay=0.997, eps=1e-5):
+    """slim.batch_norm (fused): normalise with the biased batch variance; the moving average gets
+    the unbiased one.  Returns (y, new_moving_mean, new_moving_var)."""
+    c = x.shape[-1]
+    flat = x.reshape(-1, c)
+    if training:
+        m = flat.shape[0]
+        mean = flat.double().mean(0)
+        var = (flat.double() ** 2).mean(0) - mean ** 2
+        var = torch.clamp(var, min=0.0)
+        invstd = (1.0 / torch.sqrt(var + eps)).float()
+        mean = mean.float()
+        nm = moving_mean * decay + mean.detach() * (1 - decay)
+        unb = var.detach().float() * (m / max(m - 1, 1))
+        nv = moving_var * decay + unb * (1 - decay)
+    else:
+        mean = moving_mean
+        invstd = 1.0 / torch.sqrt(moving_var + eps)
+        nm, nv = moving_mean, moving_var
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    return x * scale + shift, nm, nv
+
+
+def mean_image_subtraction(images, means=(123.68, 116.78, 103.94)):
+    """nets/model.py:18-31."""
+    if images.shape[-1] != len(means):
+        raise ValueError('len(means) must match the number of channels')
+    return images - torch.tensor(means, dtype=images.dtype)
+
+
+def softmax(x):
+    """slim.softmax over the last axis (example.py:13-21 known answer)."""
+    return torch.softmax(x, dim=-1)
+
+
+# ------------------------------------------------------------------------------- VGG
+VGG_CFG = [("conv1", 2, 64), ("conv2", 2, 128), ("conv3", 3, 256), ("conv4", 3, 512), ("conv5", 3, 512)]
+
+
+def vgg_layer_names():
+    names = []
+    for block, reps, cout in VGG_CFG:
+        for r in range(1, reps + 1):
+            names.append(("%s/%s_%d" % (block, block, r), 3, cout, 1))
+    names.append(("fc6", 3, 1024, 6))
+    names.append(("fc7", 1, 1024, 1))
+    return names
+
+
+def init_vgg_params(rng, prefix="", normalizer="bn", width_div=1, cin=3):
+    """He-normal weights (seeded), BN gamma=1 beta=0 or zero biases; names as slim creates them."""
+    p = {}
+    c_prev = cin
+    for name, k, cout, _ in vgg_layer_names():
+        cout = max(cout // width_div, 8)
+        std = math.sqrt(2.0 / (k * k * c_prev))
+        p[prefix + name + "/weights"] = (rng.standard_normal((k, k, c_prev, cout)) * std).astype(np.float32)
+        if normalizer == "bn":
+            p[prefix + name + "/BatchNorm/gamma"] = np.ones(cout, np.float32)
+            p[prefix + name + "/BatchNorm/beta"] = np.zeros(cout, np.float32)
+            p[prefix + name + "/BatchNorm/moving_mean"] = np.zeros(cout, np.float32)
+            p[prefix + name + "/BatchNorm/moving_variance"] = np.ones(cout, np.float32)
+        else:
+            p[prefix + name + "/biases"] = np.zeros(cout, np.float32)
+        c_prev = cout
+    return p
+
+
+def _conv_block(x, p, name, rate, normalizer, mixed, updates, bn_training=True):
+    w = p[name + "/weights"]
+    y = conv2d(q(x, mixed), q(w, mixed), 1, rate)       # f16 operands, f32 accumulate
+    if normalizer == "bn":
+        y = qg(q(y, mixed), mixed)                       # stored f16; its gradient is stored f16
+        y, nm, nv = batch_norm(y, p[name + "/BatchNorm/gamma"], p[name + "/BatchNorm/beta"],
+                               p[name + "/BatchNorm/moving_mean"], p[name + "/BatchNorm/moving_variance"],
+                               bn_training)
+        updates[name + "/BatchNorm/moving_mean"] = nm
+        updates[name + "/BatchNorm/moving_variance"] = nv
+    else:
+        y = y + p[name + "/biases"]
+    a = q(torch.relu(y), mixed)
+    return a
+
+
+def vgg_basenet(x, p, prefix="", normalizer="bn", mixed=False, updates=None):
+    """nets/vgg.py:6-42.  x: mean-subtracted NHWC image.  Returns (net, end_points)."""
+    updates = {} if updates is None else updates
+    end_points = {}
+    net = q(x, mixed)
+    for bi, (block, reps, _) in enumerate(VGG_CFG):
+        for r in range(1, reps + 1):
+            name = "%s%s/%s_%d" % (prefix, block, block, r)
+            net = _conv_block(qg(net, mixed) if not (bi == 0 and r == 1) else net, p, name, 1,
+                              normalizer, mixed, updates)
+        end_points["%s_%d" % (block, reps)] = net
+        if bi < 4:
+            net = max_pool(net, 2, 2)
+        else:
+            net = max_pool(net, 3, 1)
+    net = _conv_block(qg(net, mixed), p, prefix + "fc6", 6, normalizer, mixed, updates)
+    end_points["fc6"] = net
+    net = _conv_block(qg(net, mixed), p, prefix + "fc7", 1, normalizer, mixed, updates)
+    end_points["fc7"] = net
+    return net, end_points
+
+
+# ----------------------------------------------------------------- model_vgg (BN heads)
+def init_model_vgg_params(rng, width_div=1):
+    p = init_vgg_params(rng, "", "bn", width_div)
+    chans = {"fc7": max(1024 // width_div, 8), "conv5_3": max(512 // width_div, 8),
+             "conv4_3": max(512 // width_div, 8), "conv3_3": max(256 // width_div, 8)}
+    # slim auto-names inside feature_fusion: pixel Conv..Conv_4, link Conv_5..Conv_9
+    order = ["fc7", "conv5_3", "conv4_3", "conv3_3"]
+    for base, cout in ((0, 2), (5, 16)):
+        for i, key in enumerate(order):
+            nm = "feature_fusion/Conv" + ("_%d" % (base + i) if base + i else "")
+            cin = chans[key]
+            p[nm + "/weights"] = (rng.standard_normal((1, 1, cin, cout)) * math.sqrt(2.0 / cin)).astype(np.float32)
+            _bn_init(p, nm, cout)
+        nm = "feature_fusion/Conv_%d" % (base + 4)
+        p[nm + "/weights"] = (rng.standard_normal((1, 1, cout, cout)) * math.sqrt(2.0 / cout)).astype(np.float32)
+        _bn_init(p, nm, cout)
+    return p
+
+
+def _bn_init(p, nm, c):
+    p[nm + "/BatchNorm/gamma"] = np.ones(c, np.float32)
+    p[nm + "/BatchNorm/beta"] = np.zeros(c, np.float32)
+    p[nm + "/BatchNorm/moving_mean"] = np.zeros(c, np.float32)
+    p[nm + "/BatchNorm/moving_variance"] = np.ones(c, np.float32)
+
+
+def _head(feat, p, nm, is_training, mixed, updates):
+    """slim.conv2d(feat, c, 1) with BN + ReLU (nets/model_vgg_16.py:160-172)."""
+    z = conv2d(q(feat, mixed), q(p[nm + "/weights"], mixed), 1, 1)
+    z, nmn, nv = batch_norm(z, p[nm + "/BatchNorm/gamma"], p[nm + "/BatchNorm/beta"],
+                            p[nm + "/BatchNorm/moving_mean"], p[nm + "/BatchNorm/moving_variance"],
+                            is_training)
+    updates[nm + "/BatchNorm/moving_mean"] = nmn
+    updates[nm + "/BatchNorm/moving_variance"] = nv
+    return torch.relu(z)
+
+
+def _head_f32(x, p, nm, is_training, updates):
+    z = conv2d(x, p[nm + "/weights"], 1, 1)
+    z, nmn, nv = batch_norm(z, p[nm + "/BatchNorm/gamma"], p[nm + "/BatchNorm/beta"],
+                            p[nm + "/BatchNorm/moving_mean"], p[nm + "/BatchNorm/moving_variance"],
+                            is_training)
+    updates[nm + "/BatchNorm/moving_mean"] = nmn
+    updates[nm + "/BatchNorm/moving_variance"] = nv
+    return torch.relu(z)
+
+
+def model_vgg(images, p, is_training=True, mixed=False, updates=None):
+    """nets/model_vgg_16.py:138-177.  Returns (pixel_cls, link_cls, end_points)."""
+    updates = {} if updates is None else updates
+    x = mean_image_subtraction(images)
+    _, ep = vgg_basenet(x, p, "", "bn", mixed, updates)
+    outs = []
+    for base, c in ((0, 2), (5, 16)):
+        def nm(i):
+            return "feature_fusion/Conv" + ("_%d" % (base + i) if base + i else "")
+        f = {k: qg(ep[k], mixed) for k in ("fc7", "conv5_3", "conv4_3", "conv3_3")}
+        s1 = _head(f["fc7"], p, nm(0), is_training, mixed, updates) + \
+            _head(f["conv5_3"], p, nm(1), is_training, mixed, updates)
+        s2 = resize_bilinear_x2(s1) + _head(f["conv4_3"], p, nm(2), is_training, mixed, updates)
+        s3 = resize_bilinear_x2(s2) + _head(f["conv3_3"], p, nm(3), is_training, mixed, updates)
+        outs.append(_head_f32(s3, p, nm(4), is_training, updates))
+    return outs[0], outs[1], ep
+
+
+# ------------------------------------------------------------------------------ losses
+def dice_coefficient(y_true_cls, y_pred_cls, training_mask):
+    """nets/model_vgg_16.py:179-193 (== nets/model.py:145-159), TF broadcasting included."""
+    eps = 1e-5
+    inter = torch.sum(y_true_cls * y_pred_cls * training_mask)
+    union = torch.sum(y_true_cls * training_mask) + torch.sum(y_pred_cls * training_mask) + eps
+    return 1.0 - (2 * inter / union)
+
+
+def dice_loss(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mask):
+    """nets/model_vgg_16.py:196-225."""
+    cls = dice_coefficient(y_true_pixel, y_pred_pixel, training_mask) * 2
+    gts = torch.split(y_true_link, y_true_link.shape[-1] // 8, dim=3)
+    prs = torch.split(y_pred_link, y_pred_link.shape[-1] // 8, dim=3)
+    link = sum(dice_coefficient(g, pr, training_mask) for g, pr in zip(gts, prs))
+    return link + cls
+
+
+# ----------------------------------------------------------------------- optimiser step
+def l2_regularizer_grad(w, scale):
+    """slim.l2_regularizer(s)(w) = s*sum(w^2)/2 -> gradient s*w."""
+    return scale * w
+
+
+def exponential_decay(lr, step, decay_steps=5000, rate=0.94, staircase=True):
+    """tf.train.exponential_decay (multigpu_train.py:104)."""
+    e = step // decay_steps if staircase else step / decay_steps
+    return lr * rate ** e
+
+
+def adam_update(w, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), eps outside the bias correction."""
+    lr_t = lr * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    w = w - lr_t * m / (np.sqrt(v) + eps)
+    return w, m, v
+
+
+def ema_decay(decay, num_updates):
+    """tf.train.ExponentialMovingAverage(decay, num_updates): min(d, (1+n)/(10+n))."""
+    return min(decay, (1.0 + num_updates) / (10.0 + num_updates))
+
+
+# ----------------------------------------------------------------------------- helpers
+def to_torch_params(p, requires_grad=True):
+    out = {}
+    for k, v in p.items():
+        t = torch.from_numpy(np.array(v, dtype=np.float32))
+        trainable = not (k.endswith("moving_mean") or k.endswith("moving_variance"))
+        t.requires_grad_(requires_grad and trainable)
+        out[k] = t
+    return out
+
+
+def synthetic_batch(rng, n, size, rects=8):
+    """Synthetic training batch of SURVEY §8d: images U[0,255), pixel label = union of random
+    axis-aligned rectangles at 1/4 resolution, link label = 1 where the neighbour in that direction
+    (order of §3.4: left, left_down, left_up, right, right_down, right_up, up, down) shares a
+    rectangle (border = 1), mask = 1."""
+    q4 = size // 4
+    images = rng.uniform(0, 255, size=(n, size, size, 3)).astype(np.float32)
+    ids = np.zeros((n, q4, q4), np.int32)
+    for b in range(n):
+        for k in range(rects):
+            hh = int(rng.integers(max(2, q4 // 16), max(3, q4 * 3 // 8)))
+            ww = int(rng.integers(max(2, q4 // 16), max(3, q4 * 3 // 8)))
+            y0 = int(rng.integers(0, q4 - hh + 1))
+            x0 = int(rng.integers(0, q4 - ww + 1))
+            ids[b, y0:y0 + hh, x0:x0 + ww] = k + 1
+    pixel = (ids > 0).astype(np.float32)[..., None]
+    offs = [(-1, 0), (-1, 1), (-1, -1), (1, 0), (1, 1), (1, -1), (0, -1), (0, 1)]   # (dx, dy)
+    link = np.zeros((n, q4, q4, 8), np.float32)
+    pad = np.pad(ids, ((0, 0), (1, 1), (1, 1)), constant_values=-1)
+    for d, (dx, dy) in enumerate(offs):
+        nb = pad[:, 1 + dy:1 + dy + q4, 1 + dx:1 + dx + q4]
+        same = (nb == ids) | (nb == -1)
+        link[..., d] = ((ids > 0) & same).astype(np.float32)
+    mask = np.ones((n, q4, q4, 1), np.float32)
+    return images, pixel, link, mask

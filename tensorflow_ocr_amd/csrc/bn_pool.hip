@@ -1,0 +1,569 @@
+// HBM-bound streaming kernels around the convolutions: image preparation,
+// training-mode batch norm (statistics finalisation, fused normalise+ReLU+2x2
+// max-pool, fused backward), and the general k x k max-pool (pool5, ResNet pool1,
+// subsample).  All f16 tensors are NHWC and are accessed 16 bytes (8 channels)
+// per lane.
+//
+// Reference semantics: slim.batch_norm decay 0.997 / eps 1e-5 / scale=True
+// (nets/resnet_utils.py:232-246, nets/model_vgg_16.py:144), slim.max_pool2d SAME
+// (nets/vgg.py:16-32), mean_image_subtraction (nets/model.py:18-31).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- image prep
+__global__ void prep_images_kernel(const float* __restrict__ img, half_t* __restrict__ out,
+                                   size_t npix, float m0, float m1, float m2) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  float r = img[i * 3 + 0] - m0, g = img[i * 3 + 1] - m1, b = img[i * 3 + 2] - m2;
+  half4_t o = {(half_t)r, (half_t)g, (half_t)b, (half_t)0.f};
+  *reinterpret_cast<half4_t*>(out + i * 4) = o;
+}
+
+// ------------------------------------------------- per-channel partial reduce
+// partial [T][2][C] f32  ->  stage [R][2][C] f64, R = ceil(T/256)
+__global__ void reduce_stage1_kernel(const float* __restrict__ partial, double* __restrict__ stage,
+                                     int T, int C) {
+  __shared__ double red[4][2][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const int t0 = blockIdx.x * 256;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    for (int t = t0 + rl; t < t0 + 256 && t < T; t += 4) {
+      s += (double)partial[((size_t)t * 2 + 0) * C + c];
+      q += (double)partial[((size_t)t * 2 + 1) * C + c];
+    }
+  }
+  red[rl][0][cl] = s;
+  red[rl][1][cl] = q;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    s = red[0][0][cl] + red[1][0][cl] + red[2][0][cl] + red[3][0][cl];
+    q = red[0][1][cl] + red[1][1][cl] + red[2][1][cl] + red[3][1][cl];
+    stage[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
+    stage[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stage, int R, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float decay, float* __restrict__ moving_mean,
+                                   float* __restrict__ moving_var, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int r = 0; r < R; ++r) {
+    s += stage[((size_t)r * 2 + 0) * C + c];
+    q += stage[((size_t)r * 2 + 1) * C + c];
+  }
+  double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float g = gamma ? gamma[c] : 1.f;
+  float b = beta ? beta[c] : 0.f;
+  float sc = g * invstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  if (save_mean) save_mean[c] = (float)mean;
+  if (save_invstd) save_invstd[c] = invstd;
+  if (moving_mean) {
+    // fused batch norm feeds the unbiased variance to the moving average
+    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    moving_mean[c] = moving_mean[c] * decay + (float)mean * (1.f - decay);
+    moving_var[c] = moving_var[c] * decay + (float)unbiased * (1.f - decay);
+  }
+}
+
+__global__ void bn_inference_params_kernel(const float* gamma, const float* beta, const float* mm,
+                                           const float* mv, float eps, int C, float* scale,
+                                           float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float invstd = 1.f / sqrtf(mv[c] + eps);
+  float sc = (gamma ? gamma[c] : 1.f) * invstd;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - mm[c] * sc;
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ stage, int R, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int r = 0; r < R; ++r) {
+    s += stage[((size_t)r * 2 + 0) * C + c];
+    q += stage[((size_t)r * 2 + 1) * C + c];
+  }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+}
+
+// ------------------------------------------------ fused normalise+ReLU(+pool)
+// pool == 0: one unit = one pixel.  pool == 2: one unit = one 2x2 window
+// (SAME, stride 2: windows hanging over an odd edge ignore the missing pixels).
+template <bool RELU>
+__device__ __forceinline__ void bn_act8(const half8_t& v, const float* sc, const float* sh, float* out) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float f = (float)v[e] * sc[e] + sh[e];
+    out[e] = RELU ? (f > 0.f ? f : 0.f) : f;
+  }
+}
+
+template <bool RELU, int POOL>
+__global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__ y,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int n, int h,
+                                                      int w, int c, half_t* __restrict__ a_full,
+                                                      half_t* __restrict__ a_pool) {
+  const int chunks = c >> 3;
+  const int oh = POOL ? (h + 1) / 2 : h, ow = POOL ? (w + 1) / 2 : w;
+  const size_t units = (size_t)n * oh * ow;
+  const size_t total = units * chunks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    const size_t u = i / chunks;
+    float sc[8], sh[8];
+    const f32x4* scp = reinterpret_cast<const f32x4*>(scale + ch * 8);
+    const f32x4* shp = reinterpret_cast<const f32x4*>(shift + ch * 8);
+    f32x4 s0 = scp[0], s1 = scp[1], h0 = shp[0], h1 = shp[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = h0[e]; sh[4 + e] = h1[e]; }
+    if (POOL == 0) {
+      half8_t v = *reinterpret_cast<const half8_t*>(y + u * c + ch * 8);
+      float f[8];
+      bn_act8<RELU>(v, sc, sh, f);
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
+      *reinterpret_cast<half8_t*>(a_full + u * c + ch * 8) = o;
+    } else {
+      const int ox = (int)(u % ow);
+      const size_t t = u / ow;
+      const int oy = (int)(t % oh);
+      const int img = (int)(t / oh);
+      float m[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int iy = oy * 2 + dy, ix = ox * 2 + dx;
+          if (iy < h && ix < w) {
+            const size_t off = (((size_t)img * h + iy) * w + ix) * c + ch * 8;
+            half8_t v = *reinterpret_cast<const half8_t*>(y + off);
+            float f[8];
+            bn_act8<RELU>(v, sc, sh, f);
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              o[e] = (half_t)f[e];
+              float fr = (float)o[e];
+              m[e] = fr > m[e] ? fr : m[e];
+            }
+            if (a_full) *reinterpret_cast<half8_t*>(a_full + off) = o;
+          }
+        }
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
+      *reinterpret_cast<half8_t*>(a_pool + u * c + ch * 8) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------ fused backward
+// dz = (da_full [+ routed da_pool]) * [z > 0];   partial sums of dz and dz*xhat.
+// MODE 0: reduce (writes partial[blk][2][C]);  MODE 1: apply (writes dy f16).
+struct BnBwdP {
+  int n, h, w, c, relu, pool;
+  float inv_count;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
+    BnBwdP p, const half_t* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ dgamma,
+    const float* __restrict__ dbeta, const half_t* __restrict__ da_full,
+    const half_t* __restrict__ da_pool, float* __restrict__ partial, half_t* __restrict__ dy) {
+  __shared__ float red[256 * 16];
+  const int c = p.c, chunks = c >> 3;
+  const int lanes = 256 / chunks;  // unit lanes per block
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  const int oh = p.pool ? (p.h + 1) / 2 : p.h, ow = p.pool ? (p.w + 1) / 2 : p.w;
+  const size_t units = (size_t)p.n * oh * ow;
+
+  float sc[8], sh[8], mu[8], is[8], k_dz[8], k_dzx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int cc = ch * 8 + e;
+    sc[e] = scale[cc];
+    sh[e] = shift[cc];
+    mu[e] = mean[cc];
+    is[e] = invstd[cc];
+    if (MODE == 1) {
+      k_dz[e] = dbeta[cc] * p.inv_count;
+      k_dzx[e] = dgamma[cc] * p.inv_count;
+    }
+  }
+  float s_dz[8], s_dzx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s_dz[e] = 0.f; s_dzx[e] = 0.f; }
+
+  for (size_t u = (size_t)blockIdx.x * lanes + ul; u < units; u += (size_t)gridDim.x * lanes) {
+    if (!p.pool) {
+      const size_t off = u * c + ch * 8;
+      half8_t v = *reinterpret_cast<const half8_t*>(y + off);
+      half8_t g = *reinterpret_cast<const half8_t*>(da_full + off);
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float yv = (float)v[e];
+        float z = (float)(half_t)(yv * sc[e] + sh[e]);  // the stored f16 activation
+        float dz = (!p.relu || z > 0.f) ? (float)g[e] : 0.f;
+        float xh = (yv - mu[e]) * is[e];
+        if (MODE == 0) {
+          s_dz[e] += dz;
+          s_dzx[e] += dz * xh;
+        } else {
+          o[e] = (half_t)(sc[e] * (dz - k_dz[e] - xh * k_dzx[e]));
+        }
+      }
+      if (MODE == 1) *reinterpret_cast<half8_t*>(dy + off) = o;
+    } else {
+      const int ox = (int)(u % ow);
+      const size_t t = u / ow;
+      const int oy = (int)(t % oh);
+      const int img = (int)(t / oh);
+      half8_t gp = *reinterpret_cast<const half8_t*>(da_pool + u * c + ch * 8);
+      half8_t v[4];
+      float a[4][8];
+      bool valid[4];
+      size_t offs[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int iy = oy * 2 + (k >> 1), ix = ox * 2 + (k & 1);
+        valid[k] = iy < p.h && ix < p.w;
+        offs[k] = (((size_t)img * p.h + (valid[k] ? iy : 0)) * p.w + (valid[k] ? ix : 0)) * c + ch * 8;
+        if (valid[k]) v[k] = *reinterpret_cast<const half8_t*>(y + offs[k]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = -INFINITY;
+          if (valid[k]) {
+            z = (float)v[k][e] * sc[e] + sh[e];
+            if (p.relu && z < 0.f) z = 0.f;
+            z = (float)(half_t)z;  // the stored f16 activation
+          }
+          a[k][e] = z;
+        }
+      }
+      int arg[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int best = 0;
+        float bv = a[0][e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+          if (a[k][e] > bv) { bv = a[k][e]; best = k; }
+        arg[e] = best;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!valid[k]) continue;
+        half8_t gf;
+        if (da_full) gf = *reinterpret_cast<const half8_t*>(da_full + offs[k]);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float yv = (float)v[k][e];
+          float g = (arg[e] == k) ? (float)gp[e] : 0.f;
+          if (da_full) g += (float)gf[e];
+          float dz = (!p.relu || a[k][e] > 0.f) ? g : 0.f;
+          float xh = (yv - mu[e]) * is[e];
+          if (MODE == 0) {
+            s_dz[e] += dz;
+            s_dzx[e] += dz * xh;
+          } else {
+            o[e] = (half_t)(sc[e] * (dz - k_dz[e] - xh * k_dzx[e]));
+          }
+        }
+        if (MODE == 1) *reinterpret_cast<half8_t*>(dy + offs[k]) = o;
+      }
+    }
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(ul * chunks + ch) * 16 + e] = s_dz[e];
+      red[(ul * chunks + ch) * 16 + 8 + e] = s_dzx[e];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * c; j += 256) {
+      const int which = j / c, cc = j % c;
+      const int ch2 = cc >> 3, e = (cc & 7) + which * 8;
+      float tot = 0.f;
+      for (int l = 0; l < lanes; ++l) tot += red[(l * chunks + ch2) * 16 + e];
+      partial[((size_t)blockIdx.x * 2 + which) * c + cc] = tot;
+    }
+  }
+}
+
+// --------------------------------------------------------- general max-pool
+struct PoolP {
+  int n, h, w, c, oh, ow, k, stride, pt, pl;
+};
+
+__global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, half_t* __restrict__ y) {
+  const int chunks = p.c >> 3;
+  const size_t total = (size_t)p.n * p.oh * p.ow * chunks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    size_t u = i / chunks;
+    const int ox = (int)(u % p.ow);
+    u /= p.ow;
+    const int oy = (int)(u % p.oh);
+    const int img = (int)(u / p.oh);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int ky = 0; ky < p.k; ++ky)
+      for (int kx = 0; kx < p.k; ++kx) {
+        const int iy = oy * p.stride + ky - p.pt, ix = ox * p.stride + kx - p.pl;
+        if (iy < 0 || iy >= p.h || ix < 0 || ix >= p.w) continue;
+        half8_t v = *reinterpret_cast<const half8_t*>(
+            x + (((size_t)img * p.h + iy) * p.w + ix) * p.c + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (float)v[e] > m[e] ? (float)v[e] : m[e];
+      }
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
+    *reinterpret_cast<half8_t*>(y + i * 8) = o;
+  }
+}
+
+// gather form: every input pixel re-derives the arg-max (first maximum in
+// row-major window order) of each window that covers it.
+__global__ void maxpool_bwd_kernel(PoolP p, const half_t* __restrict__ x,
+                                   const half_t* __restrict__ dy, half_t* __restrict__ dx,
+                                   int accumulate) {
+  const int chunks = p.c >> 3;
+  const size_t total = (size_t)p.n * p.h * p.w * chunks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    size_t u = i / chunks;
+    const int ix = (int)(u % p.w);
+    u /= p.w;
+    const int iy = (int)(u % p.h);
+    const int img = (int)(u / p.h);
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    const half_t* xb = x + (size_t)img * p.h * p.w * p.c + ch * 8;
+    for (int ky = 0; ky < p.k; ++ky) {
+      const int ny = iy + p.pt - ky;
+      if (ny < 0 || ny % p.stride) continue;
+      const int oy = ny / p.stride;
+      if (oy >= p.oh) continue;
+      for (int kx = 0; kx < p.k; ++kx) {
+        const int nx = ix + p.pl - kx;
+        if (nx < 0 || nx % p.stride) continue;
+        const int ox = nx / p.stride;
+        if (ox >= p.ow) continue;
+        // window (oy,ox): find first max
+        float bv[8];
+        int bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bv[e] = -INFINITY; bi[e] = -1; }
+        for (int wy = 0; wy < p.k; ++wy)
+          for (int wx = 0; wx < p.k; ++wx) {
+            const int yy = oy * p.stride + wy - p.pt, xx = ox * p.stride + wx - p.pl;
+            if (yy < 0 || yy >= p.h || xx < 0 || xx >= p.w) continue;
+            half8_t v = *reinterpret_cast<const half8_t*>(xb + ((size_t)yy * p.w + xx) * p.c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if ((float)v[e] > bv[e]) { bv[e] = (float)v[e]; bi[e] = wy * p.k + wx; }
+          }
+        half8_t d = *reinterpret_cast<const half8_t*>(
+            dy + (((size_t)img * p.oh + oy) * p.ow + ox) * p.c + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (bi[e] == ky * p.k + kx) g[e] += (float)d[e];
+      }
+    }
+    half8_t o;
+    if (accumulate) {
+      half8_t old = *reinterpret_cast<const half8_t*>(dx + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] += (float)old[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)g[e];
+    *reinterpret_cast<half8_t*>(dx + i * 8) = o;
+  }
+}
+
+inline unsigned stream_grid(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+int bwd_blocks(int n, int h, int w, int c, int pool) {
+  const int chunks = c >> 3;
+  const int lanes = 256 / chunks;
+  const int oh = pool ? (h + 1) / 2 : h, ow = pool ? (w + 1) / 2 : w;
+  size_t units = (size_t)n * oh * ow;
+  size_t b = (units + lanes - 1) / lanes;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int ocr_prep_images_f16(const void* images_f32, int64_t npix, float m0, float m1,
+                                   float m2, void* out_f16x4, void* stream) {
+  OCR_CHECK_ARG(images_f32 && out_f16x4 && npix > 0);
+  hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(images_f32),
+                     static_cast<half_t*>(out_f16x4), (size_t)npix, m0, m1, m2);
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_bn_reduce_workspace(int T, int C) {
+  return (size_t)ocr_cdiv(T, 256) * 2 * C * sizeof(double);
+}
+
+extern "C" int ocr_bn_finalize(const void* partial, int T, int C, double count, const void* gamma,
+                               const void* beta, float eps, float decay, void* moving_mean,
+                               void* moving_var, void* scale, void* shift, void* save_mean,
+                               void* save_invstd, void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(partial && scale && shift && workspace && T > 0 && C > 0 && count > 0);
+  OCR_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
+  if (ws_bytes < ocr_bn_reduce_workspace(T, C)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int R = ocr_cdiv(T, 256);
+  hipLaunchKernelGGL(reduce_stage1_kernel, dim3(R, ocr_cdiv(C, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ocr_cdiv(C, 64)), dim3(64), 0, st,
+                     static_cast<const double*>(workspace), R, C, count,
+                     static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, decay,
+                     static_cast<float*>(moving_mean), static_cast<float*>(moving_var),
+                     static_cast<float*>(scale), static_cast<float*>(shift),
+                     static_cast<float*>(save_mean), static_cast<float*>(save_invstd));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_inference_params(const void* gamma, const void* beta, const void* moving_mean,
+                                       const void* moving_var, float eps, int C, void* scale,
+                                       void* shift, void* stream) {
+  OCR_CHECK_ARG(moving_mean && moving_var && scale && shift && C > 0);
+  hipLaunchKernelGGL(bn_inference_params_kernel, dim3(ocr_cdiv(C, 64)), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(gamma),
+                     static_cast<const float*>(beta), static_cast<const float*>(moving_mean),
+                     static_cast<const float*>(moving_var), eps, C, static_cast<float*>(scale),
+                     static_cast<float*>(shift));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_relu_f16(const void* y, const void* scale, const void* shift, int n, int h,
+                               int w, int c, int relu, int pool, void* a_full, void* a_pool,
+                               void* stream) {
+  OCR_CHECK_ARG(y && scale && shift && n > 0 && h > 0 && w > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0);
+  OCR_CHECK_ARG(pool == 0 || pool == 2);
+  OCR_CHECK_ARG(pool ? a_pool != nullptr : a_full != nullptr);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int oh = pool ? (h + 1) / 2 : h, ow = pool ? (w + 1) / 2 : w;
+  const size_t total = (size_t)n * oh * ow * (c / 8);
+  dim3 grid(stream_grid(total));
+  const half_t* yp = static_cast<const half_t*>(y);
+  const float* sc = static_cast<const float*>(scale);
+  const float* sh = static_cast<const float*>(shift);
+  half_t* af = static_cast<half_t*>(a_full);
+  half_t* ap = static_cast<half_t*>(a_pool);
+  if (pool == 0) {
+    if (relu) hipLaunchKernelGGL((bn_relu_kernel<true, 0>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap);
+    else hipLaunchKernelGGL((bn_relu_kernel<false, 0>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap);
+  } else {
+    if (relu) hipLaunchKernelGGL((bn_relu_kernel<true, 2>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap);
+    else hipLaunchKernelGGL((bn_relu_kernel<false, 2>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap);
+  }
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_bwd_num_partials(int n, int h, int w, int c, int pool) {
+  if (n <= 0 || h <= 0 || w <= 0 || c % 8 || !pow2(c / 8) || c / 8 > 256) return OCR_ERR_UNSUPPORTED;
+  return bwd_blocks(n, h, w, c, pool);
+}
+
+extern "C" int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void* shift,
+                                   const void* save_mean, const void* save_invstd,
+                                   const void* da_full, const void* da_pool, int n, int h, int w,
+                                   int c, int relu, int pool, void* dgamma, void* dbeta, void* dy,
+                                   void* partial, void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(y && scale && shift && save_mean && save_invstd && dgamma && dbeta && dy);
+  OCR_CHECK_ARG(partial && workspace);
+  OCR_CHECK_ARG(pool == 0 || pool == 2);
+  OCR_CHECK_ARG(pool ? da_pool != nullptr : da_full != nullptr);
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int T = bwd_blocks(n, h, w, c, pool);
+  if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
+  BnBwdP p{n, h, w, c, relu, pool, (float)(1.0 / ((double)n * h * w))};
+  const half_t* yp = static_cast<const half_t*>(y);
+  hipLaunchKernelGGL(bn_relu_bwd_kernel<0>, dim3(T), dim3(256), 0, st, p, yp,
+                     static_cast<const float*>(scale), static_cast<const float*>(shift),
+                     static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                     (const float*)nullptr, (const float*)nullptr,
+                     static_cast<const half_t*>(da_full), static_cast<const half_t*>(da_pool),
+                     static_cast<float*>(partial), (half_t*)nullptr);
+  const int R = ocr_cdiv(T, 256);
+  hipLaunchKernelGGL(reduce_stage1_kernel, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ocr_cdiv(c, 64)), dim3(64), 0, st,
+                     static_cast<const double*>(workspace), R, c, static_cast<float*>(dgamma),
+                     static_cast<float*>(dbeta));
+  hipLaunchKernelGGL(bn_relu_bwd_kernel<1>, dim3(T), dim3(256), 0, st, p, yp,
+                     static_cast<const float*>(scale), static_cast<const float*>(shift),
+                     static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                     static_cast<const float*>(dgamma), static_cast<const float*>(dbeta),
+                     static_cast<const half_t*>(da_full), static_cast<const half_t*>(da_pool),
+                     (float*)nullptr, static_cast<half_t*>(dy));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k, int stride,
+                               int pad_top, int pad_left, int oh, int ow, void* y, void* stream) {
+  OCR_CHECK_ARG(x && y && n > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0);
+  PoolP p{n, h, w, c, oh, ow, k, stride, pad_top, pad_left};
+  const size_t total = (size_t)n * oh * ow * (c / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x),
+                     static_cast<half_t*>(y));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_maxpool_bwd_f16(const void* x, const void* dy, int n, int h, int w, int c, int k,
+                                   int stride, int pad_top, int pad_left, int oh, int ow, void* dx,
+                                   int accumulate, void* stream) {
+  OCR_CHECK_ARG(x && dy && dx && n > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0);
+  PoolP p{n, h, w, c, oh, ow, k, stride, pad_top, pad_left};
+  const size_t total = (size_t)n * h * w * (c / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x),
+                     static_cast<const half_t*>(dy), static_cast<half_t*>(dx), accumulate);
+  return ocr_launch_status();
+}

@@ -1,0 +1,100 @@
+// Shared epilogue of the MFMA convolution kernels: 32x32 f32 accumulator tiles
+// (rows = cout, cols = pixels of an 8x32 spatial tile) -> LDS [256 px][BN] f16
+// -> 16-byte coalesced row stores, with optional bias / ReLU / accumulate and
+// the per-tile per-cout sum / sum-of-squares needed by training-mode batch norm.
+#pragma once
+#include "common.h"
+
+constexpr int TILE_H = 8;
+constexpr int TILE_W = 32;
+
+// LDS needed by the epilogue for a BN-wide tile.
+constexpr size_t conv_epilogue_lds(int bn) { return 256 * (bn * 2 + 16) + 256 * 16 * sizeof(float); }
+
+template <int BN, int TCO, int TPX, int WCO>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* smem, int flags,
+                                              const float* __restrict__ bias,
+                                              half_t* __restrict__ y, float* __restrict__ stats,
+                                              int img, int tyi, int txi, int mt, int co0, int oh,
+                                              int ow, int cout) {
+  constexpr int OSTR = BN * 2 + 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int wco = wave % WCO, wpx = wave / WCO;
+  char* otile = smem;
+  float* red = reinterpret_cast<float*>(smem + 256 * OSTR);
+  const bool has_bias = (flags & OCR_CONV_BIAS) != 0;
+  const bool relu = (flags & OCR_CONV_RELU) != 0;
+#pragma unroll
+  for (int i = 0; i < TCO; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = wco * TCO * 32 + i * 32 + q * 8 + hh * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (has_bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + col + e];
+      }
+#pragma unroll
+      for (int t = 0; t < TPX; ++t) {
+        const int px = (wpx * TPX + t) * 32 + r;
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][t][q * 4 + e] + bv[e];
+          if (relu) v = v > 0.f ? v : 0.f;
+          o[e] = (half_t)v;
+        }
+        *reinterpret_cast<half4_t*>(otile + px * OSTR + col * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NC = BN / 8;    // 16-byte chunks per output row
+  constexpr int RG = 256 / NC;  // row groups
+  constexpr int PPT = 256 / RG; // pixels per thread
+  const int c = tid % NC, rg = tid / NC;
+  const bool accum = (flags & OCR_CONV_ACCUM_F16) != 0;
+  const bool do_stats = (flags & OCR_CONV_STATS) != 0;
+  float s[8], q2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
+#pragma unroll 4
+  for (int k = 0; k < PPT; ++k) {
+    const int px = rg + k * RG;
+    const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
+    if (oy < oh && ox < ow) {
+      half8_t v = *reinterpret_cast<const half8_t*>(otile + px * OSTR + c * 16);
+      half_t* dst = y + (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
+      if (accum) {
+        half8_t old = *reinterpret_cast<const half8_t*>(dst);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+      }
+      *reinterpret_cast<half8_t*>(dst) = v;
+      if (do_stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)v[e];
+          s[e] += f;
+          q2[e] += f * f;
+        }
+      }
+    }
+  }
+  if (do_stats) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(rg * NC + c) * 16 + e] = s[e];
+      red[(rg * NC + c) * 16 + 8 + e] = q2[e];
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int cc2 = tid >> 4, e = tid & 15;
+      float tot = 0.f;
+      for (int g = 0; g < RG; ++g) tot += red[(g * NC + cc2) * 16 + e];
+      stats[((size_t)mt * 2 + (e >> 3)) * cout + co0 + cc2 * 8 + (e & 7)] = tot;
+    }
+  }
+}

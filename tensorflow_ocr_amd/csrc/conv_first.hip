@@ -1,0 +1,232 @@
+// First VGG convolution (conv1_1, cin = 3; reference nets/vgg.py:14) and its
+// weight gradient.  The image is kept as [n,h,w,4] f16 (RGB minus mean, 4th
+// channel zero: ocr_prep_images_f16) so a pixel is one 8-byte word.
+//
+// Forward: per kernel row ky one MFMA k-step of 16 = 4 pixels (kx = 0..3, the
+// 4th with zero weights) x 4 channels, i.e. a lane's 8 k-values are two adjacent
+// pixels = 16 contiguous bytes of the LDS halo tile.  K is padded 27 -> 48, which
+// is irrelevant: the layer is bound by its 64-channel output stream.
+//
+// Weight gradient: 27 x cout outputs, K = all pixels.  A VALU kernel: one lane
+// per cout, all 27 (ky,kx,c) sums in registers, the halo pixel (4 channels) is a
+// wave-uniform 8-byte LDS broadcast.  Partials per workgroup -> fixed-order sum.
+#include "common.h"
+#include "conv_epilogue.h"
+
+namespace {
+
+constexpr int HW = 36;  // halo row pitch in pixels (34 used + 2 so kx=3 stays in range)
+
+struct FirstP {
+  int n, h, w, cout, tiles_x, tiles_y, m_tiles, flags;
+};
+
+__device__ __forceinline__ void load_halo4(const half_t* __restrict__ x4, char* halo, int img, int h,
+                                           int w, int iy0, int ix0) {
+  for (int i = threadIdx.x; i < 10 * HW; i += 256) {
+    const int hy = i / HW, hx = i - hy * HW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    u32x2 v = {0u, 0u};
+    if (iy >= 0 && iy < h && ix >= 0 && ix < w)
+      v = *reinterpret_cast<const u32x2*>(x4 + (((size_t)img * h + iy) * w + ix) * 4);
+    *reinterpret_cast<u32x2*>(halo + i * 8) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_first_kernel(FirstP p, const half_t* __restrict__ x4,
+                                                         const half_t* __restrict__ wf,
+                                                         const float* __restrict__ bias,
+                                                         half_t* __restrict__ y,
+                                                         float* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int n_tiles = p.cout / 64;
+  const int nt = blockIdx.x % n_tiles;
+  const int mt = blockIdx.x / n_tiles;
+  const int txi = mt % p.tiles_x;
+  const int tmp = mt / p.tiles_x;
+  const int tyi = tmp % p.tiles_y;
+  const int img = tmp / p.tiles_y;
+  const int co0 = nt * 64;
+
+  half8_t a[3][2];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      a[ky][i] = *reinterpret_cast<const half8_t*>(wf + ((size_t)(ky * p.cout + co0 + i * 32 + r)) * 16 + 8 * hh);
+
+  load_halo4(x4, halo, img, p.h, p.w, tyi * TILE_H - 1, txi * TILE_W - 1);
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.f;
+
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ty = wave * 2 + t;
+      const char* src = halo + ((ty + ky) * HW + r + 2 * hh) * 8;
+      half4_t lo = *reinterpret_cast<const half4_t*>(src);
+      half4_t hi = *reinterpret_cast<const half4_t*>(src + 8);
+      half8_t b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky][i], b, acc[i][t], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  conv_epilogue<64, 2, 2, 1>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt, co0, p.h, p.w,
+                             p.cout);
+}
+
+// ---- weight gradient -------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const half_t* __restrict__ x4,
+                                                               const half_t* __restrict__ dy,
+                                                               float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) char halo[10 * HW * 8];
+  __shared__ __attribute__((aligned(16))) half_t dyt[256 * 64];
+  __shared__ float red[4 * 27 * 64];
+  const int tid = threadIdx.x, co = tid & 63, wave = tid >> 6;
+  const int co0 = blockIdx.y * 64;
+  float acc[27];
+#pragma unroll
+  for (int j = 0; j < 27; ++j) acc[j] = 0.f;
+
+  for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
+    const int txi = mt % p.tiles_x;
+    const int tmp = mt / p.tiles_x;
+    const int tyi = tmp % p.tiles_y;
+    const int img = tmp / p.tiles_y;
+    __syncthreads();
+    load_halo4(x4, halo, img, p.h, p.w, tyi * TILE_H - 1, txi * TILE_W - 1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = u * 256 + tid;
+      const int px = idx >> 3, c = idx & 7;
+      const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (oy < p.h && ox < p.w)
+        v = *reinterpret_cast<const u32x4*>(dy + (((size_t)img * p.h + oy) * p.w + ox) * p.cout + co0 + c * 8);
+      *reinterpret_cast<u32x4*>(dyt + px * 64 + c * 8) = v;
+    }
+    __syncthreads();
+    for (int pl = 0; pl < 64; ++pl) {
+      const int px = wave * 64 + pl;
+      const int ty = px >> 5, tx = px & 31;
+      const float d = (float)dyt[px * 64 + co];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          half4_t xv = *reinterpret_cast<const half4_t*>(halo + ((ty + ky) * HW + tx + kx) * 8);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[(ky * 3 + kx) * 3 + c] += (float)xv[c] * d;
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 27; ++j) red[(wave * 27 + j) * 64 + co] = acc[j];
+  __syncthreads();
+  for (int i = tid; i < 27 * 64; i += 256) {
+    const int j = i >> 6, c2 = i & 63;
+    float v = red[(0 * 27 + j) * 64 + c2] + red[(1 * 27 + j) * 64 + c2] +
+              red[(2 * 27 + j) * 64 + c2] + red[(3 * 27 + j) * 64 + c2];
+    partial[((size_t)blockIdx.x * 27 + j) * p.cout + co0 + c2] = v;
+  }
+}
+
+__global__ void first_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                    int elems, int blocks) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= elems) return;
+  float a = 0.f;
+  for (int b = 0; b < blocks; ++b) a += partial[(size_t)b * elems + i];
+  dw[i] = a;
+}
+
+// HWIO f32 [3,3,3,cout] -> [3][cout][16] f16 (k = kx*4 + c)
+__global__ void pack_first_kernel(const float* __restrict__ w, half_t* __restrict__ out, int cout) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * cout * 16) return;
+  const int k = i & 15, co = (i >> 4) % cout, ky = (i >> 4) / cout;
+  const int kx = k >> 2, c = k & 3;
+  float v = (kx < 3 && c < 3) ? w[((ky * 3 + kx) * 3 + c) * cout + co] : 0.f;
+  out[i] = (half_t)v;
+}
+
+int wgrad_blocks(int m_tiles) { return m_tiles < 1024 ? m_tiles : 1024; }
+
+int fill(FirstP* p, int n, int h, int w, int cout, int flags) {
+  OCR_CHECK_ARG(n > 0 && h > 0 && w > 0);
+  OCR_CHECK_SHAPE(cout % 64 == 0);
+  p->n = n; p->h = h; p->w = w; p->cout = cout; p->flags = flags;
+  p->tiles_x = ocr_cdiv(w, TILE_W);
+  p->tiles_y = ocr_cdiv(h, TILE_H);
+  p->m_tiles = n * p->tiles_x * p->tiles_y;
+  return OCR_OK;
+}
+
+}  // namespace
+
+extern "C" int ocr_conv2d_first_num_mtiles(int n, int h, int w) {
+  return n * ocr_cdiv(w, TILE_W) * ocr_cdiv(h, TILE_H);
+}
+
+extern "C" int ocr_pack_weights_first_f16(const void* w_hwio_f32, int cout, void* w_first,
+                                          void* stream) {
+  OCR_CHECK_ARG(w_hwio_f32 && w_first && cout > 0);
+  hipLaunchKernelGGL(pack_first_kernel, dim3(ocr_cdiv(3 * cout * 16, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(w_hwio_f32),
+                     static_cast<half_t*>(w_first), cout);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_conv2d_first_f16(int n, int h, int w, int cout, const void* x4,
+                                    const void* w_first, const void* bias, int flags, void* y,
+                                    void* stats, void* stream) {
+  FirstP p;
+  int rc = fill(&p, n, h, w, cout, flags);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x4 && w_first && y);
+  OCR_CHECK_ARG(!(flags & OCR_CONV_BIAS) || bias);
+  OCR_CHECK_ARG(!(flags & OCR_CONV_STATS) || stats);
+  const size_t lds = conv_epilogue_lds(64);
+  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(p.m_tiles * (cout / 64))), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x4),
+                     static_cast<const half_t*>(w_first), static_cast<const float*>(bias),
+                     static_cast<half_t*>(y), static_cast<float*>(stats));
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_conv2d_first_wgrad_workspace(int n, int h, int w, int cout) {
+  const int mt = ocr_conv2d_first_num_mtiles(n, h, w);
+  return (size_t)wgrad_blocks(mt) * 27 * cout * sizeof(float);
+}
+
+extern "C" int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const void* x4,
+                                          const void* dy, void* dw, void* workspace,
+                                          size_t ws_bytes, void* stream) {
+  FirstP p;
+  int rc = fill(&p, n, h, w, cout, 0);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x4 && dy && dw && workspace);
+  if (ws_bytes < ocr_conv2d_first_wgrad_workspace(n, h, w, cout)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int blocks = wgrad_blocks(p.m_tiles);
+  hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks, cout / 64), dim3(256), 0, st, p,
+                     static_cast<const half_t*>(x4), static_cast<const half_t*>(dy),
+                     static_cast<float*>(workspace));
+  const int elems = 27 * cout;
+  hipLaunchKernelGGL(first_reduce_kernel, dim3(ocr_cdiv(elems, 256)), dim3(256), 0, st,
+                     static_cast<const float*>(workspace), static_cast<float*>(dw), elems, blocks);
+  return ocr_launch_status();
+}

@@ -21,6 +21,7 @@
 //     f16 tensor, and emits per-tile per-cout sum and sum of squares of the
 //     stored (f16-rounded) values for training-mode batch norm.
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -29,8 +30,6 @@ struct ConvP {
   int tiles_x, tiles_y, n_tiles, HT, WT, halo_bytes;
 };
 
-constexpr int TILE_H = 8;
-constexpr int TILE_W = 32;
 
 template <int BN, int CK, int WCO>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
@@ -44,7 +43,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   constexpr int KSTEPS = CK / 16;
   constexpr int CPP = CK / 8;  // 16-byte chunks per pixel / per weight row
   constexpr int NWLD = BN * CPP / 256;
-  constexpr int OSTR = BN * 2 + 16;
   static_assert(NWLD >= 1, "weight slice smaller than one pass");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,92 +167,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 
   // ---- epilogue: accumulators -> LDS [256 px][BN] f16 -> coalesced rows ----
   __syncthreads();
-  char* otile = smem;
-  float* red = reinterpret_cast<float*>(smem + 256 * OSTR);
-  const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0;
-  const bool relu = (p.flags & OCR_CONV_RELU) != 0;
-#pragma unroll
-  for (int i = 0; i < TCO; ++i) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = wco * TCO * 32 + i * 32 + q * 8 + hh * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (has_bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + col + e];
-      }
-#pragma unroll
-      for (int t = 0; t < TPX; ++t) {
-        const int px = (wpx * TPX + t) * 32 + r;
-        half4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[i][t][q * 4 + e] + bv[e];
-          if (relu) v = v > 0.f ? v : 0.f;
-          o[e] = (half_t)v;
-        }
-        *reinterpret_cast<half4_t*>(otile + px * OSTR + col * 2) = o;
-      }
-    }
-  }
-  __syncthreads();
-  {
-    constexpr int NC = BN / 8;      // 16-byte chunks per output row
-    constexpr int RG = 256 / NC;    // row groups
-    constexpr int PPT = 256 / RG;   // pixels per thread
-    const int c = tid % NC, rg = tid / NC;
-    const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0;
-    const bool do_stats = (p.flags & OCR_CONV_STATS) != 0;
-    float s[8], q2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
-#pragma unroll 4
-    for (int k = 0; k < PPT; ++k) {
-      const int px = rg + k * RG;
-      const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
-      if (oy < p.oh && ox < p.ow) {
-        half8_t v = *reinterpret_cast<const half8_t*>(otile + px * OSTR + c * 16);
-        half_t* dst = y + (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8;
-        if (accum) {
-          half8_t old = *reinterpret_cast<const half8_t*>(dst);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
-        }
-        *reinterpret_cast<half8_t*>(dst) = v;
-        if (do_stats) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float f = (float)v[e];
-            s[e] += f;
-            q2[e] += f * f;
-          }
-        }
-      }
-    }
-    if (do_stats) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[(rg * NC + c) * 16 + e] = s[e];
-        red[(rg * NC + c) * 16 + 8 + e] = q2[e];
-      }
-      __syncthreads();
-      if (tid < 2 * BN) {
-        const int cc2 = tid >> 4, e = tid & 15;
-        float tot = 0.f;
-        for (int g = 0; g < RG; ++g) tot += red[(g * NC + cc2) * 16 + e];
-        stats[((size_t)mt * 2 + (e >> 3)) * p.cout + co0 + cc2 * 8 + (e & 7)] = tot;
-      }
-    }
-  }
+  conv_epilogue<BN, TCO, TPX, WCO>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt, co0,
+                                   p.oh, p.ow, p.cout);
 }
 
 template <int BN, int CK, int WCO>
 int launch(const ConvP& p, const void* x, const void* w, const void* bias, void* y,
            void* stats, hipStream_t st) {
   constexpr int PSTR = CK * 2 + 16;
-  constexpr int OSTR = BN * 2 + 16;
   size_t main_bytes = (size_t)p.halo_bytes + 2 * BN * PSTR;
-  size_t epi_bytes = 256 * OSTR + 256 * 16 * sizeof(float);
+  size_t epi_bytes = conv_epilogue_lds(BN);
   size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (lds > 160 * 1024) return OCR_ERR_UNSUPPORTED;
   auto kern = conv_igemm_kernel<BN, CK, WCO>;

@@ -1,0 +1,525 @@
+// PixelLink fuse heads: 1x1 convolutions from wide f16 feature maps to a few
+// channels (2 pixel + 16 link logits), their gradients, and the "small-channel"
+// f32 tensors [P][C] (C <= 32) that the unpool+add pyramid, the head batch
+// norms and the final 1x1 predication convs work on.
+//
+// Reference: nets/model_vgg_16.py:160-175 (BN'd heads), nets/pixellink.py:55-67
+// (bias heads), nets/model.py:129-141 (ResNet heads), unpool = legacy
+// tf.image.resize_bilinear x2 (nets/model.py:14-15).
+//
+// The wide->narrow convs are HBM-bound (each feature byte is read once and
+// 18 outputs are produced), so they stream the features straight from global
+// memory into MFMA B-fragments (16 B per lane) with the tiny weight matrix as A.
+#include "common.h"
+
+namespace {
+
+// out[p][co] = sum_ci x[p][ci] * w[co][ci]     (w rows >= cout are zero)
+__global__ __launch_bounds__(256) void conv1x1_small_kernel(const half_t* __restrict__ x,
+                                                            const half_t* __restrict__ w,
+                                                            const float* __restrict__ bias, int P,
+                                                            int cin, int cout,
+                                                            float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int p = (blockIdx.x * 4 + wave) * 32 + r;
+  const bool ok = p < P;
+  const half_t* xp = x + (size_t)(ok ? p : 0) * cin + 8 * hh;
+  const half_t* wp = w + (size_t)r * cin + 8 * hh;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+  for (int k = 0; k < cin; k += 16) {
+    half8_t a = *reinterpret_cast<const half8_t*>(wp + k);
+    half8_t b = ok ? *reinterpret_cast<const half8_t*>(xp + k) : zero;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+  }
+  if (ok) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      if (co < cout) out[(size_t)p * cout + co] = acc[e] + (bias ? bias[co] : 0.f);
+    }
+  }
+}
+
+// dx[p][ci] (+)= sum_co dz[p][co] * w[ci][co]     (w_ck f16 [cin][32], cols >= cout zero)
+__global__ __launch_bounds__(256) void conv1x1_small_dgrad_kernel(const float* __restrict__ dz,
+                                                                  const half_t* __restrict__ w_ck,
+                                                                  int P, int cin, int cout,
+                                                                  half_t* __restrict__ dx,
+                                                                  int accumulate, float gscale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int p = (blockIdx.x * 4 + wave) * 32 + r;
+  const bool ok = p < P;
+  half8_t b[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int co = ks * 16 + 8 * hh + j;
+      b[ks][j] = (half_t)((ok && co < cout) ? dz[(size_t)p * cout + co] * gscale : 0.f);
+    }
+  for (int ct = 0; ct < cin / 32; ++ct) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8_t a = *reinterpret_cast<const half8_t*>(w_ck + (size_t)(ct * 32 + r) * 32 + ks * 16 + 8 * hh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks], acc, 0, 0, 0);
+    }
+    if (ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        half_t* dst = dx + (size_t)p * cin + ct * 32 + q * 8 + 4 * hh;
+        half4_t o;
+        if (accumulate) {
+          half4_t old = *reinterpret_cast<const half4_t*>(dst);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)(acc[q * 4 + e] + (float)old[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)acc[q * 4 + e];
+        }
+        *reinterpret_cast<half4_t*>(dst) = o;
+      }
+    }
+  }
+}
+
+// partial[s][ci][co] = sum over the strip's pixels of x[p][ci] * dz[p][co]
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1x1_small_wgrad_kernel(const half_t* __restrict__ x,
+                                                                  const float* __restrict__ dz,
+                                                                  int P, int cin, int strip,
+                                                                  float* __restrict__ partial) {
+  const int ci = blockIdx.y * 256 + threadIdx.x;
+  const int p0 = blockIdx.x * strip;
+  int p1 = p0 + strip;
+  if (p1 > P) p1 = P;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+  if (ci < cin) {
+    for (int p = p0; p < p1; ++p) {
+      const float xv = (float)x[(size_t)p * cin + ci];
+      const float* d = dz + (size_t)p * COUT;
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc[c] += xv * d[c];
+    }
+    float* dst = partial + ((size_t)blockIdx.x * cin + ci) * COUT;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) dst[c] = acc[c];
+  }
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                    int elems, int S, float scale) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= elems) return;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) a += partial[(size_t)s * elems + i];
+  out[i] = a * scale;
+}
+
+// ---------------------------------------------------- small-channel f32 ops
+// per-channel sum / sum of squares partials of x [P][C]
+__global__ __launch_bounds__(256) void sc_stats_kernel(const float* __restrict__ x, int P, int C,
+                                                       float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  const int lanes = 256 / C;
+  const int c = threadIdx.x % C, l = threadIdx.x / C;
+  float s = 0.f, q = 0.f;
+  if (l < lanes) {
+    for (size_t p = (size_t)blockIdx.x * lanes + l; p < (size_t)P; p += (size_t)gridDim.x * lanes) {
+      float v = x[p * C + c];
+      s += v;
+      q += v * v;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < 2 * C) {
+    const int which = threadIdx.x / C, cc = threadIdx.x % C;
+    float t = 0.f;
+    for (int k = 0; k < lanes; ++k) t += red[which][k * C + cc];
+    partial[((size_t)blockIdx.x * 2 + which) * C + cc] = t;
+  }
+}
+
+__device__ __forceinline__ float sc_act(float z, float sc, float sh, int relu) {
+  float v = z * sc + sh;
+  return (relu && v < 0.f) ? 0.f : v;
+}
+
+// legacy tf.image.resize_bilinear x2 (align_corners=False, no half-pixel centres):
+// out[2i] = in[i], out[2i+1] = (in[i] + in[min(i+1, H-1)]) / 2, separably.
+__device__ __forceinline__ float unpool_at(const float* __restrict__ prev, int img, int oy, int ox,
+                                           int lh, int lw, int C, int c) {
+  const int y0 = oy >> 1, x0 = ox >> 1;
+  const int y1 = (oy & 1) ? (y0 + 1 < lh ? y0 + 1 : lh - 1) : y0;
+  const int x1 = (ox & 1) ? (x0 + 1 < lw ? x0 + 1 : lw - 1) : x0;
+  const float wy = (oy & 1) ? 0.5f : 0.f, wx = (ox & 1) ? 0.5f : 0.f;
+  const float* b = prev + (size_t)img * lh * lw * C + c;
+  const float v00 = b[((size_t)y0 * lw + x0) * C], v01 = b[((size_t)y0 * lw + x1) * C];
+  const float v10 = b[((size_t)y1 * lw + x0) * C], v11 = b[((size_t)y1 * lw + x1) * C];
+  const float top = v00 + (v01 - v00) * wx;
+  const float bot = v10 + (v11 - v10) * wx;
+  return top + (bot - top) * wy;
+}
+
+// out = [act(za*sa+ha)] + [act(zb*sb+hb)] + [unpool2x(prev)]      (any subset)
+__global__ void sc_fuse_kernel(const float* __restrict__ za, const float* __restrict__ sa,
+                               const float* __restrict__ ha, const float* __restrict__ zb,
+                               const float* __restrict__ sb, const float* __restrict__ hb,
+                               const float* __restrict__ prev, int n, int h, int w, int C, int relu,
+                               float* __restrict__ out) {
+  const size_t total = (size_t)n * h * w * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    float v = 0.f;
+    if (za) v += sa ? sc_act(za[i], sa[c], ha[c], relu) : za[i];
+    if (zb) v += sb ? sc_act(zb[i], sb[c], hb[c], relu) : zb[i];
+    if (prev) {
+      size_t u = i / C;
+      const int ox = (int)(u % w);
+      u /= w;
+      const int oy = (int)(u % h);
+      const int img = (int)(u / h);
+      v += unpool_at(prev, img, oy, ox, h >> 1, w >> 1, C, c);
+    }
+    out[i] = v;
+  }
+}
+
+// dprev[n, lh, lw, C] = transpose of unpool2x applied to dout[n, 2lh, 2lw, C]
+__global__ void sc_unpool_bwd_kernel(const float* __restrict__ dout, int n, int lh, int lw, int C,
+                                     float* __restrict__ dprev) {
+  const size_t total = (size_t)n * lh * lw * C;
+  const int H = lh * 2, W = lw * 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    size_t u = i / C;
+    const int x = (int)(u % lw);
+    u /= lw;
+    const int y = (int)(u % lh);
+    const int img = (int)(u / lh);
+    const float* b = dout + (size_t)img * H * W * C + c;
+    // 1-D weights of input sample y onto output rows: row 2y (1), 2y+1 (.5, or 1 at the
+    // clamped last row), 2y-1 (.5)
+    int ry[3], rx[3];
+    float wy[3], wx[3];
+    ry[0] = 2 * y; wy[0] = 1.f;
+    ry[1] = 2 * y + 1; wy[1] = (y == lh - 1) ? 1.f : 0.5f;
+    ry[2] = 2 * y - 1; wy[2] = (y > 0) ? 0.5f : 0.f;
+    rx[0] = 2 * x; wx[0] = 1.f;
+    rx[1] = 2 * x + 1; wx[1] = (x == lw - 1) ? 1.f : 0.5f;
+    rx[2] = 2 * x - 1; wx[2] = (x > 0) ? 0.5f : 0.f;
+    float g = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (wy[a] == 0.f) continue;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (wx[d] == 0.f) continue;
+        g += wy[a] * wx[d] * b[((size_t)ry[a] * W + rx[d]) * C];
+      }
+    }
+    dprev[i] = g;
+  }
+}
+
+// BN(+ReLU) backward on [P][C] f32.  MODE 0: partial sums; MODE 1: dz.
+template <int MODE>
+__global__ __launch_bounds__(256) void sc_bn_bwd_kernel(const float* __restrict__ z,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        const float* __restrict__ dgamma,
+                                                        const float* __restrict__ dbeta,
+                                                        const float* __restrict__ dout, int P, int C,
+                                                        int relu, float inv_count,
+                                                        float* __restrict__ partial,
+                                                        float* __restrict__ dz) {
+  __shared__ float red[2][256];
+  const int lanes = 256 / C;
+  const int c = threadIdx.x % C, l = threadIdx.x / C;
+  float s = 0.f, q = 0.f;
+  if (l < lanes) {
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const float kd = MODE ? dbeta[c] * inv_count : 0.f, kx = MODE ? dgamma[c] * inv_count : 0.f;
+    for (size_t p = (size_t)blockIdx.x * lanes + l; p < (size_t)P; p += (size_t)gridDim.x * lanes) {
+      const float zv = z[p * C + c];
+      const float a = zv * sc + sh;
+      const float g = (!relu || a > 0.f) ? dout[p * C + c] : 0.f;
+      const float xh = (zv - mu) * is;
+      if (MODE == 0) {
+        s += g;
+        q += g * xh;
+      } else {
+        dz[p * C + c] = sc * (g - kd - xh * kx);
+      }
+    }
+  }
+  if (MODE == 0) {
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+      const int which = threadIdx.x / C, cc = threadIdx.x % C;
+      float t = 0.f;
+      for (int k = 0; k < lanes; ++k) t += red[which][k * C + cc];
+      partial[((size_t)blockIdx.x * 2 + which) * C + cc] = t;
+    }
+  }
+}
+
+// pointwise f32 conv on a channel slice: out[p][oo+co] = b[co] + sum_ci x[p][xo+ci] w[ci][co]
+__global__ void sc_pointwise_fwd_kernel(const float* __restrict__ x, int ldx, int xo, int cin,
+                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                        int P, float* __restrict__ out, int ldo, int oo, int cout) {
+  const size_t total = (size_t)P * cout;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int co = (int)(i % cout);
+    const size_t p = i / cout;
+    float a = bias ? bias[co] : 0.f;
+    for (int ci = 0; ci < cin; ++ci) a += x[p * ldx + xo + ci] * w[ci * cout + co];
+    out[p * ldo + oo + co] = a;
+  }
+}
+
+// dx[p][xo+ci] = sum_co dout[p][oo+co] w[ci][co]
+__global__ void sc_pointwise_dgrad_kernel(const float* __restrict__ dout, int ldo, int oo, int cout,
+                                          const float* __restrict__ w, int P,
+                                          float* __restrict__ dx, int ldx, int xo, int cin) {
+  const size_t total = (size_t)P * cin;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ci = (int)(i % cin);
+    const size_t p = i / cin;
+    float a = 0.f;
+    for (int co = 0; co < cout; ++co) a += dout[p * ldo + oo + co] * w[ci * cout + co];
+    dx[p * ldx + xo + ci] = a;
+  }
+}
+
+// partial[blk][ci][co] (+ bias partial [blk][cin*cout + co]) over the block's pixels
+__global__ __launch_bounds__(256) void sc_pointwise_wgrad_kernel(
+    const float* __restrict__ x, int ldx, int xo, int cin, const float* __restrict__ dout, int ldo,
+    int oo, int cout, int P, float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int pairs = cin * cout + cout;  // weights then bias
+  float* dst = partial + (size_t)blockIdx.x * pairs;
+  for (int j = 0; j < pairs; ++j) {
+    const bool is_b = j >= cin * cout;
+    const int ci = is_b ? 0 : j / cout, co = is_b ? j - cin * cout : j % cout;
+    float a = 0.f;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)P; p += (size_t)gridDim.x * 256)
+      a += (is_b ? 1.f : x[p * ldx + xo + ci]) * dout[p * ldo + oo + co];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) dst[j] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+
+unsigned sgrid(size_t items) {
+  size_t b = (items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+int sc_blocks(int P, int C) {
+  const int lanes = 256 / C;
+  int b = ocr_cdiv(P, lanes * 8);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return b;
+}
+
+}  // namespace
+
+extern "C" int ocr_conv1x1_small_f16(const void* x, const void* w_kc32, const void* bias, int P,
+                                     int cin, int cout, void* out_f32, void* stream) {
+  OCR_CHECK_ARG(x && w_kc32 && out_f32 && P > 0);
+  OCR_CHECK_SHAPE(cin % 16 == 0 && cout >= 1 && cout <= 32);
+  hipLaunchKernelGGL(conv1x1_small_kernel, dim3(ocr_cdiv(P, 128)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(x),
+                     static_cast<const half_t*>(w_kc32), static_cast<const float*>(bias), P, cin,
+                     cout, static_cast<float*>(out_f32));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_conv1x1_small_dgrad_f16(const void* dz_f32, const void* w_ck32, int P, int cin,
+                                           int cout, float grad_scale, void* dx_f16, int accumulate,
+                                           void* stream) {
+  OCR_CHECK_ARG(dz_f32 && w_ck32 && dx_f16 && P > 0);
+  OCR_CHECK_SHAPE(cin % 32 == 0 && cout >= 1 && cout <= 32);
+  hipLaunchKernelGGL(conv1x1_small_dgrad_kernel, dim3(ocr_cdiv(P, 128)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(dz_f32),
+                     static_cast<const half_t*>(w_ck32), P, cin, cout,
+                     static_cast<half_t*>(dx_f16), accumulate, grad_scale);
+  return ocr_launch_status();
+}
+
+static int small_wgrad_strips(int P) {
+  int s = ocr_cdiv(P, 512);
+  if (s > 512) s = 512;
+  if (s < 1) s = 1;
+  return s;
+}
+
+extern "C" size_t ocr_conv1x1_small_wgrad_workspace(int P, int cin, int cout) {
+  return (size_t)small_wgrad_strips(P) * cin * cout * sizeof(float);
+}
+
+extern "C" int ocr_conv1x1_small_wgrad_f16(const void* x, const void* dz_f32, int P, int cin,
+                                           int cout, void* dw_f32, void* workspace, size_t ws_bytes,
+                                           void* stream) {
+  OCR_CHECK_ARG(x && dz_f32 && dw_f32 && workspace && P > 0);
+  if (ws_bytes < ocr_conv1x1_small_wgrad_workspace(P, cin, cout)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int S = small_wgrad_strips(P);
+  const int strip = ocr_cdiv(P, S);
+  dim3 grid(S, ocr_cdiv(cin, 256));
+  const half_t* xp = static_cast<const half_t*>(x);
+  const float* dp = static_cast<const float*>(dz_f32);
+  float* ws = static_cast<float*>(workspace);
+  switch (cout) {
+    case 1: hipLaunchKernelGGL(conv1x1_small_wgrad_kernel<1>, grid, dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+    case 2: hipLaunchKernelGGL(conv1x1_small_wgrad_kernel<2>, grid, dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+    case 8: hipLaunchKernelGGL(conv1x1_small_wgrad_kernel<8>, grid, dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+    case 9: hipLaunchKernelGGL(conv1x1_small_wgrad_kernel<9>, grid, dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+    case 16: hipLaunchKernelGGL(conv1x1_small_wgrad_kernel<16>, grid, dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+    case 18: hipLaunchKernelGGL(conv1x1_small_wgrad_kernel<18>, grid, dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+    default: return OCR_ERR_UNSUPPORTED;
+  }
+  const int elems = cin * cout;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(ocr_cdiv(elems, 256)), dim3(256), 0, st, ws,
+                     static_cast<float*>(dw_f32), elems, S, 1.f);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_sc_num_partials(int P, int C) {
+  if (P <= 0 || C <= 0 || C > 128) return OCR_ERR_UNSUPPORTED;
+  return sc_blocks(P, C);
+}
+
+extern "C" int ocr_sc_stats(const void* x, int P, int C, void* partial, void* stream) {
+  OCR_CHECK_ARG(x && partial && P > 0);
+  OCR_CHECK_SHAPE(C > 0 && C <= 128);
+  hipLaunchKernelGGL(sc_stats_kernel, dim3(sc_blocks(P, C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(x), P, C,
+                     static_cast<float*>(partial));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_sc_fuse(const void* za, const void* sa, const void* ha, const void* zb,
+                           const void* sb, const void* hb, const void* prev, int n, int h, int w,
+                           int C, int relu, void* out, void* stream) {
+  OCR_CHECK_ARG(out && n > 0 && h > 0 && w > 0 && C > 0);
+  OCR_CHECK_ARG((sa == nullptr) == (ha == nullptr) && (sb == nullptr) == (hb == nullptr));
+  OCR_CHECK_ARG(!prev || (h % 2 == 0 && w % 2 == 0));
+  hipLaunchKernelGGL(sc_fuse_kernel, dim3(sgrid((size_t)n * h * w * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(za),
+                     static_cast<const float*>(sa), static_cast<const float*>(ha),
+                     static_cast<const float*>(zb), static_cast<const float*>(sb),
+                     static_cast<const float*>(hb), static_cast<const float*>(prev), n, h, w, C,
+                     relu, static_cast<float*>(out));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_sc_unpool_bwd(const void* dout, int n, int lh, int lw, int C, void* dprev,
+                                 void* stream) {
+  OCR_CHECK_ARG(dout && dprev && n > 0 && lh > 0 && lw > 0 && C > 0);
+  hipLaunchKernelGGL(sc_unpool_bwd_kernel, dim3(sgrid((size_t)n * lh * lw * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(dout), n, lh, lw, C,
+                     static_cast<float*>(dprev));
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_bn_reduce_workspace(int T, int C);
+extern "C" int ocr_sc_bn_bwd(const void* z, const void* scale, const void* shift,
+                             const void* save_mean, const void* save_invstd, const void* dout, int P,
+                             int C, int relu, void* dgamma, void* dbeta, void* dz, void* partial,
+                             void* stream) {
+  OCR_CHECK_ARG(z && scale && shift && save_mean && save_invstd && dout && dgamma && dbeta && dz &&
+                partial);
+  OCR_CHECK_SHAPE(C > 0 && C <= 128 && P > 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int T = sc_blocks(P, C);
+  const float* zp = static_cast<const float*>(z);
+  hipLaunchKernelGGL(sc_bn_bwd_kernel<0>, dim3(T), dim3(256), 0, st, zp,
+                     static_cast<const float*>(scale), static_cast<const float*>(shift),
+                     static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                     (const float*)nullptr, (const float*)nullptr, static_cast<const float*>(dout),
+                     P, C, relu, 0.f, static_cast<float*>(partial), (float*)nullptr);
+  // partial [T][2][C]: sum rows into dbeta / dgamma (T <= 1024, tiny)
+  float* part = static_cast<float*>(partial);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, part,
+                     part + (size_t)T * 2 * C, 2 * C, T, 1.f);
+  if (hipMemcpyAsync(dbeta, part + (size_t)T * 2 * C, C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(dgamma, part + (size_t)T * 2 * C + C, C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return OCR_ERR_HIP;
+  hipLaunchKernelGGL(sc_bn_bwd_kernel<1>, dim3(T), dim3(256), 0, st, zp,
+                     static_cast<const float*>(scale), static_cast<const float*>(shift),
+                     static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                     static_cast<const float*>(dgamma), static_cast<const float*>(dbeta),
+                     static_cast<const float*>(dout), P, C, relu, (float)(1.0 / (double)P),
+                     (float*)nullptr, static_cast<float*>(dz));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_sc_pointwise_fwd(const void* x, int ldx, int xo, int cin, const void* w,
+                                    const void* bias, int P, void* out, int ldo, int oo, int cout,
+                                    void* stream) {
+  OCR_CHECK_ARG(x && w && out && P > 0 && cin > 0 && cout > 0);
+  hipLaunchKernelGGL(sc_pointwise_fwd_kernel, dim3(sgrid((size_t)P * cout)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(x), ldx, xo, cin,
+                     static_cast<const float*>(w), static_cast<const float*>(bias), P,
+                     static_cast<float*>(out), ldo, oo, cout);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_sc_pointwise_dgrad(const void* dout, int ldo, int oo, int cout, const void* w,
+                                      int P, void* dx, int ldx, int xo, int cin, void* stream) {
+  OCR_CHECK_ARG(dout && w && dx && P > 0 && cin > 0 && cout > 0);
+  hipLaunchKernelGGL(sc_pointwise_dgrad_kernel, dim3(sgrid((size_t)P * cin)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(dout), ldo, oo,
+                     cout, static_cast<const float*>(w), P, static_cast<float*>(dx), ldx, xo, cin);
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_sc_pointwise_wgrad_workspace(int cin, int cout) {
+  return (size_t)(256 + 1) * (cin * cout + cout) * sizeof(float);
+}
+
+// dw [cin][cout] and db [cout] (db may be NULL)
+extern "C" int ocr_sc_pointwise_wgrad(const void* x, int ldx, int xo, int cin, const void* dout,
+                                      int ldo, int oo, int cout, int P, void* dw, void* db,
+                                      void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(x && dout && dw && workspace && P > 0 && cin > 0 && cout > 0);
+  if (ws_bytes < ocr_sc_pointwise_wgrad_workspace(cin, cout)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int B = 256;
+  const int pairs = cin * cout + cout;
+  float* ws = static_cast<float*>(workspace);
+  float* tot = ws + (size_t)B * pairs;
+  hipLaunchKernelGGL(sc_pointwise_wgrad_kernel, dim3(B), dim3(256), 0, st,
+                     static_cast<const float*>(x), ldx, xo, cin, static_cast<const float*>(dout),
+                     ldo, oo, cout, P, ws);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(ocr_cdiv(pairs, 256)), dim3(256), 0, st, ws, tot,
+                     pairs, B, 1.f);
+  if (hipMemcpyAsync(dw, tot, (size_t)cin * cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return OCR_ERR_HIP;
+  if (db && hipMemcpyAsync(db, tot + cin * cout, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return OCR_ERR_HIP;
+  return ocr_launch_status();
+}

@@ -1,0 +1,159 @@
+// Parameter update and weight re-packing.
+//
+// The host keeps all trainable parameters of a tower in ONE flat f32 buffer
+// (regularised conv weights first, then everything else) with gradients, Adam
+// moments and EMA shadows in identically laid out buffers, so the whole update —
+// L2 regulariser gradient, un-scaling of the f16 loss scale, Adam, exponential
+// moving average — is a single streaming launch.
+//
+// Reference: tf.train.AdamOptimizer + exponential_decay + ExponentialMovingAverage
+// (multigpu_train.py:103-107,137-142), slim.l2_regularizer (nets/model.py:103),
+// MomentumOptimizer (train_pixellink.py:243).
+#include "common.h"
+
+namespace {
+
+struct AdamP {
+  float lr_t, beta1, beta2, eps, wd, inv_scale, ema_decay;
+  long long n, n_reg;
+};
+
+__global__ void adam_kernel(AdamP a, float* __restrict__ w, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v,
+                            float* __restrict__ ema) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+    float wi = w[i];
+    float gi = g[i] * a.inv_scale;
+    if (i < a.n_reg) gi += a.wd * wi;
+    const float mi = a.beta1 * m[i] + (1.f - a.beta1) * gi;
+    const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    wi -= a.lr_t * mi / (sqrtf(vi) + a.eps);
+    w[i] = wi;
+    if (ema) {
+      const float s = ema[i];
+      ema[i] = s - (1.f - a.ema_decay) * (s - wi);
+    }
+  }
+}
+
+struct MomP {
+  float lr, momentum, wd, inv_scale, ema_decay;
+  long long n, n_reg;
+};
+
+__global__ void momentum_kernel(MomP a, float* __restrict__ w, const float* __restrict__ g,
+                                float* __restrict__ acc, float* __restrict__ ema) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+    float wi = w[i];
+    float gi = g[i] * a.inv_scale;
+    if (i < a.n_reg) gi += a.wd * wi;
+    const float ai = a.momentum * acc[i] + gi;
+    acc[i] = ai;
+    wi -= a.lr * ai;
+    w[i] = wi;
+    if (ema) {
+      const float s = ema[i];
+      ema[i] = s - (1.f - a.ema_decay) * (s - wi);
+    }
+  }
+}
+
+// HWIO f32 [taps][cin][cout] -> w_kc f16 [taps][cout][cin] and w_ck f16 [taps][cin][cout]
+__global__ void pack_weights_kernel(const float* __restrict__ w, int taps, int cin, int cout,
+                                    half_t* __restrict__ w_kc, half_t* __restrict__ w_ck) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* wt = w + (size_t)tap * cin * cout;
+  for (int k = ty; k < 32; k += 8) {
+    const int ci = ci0 + k, co = co0 + tx;
+    float v = (ci < cin && co < cout) ? wt[(size_t)ci * cout + co] : 0.f;
+    tile[k][tx] = v;
+    if (w_ck && ci < cin && co < cout) w_ck[((size_t)tap * cin + ci) * cout + co] = (half_t)v;
+  }
+  __syncthreads();
+  if (w_kc) {
+    for (int k = ty; k < 32; k += 8) {
+      const int co = co0 + k, ci = ci0 + tx;
+      if (ci < cin && co < cout) w_kc[((size_t)tap * cout + co) * cin + ci] = (half_t)tile[tx][k];
+    }
+  }
+}
+
+// head weights f32 [cin][cout<=32] -> w_kc32 f16 [32][cin], w_ck32 f16 [cin][32] (zero padded)
+__global__ void pack_small_kernel(const float* __restrict__ w, int cin, int cout,
+                                  half_t* __restrict__ w_kc32, half_t* __restrict__ w_ck32) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cin * 32) return;
+  const int ci = i >> 5, co = i & 31;
+  const float v = co < cout ? w[ci * cout + co] : 0.f;
+  w_ck32[i] = (half_t)v;
+  w_kc32[(size_t)co * cin + ci] = (half_t)v;
+}
+
+__global__ void scale_kernel(float* __restrict__ x, long long n, float s) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    x[i] *= s;
+}
+
+unsigned ogrid(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int ocr_adam_step(void* w, const void* g, void* m, void* v, void* ema, int64_t n,
+                             int64_t n_regularized, float lr_t, float beta1, float beta2, float eps,
+                             float weight_decay, float inv_loss_scale, float ema_decay,
+                             void* stream) {
+  OCR_CHECK_ARG(w && g && m && v && n > 0 && n_regularized >= 0 && n_regularized <= n);
+  AdamP a{lr_t, beta1, beta2, eps, weight_decay, inv_loss_scale, ema_decay, n, n_regularized};
+  hipLaunchKernelGGL(adam_kernel, dim3(ogrid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                     static_cast<float*>(w), static_cast<const float*>(g), static_cast<float*>(m),
+                     static_cast<float*>(v), static_cast<float*>(ema));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_momentum_step(void* w, const void* g, void* accum, void* ema, int64_t n,
+                                 int64_t n_regularized, float lr, float momentum, float weight_decay,
+                                 float inv_loss_scale, float ema_decay, void* stream) {
+  OCR_CHECK_ARG(w && g && accum && n > 0 && n_regularized >= 0 && n_regularized <= n);
+  MomP a{lr, momentum, weight_decay, inv_loss_scale, ema_decay, n, n_regularized};
+  hipLaunchKernelGGL(momentum_kernel, dim3(ogrid(n)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a, static_cast<float*>(w),
+                     static_cast<const float*>(g), static_cast<float*>(accum),
+                     static_cast<float*>(ema));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_pack_weights_f16(const void* w_hwio_f32, int taps, int cin, int cout, void* w_kc,
+                                    void* w_ck, void* stream) {
+  OCR_CHECK_ARG(w_hwio_f32 && (w_kc || w_ck) && taps > 0 && cin > 0 && cout > 0);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(ocr_cdiv(cout, 32), ocr_cdiv(cin, 32), taps),
+                     dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(w_hwio_f32), taps, cin, cout,
+                     static_cast<half_t*>(w_kc), static_cast<half_t*>(w_ck));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_pack_weights_small_f16(const void* w_f32, int cin, int cout, void* w_kc32,
+                                          void* w_ck32, void* stream) {
+  OCR_CHECK_ARG(w_f32 && w_kc32 && w_ck32 && cin > 0 && cout > 0 && cout <= 32);
+  hipLaunchKernelGGL(pack_small_kernel, dim3(ocr_cdiv(cin * 32, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(w_f32), cin, cout,
+                     static_cast<half_t*>(w_kc32), static_cast<half_t*>(w_ck32));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_scale_f32(void* x, int64_t n, float s, void* stream) {
+  OCR_CHECK_ARG(x && n > 0);
+  hipLaunchKernelGGL(scale_kernel, dim3(ogrid(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<float*>(x), (long long)n, s);
+  return ocr_launch_status();
+}

@@ -1,0 +1,257 @@
+"""Host-side plumbing that stands in for the TF-1.4 graph/session the reference drives
+(`tf.variable_scope`, `tf.get_variable`, `opt.compute_gradients`): a variable store with
+TF-slim variable names, activation handles, and a reverse-mode tape.
+
+Nothing here computes: every FLOP happens in libocr_hip.so via `ops`.  torch is used for
+device memory only.
+"""
+import contextlib
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+F16, F32 = torch.float16, torch.float32
+
+
+class Variable:
+    """A TF variable: f32 master copy in the store's flat buffer, optional gradient view."""
+
+    def __init__(self, name, shape, init, trainable, regularized):
+        self.name = name
+        self.shape = tuple(int(s) for s in shape)
+        self.init = init            # numpy f32 until the store is materialised
+        self.trainable = trainable
+        self.regularized = regularized
+        self.data = None            # torch f32 view
+        self.grad = None            # torch f32 view (trainable only)
+        self.packed = {}            # kind -> (version, tensor)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+
+class VariableStore:
+    """Name -> Variable, materialised as flat f32 device buffers:
+    [regularised trainables | other trainables] for params / grads (one Adam launch, one
+    all-reduce bucket list) and a second flat buffer for non-trainables (BN moving stats)."""
+
+    def __init__(self, device):
+        self.vars = {}
+        self.order = []
+        self.device = device
+        self.version = 0            # bumped by every optimiser step -> f16 packs are stale
+        self.flat = self.flat_grad = self.flat_aux = None
+        self.n_reg = 0
+
+    def get(self, name, shape, initializer, trainable=True, regularized=False):
+        v = self.vars.get(name)
+        if v is not None:
+            if tuple(shape) != v.shape:
+                raise ValueError("variable %s exists with shape %s, requested %s" % (name, v.shape, tuple(shape)))
+            return v
+        if self.flat is not None:
+            raise RuntimeError("variable %s created after the store was materialised" % name)
+        init = np.ascontiguousarray(np.asarray(initializer(tuple(shape)), dtype=np.float32).reshape(shape))
+        v = Variable(name, shape, None, trainable, regularized)
+        v.data = torch.from_numpy(init).to(self.device)
+        if trainable:
+            v.grad = torch.zeros_like(v.data)
+        self.vars[name] = v
+        self.order.append(name)
+        return v
+
+    def materialise(self):
+        """Gather every variable into the flat buffers (idempotent); views replace the
+        per-variable tensors used while the graph was being built."""
+        if self.flat is not None:
+            return
+        tr = [self.vars[n] for n in self.order if self.vars[n].trainable]
+        reg = [v for v in tr if v.regularized]
+        oth = [v for v in tr if not v.regularized]
+        aux = [self.vars[n] for n in self.order if not self.vars[n].trainable]
+
+        def pack(vs, pad=4):
+            offs, o = [], 0
+            for v in vs:
+                offs.append(o)
+                o += (v.size + pad - 1) // pad * pad   # keep every view 16-byte aligned
+            return offs, o
+
+        offs_r, nr = pack(reg)
+        offs_o, no = pack(oth)
+        offs_a, na = pack(aux)
+        self.n_reg = nr
+        self.flat = torch.zeros(max(nr + no, 1), dtype=F32, device=self.device)
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.flat_aux = torch.zeros(max(na, 1), dtype=F32, device=self.device)
+        for v, o in list(zip(reg, offs_r)) + [(v, nr + o) for v, o in zip(oth, offs_o)]:
+            view = self.flat[o:o + v.size].view(v.shape)
+            view.copy_(v.data)
+            gview = self.flat_grad[o:o + v.size].view(v.shape)
+            gview.copy_(v.grad)
+            v.data, v.grad = view, gview
+        for v, o in zip(aux, offs_a):
+            view = self.flat_aux[o:o + v.size].view(v.shape)
+            view.copy_(v.data)
+            v.data = view
+
+    def trainable(self):
+        return [self.vars[n] for n in self.order if self.vars[n].trainable]
+
+    def state_dict(self):
+        return {n: self.vars[n].data.detach().cpu().numpy().copy() for n in self.order}
+
+    def load_state_dict(self, sd, strict=True):
+        for n, arr in sd.items():
+            if n not in self.vars:
+                if strict:
+                    raise KeyError(n)
+                continue
+            v = self.vars[n]
+            a = np.asarray(arr, dtype=np.float32).reshape(v.shape)
+            v.data.copy_(torch.from_numpy(a))
+        self.version += 1
+
+
+class Act:
+    """Activation handle: device tensor + (lazily created) gradient."""
+
+    __slots__ = ("data", "grad", "requires_grad", "name")
+
+    def __init__(self, data, requires_grad=True, name=""):
+        self.data = data
+        self.grad = None
+        self.requires_grad = requires_grad
+        self.name = name
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+
+class Graph:
+    """One tower: variable store + tape + scratch.  `loss_scale` multiplies the loss gradient so
+    that f16 activation gradients stay in range; the optimiser divides it out."""
+
+    def __init__(self, device="cuda:0", loss_scale=1024.0, seed=1):
+        self.device = torch.device(device)
+        self.store = VariableStore(self.device)
+        self.tape = []
+        self.scope = []
+        self.loss_scale = float(loss_scale)
+        self.rng = np.random.default_rng(seed)
+        self.ws = None
+        self.ws_small = None
+        self.collections = {"losses": [], "update_ops": []}
+        self.building = True
+
+    # --- scopes / variables (tf.variable_scope, tf.get_variable) ---
+    @contextlib.contextmanager
+    def variable_scope(self, name):
+        if name:
+            self.scope.append(name)
+        try:
+            yield
+        finally:
+            if name:
+                self.scope.pop()
+
+    def full_name(self, name):
+        return "/".join(self.scope + [name])
+
+    def get_variable(self, name, shape, initializer, trainable=True, regularized=False):
+        return self.store.get(self.full_name(name), shape, initializer, trainable, regularized)
+
+    # --- device memory ---
+    def workspace(self):
+        if self.ws is None:
+            self.ws = ops.Workspace(self.device, 256 << 20)
+            self.ws_small = ops.Workspace(self.device, 8 << 20)
+        return self.ws
+
+    def empty(self, shape, dtype=F16):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype=F32):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def ensure_materialised(self):
+        self.store.materialise()
+
+    def packed(self, var, kind, fn):
+        """f16 re-pack of a variable, refreshed when the optimiser has stepped."""
+        ent = var.packed.get(kind)
+        if ent is None or ent[0] != self.store.version:
+            t = fn(ent[1] if ent is not None else None)
+            var.packed[kind] = (self.store.version, t)
+            return t
+        return ent[1]
+
+    # --- tape ---
+    def record(self, fn, produces=()):
+        """`produces`: the variables whose gradients are complete once `fn` has run."""
+        self.tape.append((fn, tuple(produces)))
+
+    def backward(self, on_grads_ready=None):
+        """Run the tape in reverse (the loss op seeds its own gradient).  `on_grads_ready(vars)` is
+        called as soon as a closure has finished a set of parameter gradients — the hook the
+        data-parallel all-reduce uses to overlap communication with the rest of backward."""
+        for fn, produces in reversed(self.tape):
+            fn()
+            if on_grads_ready is not None and produces:
+                on_grads_ready(produces)
+        self.tape.clear()
+
+    def reset_tape(self):
+        self.tape.clear()
+        self.collections["losses"].clear()
+
+
+_default = None
+
+
+def get_default_graph():
+    global _default
+    if _default is None:
+        _default = Graph()
+    return _default
+
+
+def set_default_graph(g):
+    global _default
+    _default = g
+    return g
+
+
+# --- initialisers (slim defaults) -------------------------------------------------------
+def xavier_uniform(rng):
+    def init(shape):
+        if len(shape) == 4:
+            fan_in, fan_out = shape[0] * shape[1] * shape[2], shape[0] * shape[1] * shape[3]
+        else:
+            fan_in, fan_out = shape[0], shape[-1]
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, size=shape)
+    return init
+
+
+def variance_scaling(rng, factor=2.0):
+    """slim.variance_scaling_initializer(): truncated normal, FAN_IN, factor 2."""
+    def init(shape):
+        fan_in = shape[0] * shape[1] * shape[2] if len(shape) == 4 else shape[0]
+        std = math.sqrt(1.3 * factor / fan_in)
+        x = rng.normal(0.0, std, size=shape)
+        bad = np.abs(x) > 2 * std
+        while bad.any():
+            x[bad] = rng.normal(0.0, std, size=int(bad.sum()))
+            bad = np.abs(x) > 2 * std
+        return x
+    return init
+
+
+def constant(value):
+    return lambda shape: np.full(shape, value, dtype=np.float32)

@@ -1,0 +1,338 @@
+"""slim-style layers (conv2d [+batch_norm] [+relu] [+max_pool2d], heads) driving the HIP kernels.
+
+Each function runs the forward kernels immediately and records ONE backward closure on the
+graph's tape.  Variable names follow tf.contrib.slim so checkpoints/state-dicts line up with
+the reference: `<scope>/weights`, `<scope>/biases`,
+`<scope>/BatchNorm/{gamma,beta,moving_mean,moving_variance}`.
+"""
+import torch
+
+from . import ops
+from .graph import Act, F16, F32, constant, variance_scaling, xavier_uniform
+from ._lib import CONV_ACCUM_F16, CONV_BIAS, CONV_RELU, CONV_STATS
+
+BN_DECAY = 0.997
+BN_EPS = 1e-5
+
+
+def _bn_vars(g, C):
+    with g.variable_scope("BatchNorm"):
+        gamma = g.get_variable("gamma", (C,), constant(1.0))
+        beta = g.get_variable("beta", (C,), constant(0.0))
+        mm = g.get_variable("moving_mean", (C,), constant(0.0), trainable=False)
+        mv = g.get_variable("moving_variance", (C,), constant(1.0), trainable=False)
+    return gamma, beta, mm, mv
+
+
+def _packs(g, w, first):
+    """f16 operand layouts of a conv weight: forward [tap][cout][cin] and dgrad [tap][cin][cout]."""
+    kh, kw, cin, cout = w.shape
+    if first:
+        def mk(old):
+            t = old if old is not None else g.empty((3, cout, 16))
+            ops.pack_weights_first(w.data, t)
+            return t
+        return g.packed(w, "first", mk), None
+
+    def mk(old):
+        if old is None:
+            old = (g.empty((kh * kw, cout, cin)), g.empty((kh * kw, cin, cout)))
+        ops.pack_weights(w.data, old[0], old[1])
+        return old
+    return g.packed(w, "kc_ck", mk)
+
+
+def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True, pool=0,
+           keep_full=True, is_training=True, bn_training=None, first=False, weight_decay=True,
+           initializer=None):
+    """slim.conv2d(+batch_norm)(+ReLU), optionally fused with the following 2x2/2 max-pool.
+
+    x: Act f16 [n,h,w,cin] (for `first`: the [n,h,w,4] prepared image).
+    normalizer: "bn" (no bias, slim drops it) or None (bias).
+    Returns (full, pooled) Acts; `full` is None when keep_full=False and pool>0.
+    Reference: nets/vgg.py:14-39 under resnet_arg_scope (nets/model_vgg_16.py:144) or the
+    PixelLink bias scope (nets/pixellink.py:41-48).
+    """
+    n, h, w, cin_x = x.shape
+    cin = 3 if first else cin_x
+    bn_training = is_training if bn_training is None else bn_training
+    with g.variable_scope(scope):
+        init = initializer or variance_scaling(g.rng)
+        wv = g.get_variable("weights", (k, k, cin, cout), init, regularized=weight_decay)
+        if normalizer == "bn":
+            gamma, beta, mm, mv = _bn_vars(g, cout)
+            bias = None
+        else:
+            bias = g.get_variable("biases", (cout,), constant(0.0))
+    ws = g.workspace()
+    w_fwd, w_dg = _packs(g, wv, first)
+    if first:
+        d = None
+        oh, ow = h, w
+        mt = ops.conv2d_first_num_mtiles(n, h, w)
+    else:
+        d = ops.conv_desc((n, h, w, cin), cout, k, k, stride, rate)
+        oh, ow = d.oh, d.ow
+        mt = ops.conv2d_num_mtiles(d)
+    y = g.empty((n, oh, ow, cout))
+
+    if normalizer == "bn":
+        train_stats = bn_training
+        flags = CONV_STATS if train_stats else 0
+        part, stage = g.ws_small.two(mt * 2 * cout * 4, ops.bn_reduce_workspace(mt, cout))
+        if first:
+            ops.conv2d_first(x.data, w_fwd, y, flags, None, part if train_stats else None)
+        else:
+            d.flags = flags
+            ops.conv2d(d, x.data, w_fwd, y, None, part if train_stats else None)
+        scale, shift = g.empty((cout,), F32), g.empty((cout,), F32)
+        mean, invstd = g.empty((cout,), F32), g.empty((cout,), F32)
+        if train_stats:
+            ops.bn_finalize(part, mt, cout, float(n) * oh * ow, gamma.data, beta.data, BN_EPS, BN_DECAY,
+                            mm.data, mv.data, scale, shift, mean, invstd, stage)
+        else:
+            ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
+        full = pooled = None
+        if pool:
+            pooled = g.empty((n, (oh + 1) // 2, (ow + 1) // 2, cout))
+            if keep_full:
+                full = g.empty((n, oh, ow, cout))
+            ops.bn_relu(y, scale, shift, relu, 2, full, pooled)
+        else:
+            full = g.empty((n, oh, ow, cout))
+            ops.bn_relu(y, scale, shift, relu, 0, full, None)
+        a_full = Act(full, name=scope) if full is not None else None
+        a_pool = Act(pooled, name=scope + "/pool") if pooled is not None else None
+
+        def backward():
+            if not train_stats:
+                raise NotImplementedError("backward through inference-mode batch norm")
+            da_full = a_full.grad if a_full is not None else None
+            da_pool = a_pool.grad if a_pool is not None else None
+            if da_full is None and da_pool is None:
+                return
+            if pool and da_pool is None:
+                da_pool = torch.zeros_like(a_pool.data)
+            if not pool and da_full is None:
+                return
+            dy = g.empty(y.shape)
+            ops.bn_relu_bwd(y, scale, shift, mean, invstd, da_full, da_pool, relu, 2 if pool else 0,
+                            gamma.grad, beta.grad, dy, ws)
+            _conv_backward(g, x, wv, w_dg, d, dy, first)
+            if a_full is not None:
+                a_full.grad = None
+            if a_pool is not None:
+                a_pool.grad = None
+        g.record(backward, (wv, gamma, beta))
+        return a_full, a_pool
+
+    # bias (+ReLU) path: PixelLinkNet's VGG (nets/pixellink.py:41-48)
+    flags = CONV_BIAS | (CONV_RELU if relu else 0)
+    if first:
+        ops.conv2d_first(x.data, w_fwd, y, flags, bias.data, None)
+    else:
+        d.flags = flags
+        ops.conv2d(d, x.data, w_fwd, y, bias.data, None)
+    a_full = Act(y, name=scope)
+    a_pool = None
+    if pool:
+        _, pt = ops.same_pad(oh, 2, 2)
+        _, pl = ops.same_pad(ow, 2, 2)
+        pooled = g.empty((n, (oh + 1) // 2, (ow + 1) // 2, cout))
+        ops.maxpool(y, 2, 2, (pt, pl), pooled)
+        a_pool = Act(pooled, name=scope + "/pool")
+
+    def backward_bias():
+        raise NotImplementedError("bias-path backward is wired in layers_bias (PixelLinkNet)")
+    g.record(backward_bias)
+    return a_full, a_pool
+
+
+def _conv_backward(g, x, wv, w_dg, d, dy, first):
+    """Weight gradient (always) and input gradient (when the input needs one)."""
+    ws = g.workspace()
+    if first:
+        ops.conv2d_first_wgrad(x.data, dy, wv.grad, ws)
+        return
+    dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, d.kh, d.kw, d.stride, d.dilation,
+                      d.pad_top, d.pad_left, 0, 0)
+    ops.conv2d_wgrad(dd, x.data, dy, wv.grad, ws)
+    if not x.requires_grad:
+        return
+    if d.stride != 1:
+        raise NotImplementedError("strided dgrad")
+    # dx = conv(dy, W^T flipped): input = dy [n,oh,ow,cout], output = [n,h,w,cin]
+    pt = d.dilation * (d.kh - 1) - d.pad_top
+    pl = d.dilation * (d.kw - 1) - d.pad_left
+    flags = 0
+    if x.grad is None:
+        x.grad = g.empty(x.shape)
+    else:
+        flags |= CONV_ACCUM_F16
+    dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1,
+                      flags)
+    ops.conv2d(dg, dy, w_dg, x.grad, None, None)
+
+
+def max_pool2d(g, x, k, stride, scope="pool"):
+    """slim.max_pool2d(padding='SAME') as a standalone op (pool5 3x3/1, ResNet pool1, subsample)."""
+    n, h, w, c = x.shape
+    oh, pt = ops.same_pad(h, k, stride)
+    ow, pl = ops.same_pad(w, k, stride)
+    y = g.empty((n, oh, ow, c))
+    ops.maxpool(x.data, k, stride, (pt, pl), y)
+    out = Act(y, name=scope)
+
+    def backward():
+        if out.grad is None or not x.requires_grad:
+            return
+        acc = x.grad is not None
+        if not acc:
+            x.grad = g.empty(x.shape)
+        ops.maxpool_bwd(x.data, out.grad, k, stride, (pt, pl), x.grad, acc)
+        out.grad = None
+    g.record(backward)
+    return out
+
+
+def prep_images(g, images):
+    """mean_image_subtraction (nets/model.py:18-31) + f16 cast into the [n,h,w,4] layout."""
+    if images.shape[-1] != 3:
+        raise ValueError("len(means) must match the number of channels")
+    n, h, w, _ = images.shape
+    x4 = g.empty((n, h, w, 4))
+    ops.prep_images(images, x4)
+    return Act(x4, requires_grad=False, name="images")
+
+
+# ---------------------------------------------------------------------------- fuse heads
+class SmallAct:
+    """f32 [n,h,w,C] head tensor."""
+    __slots__ = ("data", "grad")
+
+    def __init__(self, data):
+        self.data = data
+        self.grad = None
+
+
+def head_conv_bn(g, feat, names, couts, is_training=True, relu=True):
+    """The BN'd 1x1 fuse convs that several heads apply to ONE feature map, evaluated in a single
+    pass over the feature: slim.conv2d(feat, c, 1) for c in couts (nets/model_vgg_16.py:160-172).
+    Returns (z, scale, shift, ctx): z = raw conv output [n,h,w,sum(couts)] f32."""
+    n, h, w, cin = feat.shape
+    C = sum(couts)
+    ws = g.workspace()
+    # one merged parameter per source; columns map onto the reference variables `names`
+    with g.variable_scope("+".join(names)):
+        wv = g.get_variable("weights", (cin, C), _merged_init(g, cin, couts), regularized=True)
+        gamma, beta, mm, mv = _bn_vars(g, C)
+
+    def mk(old):
+        if old is None:
+            old = (g.empty((32, cin)), g.empty((cin, 32)))
+        ops.pack_weights_small(wv.data, old[0], old[1])
+        return old
+    w_kc32, w_ck32 = g.packed(wv, "small", mk)
+    z = g.empty((n, h, w, C), F32)
+    ops.conv1x1_small(feat.data, w_kc32, C, z)
+    P = n * h * w
+    scale, shift = g.empty((C,), F32), g.empty((C,), F32)
+    mean, invstd = g.empty((C,), F32), g.empty((C,), F32)
+    if is_training:
+        T = ops.sc_num_partials(P, C)
+        part, stage = g.ws_small.two(T * 2 * C * 4, ops.bn_reduce_workspace(T, C))
+        ops.sc_stats(z, C, part)
+        ops.bn_finalize(part, T, C, float(P), gamma.data, beta.data, BN_EPS, BN_DECAY, mm.data, mv.data,
+                        scale, shift, mean, invstd, stage)
+    else:
+        ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
+    out = SmallAct(z)   # grad of out = gradient w.r.t. relu(bn(z))
+
+    def backward():
+        if out.grad is None:
+            return
+        dz = g.empty(z.shape, F32)
+        ops.sc_bn_bwd(z, scale, shift, mean, invstd, out.grad, relu, gamma.grad, beta.grad, dz, ws)
+        ops.conv1x1_small_wgrad(feat.data, dz, C, wv.grad, ws)
+        if feat.requires_grad:
+            acc = feat.grad is not None
+            if not acc:
+                feat.grad = g.empty(feat.shape)
+            ops.conv1x1_small_dgrad(dz, w_ck32, C, feat.grad, acc)
+        out.grad = None
+    g.record(backward, (wv, gamma, beta))
+    return out, scale, shift
+
+
+def _merged_init(g, cin, couts):
+    def init(shape):
+        import numpy as np
+        cols = [variance_scaling(g.rng)((1, 1, cin, c)).reshape(cin, c) for c in couts]
+        return np.concatenate(cols, axis=1)
+    return init
+
+
+def fuse(g, shape, a=None, b=None, prev=None, relu=True):
+    """out = relu(bn(a.z)) + relu(bn(b.z)) + unpool(prev)   (any subset) on f32 head tensors.
+    a, b: (SmallAct z, scale, shift) triples from head_conv_bn; prev: SmallAct at half resolution."""
+    out = SmallAct(g.empty(shape, F32))
+    za, sa, ha = (a[0].data, a[1], a[2]) if a is not None else (None, None, None)
+    zb, sb, hb = (b[0].data, b[1], b[2]) if b is not None else (None, None, None)
+    ops.sc_fuse(out.data, za, sa, ha, zb, sb, hb, prev.data if prev is not None else None, relu)
+
+    def backward():
+        if out.grad is None:
+            return
+        # the add fans the same gradient out to every branch; the BN/ReLU part of a and b is
+        # differentiated inside head_conv_bn's closure
+        for br in (a, b):
+            if br is not None:
+                if br[0].grad is not None:
+                    raise RuntimeError("head tensor used twice")
+                br[0].grad = out.grad
+        if prev is not None:
+            dprev = g.empty(prev.data.shape, F32)
+            ops.sc_unpool_bwd(out.grad, dprev)
+            prev.grad = dprev
+        out.grad = None
+    g.record(backward)
+    return out
+
+
+def pointwise_bn(g, x, xo, c, scope, is_training=True, relu=True):
+    """Final predication conv on a channel slice of a head tensor:
+    out = relu(bn(conv1x1(x[..., xo:xo+c], c)))   (pixel_cls / link_cls,
+    nets/model_vgg_16.py:166,173).  Returns a contiguous SmallAct [n,h,w,c]."""
+    n, h, w, C = x.data.shape
+    P = n * h * w
+    ws = g.workspace()
+    with g.variable_scope(scope):
+        wv = g.get_variable("weights", (1, 1, c, c), variance_scaling(g.rng), regularized=True)
+        gamma, beta, mm, mv = _bn_vars(g, c)
+    z = g.empty((n, h, w, c), F32)
+    ops.sc_pointwise_fwd(x.data, xo, c, wv.data, z, 0, c)
+    scale, shift = g.empty((c,), F32), g.empty((c,), F32)
+    mean, invstd = g.empty((c,), F32), g.empty((c,), F32)
+    if is_training:
+        T = ops.sc_num_partials(P, c)
+        part, stage = g.ws_small.two(T * 2 * c * 4, ops.bn_reduce_workspace(T, c))
+        ops.sc_stats(z, c, part)
+        ops.bn_finalize(part, T, c, float(P), gamma.data, beta.data, BN_EPS, BN_DECAY, mm.data, mv.data,
+                        scale, shift, mean, invstd, stage)
+    else:
+        ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
+    out = SmallAct(g.empty((n, h, w, c), F32))
+    ops.sc_fuse(out.data, z, scale, shift, relu=relu)
+
+    def backward():
+        if out.grad is None:
+            return
+        dz = g.empty(z.shape, F32)
+        ops.sc_bn_bwd(z, scale, shift, mean, invstd, out.grad, relu, gamma.grad, beta.grad, dz, ws)
+        ops.sc_pointwise_wgrad(x.data, xo, c, dz, 0, c, wv.grad, None, ws)
+        if x.grad is None:
+            x.grad = g.zeros(x.data.shape, F32)
+        ops.sc_pointwise_dgrad(dz, 0, c, wv.data, x.grad, xo, c)
+        out.grad = None
+    g.record(backward, (wv, gamma, beta))
+    return out

@@ -1,0 +1,99 @@
+"""Mirror of reference nets/model_vgg_16.py: `model_vgg` (VGG-16 trunk + BN'd PixelLink fuse
+heads, :138-177), `dice_coefficient` (:179-193), `loss` (:196-225) with the same call
+signatures and output names (pixel_cls [N,H/4,W/4,2], link_cls [N,H/4,W/4,16]).
+"""
+import numpy as np
+import torch
+
+from .. import layers, ops
+from ..graph import F32, get_default_graph
+from . import vgg
+
+
+def unpool(inputs, graph=None):
+    """tf.image.resize_bilinear x2, legacy sampling (nets/model_vgg_16.py:15-16)."""
+    g = graph or get_default_graph()
+    n, h, w, c = inputs.data.shape
+    return layers.fuse(g, (n, 2 * h, 2 * w, c), prev=inputs)
+
+
+def mean_image_subtraction(images, means=(123.68, 116.78, 103.94), graph=None):
+    """nets/model_vgg_16.py:19-32.  Returns the prepared f16 [n,h,w,4] image Act."""
+    g = graph or get_default_graph()
+    if len(means) != images.shape[-1]:
+        raise ValueError('len(means) must match the number of channels')
+    return layers.prep_images(g, _to_device(g, images))
+
+
+def _to_device(g, arr, dtype=F32):
+    if isinstance(arr, torch.Tensor):
+        return arr.to(device=g.device, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(g.device)
+
+
+def model_vgg(images, weight_decay=1e-5, is_training=True, graph=None):
+    """nets/model_vgg_16.py:138-177.  images: [N,H,W,3] float (0..255).  Returns (pixel_cls, link_cls)."""
+    g = graph or get_default_graph()
+    g.weight_decay = weight_decay
+    x4 = mean_image_subtraction(images, graph=g)
+    _, end_points = vgg.basenet(x4, scope='vgg_16', graph=g, normalizer="bn", is_training=is_training)
+    g.end_points = end_points
+    with g.variable_scope('feature_fusion'):
+        # slim auto-names: pixel convs Conv..Conv_4, link convs Conv_5..Conv_9
+        srcs = [('fc7', ('Conv', 'Conv_5')), ('conv5_3', ('Conv_1', 'Conv_6')),
+                ('conv4_3', ('Conv_2', 'Conv_7')), ('conv3_3', ('Conv_3', 'Conv_8'))]
+        heads = {}
+        for key, names in srcs:
+            heads[key] = layers.head_conv_bn(g, end_points[key], names, (2, 16), is_training=is_training)
+        n, h, w, _ = end_points['fc7'].shape
+        s1 = layers.fuse(g, (n, h, w, 18), a=heads['fc7'], b=heads['conv5_3'])
+        s2 = layers.fuse(g, (n, 2 * h, 2 * w, 18), a=heads['conv4_3'], prev=s1)
+        s3 = layers.fuse(g, (n, 4 * h, 4 * w, 18), a=heads['conv3_3'], prev=s2)
+        pixel_cls = layers.pointwise_bn(g, s3, 0, 2, 'Conv_4', is_training=is_training)
+        link_cls = layers.pointwise_bn(g, s3, 2, 16, 'Conv_9', is_training=is_training)
+    return pixel_cls, link_cls
+
+
+class Scalar:
+    """Device scalar (the loss) with its components; `.item()` syncs."""
+
+    def __init__(self, buf):
+        self.data = buf
+
+    def item(self):
+        return float(self.data[0].item())
+
+    def terms(self):
+        return self.data[1:10].detach().cpu().numpy()
+
+
+def dice_coefficient(y_true_cls, y_pred_cls, training_mask, graph=None):
+    """nets/model_vgg_16.py:179-193 for one map (host convenience: builds the 9-map call with
+    zero link maps and returns the pixel term)."""
+    g = graph or get_default_graph()
+    yt = _to_device(g, y_true_cls)
+    yp = y_pred_cls.data if hasattr(y_pred_cls, "data") and not isinstance(y_pred_cls, torch.Tensor) else _to_device(g, y_pred_cls)
+    m = _to_device(g, training_mask)
+    P = m.numel()
+    ztl = g.zeros((P, 8))
+    sums, out = g.zeros((27,)), g.zeros((10,))
+    ops.dice_loss_fwd(yt, yp, ztl, ztl, m, sums, out, g.workspace())
+    return Scalar(out[1:2].clone())
+
+
+def loss(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mask, graph=None):
+    """nets/model_vgg_16.py:196-225: 2*dice(pixel) + sum_8 dice(link_i), TF broadcasting of the
+    1-channel labels against 2-/16-channel predictions included.  Records the backward seed."""
+    g = graph or get_default_graph()
+    ytp, ytl, m = _to_device(g, y_true_pixel), _to_device(g, y_true_link), _to_device(g, training_mask)
+    sums, out = g.zeros((27,)), g.zeros((10,))
+    ops.dice_loss_fwd(ytp, y_pred_pixel.data, ytl, y_pred_link.data, m, sums, out, g.workspace())
+
+    def backward():
+        y_pred_pixel.grad = g.empty(y_pred_pixel.data.shape, F32)
+        y_pred_link.grad = g.empty(y_pred_link.data.shape, F32)
+        ops.dice_loss_bwd(ytp, ytl, m, sums, g.loss_scale, y_pred_pixel.grad, y_pred_link.grad)
+    g.record(backward)
+    res = Scalar(out)
+    g.collections["losses"].append(res)
+    return res

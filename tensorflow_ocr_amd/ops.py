@@ -1,0 +1,305 @@
+"""Thin, typed wrappers over the C ABI (include/ocr_hip.h).
+
+Every function takes torch CUDA tensors purely as device-memory handles, passes raw
+pointers + the current HIP stream through ctypes, and returns nothing new except
+tensors it was asked to allocate.  There is no torch compute and no CPU fallback
+here: without libocr_hip.so every call raises `_lib.OcrHipError`.
+"""
+import ctypes
+from ctypes import byref, c_double, c_float, c_int, c_int64, c_size_t
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvDesc, CONV_ACCUM_F16, CONV_BIAS, CONV_RELU, CONV_STATS, ptr
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _st():
+    return L.stream_ptr()
+
+
+def same_pad(size, k, stride, dilation=1):
+    """TF 'SAME' padding for one spatial dim -> (out, pad_before)."""
+    k_eff = (k - 1) * dilation + 1
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k_eff - size, 0)
+    return out, total // 2
+
+
+class Workspace:
+    """Stream-ordered scratch arena shared by all kernels of one tower."""
+
+    def __init__(self, device, nbytes=64 << 20):
+        self.device = device
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def get(self, nbytes):
+        if nbytes > self.buf.numel():
+            self.buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+    def two(self, a_bytes, b_bytes):
+        """Two disjoint 256-byte aligned regions."""
+        a_al = (a_bytes + 255) // 256 * 256
+        buf = self.get(a_al + b_bytes)
+        return buf[:a_al], buf[a_al:a_al + b_bytes]
+
+
+# ----------------------------------------------------------------------------- conv
+def conv_desc(x_shape, cout, kh, kw, stride=1, dilation=1, pad=None, out_hw=None, flags=0,
+              flip=0):
+    n, h, w, cin = x_shape
+    if pad is None:
+        oh, pt = same_pad(h, kh, stride, dilation)
+        ow, pl = same_pad(w, kw, stride, dilation)
+    else:
+        pt, pl = pad
+        oh, ow = out_hw
+    return ConvDesc(n, h, w, cin, oh, ow, cout, kh, kw, stride, dilation, pt, pl, flip, flags)
+
+
+def conv2d_num_mtiles(d):
+    return L.call_int("ocr_conv2d_num_mtiles", byref(d))
+
+
+# When bench.py sets KERNEL_TIMING to a list, every implicit-GEMM conv launch is bracketed by
+# HIP events on the launch stream and logged as (variant, flops, start_event, stop_event).
+KERNEL_TIMING = None
+
+
+def conv2d_variant(d):
+    """Which conv_igemm_kernel<BN,CK,WCO> instantiation the library picks (conv_igemm.hip)."""
+    bn = 128 if d.cout % 128 == 0 else 64
+    ck = 64 if d.cin % 64 == 0 else 32
+    ht = 7 * d.stride + (d.kh - 1) * d.dilation + 1
+    wt = 31 * d.stride + (d.kw - 1) * d.dilation + 1
+    if ck == 64 and ht * wt * (64 * 2 + 16) + 2 * bn * (64 * 2 + 16) > 160 * 1024:
+        ck = 32
+    return "conv_igemm_kernel<%d,%d,%d>" % (bn, ck, 2 if bn == 128 else 1)
+
+
+def conv2d(d, x, w_kc, y, bias=None, stats=None):
+    if KERNEL_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.call("ocr_conv2d_f16", byref(d), ptr(x), ptr(w_kc), ptr(bias), ptr(y), ptr(stats), _st())
+        e1.record()
+        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+        KERNEL_TIMING.append((conv2d_variant(d), flops, e0, e1))
+        return
+    L.call("ocr_conv2d_f16", byref(d), ptr(x), ptr(w_kc), ptr(bias), ptr(y), ptr(stats), _st())
+
+
+def conv2d_wgrad(d, x, dy, dw, ws):
+    nbytes = L.call_size("ocr_conv2d_wgrad_workspace", byref(d))
+    buf = ws.get(nbytes)
+    L.call("ocr_conv2d_wgrad_f16", byref(d), ptr(x), ptr(dy), ptr(dw), ptr(buf), c_size_t(nbytes), _st())
+
+
+def conv2d_first_num_mtiles(n, h, w):
+    return L.call_int("ocr_conv2d_first_num_mtiles", c_int(n), c_int(h), c_int(w))
+
+
+def conv2d_first(x4, w_first, y, flags=0, bias=None, stats=None):
+    n, h, w, _ = x4.shape
+    cout = y.shape[-1]
+    L.call("ocr_conv2d_first_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(w_first),
+           ptr(bias), c_int(flags), ptr(y), ptr(stats), _st())
+
+
+def conv2d_first_wgrad(x4, dy, dw, ws):
+    n, h, w, _ = x4.shape
+    cout = dy.shape[-1]
+    nbytes = L.call_size("ocr_conv2d_first_wgrad_workspace", c_int(n), c_int(h), c_int(w), c_int(cout))
+    buf = ws.get(nbytes)
+    L.call("ocr_conv2d_first_wgrad_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(dy),
+           ptr(dw), ptr(buf), c_size_t(nbytes), _st())
+
+
+def pack_weights_first(w_hwio, w_first):
+    L.call("ocr_pack_weights_first_f16", ptr(w_hwio), c_int(w_hwio.shape[-1]), ptr(w_first), _st())
+
+
+def pack_weights(w_hwio, w_kc=None, w_ck=None):
+    kh, kw, cin, cout = w_hwio.shape
+    L.call("ocr_pack_weights_f16", ptr(w_hwio), c_int(kh * kw), c_int(cin), c_int(cout), ptr(w_kc),
+           ptr(w_ck), _st())
+
+
+def pack_weights_small(w, w_kc32, w_ck32):
+    cin, cout = w.shape
+    L.call("ocr_pack_weights_small_f16", ptr(w), c_int(cin), c_int(cout), ptr(w_kc32), ptr(w_ck32), _st())
+
+
+# ------------------------------------------------------------------- image / BN / pool
+def prep_images(images_f32, out_f16x4, means=(123.68, 116.78, 103.94)):
+    npix = images_f32.numel() // 3
+    L.call("ocr_prep_images_f16", ptr(images_f32), c_int64(npix), c_float(means[0]),
+           c_float(means[1]), c_float(means[2]), ptr(out_f16x4), _st())
+
+
+def bn_finalize(partial, T, C, count, gamma, beta, eps, decay, moving_mean, moving_var, scale, shift,
+                save_mean, save_invstd, ws):
+    nbytes = L.call_size("ocr_bn_reduce_workspace", c_int(T), c_int(C))
+    buf = ws
+    L.call("ocr_bn_finalize", ptr(partial), c_int(T), c_int(C), c_double(count), ptr(gamma), ptr(beta),
+           c_float(eps), c_float(decay), ptr(moving_mean), ptr(moving_var), ptr(scale), ptr(shift),
+           ptr(save_mean), ptr(save_invstd), ptr(buf), c_size_t(buf.numel() * buf.element_size()), _st())
+    return nbytes
+
+
+def bn_reduce_workspace(T, C):
+    return L.call_size("ocr_bn_reduce_workspace", c_int(T), c_int(C))
+
+
+def bn_inference_params(gamma, beta, mm, mv, eps, scale, shift):
+    L.call("ocr_bn_inference_params", ptr(gamma), ptr(beta), ptr(mm), ptr(mv), c_float(eps),
+           c_int(mm.numel()), ptr(scale), ptr(shift), _st())
+
+
+def bn_relu(y, scale, shift, relu, pool, a_full=None, a_pool=None):
+    n, h, w, c = y.shape
+    L.call("ocr_bn_relu_f16", ptr(y), ptr(scale), ptr(shift), c_int(n), c_int(h), c_int(w), c_int(c),
+           c_int(int(relu)), c_int(pool), ptr(a_full), ptr(a_pool), _st())
+
+
+def bn_bwd_num_partials(shape, pool):
+    n, h, w, c = shape
+    return L.call_int("ocr_bn_bwd_num_partials", c_int(n), c_int(h), c_int(w), c_int(c), c_int(pool))
+
+
+def bn_relu_bwd(y, scale, shift, save_mean, save_invstd, da_full, da_pool, relu, pool, dgamma, dbeta,
+                dy, ws):
+    n, h, w, c = y.shape
+    T = bn_bwd_num_partials(y.shape, pool)
+    part, stage = ws.two(T * 2 * c * 4, bn_reduce_workspace(T, c))
+    L.call("ocr_bn_relu_bwd_f16", ptr(y), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd),
+           ptr(da_full), ptr(da_pool), c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)),
+           c_int(pool), ptr(dgamma), ptr(dbeta), ptr(dy), ptr(part), ptr(stage),
+           c_size_t(stage.numel()), _st())
+
+
+def maxpool(x, k, stride, pad, y):
+    n, h, w, c = x.shape
+    _, oh, ow, _ = y.shape
+    L.call("ocr_maxpool_f16", ptr(x), c_int(n), c_int(h), c_int(w), c_int(c), c_int(k), c_int(stride),
+           c_int(pad[0]), c_int(pad[1]), c_int(oh), c_int(ow), ptr(y), _st())
+
+
+def maxpool_bwd(x, dy, k, stride, pad, dx, accumulate):
+    n, h, w, c = x.shape
+    _, oh, ow, _ = dy.shape
+    L.call("ocr_maxpool_bwd_f16", ptr(x), ptr(dy), c_int(n), c_int(h), c_int(w), c_int(c), c_int(k),
+           c_int(stride), c_int(pad[0]), c_int(pad[1]), c_int(oh), c_int(ow), ptr(dx),
+           c_int(int(accumulate)), _st())
+
+
+# ------------------------------------------------------------------------------ heads
+def conv1x1_small(x, w_kc32, cout, out, bias=None):
+    P = x.numel() // x.shape[-1]
+    L.call("ocr_conv1x1_small_f16", ptr(x), ptr(w_kc32), ptr(bias), c_int(P), c_int(x.shape[-1]),
+           c_int(cout), ptr(out), _st())
+
+
+def conv1x1_small_dgrad(dz, w_ck32, cout, dx, accumulate, grad_scale=1.0):
+    P = dx.numel() // dx.shape[-1]
+    L.call("ocr_conv1x1_small_dgrad_f16", ptr(dz), ptr(w_ck32), c_int(P), c_int(dx.shape[-1]),
+           c_int(cout), c_float(grad_scale), ptr(dx), c_int(int(accumulate)), _st())
+
+
+def conv1x1_small_wgrad(x, dz, cout, dw, ws):
+    cin = x.shape[-1]
+    P = x.numel() // cin
+    nbytes = L.call_size("ocr_conv1x1_small_wgrad_workspace", c_int(P), c_int(cin), c_int(cout))
+    buf = ws.get(nbytes)
+    L.call("ocr_conv1x1_small_wgrad_f16", ptr(x), ptr(dz), c_int(P), c_int(cin), c_int(cout), ptr(dw),
+           ptr(buf), c_size_t(nbytes), _st())
+
+
+def sc_num_partials(P, C):
+    return L.call_int("ocr_sc_num_partials", c_int(P), c_int(C))
+
+
+def sc_stats(x, C, partial):
+    P = x.numel() // C
+    L.call("ocr_sc_stats", ptr(x), c_int(P), c_int(C), ptr(partial), _st())
+
+
+def sc_fuse(out, za=None, sa=None, ha=None, zb=None, sb=None, hb=None, prev=None, relu=True):
+    n, h, w, C = out.shape
+    L.call("ocr_sc_fuse", ptr(za), ptr(sa), ptr(ha), ptr(zb), ptr(sb), ptr(hb), ptr(prev), c_int(n),
+           c_int(h), c_int(w), c_int(C), c_int(int(relu)), ptr(out), _st())
+
+
+def sc_unpool_bwd(dout, dprev):
+    n, lh, lw, C = dprev.shape
+    L.call("ocr_sc_unpool_bwd", ptr(dout), c_int(n), c_int(lh), c_int(lw), c_int(C), ptr(dprev), _st())
+
+
+def sc_bn_bwd(z, scale, shift, save_mean, save_invstd, dout, relu, dgamma, dbeta, dz, ws):
+    C = z.shape[-1]
+    P = z.numel() // C
+    T = sc_num_partials(P, C)
+    buf = ws.get((T + 1) * 2 * C * 4)
+    L.call("ocr_sc_bn_bwd", ptr(z), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(dout),
+           c_int(P), c_int(C), c_int(int(relu)), ptr(dgamma), ptr(dbeta), ptr(dz), ptr(buf), _st())
+
+
+def sc_pointwise_fwd(x, xo, cin, w, out, oo, cout, bias=None):
+    ldx, ldo = x.shape[-1], out.shape[-1]
+    P = x.numel() // ldx
+    L.call("ocr_sc_pointwise_fwd", ptr(x), c_int(ldx), c_int(xo), c_int(cin), ptr(w), ptr(bias), c_int(P),
+           ptr(out), c_int(ldo), c_int(oo), c_int(cout), _st())
+
+
+def sc_pointwise_dgrad(dout, oo, cout, w, dx, xo, cin):
+    ldx, ldo = dx.shape[-1], dout.shape[-1]
+    P = dx.numel() // ldx
+    L.call("ocr_sc_pointwise_dgrad", ptr(dout), c_int(ldo), c_int(oo), c_int(cout), ptr(w), c_int(P),
+           ptr(dx), c_int(ldx), c_int(xo), c_int(cin), _st())
+
+
+def sc_pointwise_wgrad(x, xo, cin, dout, oo, cout, dw, db, ws):
+    ldx, ldo = x.shape[-1], dout.shape[-1]
+    P = x.numel() // ldx
+    nbytes = L.call_size("ocr_sc_pointwise_wgrad_workspace", c_int(cin), c_int(cout))
+    buf = ws.get(nbytes)
+    L.call("ocr_sc_pointwise_wgrad", ptr(x), c_int(ldx), c_int(xo), c_int(cin), ptr(dout), c_int(ldo),
+           c_int(oo), c_int(cout), c_int(P), ptr(dw), ptr(db), ptr(buf), c_size_t(nbytes), _st())
+
+
+# ------------------------------------------------------------------------------- loss
+def dice_loss_fwd(yt_pixel, yp_pixel, yt_link, yp_link, mask, sums27, loss10, ws):
+    P = mask.numel()
+    pc = yp_pixel.numel() // P
+    G = yp_link.numel() // (8 * P)
+    nbytes = L.call_size("ocr_dice_workspace", c_int(P))
+    buf = ws.get(nbytes)
+    L.call("ocr_dice_loss_fwd", ptr(yt_pixel), ptr(yp_pixel), c_int(pc), ptr(yt_link), ptr(yp_link),
+           c_int(G), ptr(mask), c_int(P), ptr(sums27), ptr(loss10), ptr(buf), c_size_t(nbytes), _st())
+
+
+def dice_loss_bwd(yt_pixel, yt_link, mask, sums27, grad_scale, d_pixel, d_link):
+    P = mask.numel()
+    pc = d_pixel.numel() // P
+    G = d_link.numel() // (8 * P)
+    L.call("ocr_dice_loss_bwd", ptr(yt_pixel), c_int(pc), ptr(yt_link), c_int(G), ptr(mask), c_int(P),
+           ptr(sums27), c_float(grad_scale), ptr(d_pixel), ptr(d_link), _st())
+
+
+# -------------------------------------------------------------------------- optimiser
+def adam_step(w, g, m, v, ema, n_reg, lr_t, beta1, beta2, eps, wd, inv_scale, ema_decay):
+    L.call("ocr_adam_step", ptr(w), ptr(g), ptr(m), ptr(v), ptr(ema), c_int64(w.numel()),
+           c_int64(n_reg), c_float(lr_t), c_float(beta1), c_float(beta2), c_float(eps), c_float(wd),
+           c_float(inv_scale), c_float(ema_decay), _st())
+
+
+def momentum_step(w, g, acc, ema, n_reg, lr, momentum, wd, inv_scale, ema_decay):
+    L.call("ocr_momentum_step", ptr(w), ptr(g), ptr(acc), ptr(ema), c_int64(w.numel()), c_int64(n_reg),
+           c_float(lr), c_float(momentum), c_float(wd), c_float(inv_scale), c_float(ema_decay), _st())
+
+
+def scale_(x, s):
+    L.call("ocr_scale_f32", ptr(x), c_int64(x.numel()), c_float(s), _st())

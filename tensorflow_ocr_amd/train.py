@@ -1,0 +1,127 @@
+"""Training-step assembly: mirror of multigpu_train.py:27-36,70-85,103-142 (tower loss ->
+mean of tower gradients -> Adam with staircase exponential decay -> EMA) and of
+train_pixellink.py:179-194,222-243 (sum of pre-divided gradients -> Momentum).
+
+One process drives one GPU ("tower"); the cross-tower gradient mean of `average_gradients`
+(multigpu_train.py:70-85) is an RCCL all-reduce over the flat gradient buffer, issued by
+`dist.GradientAllReduce` on a side stream.
+"""
+import math
+
+import torch
+
+from . import ops
+from .graph import F32
+
+
+def exponential_decay(learning_rate, global_step, decay_steps=5000, decay_rate=0.94, staircase=True):
+    """tf.train.exponential_decay (multigpu_train.py:104)."""
+    e = global_step // decay_steps if staircase else global_step / decay_steps
+    return learning_rate * decay_rate ** e
+
+
+def pixellink_lr(global_step, base_lr=0.01):
+    """train_pixellink.py:222-237: base_lr * {0.1 if step<20k, 0.01 if <40k, 0.001 if <60k, else 1}."""
+    if global_step < 20000:
+        f = 0.1
+    elif global_step < 40000:
+        f = 0.01
+    elif global_step < 60000:
+        f = 0.001
+    else:
+        f = 1.0
+    return base_lr * f
+
+
+class AdamOptimizer:
+    """tf.train.AdamOptimizer + ExponentialMovingAverage(decay, num_updates=global_step) + slim L2
+    regulariser gradient, as ONE fused launch over the tower's flat parameter buffer."""
+
+    def __init__(self, graph, learning_rate=1e-4, decay_steps=5000, decay_rate=0.94,
+                 moving_average_decay=0.997, weight_decay=1e-5, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.g = graph
+        graph.ensure_materialised()
+        st = graph.store
+        self.m = torch.zeros_like(st.flat)
+        self.v = torch.zeros_like(st.flat)
+        self.ema = st.flat.clone() if moving_average_decay else None
+        self.lr0, self.decay_steps, self.decay_rate = learning_rate, decay_steps, decay_rate
+        self.mad, self.wd = moving_average_decay, weight_decay
+        self.b1, self.b2, self.eps = beta1, beta2, epsilon
+        self.global_step = 0
+
+    def learning_rate(self):
+        return exponential_decay(self.lr0, self.global_step, self.decay_steps, self.decay_rate, True)
+
+    def apply_gradients(self, grad_scale=1.0):
+        st = self.g.store
+        t = self.global_step + 1
+        lr = self.learning_rate()
+        lr_t = lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        ema_d = min(self.mad, (1.0 + self.global_step) / (10.0 + self.global_step)) if self.mad else 0.0
+        ops.adam_step(st.flat, st.flat_grad, self.m, self.v, self.ema, st.n_reg, lr_t, self.b1, self.b2,
+                      self.eps, self.wd, grad_scale / self.g.loss_scale, ema_d)
+        st.version += 1
+        self.global_step += 1
+
+    def shadow_state_dict(self):
+        """EMA shadows by variable name (what test.py:149-150 restores)."""
+        st = self.g.store
+        base = st.flat.data_ptr()
+        out = {}
+        for v in st.trainable():
+            off = (v.data.data_ptr() - base) // 4
+            out[v.name] = self.ema[off:off + v.size].view(v.shape).detach().cpu().numpy().copy()
+        return out
+
+
+class MomentumOptimizer:
+    """tf.train.MomentumOptimizer(lr, 0.9) with the PixelLink schedule (train_pixellink.py:222-243)."""
+
+    def __init__(self, graph, base_lr=0.01, momentum=0.9, weight_decay=5e-4, moving_average_decay=None):
+        self.g = graph
+        graph.ensure_materialised()
+        st = graph.store
+        self.acc = torch.zeros_like(st.flat)
+        self.ema = st.flat.clone() if moving_average_decay else None
+        self.base_lr, self.momentum, self.wd, self.mad = base_lr, momentum, weight_decay, moving_average_decay
+        self.global_step = 0
+
+    def learning_rate(self):
+        return pixellink_lr(self.global_step, self.base_lr)
+
+    def apply_gradients(self, grad_scale=1.0):
+        st = self.g.store
+        ema_d = min(self.mad, (1.0 + self.global_step) / (10.0 + self.global_step)) if self.mad else 0.0
+        ops.momentum_step(st.flat, st.flat_grad, self.acc, self.ema, st.n_reg, self.learning_rate(),
+                          self.momentum, self.wd, grad_scale / self.g.loss_scale, ema_d)
+        st.version += 1
+        self.global_step += 1
+
+
+class TrainStep:
+    """One data-parallel training step of `multigpu_train.py`'s hot loop (:118-142,171-174) for
+    this process's tower: forward -> loss -> backward (gradient buckets all-reduced while the rest
+    of backward runs) -> optimiser + EMA.  `model_fn(images) -> preds`, `loss_fn(labels..., preds)`."""
+
+    def __init__(self, graph, forward_loss, optimizer_factory, world_size=1, bucket_bytes=32 << 20):
+        self.g = graph
+        self.forward_loss = forward_loss
+        self.optimizer_factory = optimizer_factory
+        self.world = world_size
+        self.bucket_bytes = bucket_bytes
+        self.opt = None
+        self.reducer = None
+
+    def __call__(self, *batch):
+        g = self.g
+        g.reset_tape()
+        loss = self.forward_loss(g, *batch)
+        if self.opt is None:
+            from .dist import GradientAllReduce
+            self.opt = self.optimizer_factory(g)           # materialises the flat buffers
+            self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, fold_mean=True)
+        g.backward(self.reducer.on_grads_ready if self.world > 1 else None)
+        self.reducer.finish()
+        self.opt.apply_gradients(self.reducer.grad_scale)
+        return loss

@@ -1,0 +1,208 @@
+"""GPU parity of single layers (forward + backward through the C ABI) vs the CPU oracle on
+identical f16-representable inputs.  These are the well-conditioned checks: one layer deep, so the
+only differences are f32 summation order and one f16 rounding of the result."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ocr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-20))
+
+
+def _h(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,rate,pool", [
+    (2, 16, 40, 64, 64, 3, 1, 0),
+    (1, 24, 32, 64, 128, 3, 1, 2),
+    (2, 9, 11, 128, 64, 3, 1, 2),      # odd sizes: ragged tiles and SAME pooling edge
+    (1, 12, 12, 64, 128, 3, 6, 0),     # fc6-style dilation
+    (2, 8, 8, 128, 128, 1, 1, 0),      # fc7-style 1x1
+])
+def test_conv_bn_relu_pool(device, n, h, w, cin, cout, k, rate, pool):
+    from tensorflow_ocr_amd import layers
+    from tensorflow_ocr_amd.graph import Act, Graph
+    rng = np.random.default_rng(1)
+    x = _h(rng.standard_normal((n, h, w, cin)))
+    wt = _h(rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin)))
+    gamma = (1 + 0.1 * rng.standard_normal(cout)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    oh, ow = (h + 1) // 2 if pool else h, (w + 1) // 2 if pool else w
+    gout = _h(rng.standard_normal((n, oh, ow, cout)) * 0.1)
+    gfull = _h(rng.standard_normal((n, h, w, cout)) * 0.1) if pool else None
+
+    # ---- device
+    g = Graph(device, loss_scale=1.0)
+    xa = Act(torch.from_numpy(x).half().to(device))
+    full, pooled = layers.conv2d(g, xa, cout, k, "L", rate=rate, pool=pool)
+    g.reset_tape()
+    g.store.load_state_dict({"L/weights": wt, "L/BatchNorm/gamma": gamma, "L/BatchNorm/beta": beta,
+                             "L/BatchNorm/moving_mean": np.zeros(cout, np.float32),
+                             "L/BatchNorm/moving_variance": np.ones(cout, np.float32)})
+    full, pooled = layers.conv2d(g, xa, cout, k, "L", rate=rate, pool=pool)
+    out_d = (pooled if pool else full).data.float().cpu().numpy()
+    if pool:
+        pooled.grad = torch.from_numpy(gout).half().to(device)
+        full.grad = torch.from_numpy(gfull).half().to(device)
+    else:
+        full.grad = torch.from_numpy(gout).half().to(device)
+    g.backward()
+    torch.cuda.synchronize()
+    dv = g.store.vars
+    d_dw = dv["L/weights"].grad.cpu().numpy()
+    d_dg = dv["L/BatchNorm/gamma"].grad.cpu().numpy()
+    d_db = dv["L/BatchNorm/beta"].grad.cpu().numpy()
+    d_dx = xa.grad.float().cpu().numpy()
+    d_mm = dv["L/BatchNorm/moving_mean"].data.cpu().numpy()
+    d_mv = dv["L/BatchNorm/moving_variance"].data.cpu().numpy()
+
+    # ---- oracle (mixed: identical storage roundings)
+    p = {"L/weights": wt, "L/BatchNorm/gamma": gamma, "L/BatchNorm/beta": beta,
+         "L/BatchNorm/moving_mean": np.zeros(cout, np.float32),
+         "L/BatchNorm/moving_variance": np.ones(cout, np.float32)}
+    tp = O.to_torch_params(p)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    upd = {}
+    a = O._conv_block(xt, tp, "L", rate, "bn", True, upd)
+    if pool:
+        o = O.max_pool(a, 2, 2)
+        (o * torch.from_numpy(gout)).sum().backward(retain_graph=True)
+        (a * torch.from_numpy(gfull)).sum().backward()
+    else:
+        o = a
+        (o * torch.from_numpy(gout)).sum().backward()
+    o_np = o.detach().numpy()
+    assert np.abs(out_d - o_np).max() <= 2e-3 * max(1.0, np.abs(o_np).max())
+    assert _rel(d_mm, upd["L/BatchNorm/moving_mean"].numpy()) < 1e-4
+    assert np.abs(d_mv - upd["L/BatchNorm/moving_variance"].numpy()).max() < 1e-5
+    assert _rel(d_db, tp["L/BatchNorm/beta"].grad.numpy()) < 5e-3
+    assert _rel(d_dg, tp["L/BatchNorm/gamma"].grad.numpy()) < 5e-3
+    assert _rel(d_dw, tp["L/weights"].grad.numpy()) < 1e-2
+    assert _rel(d_dx, xt.grad.numpy()) < 1e-2
+
+
+def test_first_conv(device):
+    from tensorflow_ocr_amd import layers
+    from tensorflow_ocr_amd.graph import Graph
+    rng = np.random.default_rng(2)
+    n, h, w, cout = 2, 20, 45, 64
+    img = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    wt = _h(rng.standard_normal((3, 3, 3, cout)) * 0.05)
+    gout = _h(rng.standard_normal((n, h, w, cout)) * 0.1)
+    g = Graph(device, loss_scale=1.0)
+    x4 = layers.prep_images(g, torch.from_numpy(img).to(device))
+    layers.conv2d(g, x4, cout, 3, "c", first=True)
+    g.reset_tape()
+    g.store.load_state_dict({"c/weights": wt})
+    full, _ = layers.conv2d(g, x4, cout, 3, "c", first=True)
+    full.grad = torch.from_numpy(gout).half().to(device)
+    g.backward()
+    torch.cuda.synchronize()
+    p = {"c/weights": wt, "c/BatchNorm/gamma": np.ones(cout, np.float32), "c/BatchNorm/beta": np.zeros(cout, np.float32),
+         "c/BatchNorm/moving_mean": np.zeros(cout, np.float32), "c/BatchNorm/moving_variance": np.ones(cout, np.float32)}
+    tp = O.to_torch_params(p)
+    xm = O.q(O.mean_image_subtraction(torch.from_numpy(img)), True)
+    a = O._conv_block(xm, tp, "c", 1, "bn", True, {})
+    (a * torch.from_numpy(gout)).sum().backward()
+    assert np.abs(full.data.float().cpu().numpy() - a.detach().numpy()).max() < 4e-3
+    assert _rel(g.store.vars["c/weights"].grad.cpu().numpy(), tp["c/weights"].grad.numpy()) < 1e-2
+    assert _rel(g.store.vars["c/BatchNorm/gamma"].grad.cpu().numpy(), tp["c/BatchNorm/gamma"].grad.numpy()) < 5e-3
+
+
+def test_maxpool3x3s1(device):
+    from tensorflow_ocr_amd import layers
+    from tensorflow_ocr_amd.graph import Act, Graph
+    rng = np.random.default_rng(3)
+    x = _h(np.round(rng.standard_normal((2, 7, 9, 16)) * 2) / 2)     # many ties
+    gout = _h(rng.standard_normal((2, 7, 9, 16)))
+    g = Graph(device, loss_scale=1.0)
+    xa = Act(torch.from_numpy(x).half().to(device))
+    y = layers.max_pool2d(g, xa, 3, 1)
+    y.grad = torch.from_numpy(gout).half().to(device)
+    g.backward()
+    xt = torch.from_numpy(x).requires_grad_(True)
+    yo = O.max_pool(xt, 3, 1)
+    (yo * torch.from_numpy(gout)).sum().backward()
+    assert np.array_equal(y.data.float().cpu().numpy(), yo.detach().numpy())
+    assert np.abs(xa.grad.float().cpu().numpy() - xt.grad.numpy()).max() < 2e-2
+
+
+def test_heads_and_dice(device):
+    """fuse heads (1x1 small convs + BN + ReLU + unpool/add pyramid + predication convs) and dice."""
+    from tensorflow_ocr_amd import checkpoint, layers
+    from tensorflow_ocr_amd.graph import Act, Graph
+    from tensorflow_ocr_amd.nets import model_vgg_16 as M
+    rng = np.random.default_rng(4)
+    n, h = 2, 6
+    chans = {"fc7": 128, "conv5_3": 64, "conv4_3": 64, "conv3_3": 32}
+    sizes = {"fc7": h, "conv5_3": h, "conv4_3": 2 * h, "conv3_3": 4 * h}
+    feats = {k: _h(np.abs(rng.standard_normal((n, sizes[k], sizes[k], c)))) for k, c in chans.items()}
+    order = ["fc7", "conv5_3", "conv4_3", "conv3_3"]
+    p = {}
+    for base, cout in ((0, 2), (5, 16)):
+        for i, key in enumerate(order):
+            nm = "feature_fusion/Conv" + ("_%d" % (base + i) if base + i else "")
+            p[nm + "/weights"] = _h(rng.standard_normal((1, 1, chans[key], cout)) * np.sqrt(2.0 / chans[key]))
+            O._bn_init(p, nm, cout)
+            p[nm + "/BatchNorm/gamma"] = (1 + 0.1 * rng.standard_normal(cout)).astype(np.float32)
+            p[nm + "/BatchNorm/beta"] = (0.2 * rng.standard_normal(cout)).astype(np.float32)
+        nm = "feature_fusion/Conv_%d" % (base + 4)
+        p[nm + "/weights"] = (rng.standard_normal((1, 1, cout, cout)) * np.sqrt(2.0 / cout)).astype(np.float32)
+        O._bn_init(p, nm, cout)
+        p[nm + "/BatchNorm/beta"] = (0.3 + 0.2 * rng.standard_normal(cout)).astype(np.float32)
+    q4 = 4 * h
+    pixel = (rng.uniform(size=(n, q4, q4, 1)) < 0.3).astype(np.float32)
+    link = (rng.uniform(size=(n, q4, q4, 8)) < 0.3).astype(np.float32)
+    mask = (rng.uniform(size=(n, q4, q4, 1)) < 0.9).astype(np.float32)
+
+    def build(g, acts):
+        with g.variable_scope('feature_fusion'):
+            srcs = [('fc7', ('Conv', 'Conv_5')), ('conv5_3', ('Conv_1', 'Conv_6')),
+                    ('conv4_3', ('Conv_2', 'Conv_7')), ('conv3_3', ('Conv_3', 'Conv_8'))]
+            hd = {k: layers.head_conv_bn(g, acts[k], nm, (2, 16)) for k, nm in srcs}
+            s1 = layers.fuse(g, (n, h, h, 18), a=hd['fc7'], b=hd['conv5_3'])
+            s2 = layers.fuse(g, (n, 2 * h, 2 * h, 18), a=hd['conv4_3'], prev=s1)
+            s3 = layers.fuse(g, (n, 4 * h, 4 * h, 18), a=hd['conv3_3'], prev=s2)
+            return layers.pointwise_bn(g, s3, 0, 2, 'Conv_4'), layers.pointwise_bn(g, s3, 2, 16, 'Conv_9')
+
+    g = Graph(device, loss_scale=64.0)
+    acts = {k: Act(torch.from_numpy(v).half().to(device)) for k, v in feats.items()}
+    build(g, acts)
+    g.reset_tape()
+    g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, p))
+    px, lk = build(g, acts)
+    L = M.loss(pixel, px, link, lk, mask, graph=g)
+    g.backward()
+    torch.cuda.synchronize()
+
+    tp = O.to_torch_params(p)
+    ft = {k: torch.from_numpy(v).requires_grad_(True) for k, v in feats.items()}
+    outs = []
+    upd = {}
+    for base, c in ((0, 2), (5, 16)):
+        def nm(i):
+            return "feature_fusion/Conv" + ("_%d" % (base + i) if base + i else "")
+        s1 = O._head(ft["fc7"], tp, nm(0), True, True, upd) + O._head(ft["conv5_3"], tp, nm(1), True, True, upd)
+        s2 = O.resize_bilinear_x2(s1) + O._head(ft["conv4_3"], tp, nm(2), True, True, upd)
+        s3 = O.resize_bilinear_x2(s2) + O._head(ft["conv3_3"], tp, nm(3), True, True, upd)
+        outs.append(O._head_f32(s3, tp, nm(4), True, upd))
+    Lo = O.dice_loss(torch.from_numpy(pixel), outs[0], torch.from_numpy(link), outs[1], torch.from_numpy(mask))
+    Lo.backward()
+    assert np.abs(px.data.cpu().numpy() - outs[0].detach().numpy()).max() < 1e-4
+    assert np.abs(lk.data.cpu().numpy() - outs[1].detach().numpy()).max() < 1e-4
+    assert abs(L.item() - float(Lo)) < 1e-5
+    gr = checkpoint.internal_to_tf({nm_: (v.grad / 64.0).cpu().numpy() for nm_, v in g.store.vars.items() if v.trainable})
+    for k in sorted(gr):
+        r = _rel(gr[k], tp[k].grad.numpy())
+        print("%-45s %.3e" % (k, r))
+        assert r < 2e-3, k
+    for k in order:
+        r = _rel(acts[k].grad.float().cpu().numpy() / 64.0, ft[k].grad.numpy())
+        print("dfeat %-10s %.3e" % (k, r))
+        assert r < 1e-2
