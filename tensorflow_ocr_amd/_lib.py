@@ -32,6 +32,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime; import it first so libocr_hip.so binds to the SAME
+    # libamdhip64 (streams and device pointers come from torch's allocator).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise OcrHipError(
             "libocr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

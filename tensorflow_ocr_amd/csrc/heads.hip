@@ -308,24 +308,40 @@ __global__ void sc_pointwise_dgrad_kernel(const float* __restrict__ dout, int ld
   }
 }
 
-// partial[blk][ci][co] (+ bias partial [blk][cin*cout + co]) over the block's pixels
+// partial[blk][ci*cout+co] (weights) and partial[blk][cin*cout+co] (bias) over the block's strip
+// of pixels; the strip is staged through LDS 64 pixels at a time, one thread per output pair.
 __global__ __launch_bounds__(256) void sc_pointwise_wgrad_kernel(
     const float* __restrict__ x, int ldx, int xo, int cin, const float* __restrict__ dout, int ldo,
-    int oo, int cout, int P, float* __restrict__ partial) {
-  __shared__ float red[256];
+    int oo, int cout, int P, int strip, float* __restrict__ partial) {
+  __shared__ float xs[64 * 32], ds[64 * 32];
   const int pairs = cin * cout + cout;  // weights then bias
-  float* dst = partial + (size_t)blockIdx.x * pairs;
-  for (int j = 0; j < pairs; ++j) {
-    const bool is_b = j >= cin * cout;
-    const int ci = is_b ? 0 : j / cout, co = is_b ? j - cin * cout : j % cout;
-    float a = 0.f;
-    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)P; p += (size_t)gridDim.x * 256)
-      a += (is_b ? 1.f : x[p * ldx + xo + ci]) * dout[p * ldo + oo + co];
-    a = wave_sum(a);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  const int p0 = blockIdx.x * strip;
+  int p1 = p0 + strip;
+  if (p1 > P) p1 = P;
+  float acc[2] = {0.f, 0.f};  // pairs <= 512
+  for (int pb = p0; pb < p1; pb += 64) {
+    const int np = (p1 - pb) < 64 ? (p1 - pb) : 64;
     __syncthreads();
-    if (threadIdx.x == 0) dst[j] = red[0] + red[1] + red[2] + red[3];
+    for (int i = threadIdx.x; i < np * cin; i += 256) xs[i] = x[(size_t)(pb + i / cin) * ldx + xo + i % cin];
+    for (int i = threadIdx.x; i < np * cout; i += 256) ds[i] = dout[(size_t)(pb + i / cout) * ldo + oo + i % cout];
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = threadIdx.x + k * 256;
+      if (j < pairs) {
+        const bool is_b = j >= cin * cout;
+        const int ci = is_b ? 0 : j / cout, co = is_b ? j - cin * cout : j % cout;
+        float a = acc[k];
+        if (is_b) for (int q = 0; q < np; ++q) a += ds[q * cout + co];
+        else for (int q = 0; q < np; ++q) a += xs[q * cin + ci] * ds[q * cout + co];
+        acc[k] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int j = threadIdx.x + k * 256;
+    if (j < pairs) partial[(size_t)blockIdx.x * pairs + j] = acc[k];
   }
 }
 
@@ -370,8 +386,8 @@ extern "C" int ocr_conv1x1_small_dgrad_f16(const void* dz_f32, const void* w_ck3
 }
 
 static int small_wgrad_strips(int P) {
-  int s = ocr_cdiv(P, 512);
-  if (s > 512) s = 512;
+  int s = ocr_cdiv(P, 2048);
+  if (s > 256) s = 256;
   if (s < 1) s = 1;
   return s;
 }
@@ -512,9 +528,10 @@ extern "C" int ocr_sc_pointwise_wgrad(const void* x, int ldx, int xo, int cin, c
   const int pairs = cin * cout + cout;
   float* ws = static_cast<float*>(workspace);
   float* tot = ws + (size_t)B * pairs;
+  OCR_CHECK_SHAPE(cin <= 32 && cout <= 32 && pairs <= 512);
   hipLaunchKernelGGL(sc_pointwise_wgrad_kernel, dim3(B), dim3(256), 0, st,
                      static_cast<const float*>(x), ldx, xo, cin, static_cast<const float*>(dout),
-                     ldo, oo, cout, P, ws);
+                     ldo, oo, cout, P, ocr_cdiv(P, B), ws);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(ocr_cdiv(pairs, 256)), dim3(256), 0, st, ws, tot,
                      pairs, B, 1.f);
   if (hipMemcpyAsync(dw, tot, (size_t)cin * cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)

@@ -61,16 +61,22 @@ __global__ __launch_bounds__(256) void dice_reduce_kernel(DiceP d, const float* 
 // sums[27] (I, A, B per map), loss[0] = total, loss[1..9] = the nine dice terms
 __global__ void dice_finalize_kernel(const float* __restrict__ partial, int T,
                                      float* __restrict__ sums, float* __restrict__ loss) {
+  __shared__ double part[8][32];
   __shared__ double tot[27];
-  const int j = threadIdx.x;
-  if (j < 27) {
-    double a = 0.0;
-    for (int t = 0; t < T; ++t) a += (double)partial[(size_t)t * 27 + j];
-    tot[j] = a;
-    sums[j] = (float)a;
+  const int j = threadIdx.x & 31, g = threadIdx.x >> 5;   // 256 threads: 8 row groups x 32 cols
+  double a = 0.0;
+  if (j < 27)
+    for (int t = g; t < T; t += 8) a += (double)partial[(size_t)t * 27 + j];
+  part[g][j] = a;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double s = 0.0;
+    for (int k = 0; k < 8; ++k) s += part[k][threadIdx.x];
+    tot[threadIdx.x] = s;
+    sums[threadIdx.x] = (float)s;
   }
   __syncthreads();
-  if (j == 0) {
+  if (threadIdx.x == 0) {
     double total = 0.0;
     for (int k = 0; k < 9; ++k) {
       const double I = tot[3 * k], U = tot[3 * k + 1] + tot[3 * k + 2] + 1e-5;
@@ -133,7 +139,7 @@ extern "C" int ocr_dice_loss_fwd(const void* y_true_pixel, const void* y_pred_pi
                      static_cast<const float*>(y_true_pixel), static_cast<const float*>(y_pred_pixel),
                      static_cast<const float*>(y_true_link), static_cast<const float*>(y_pred_link),
                      static_cast<const float*>(training_mask), static_cast<float*>(workspace));
-  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, st,
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, st,
                      static_cast<const float*>(workspace), T, static_cast<float*>(sums27),
                      static_cast<float*>(loss10));
   return ocr_launch_status();
