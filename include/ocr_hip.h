@@ -95,6 +95,126 @@ int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const void* x4,
                                void* workspace, size_t ws_bytes, void* stream);
 size_t ocr_conv2d_first_wgrad_workspace(int n, int h, int w, int cout);
 
+/* f32 HWIO master weights -> the f16 operand layouts of the MFMA kernels (done once per optimiser
+ * step).  w_kc [taps][cout][cin] feeds ocr_conv2d_f16 forward; w_ck [taps][cin][cout] (a plain
+ * cast) feeds the input gradient: call ocr_conv2d_f16 on dy with cin/cout swapped, flip_taps = 1
+ * and pad' = dilation*(k-1) - pad.  Either output may be NULL. */
+int ocr_pack_weights_f16(const void* w_hwio_f32, int taps, int cin, int cout, void* w_kc,
+                         void* w_ck, void* stream);
+int ocr_pack_weights_first_f16(const void* w_hwio_f32, int cout, void* w_first, void* stream);
+/* head weights f32 [cin][cout<=32] -> w_kc32 f16 [32][cin] and w_ck32 f16 [cin][32], zero padded */
+int ocr_pack_weights_small_f16(const void* w_f32, int cin, int cout, void* w_kc32, void* w_ck32,
+                               void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Image preparation: mean_image_subtraction (nets/model.py:18-31) + f16 cast.
+ * images f32 [npix][3] -> f16 [npix][4] (4th channel 0).
+ * ------------------------------------------------------------------------- */
+int ocr_prep_images_f16(const void* images_f32, int64_t npix, float m0, float m1, float m2,
+                        void* out_f16x4, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * slim.batch_norm (decay .997, eps 1e-5, scale; nets/resnet_utils.py:232-246,
+ * nets/model_vgg_16.py:144-157) in training mode, fused with ReLU and the
+ * following slim.max_pool2d 2x2/2 SAME (nets/vgg.py:16-28).
+ * ------------------------------------------------------------------------- */
+/* partial [T][2][C] f32 (sum, sum of squares per row block; from OCR_CONV_STATS or ocr_sc_stats)
+ * -> scale/shift (a = y*scale + shift), saved mean / 1/std, moving-average update with the
+ * unbiased variance.  gamma/beta/moving_* may be NULL.  workspace >= ocr_bn_reduce_workspace. */
+size_t ocr_bn_reduce_workspace(int T, int C);
+int ocr_bn_finalize(const void* partial, int T, int C, double count, const void* gamma,
+                    const void* beta, float eps, float decay, void* moving_mean, void* moving_var,
+                    void* scale, void* shift, void* save_mean, void* save_invstd, void* workspace,
+                    size_t ws_bytes, void* stream);
+int ocr_bn_inference_params(const void* gamma, const void* beta, const void* moving_mean,
+                            const void* moving_var, float eps, int C, void* scale, void* shift,
+                            void* stream);
+/* a = [relu](y*scale+shift) f16; pool = 0: a_full; pool = 2: a_pool [n,ceil(h/2),ceil(w/2),c]
+ * (+ a_full if non-NULL). */
+int ocr_bn_relu_f16(const void* y, const void* scale, const void* shift, int n, int h, int w, int c,
+                    int relu, int pool, void* a_full, void* a_pool, void* stream);
+/* Backward of the same fused op.  da_full: gradient w.r.t. the full-resolution activation (may be
+ * NULL when pool = 2); da_pool: gradient w.r.t. the pooled activation, routed to the first maximum
+ * of each window.  Writes dgamma, dbeta [c] f32 and dy f16 (gradient w.r.t. the conv output).
+ * partial: f32 [ocr_bn_bwd_num_partials][2][c]; workspace >= ocr_bn_reduce_workspace(T, c). */
+int ocr_bn_bwd_num_partials(int n, int h, int w, int c, int pool);
+int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void* shift, const void* save_mean,
+                        const void* save_invstd, const void* da_full, const void* da_pool, int n,
+                        int h, int w, int c, int relu, int pool, void* dgamma, void* dbeta, void* dy,
+                        void* partial, void* workspace, size_t ws_bytes, void* stream);
+
+/* slim.max_pool2d k x k / stride SAME as a standalone op (pool5 3x3/1 nets/vgg.py:32; ResNet
+ * pool1 3x3/2 nets/resnet_v1.py:194; subsample 1x1/s nets/resnet_utils.py:74), f16 NHWC. */
+int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k, int stride, int pad_top,
+                    int pad_left, int oh, int ow, void* y, void* stream);
+int ocr_maxpool_bwd_f16(const void* x, const void* dy, int n, int h, int w, int c, int k,
+                        int stride, int pad_top, int pad_left, int oh, int ow, void* dx,
+                        int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * PixelLink fuse heads (nets/model_vgg_16.py:160-175, nets/pixellink.py:55-67,
+ * nets/model.py:129-141): wide f16 feature -> few f32 channels, and the f32
+ * "small-channel" tensors [P][C] the unpool+add pyramid works on.
+ * ------------------------------------------------------------------------- */
+int ocr_conv1x1_small_f16(const void* x, const void* w_kc32, const void* bias, int P, int cin,
+                          int cout, void* out_f32, void* stream);
+int ocr_conv1x1_small_dgrad_f16(const void* dz_f32, const void* w_ck32, int P, int cin, int cout,
+                                float grad_scale, void* dx_f16, int accumulate, void* stream);
+size_t ocr_conv1x1_small_wgrad_workspace(int P, int cin, int cout);
+int ocr_conv1x1_small_wgrad_f16(const void* x, const void* dz_f32, int P, int cin, int cout,
+                                void* dw_f32, void* workspace, size_t ws_bytes, void* stream);
+/* per-channel sum / sum-of-squares partials [ocr_sc_num_partials][2][C] of x f32 [P][C] */
+int ocr_sc_num_partials(int P, int C);
+int ocr_sc_stats(const void* x, int P, int C, void* partial, void* stream);
+/* out[n,h,w,C] = [act(za*sa+ha)] + [act(zb*sb+hb)] + [unpool2x(prev[n,h/2,w/2,C])]; any subset;
+ * unpool = tf.image.resize_bilinear x2 with TF-1.4 legacy sampling (nets/model.py:14-15). */
+int ocr_sc_fuse(const void* za, const void* sa, const void* ha, const void* zb, const void* sb,
+                const void* hb, const void* prev, int n, int h, int w, int C, int relu, void* out,
+                void* stream);
+int ocr_sc_unpool_bwd(const void* dout, int n, int lh, int lw, int C, void* dprev, void* stream);
+/* BN(+ReLU) backward on f32 [P][C]; partial must hold (ocr_sc_num_partials + 1)*2*C floats */
+int ocr_sc_bn_bwd(const void* z, const void* scale, const void* shift, const void* save_mean,
+                  const void* save_invstd, const void* dout, int P, int C, int relu, void* dgamma,
+                  void* dbeta, void* dz, void* partial, void* stream);
+/* pointwise f32 conv on channel slices: out[p][oo+co] = b[co] + sum_ci x[p][xo+ci] w[ci][co] */
+int ocr_sc_pointwise_fwd(const void* x, int ldx, int xo, int cin, const void* w, const void* bias,
+                         int P, void* out, int ldo, int oo, int cout, void* stream);
+int ocr_sc_pointwise_dgrad(const void* dout, int ldo, int oo, int cout, const void* w, int P,
+                           void* dx, int ldx, int xo, int cin, void* stream);
+size_t ocr_sc_pointwise_wgrad_workspace(int cin, int cout);
+int ocr_sc_pointwise_wgrad(const void* x, int ldx, int xo, int cin, const void* dout, int ldo,
+                           int oo, int cout, int P, void* dw, void* db, void* workspace,
+                           size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Dice loss (nets/model_vgg_16.py:179-225 == nets/model.py:145-159):
+ * loss = 2*dice(pixel) + sum_8 dice(link_i), labels/mask 1 channel, predictions
+ * pc (pixel) / G per direction (link) channels with TF broadcasting.
+ * sums27: (I, sum y*m, sum p*m) x 9; loss10: [total, 9 dice terms].
+ * ------------------------------------------------------------------------- */
+size_t ocr_dice_workspace(int P);
+int ocr_dice_loss_fwd(const void* y_true_pixel, const void* y_pred_pixel, int pc,
+                      const void* y_true_link, const void* y_pred_link, int G,
+                      const void* training_mask, int P, void* sums27, void* loss10,
+                      void* workspace, size_t ws_bytes, void* stream);
+int ocr_dice_loss_bwd(const void* y_true_pixel, int pc, const void* y_true_link, int G,
+                      const void* training_mask, int P, const void* sums27, float grad_scale,
+                      void* d_pred_pixel, void* d_pred_link, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Optimisers over the flat parameter buffer: elements [0, n_regularized) also get
+ * the slim.l2_regularizer gradient weight_decay*w.  g is multiplied by
+ * inv_loss_scale first.  ema (may be NULL) follows ExponentialMovingAverage.
+ * multigpu_train.py:103-107,137-142; train_pixellink.py:243.
+ * ------------------------------------------------------------------------- */
+int ocr_adam_step(void* w, const void* g, void* m, void* v, void* ema, int64_t n,
+                  int64_t n_regularized, float lr_t, float beta1, float beta2, float eps,
+                  float weight_decay, float inv_loss_scale, float ema_decay, void* stream);
+int ocr_momentum_step(void* w, const void* g, void* accum, void* ema, int64_t n,
+                      int64_t n_regularized, float lr, float momentum, float weight_decay,
+                      float inv_loss_scale, float ema_decay, void* stream);
+int ocr_scale_f32(void* x, int64_t n, float s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocr_hip.so")
+LIB_PATH = os.environ.get("OCR_HIP_LIB", os.path.join(_HERE, "libocr_hip.so"))
 
 
 class OcrHipError(RuntimeError):

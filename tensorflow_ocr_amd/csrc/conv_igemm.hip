@@ -22,6 +22,7 @@
 //     stored (f16-rounded) values for training-mode batch norm.
 #include "common.h"
 #include "conv_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,7 +33,7 @@ struct ConvP {
 
 
 template <int BN, int CK, int WCO>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(
+__global__ __launch_bounds__(256, OCR_WPS) void conv_igemm_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y,
     float* __restrict__ stats) {
@@ -212,6 +213,7 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, int* bn, int* ck) {
   p->WT = (TILE_W - 1) * d->stride + (d->kw - 1) * d->dilation + 1;
   *bn = (d->cout % 128 == 0) ? 128 : 64;
   int c = (d->cin % 64 == 0) ? 64 : 32;
+  if (const char* e = getenv("OCR_CONV_CK")) { if (atoi(e) == 32) c = 32; }
   // keep halo + weight ring within the 160 KiB LDS
   auto need = [&](int ckk) {
     return (size_t)p->HT * p->WT * (ckk * 2 + 16) + 2 * (size_t)(*bn) * (ckk * 2 + 16);

@@ -1,0 +1,151 @@
+"""CPU tests of the host logic: the C-ABI library loads and exports every symbol that
+include/ocr_hip.h declares (no compute without a GPU), TF padding helper, checkpoint name
+mapping, bucket planning, LR schedules, and the world_size-2 gloo all-reduce path."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ocr_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ocr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tensorflow_ocr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.ocr_abi_version.restype = ctypes.c_int
+    assert lib.ocr_abi_version() == 1
+    lib.ocr_status_string.restype = ctypes.c_char_p
+    assert lib.ocr_status_string(0) == b"ok" and b"unsupported" in lib.ocr_status_string(-2)
+
+
+def test_abi_rejects_bad_arguments_without_touching_the_gpu():
+    from tensorflow_ocr_amd import _lib
+    lib = _lib.load()
+    lib.ocr_conv2d_f16.restype = ctypes.c_int
+    d = _lib.ConvDesc(1, 8, 8, 24, 8, 8, 64, 3, 3, 1, 1, 1, 1, 0, 0)      # cin % 32 != 0
+    assert lib.ocr_conv2d_f16(ctypes.byref(d), None, None, None, None, None, None) == -2
+    d = _lib.ConvDesc(1, 8, 8, 64, 8, 8, 64, 3, 3, 1, 1, 1, 1, 0, 0)
+    assert lib.ocr_conv2d_f16(ctypes.byref(d), None, None, None, None, None, None) == -1   # NULL x
+    with pytest.raises(_lib.OcrHipError):
+        _lib.call("ocr_conv2d_f16", ctypes.byref(d), None, None, None, None, None, None)
+
+
+def test_product_path_has_no_oracle_import():
+    pkg = os.path.join(ROOT, "tensorflow_ocr_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dp, f)
+
+
+def test_same_pad_matches_oracle():
+    from oracle import ocr_oracle as O
+    from tensorflow_ocr_amd import ops
+    for size in (1, 7, 32, 33, 320, 512):
+        for k, s, d in ((3, 1, 1), (2, 2, 1), (3, 2, 1), (3, 1, 6), (1, 2, 1), (7, 2, 1)):
+            out, before, _ = O.tf_same_pad(size, k, s, d)
+            assert ops.same_pad(size, k, s, d) == (out, before)
+
+
+def test_checkpoint_name_mapping_roundtrip():
+    from tensorflow_ocr_amd import checkpoint
+    rng = np.random.default_rng(0)
+    tf_sd = {"feature_fusion/Conv/weights": rng.standard_normal((1, 1, 8, 2)).astype(np.float32),
+             "feature_fusion/Conv_5/weights": rng.standard_normal((1, 1, 8, 16)).astype(np.float32),
+             "feature_fusion/Conv/BatchNorm/gamma": rng.standard_normal(2).astype(np.float32),
+             "feature_fusion/Conv_5/BatchNorm/gamma": rng.standard_normal(16).astype(np.float32),
+             "conv1/conv1_1/weights": rng.standard_normal((3, 3, 3, 4)).astype(np.float32)}
+    internal = ["feature_fusion/Conv+Conv_5/weights", "feature_fusion/Conv+Conv_5/BatchNorm/gamma",
+                "conv1/conv1_1/weights"]
+    isd = checkpoint.tf_to_internal(internal, tf_sd)
+    assert isd["feature_fusion/Conv+Conv_5/weights"].shape == (8, 18)
+    assert np.array_equal(isd["feature_fusion/Conv+Conv_5/weights"][:, :2], tf_sd["feature_fusion/Conv/weights"][0, 0])
+    back = checkpoint.internal_to_tf(isd)
+    for k, v in tf_sd.items():
+        assert np.array_equal(back[k], v), k
+
+
+def test_bucket_planner_covers_buffer_on_variable_boundaries():
+    from tensorflow_ocr_amd.dist import plan_buckets
+    ranges = [(0, 10), (10, 30), (30, 35), (35, 100)]
+    for cap in (1, 20, 40, 1000):
+        b = plan_buckets(ranges, 100, cap)
+        assert b[0][0] == 0 and b[-1][1] == 100
+        assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+        starts = {s for s, _ in ranges} | {100}
+        assert all(s in starts and e in starts for s, e in b)
+    assert plan_buckets(ranges, 100, 1000) == [(0, 100)]
+
+
+def test_lr_schedules():
+    from tensorflow_ocr_amd.train import exponential_decay, pixellink_lr
+    assert exponential_decay(1e-4, 4999) == 1e-4
+    assert abs(exponential_decay(1e-4, 10000) - 1e-4 * 0.94 ** 2) < 1e-15
+    assert abs(pixellink_lr(0) - 1e-3) < 1e-12 and abs(pixellink_lr(20000) - 1e-4) < 1e-12
+    assert abs(pixellink_lr(40000) - 1e-5) < 1e-12 and pixellink_lr(60000) == 0.01
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as td
+from tensorflow_ocr_amd import dist
+from tensorflow_ocr_amd.graph import VariableStore, constant
+rank, world, _ = dist.init_process_group_from_env("gloo")
+st = VariableStore(torch.device("cpu"))
+a = st.get("a/weights", (3, 3, 2, 4), constant(1.0), regularized=True)
+b = st.get("b/weights", (5, 7), constant(2.0), regularized=True)
+c = st.get("a/BatchNorm/gamma", (4,), constant(1.0))
+st.materialise()
+red = dist.GradientAllReduce(st, world, bucket_bytes=64 * 4, op="mean")
+assert len(red.buckets) >= 2
+for step in range(2):
+    a.grad.fill_(float(rank + 1)); b.grad.fill_(10.0 * (rank + 1)); c.grad.fill_(100.0 * (rank + 1))
+    red.on_grads_ready([b]); red.on_grads_ready([a, c])          # reverse creation order
+    red.finish()
+    mean = (1 + world) / 2.0
+    assert torch.allclose(a.grad, torch.full_like(a.grad, mean)), a.grad
+    assert torch.allclose(b.grad, torch.full_like(b.grad, 10 * mean))
+    assert torch.allclose(c.grad, torch.full_like(c.grad, 100 * mean))
+# fold_mean leaves the SUM and reports the scale
+red2 = dist.GradientAllReduce(st, world, fold_mean=True)
+a.grad.fill_(float(rank + 1)); red2.finish()
+assert torch.allclose(a.grad, torch.full_like(a.grad, world * (world + 1) / 2.0)) and red2.grad_scale == 1.0 / world
+td.barrier(); td.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_gradient_allreduce_world2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER % ROOT)
+    procs = []
+    port = 29500 + os.getpid() % 2000
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o

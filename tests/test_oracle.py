@@ -1,0 +1,101 @@
+"""CPU tests of the oracle: the reference's one known-answer value, the TF-1.4 semantics of
+SURVEY.md §3.5 stated as hand-computed cases, and the committed golden fixtures."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ocr_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_softmax_known_answer_from_reference_example_py():
+    # example.py:13-21: softmax over [[1,2],[3,4],[5,6],[7,8]] pairs -> [0.268941, 0.731059]
+    x = torch.tensor([[[[1., 2.], [3., 4.], [5., 6.], [7., 8.]]]])
+    s = O.softmax(x).numpy().reshape(-1, 2)
+    assert np.allclose(s, [[0.26894142, 0.73105858]] * 4, atol=1e-6)
+
+
+def test_same_padding_is_asymmetric_like_tf():
+    assert O.tf_same_pad(512, 3, 1) == (512, 1, 1)
+    assert O.tf_same_pad(512, 2, 2) == (256, 0, 0)
+    assert O.tf_same_pad(320, 3, 2) == (160, 0, 1)      # 3x3/2 on even H pads (0,1)
+    assert O.tf_same_pad(7, 2, 2) == (4, 0, 1)
+    assert O.tf_same_pad(32, 3, 1, rate=6) == (32, 6, 6)
+
+
+def test_conv2d_same_uses_explicit_symmetric_pad_for_stride2():
+    # resnet_utils.conv2d_same: 3x3/2 pads (1,1), unlike raw SAME's (0,1)
+    x = torch.arange(16.0).reshape(1, 4, 4, 1)
+    w = torch.ones(3, 3, 1, 1)
+    a = O.conv2d_same(x, w, 2).numpy()[0, :, :, 0]
+    b = O.conv2d(x, w, 2, 1, "SAME").numpy()[0, :, :, 0]
+    assert a[0, 0] == 0 + 1 + 4 + 5            # window centred on pixel (0,0) with zero halo
+    assert b[0, 0] == sum([0, 1, 2, 4, 5, 6, 8, 9, 10])   # raw SAME window starts at (0,0)
+
+
+def test_legacy_bilinear_x2():
+    x = torch.tensor([1., 3., 7.]).reshape(1, 1, 3, 1)
+    up = O.resize_bilinear_x2(x).numpy()[0, :, :, 0]
+    assert np.allclose(up[0], [1, 2, 3, 5, 7, 7])      # out[2i]=in[i], out[2i+1]=(in[i]+in[min(i+1,W-1)])/2
+    assert np.allclose(up[1], up[0])                    # H=1: the second row clamps
+
+
+def test_max_pool_gradient_goes_to_first_maximum():
+    x = torch.tensor([[2., 2.], [2., 1.]]).reshape(1, 2, 2, 1).requires_grad_(True)
+    O.max_pool(x, 2, 2).sum().backward()
+    assert np.array_equal(x.grad.numpy().reshape(2, 2), [[1, 0], [0, 0]])
+
+
+def test_batch_norm_moving_variance_is_unbiased():
+    x = torch.tensor([[0.], [2.]]).reshape(2, 1, 1, 1)
+    y, mm, mv = O.batch_norm(x, torch.ones(1), torch.zeros(1), torch.zeros(1), torch.ones(1), True,
+                             decay=0.5, eps=0.0)
+    assert np.allclose(y.numpy().ravel(), [-1, 1])           # biased variance 1 normalises
+    assert np.allclose(mm.numpy(), [0.5]) and np.allclose(mv.numpy(), [0.5 * 1 + 0.5 * 2.0])
+
+
+def test_dice_broadcasting_matches_hand_sum():
+    y = torch.tensor([1., 0.]).reshape(1, 1, 2, 1)
+    p = torch.tensor([[.5, .25], [.5, .5]]).reshape(1, 1, 2, 2)
+    m = torch.ones(1, 1, 2, 1)
+    d = O.dice_coefficient(y, p, m).item()
+    assert abs(d - (1 - 2 * 0.75 / (1 + 1.75 + 1e-5))) < 1e-6
+
+
+def test_adam_and_ema_formulas():
+    w, m, v = O.adam_update(np.float32(1.0), np.float32(0.5), 0.0, 0.0, 1, 1e-4)
+    # first step: m = 0.05, v = 2.5e-4, lr_t = lr*sqrt(1-.999)/(1-.9) -> update = lr (up to eps)
+    assert abs(w - (1.0 - 1e-4)) < 2e-7 and abs(m - 0.05) < 1e-8 and abs(v - 2.5e-4) < 1e-9
+    assert O.ema_decay(0.997, 0) == 0.1 and O.ema_decay(0.997, 10 ** 6) == 0.997
+    assert abs(O.exponential_decay(1e-4, 5000) - 0.94e-4) < 1e-12
+    assert O.exponential_decay(1e-4, 4999) == 1e-4
+
+
+def test_golden_primitives():
+    g = np.load(os.path.join(GOLD, "primitives.npz"))
+    t = torch.from_numpy
+    assert np.allclose(O.resize_bilinear_x2(t(g["x"])).numpy(), g["up"], atol=1e-6)
+    assert np.array_equal(O.max_pool(t(g["xp"]), 2, 2).numpy(), g["p22"])
+    assert np.array_equal(O.max_pool(t(g["xp"]), 3, 1).numpy(), g["p31"])
+    assert np.array_equal(O.max_pool(t(g["xp"]), 3, 2).numpy(), g["p32"])
+    assert np.allclose(O.conv2d(t(g["xp"]), t(g["w"]), 1, 1).numpy(), g["c1"], atol=1e-5)
+    assert np.allclose(O.conv2d(t(g["xp"]), t(g["w"]), 1, 6).numpy(), g["c6"], atol=1e-5)
+    assert np.allclose(O.conv2d_same(t(g["xp"]), t(g["w"]), 2).numpy(), g["cs2"], atol=1e-5)
+    d = O.dice_loss(t(g["yt"]), t(g["pp"]), t(g["yl"]), t(g["pl"]), t(g["m"])).item()
+    assert abs(d - float(g["dice"])) < 1e-5
+
+
+def test_golden_model_vgg_small():
+    g = np.load(os.path.join(GOLD, "model_vgg_w8_64.npz"))
+    rng = np.random.default_rng(7)
+    p = O.init_model_vgg_params(rng, width_div=8)
+    images, pixel, link, mask = O.synthetic_batch(rng, 1, 64)
+    assert np.array_equal(images, g["images"]) and np.array_equal(link, g["link"])
+    tp = O.to_torch_params(p)
+    px, lk, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=False)
+    L = O.dice_loss(torch.from_numpy(pixel), px, torch.from_numpy(link), lk, torch.from_numpy(mask))
+    assert np.allclose(px.detach().numpy(), g["pixel_cls"], atol=2e-4)
+    assert np.allclose(lk.detach().numpy(), g["link_cls"], atol=2e-4)
+    assert abs(L.item() - float(g["loss"])) < 1e-4
