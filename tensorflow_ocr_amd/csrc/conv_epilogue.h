@@ -9,23 +9,23 @@ constexpr int TILE_H = 8;
 constexpr int TILE_W = 32;
 
 // LDS needed by the epilogue for a BN-wide tile.
-constexpr size_t conv_epilogue_lds(int bn) { return 256 * (bn * 2 + 16) + 256 * 16 * sizeof(float); }
+constexpr size_t conv_epilogue_lds(int bn, int nt = 256) { return 256 * (bn * 2 + 16) + nt * 16 * sizeof(float); }
 
-template <int BN, int TCO, int TPX, int WCO>
+template <int BN, int TCO, int TPX, int WCO, int NT = 256>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* smem, int flags,
                                               const float* __restrict__ bias,
                                               half_t* __restrict__ y, float* __restrict__ stats,
                                               int img, int tyi, int txi, int mt, int co0, int oh,
-                                              int ow, int cout) {
+                                              int ow, int cout, int wco, int wpx, bool active) {
   constexpr int OSTR = BN * 2 + 16;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
   const int r = lane & 31, hh = lane >> 5;
-  const int wco = wave % WCO, wpx = wave / WCO;
   char* otile = smem;
   float* red = reinterpret_cast<float*>(smem + 256 * OSTR);
   const bool has_bias = (flags & OCR_CONV_BIAS) != 0;
   const bool relu = (flags & OCR_CONV_RELU) != 0;
+  if (active) {
 #pragma unroll
   for (int i = 0; i < TCO; ++i) {
 #pragma unroll
@@ -50,9 +50,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* sme
       }
     }
   }
+  }
   __syncthreads();
   constexpr int NC = BN / 8;    // 16-byte chunks per output row
-  constexpr int RG = 256 / NC;  // row groups
+  constexpr int RG = NT / NC;   // row groups
   constexpr int PPT = 256 / RG; // pixels per thread
   const int c = tid % NC, rg = tid / NC;
   const bool accum = (flags & OCR_CONV_ACCUM_F16) != 0;

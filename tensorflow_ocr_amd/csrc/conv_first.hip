@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstP p, const half_t*
   }
   __syncthreads();
   conv_epilogue<64, 2, 2, 1>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt, co0, p.h, p.w,
-                             p.cout);
+                             p.cout, 0, wave, true);
 }
 
 // ---- weight gradient -------------------------------------------------------

@@ -33,18 +33,18 @@ struct ConvP {
 
 
 template <int BN, int CK, int WCO>
-__global__ __launch_bounds__(256, OCR_WPS) void conv_igemm_kernel(
+__global__ __launch_bounds__(512) void conv_igemm_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y,
     float* __restrict__ stats) {
-  constexpr int WPX = 4 / WCO;
+  constexpr int NT = 512;
+  constexpr int WPX = 8 / WCO;
   constexpr int TCO = BN / WCO / 32;
   constexpr int TPX = 256 / WPX / 32;
   constexpr int PSTR = CK * 2 + 16;
   constexpr int KSTEPS = CK / 16;
   constexpr int CPP = CK / 8;  // 16-byte chunks per pixel / per weight row
-  constexpr int NWLD = BN * CPP / 256;
-  static_assert(NWLD >= 1, "weight slice smaller than one pass");
+  constexpr int NWLD = (BN * CPP + NT - 1) / NT;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
@@ -93,18 +93,18 @@ __global__ __launch_bounds__(256, OCR_WPS) void conv_igemm_kernel(
     const half_t* src = w + ((size_t)tapw * p.cout + co0) * p.cin + cc * CK;
 #pragma unroll
     for (int u = 0; u < NWLD; ++u) {
-      int idx = u * 256 + tid;
+      int idx = u * NT + tid;
       int rr = idx / CPP, c = idx % CPP;
-      wreg[u] = *reinterpret_cast<const u32x4*>(src + (size_t)rr * p.cin + c * 8);
+      if (idx < BN * CPP) wreg[u] = *reinterpret_cast<const u32x4*>(src + (size_t)rr * p.cin + c * 8);
     }
   };
   auto store_w = [&](int buf) {
     char* dst = wbuf + buf * (BN * PSTR);
 #pragma unroll
     for (int u = 0; u < NWLD; ++u) {
-      int idx = u * 256 + tid;
+      int idx = u * NT + tid;
       int rr = idx / CPP, c = idx % CPP;
-      *reinterpret_cast<u32x4*>(dst + rr * PSTR + c * 16) = wreg[u];
+      if (idx < BN * CPP) *reinterpret_cast<u32x4*>(dst + rr * PSTR + c * 16) = wreg[u];
     }
   };
 
@@ -115,12 +115,12 @@ __global__ __launch_bounds__(256, OCR_WPS) void conv_igemm_kernel(
     {
       const int total = halo_px * CPP;
       const half_t* xb = x + (size_t)img * p.h * p.w * p.cin + cc * CK;
-      for (int base = 0; base < total; base += 256 * 4) {
+      for (int base = 0; base < total; base += NT * 4) {
         u32x4 v[4];
         int off[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          int idx = base + u * 256 + tid;
+          int idx = base + u * NT + tid;
           v[u] = u32x4{0u, 0u, 0u, 0u};
           off[u] = -1;
           if (idx < total) {
@@ -139,10 +139,16 @@ __global__ __launch_bounds__(256, OCR_WPS) void conv_igemm_kernel(
       }
     }
     load_w(0, cc);
+    store_w(wb);
+    if (ntaps > 1) load_w(1, cc);
     for (int tap = 0; tap < ntaps; ++tap) {
-      store_w(wb);
+      // after this barrier: buf[wb] (this tap, and at tap 0 the halo) is visible and
+      // buf[wb^1] is free (its readers finished tap-1)
       __syncthreads();
-      if (tap + 1 < ntaps) load_w(tap + 1, cc);
+      if (tap + 1 < ntaps) {
+        store_w(wb ^ 1);
+        if (tap + 2 < ntaps) load_w(tap + 2, cc);
+      }
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
       const char* ab = wbuf + wb * (BN * PSTR) + a_lane;
       const char* bb = halo + b_lane + ((ky * p.dil) * WT + kx * p.dil) * PSTR +
@@ -166,10 +172,21 @@ __global__ __launch_bounds__(256, OCR_WPS) void conv_igemm_kernel(
     }
   }
 
-  // ---- epilogue: accumulators -> LDS [256 px][BN] f16 -> coalesced rows ----
-  __syncthreads();
-  conv_epilogue<BN, TCO, TPX, WCO>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt, co0,
-                                   p.oh, p.ow, p.cout);
+  // ---- epilogue: accumulators -> LDS [256 px][<=128 couts] f16 -> coalesced rows ----
+  if constexpr (BN <= 128) {
+    __syncthreads();
+    conv_epilogue<BN, TCO, TPX, WCO, NT>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt, co0,
+                                         p.oh, p.ow, p.cout, wco, wpx, true);
+  } else {
+    // 256-wide tiles leave through LDS in two 128-cout halves (waves wco 0,1 then 2,3)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();
+      conv_epilogue<128, TCO, TPX, 2, NT>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt,
+                                          co0 + h * 128, p.oh, p.ow, p.cout, wco & 1, wpx,
+                                          (wco >> 1) == h);
+    }
+  }
 }
 
 template <int BN, int CK, int WCO>
@@ -177,7 +194,7 @@ int launch(const ConvP& p, const void* x, const void* w, const void* bias, void*
            void* stats, hipStream_t st) {
   constexpr int PSTR = CK * 2 + 16;
   size_t main_bytes = (size_t)p.halo_bytes + 2 * BN * PSTR;
-  size_t epi_bytes = conv_epilogue_lds(BN);
+  size_t epi_bytes = conv_epilogue_lds(BN > 128 ? 128 : BN, 512);
   size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (lds > 160 * 1024) return OCR_ERR_UNSUPPORTED;
   auto kern = conv_igemm_kernel<BN, CK, WCO>;
@@ -191,7 +208,7 @@ int launch(const ConvP& p, const void* x, const void* w, const void* bias, void*
   }
   const int m_tiles = p.n * p.tiles_x * p.tiles_y;
   dim3 grid((unsigned)(m_tiles * p.n_tiles));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p,
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p,
                      static_cast<const half_t*>(x), static_cast<const half_t*>(w),
                      static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats));
@@ -211,7 +228,8 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, int* bn, int* ck) {
   p->tiles_y = ocr_cdiv(d->oh, TILE_H);
   p->HT = (TILE_H - 1) * d->stride + (d->kh - 1) * d->dilation + 1;
   p->WT = (TILE_W - 1) * d->stride + (d->kw - 1) * d->dilation + 1;
-  *bn = (d->cout % 128 == 0) ? 128 : 64;
+  *bn = (d->cout % 256 == 0) ? 256 : (d->cout % 128 == 0) ? 128 : 64;
+  if (const char* e = getenv("OCR_CONV_BN")) { int v = atoi(e); if (v == 128 && *bn == 256) *bn = 128; }
   int c = (d->cin % 64 == 0) ? 64 : 32;
   if (const char* e = getenv("OCR_CONV_CK")) { if (atoi(e) == 32) c = 32; }
   // keep halo + weight ring within the 160 KiB LDS
@@ -243,8 +261,10 @@ extern "C" int ocr_conv2d_f16(const ocr_conv_desc* d, const void* x, const void*
   OCR_CHECK_ARG(!(d->flags & OCR_CONV_BIAS) || bias);
   OCR_CHECK_ARG(!(d->flags & OCR_CONV_STATS) || stats);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (bn == 256 && ck == 64) return launch<256, 64, 4>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 256 && ck == 32) return launch<256, 32, 4>(p, x, w_kc, bias, y, stats, st);
   if (bn == 128 && ck == 64) return launch<128, 64, 2>(p, x, w_kc, bias, y, stats, st);
   if (bn == 128 && ck == 32) return launch<128, 32, 2>(p, x, w_kc, bias, y, stats, st);
-  if (bn == 64 && ck == 64) return launch<64, 64, 1>(p, x, w_kc, bias, y, stats, st);
-  return launch<64, 32, 1>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 64 && ck == 64) return launch<64, 64, 2>(p, x, w_kc, bias, y, stats, st);
+  return launch<64, 32, 2>(p, x, w_kc, bias, y, stats, st);
 }

@@ -180,6 +180,199 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   reinterpret_cast<f32x4*>(dw)[i] = a;
 }
 
+// ---------------------------------------------------------------------------
+// v2: register-blocked, software-pipelined variant (used whenever its LDS fits).
+//
+//   block per workgroup : 64 ci x COB co x all taps   (COB = 128, or 64 when cout % 128 != 0)
+//   wave tile           : 32 ci x (COB/2) co x taps   -> each shifted x fragment (2 tr-reads)
+//                         feeds COB/64 MFMAs, each dy fragment is shared by all taps:
+//                         22 LDS reads per 18 MFMAs instead of 20 per 9
+//   pixel tile          : 4 x 32 output pixels, DOUBLE-buffered in LDS; the global loads of
+//                         tile t+1 are issued before the MFMAs of tile t and written to the
+//                         other buffer afterwards (one barrier per tile)
+// ---------------------------------------------------------------------------
+constexpr int T2_H = 4;
+
+struct Wg2P {
+  int n, h, w, cin, oh, ow, cout, kh, kw, stride, dil, pt, pl;
+  int tiles_x, tiles_y, m_tiles, HT, WT, splits, tiles_per_split, nci, nco;
+};
+
+constexpr int X2STR = CIB * 2 + 64;   // 192 B: row stride = 16 dwords mod 64 -> the 4 k-rows of a
+                                       // transposing read land in 4 disjoint bank quarters
+
+template <int COB2, int MAXTAPS>
+__global__ __launch_bounds__(COB2 * 4) void wgrad2_kernel(Wg2P p, const half_t* __restrict__ x,
+                                                          const half_t* __restrict__ dy,
+                                                          float* __restrict__ slab) {
+  constexpr int NT = COB2 * 4;             // threads: 2 (ci) x COB2/32 (co) waves, 32x32 each
+  constexpr int NWCO = COB2 / 32;
+  constexpr int DSTR2 = COB2 * 2 + 64;     // bytes per dy pixel in LDS (same bank rule)
+  constexpr int DCH = COB2 / 8;            // 16-byte chunks per dy pixel
+  constexpr int NDY = 128 * DCH / NT;      // dy loads per thread per tile
+  constexpr int XPP = NT / 8;              // halo pixels covered per pass
+  constexpr int NXMAX = (224 + XPP - 1) / XPP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int halo_px = p.HT * p.WT;
+  const int halo_bytes = halo_px * X2STR;
+  const int stage_bytes = halo_bytes + 128 * DSTR2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ciw = wave / NWCO, cow = wave % NWCO;
+  const int li = lane & 15, g = lane >> 4;
+  const int q = li >> 2, pp = li & 3, hh = g >> 1, gc = g & 1;
+
+  int bid = blockIdx.x;
+  const int cob = bid % p.nco;
+  bid /= p.nco;
+  const int cib = bid % p.nci;
+  const int split = bid / p.nci;
+  const int ci0 = cib * CIB, co0 = cob * COB2;
+  const int ntaps = p.kh * p.kw;
+
+  f32x16 acc[MAXTAPS];
+#pragma unroll
+  for (int t = 0; t < MAXTAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const int a_lane = ((8 * hh + q) * p.stride) * X2STR + (ciw * 32 + 16 * gc + 4 * pp) * 2;
+  const int a_half = 4 * p.stride * X2STR;
+  const int b_lane = (8 * hh + q) * DSTR2 + (cow * 32 + 16 * gc + 4 * pp) * 2;
+  const int b_half = 4 * DSTR2;
+
+  // this thread's halo chunks (fixed across tiles): packed (hy << 16 | hx), -1 = none
+  int xpos[NXMAX];
+  const int xc = tid & 7;
+#pragma unroll
+  for (int u = 0; u < NXMAX; ++u) {
+    const int hp = u * XPP + (tid >> 3);
+    xpos[u] = -1;
+    if (hp < halo_px) {
+      const int hy = hp / p.WT;
+      xpos[u] = (hy << 16) | (hp - hy * p.WT);
+    }
+  }
+
+  const int mt_begin = split * p.tiles_per_split;
+  int mt_end = mt_begin + p.tiles_per_split;
+  if (mt_end > p.m_tiles) mt_end = p.m_tiles;
+
+  u32x4 xr[NXMAX], dr[NDY];
+  auto load_tile = [&](int mt) {
+    const int txi = mt % p.tiles_x;
+    const int tmp = mt / p.tiles_x;
+    const int tyi = tmp % p.tiles_y;
+    const int img = tmp / p.tiles_y;
+    const int iy0 = tyi * T2_H * p.stride - p.pt;
+    const int ix0 = txi * TILE_W * p.stride - p.pl;
+    const half_t* xb = x + (size_t)img * p.h * p.w * p.cin + ci0 + xc * 8;
+#pragma unroll
+    for (int u = 0; u < NXMAX; ++u) {
+      xr[u] = u32x4{0u, 0u, 0u, 0u};
+      if (xpos[u] >= 0) {
+        const int iy = iy0 + (xpos[u] >> 16), ix = ix0 + (xpos[u] & 0xffff);
+        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+          xr[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin);
+      }
+    }
+    const half_t* db = dy + (size_t)img * p.oh * p.ow * p.cout + co0;
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int idx = u * NT + tid;
+      const int px = idx / DCH, c = idx % DCH;
+      const int oy = tyi * T2_H + (px >> 5), ox = txi * TILE_W + (px & 31);
+      dr[u] = u32x4{0u, 0u, 0u, 0u};
+      if (oy < p.oh && ox < p.ow)
+        dr[u] = *reinterpret_cast<const u32x4*>(db + ((size_t)oy * p.ow + ox) * p.cout + c * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* xh = smem + buf * stage_bytes;
+    char* dyt = xh + halo_bytes;
+#pragma unroll
+    for (int u = 0; u < NXMAX; ++u)
+      if (xpos[u] >= 0)
+        *reinterpret_cast<u32x4*>(xh + (u * XPP + (tid >> 3)) * X2STR + xc * 16) = xr[u];
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int idx = u * NT + tid;
+      *reinterpret_cast<u32x4*>(dyt + (idx / DCH) * DSTR2 + (idx % DCH) * 16) = dr[u];
+    }
+  };
+
+  if (mt_begin < mt_end) {
+    load_tile(mt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int mt = mt_begin; mt < mt_end; ++mt) {
+    const int buf = (mt - mt_begin) & 1;
+    const bool more = mt + 1 < mt_end;
+    if (more) load_tile(mt + 1);
+    const char* xh = smem + buf * stage_bytes;
+    const char* dyt = xh + halo_bytes;
+#pragma unroll 1
+    for (int s = 0; s < 8; ++s) {
+      const int ty = s >> 1, tx0 = (s & 1) * 16;
+      half8_t b = tr_pair(dyt + b_lane + (ty * 32 + tx0) * DSTR2, b_half);
+      const char* abase = xh + a_lane + ((ty * p.stride) * p.WT + tx0 * p.stride) * X2STR;
+#pragma unroll
+      for (int t = 0; t < MAXTAPS; ++t) {
+        if (t < ntaps) {
+          const int ky = t / p.kw, kx = t - ky * p.kw;
+          half8_t a = tr_pair(abase + ((ky * p.dil) * p.WT + kx * p.dil) * X2STR, a_half);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int r = lane & 31, h2 = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < MAXTAPS; ++t) {
+    if (t < ntaps) {
+      float* dst = slab + (((size_t)split * ntaps + t) * p.cin + ci0 + ciw * 32) * p.cout + co0 +
+                   cow * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h2;
+        dst[(size_t)row * p.cout] = acc[t][e];
+      }
+    }
+  }
+}
+
+// returns OCR_OK when v2 applies (and fills p / cob), OCR_ERR_UNSUPPORTED otherwise
+int fill2(const ocr_conv_desc* d, Wg2P* p, int* cob) {
+  if (d->cin % 64 || d->cout % 64 || d->kh * d->kw > 9) return OCR_ERR_UNSUPPORTED;
+  *cob = (d->cout % 128 == 0) ? 128 : 64;
+  p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
+  p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
+  p->kh = d->kh; p->kw = d->kw; p->stride = d->stride; p->dil = d->dilation;
+  p->pt = d->pad_top; p->pl = d->pad_left;
+  p->tiles_x = ocr_cdiv(d->ow, TILE_W);
+  p->tiles_y = ocr_cdiv(d->oh, T2_H);
+  p->m_tiles = d->n * p->tiles_x * p->tiles_y;
+  p->HT = (T2_H - 1) * d->stride + (d->kh - 1) * d->dilation + 1;
+  p->WT = (TILE_W - 1) * d->stride + (d->kw - 1) * d->dilation + 1;
+  if (p->HT * p->WT > 7 * 32) return OCR_ERR_UNSUPPORTED;
+  const size_t stage = (size_t)p->HT * p->WT * X2STR + 128 * (*cob * 2 + 64);
+  if (2 * stage > 160 * 1024) return OCR_ERR_UNSUPPORTED;
+  p->nci = d->cin / CIB;
+  p->nco = d->cout / *cob;
+  const int blocks = p->nci * p->nco;
+  int want = ocr_cdiv(256, blocks);            // one resident workgroup per CU
+  if (want > p->m_tiles) want = p->m_tiles;
+  if (want < 1) want = 1;
+  p->tiles_per_split = ocr_cdiv(p->m_tiles, want);
+  p->splits = ocr_cdiv(p->m_tiles, p->tiles_per_split);
+  return OCR_OK;
+}
+
 int fill(const ocr_conv_desc* d, WgP* p) {
   OCR_CHECK_ARG(d != nullptr);
   OCR_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0);
@@ -210,41 +403,63 @@ int fill(const ocr_conv_desc* d, WgP* p) {
 }  // namespace
 
 extern "C" size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d) {
+  if (!d) return 0;
+  Wg2P p2;
+  int cob = 0;
+  if (fill2(d, &p2, &cob) == OCR_OK)
+    return (size_t)p2.splits * d->kh * d->kw * d->cin * d->cout * sizeof(float);
   WgP p;
   if (fill(d, &p) != OCR_OK) return 0;
   return (size_t)p.splits * d->kh * d->kw * d->cin * d->cout * sizeof(float);
 }
 
+template <typename K, typename P>
+static int launch_wg(K kern, const P& p, unsigned grid, size_t lds, const void* x, const void* dy,
+                     void* ws, hipStream_t st, unsigned threads = 256) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return OCR_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, p, static_cast<const half_t*>(x),
+                     static_cast<const half_t*>(dy), static_cast<float*>(ws));
+  return ocr_launch_status();
+}
+
 extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const void* dy,
                                     void* dw, void* workspace, size_t ws_bytes, void* stream) {
-  WgP p;
-  int rc = fill(d, &p);
-  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(d != nullptr);
+  OCR_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0);
   OCR_CHECK_ARG(x && dy && dw && workspace);
   const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
-  if (ws_bytes < (size_t)p.splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)p.HT * p.WT * XSTR + 256 * DSTR;
   const int ntaps = d->kh * d->kw;
-  dim3 grid((unsigned)(p.splits * p.nci * p.nco));
-  auto go = [&](auto kern) -> int {
-    static bool configured = false;
-    if (!configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024) != hipSuccess)
-        return OCR_ERR_HIP;
-      configured = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, static_cast<const half_t*>(x),
-                       static_cast<const half_t*>(dy), static_cast<float*>(workspace));
-    return ocr_launch_status();
-  };
-  rc = (ntaps == 1) ? go(wgrad_kernel<1>) : go(wgrad_kernel<9>);
+  int splits = 0, rc;
+  Wg2P p2;
+  int cob = 0;
+  if (fill2(d, &p2, &cob) == OCR_OK) {
+    splits = p2.splits;
+    if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
+    const size_t lds = 2 * ((size_t)p2.HT * p2.WT * X2STR + 128 * (cob * 2 + 64));
+    const unsigned grid = (unsigned)(p2.splits * p2.nci * p2.nco);
+    if (cob == 128)
+      rc = ntaps == 1 ? launch_wg(wgrad2_kernel<128, 1>, p2, grid, lds, x, dy, workspace, st, 512)
+                      : launch_wg(wgrad2_kernel<128, 9>, p2, grid, lds, x, dy, workspace, st, 512);
+    else
+      rc = ntaps == 1 ? launch_wg(wgrad2_kernel<64, 1>, p2, grid, lds, x, dy, workspace, st)
+                      : launch_wg(wgrad2_kernel<64, 9>, p2, grid, lds, x, dy, workspace, st);
+  } else {
+    WgP p;
+    rc = fill(d, &p);
+    if (rc != OCR_OK) return rc;
+    splits = p.splits;
+    if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
+    const size_t lds = (size_t)p.HT * p.WT * XSTR + 256 * DSTR;
+    const unsigned grid = (unsigned)(p.splits * p.nci * p.nco);
+    rc = ntaps == 1 ? launch_wg(wgrad_kernel<1>, p, grid, lds, x, dy, workspace, st)
+                    : launch_wg(wgrad_kernel<9>, p, grid, lds, x, dy, workspace, st);
+  }
   if (rc != OCR_OK) return rc;
   const size_t elems4 = elems / 4;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems4 + 255) / 256)), dim3(256), 0, st,
-                     static_cast<const float*>(workspace), static_cast<float*>(dw), elems4,
-                     p.splits);
+                     static_cast<const float*>(workspace), static_cast<float*>(dw), elems4, splits);
   return ocr_launch_status();
 }

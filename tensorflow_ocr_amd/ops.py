@@ -71,13 +71,13 @@ KERNEL_TIMING = None
 
 def conv2d_variant(d):
     """Which conv_igemm_kernel<BN,CK,WCO> instantiation the library picks (conv_igemm.hip)."""
-    bn = 128 if d.cout % 128 == 0 else 64
+    bn = 256 if d.cout % 256 == 0 else 128 if d.cout % 128 == 0 else 64
     ck = 64 if d.cin % 64 == 0 else 32
     ht = 7 * d.stride + (d.kh - 1) * d.dilation + 1
     wt = 31 * d.stride + (d.kw - 1) * d.dilation + 1
     if ck == 64 and ht * wt * (64 * 2 + 16) + 2 * bn * (64 * 2 + 16) > 160 * 1024:
         ck = 32
-    return "conv_igemm_kernel<%d,%d,%d>" % (bn, ck, 2 if bn == 128 else 1)
+    return "conv_igemm_kernel<%d,%d,%d>" % (bn, ck, 4 if bn == 256 else 2)
 
 
 def conv2d(d, x, w_kc, y, bias=None, stats=None):
