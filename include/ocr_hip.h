@@ -214,6 +214,7 @@ int ocr_momentum_step(void* w, const void* g, void* accum, void* ema, int64_t n,
                       int64_t n_regularized, float lr, float momentum, float weight_decay,
                       float inv_loss_scale, float ema_decay, void* stream);
 int ocr_scale_f32(void* x, int64_t n, float s, void* stream);
+int ocr_fill_f32(void* x, int64_t n, float value, void* stream);   /* n 4-byte words */
 
 #ifdef __cplusplus
 }

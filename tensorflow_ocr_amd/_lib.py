@@ -54,6 +54,36 @@ def check(status, what=""):
         raise OcrHipError("%s failed: %s (%d)" % (what or "ocr call", msg, status))
 
 
+class Recorder:
+    """Records the flat sequence of C-ABI calls (and host callbacks) of one training step so that
+    later steps replay it without re-running the Python graph logic: the step's shapes, buffers
+    and launch order are static, so the recorded (function, ctypes arguments) pairs stay valid as
+    long as every tensor they point to is kept alive (graph.Graph.keepalive)."""
+
+    def __init__(self):
+        self.entries = []     # ("c", fn, args, name, tag) | ("py", callable)
+
+    def c(self, fn, args, name):
+        self.entries.append(["c", fn, args, name, None])
+
+    def py(self, fn):
+        self.entries.append(["py", fn])
+
+    def tag_last(self, tag):
+        self.entries[-1][4] = tag
+
+
+RECORDER = None
+_fn_cache = {}
+_STREAM = None
+
+
+def set_stream(handle):
+    """Pin the stream pointer handed to every call (None: query torch each time)."""
+    global _STREAM
+    _STREAM = handle
+
+
 def ptr(t):
     """Device pointer of a torch tensor (or None -> NULL)."""
     if t is None:
@@ -62,33 +92,40 @@ def ptr(t):
 
 
 def stream_ptr():
+    if _STREAM is not None:
+        return _STREAM
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _fn(name, restype):
+    key = (name, restype)
+    fn = _fn_cache.get(key)
+    if fn is None:
+        fn = getattr(load(), name)
+        fn.restype = restype
+        _fn_cache[key] = fn
+    return fn
+
+
 def call(name, *args):
     """Call `ocr_<name>` and raise on a non-zero status."""
-    lib = load()
-    fn = getattr(lib, name)
-    fn.restype = ctypes.c_int
+    fn = _fn(name, ctypes.c_int)
     rc = fn(*args)
-    check(rc, name)
+    if rc != 0:
+        check(rc, name)
+    if RECORDER is not None:
+        RECORDER.c(fn, args, name)
     return rc
 
 
 def call_size(name, *args):
     """Call a `size_t`-returning query."""
-    lib = load()
-    fn = getattr(lib, name)
-    fn.restype = ctypes.c_size_t
-    return int(fn(*args))
+    return int(_fn(name, ctypes.c_size_t)(*args))
 
 
 def call_int(name, *args):
-    lib = load()
-    fn = getattr(lib, name)
-    fn.restype = ctypes.c_int
-    v = int(fn(*args))
+    v = int(_fn(name, ctypes.c_int)(*args))
     if v < 0:
         check(v, name)
     return v

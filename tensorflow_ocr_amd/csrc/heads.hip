@@ -392,7 +392,41 @@ static int small_wgrad_strips(int P) {
   return s;
 }
 
+namespace {
+// dz f32 [P][C] -> f16 [P][64] (zero padded): the N operand of the MFMA weight-gradient kernel
+__global__ void pad_dz_kernel(const float* __restrict__ dz, int P, int C, half_t* __restrict__ out) {
+  const size_t total = (size_t)P * 8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t p = i >> 3;
+    const int c0 = (int)(i & 7) * 8;
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((c0 + e < C) ? dz[p * C + c0 + e] : 0.f);
+    *reinterpret_cast<half8_t*>(out + i * 8) = o;
+  }
+}
+__global__ void take_cols_kernel(const float* __restrict__ in, int rows, int C, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * C) out[i] = in[(size_t)(i / C) * 64 + i % C];
+}
+}  // namespace
+
+// MFMA route: P % 32 == 0 and cin % 64 == 0 (the 1x1 weight gradient with cout padded to 64);
+// otherwise the VALU strip kernel.
+static bool small_wgrad_mfma(int P, int cin) { return P % 32 == 0 && cin % 64 == 0; }
+
+static ocr_conv_desc small_wgrad_desc(int P, int cin) {
+  ocr_conv_desc d = {1, P / 32, 32, cin, P / 32, 32, 64, 1, 1, 1, 1, 0, 0, 0, 0};
+  return d;
+}
+
+static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
 extern "C" size_t ocr_conv1x1_small_wgrad_workspace(int P, int cin, int cout) {
+  if (small_wgrad_mfma(P, cin)) {
+    ocr_conv_desc d = small_wgrad_desc(P, cin);
+    return al256((size_t)P * 64 * 2) + al256((size_t)cin * 64 * 4) + ocr_conv2d_wgrad_workspace(&d);
+  }
   return (size_t)small_wgrad_strips(P) * cin * cout * sizeof(float);
 }
 
@@ -400,8 +434,23 @@ extern "C" int ocr_conv1x1_small_wgrad_f16(const void* x, const void* dz_f32, in
                                            int cout, void* dw_f32, void* workspace, size_t ws_bytes,
                                            void* stream) {
   OCR_CHECK_ARG(x && dz_f32 && dw_f32 && workspace && P > 0);
+  OCR_CHECK_SHAPE(cout >= 1 && cout <= 32);
   if (ws_bytes < ocr_conv1x1_small_wgrad_workspace(P, cin, cout)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (small_wgrad_mfma(P, cin)) {
+    char* ws = static_cast<char*>(workspace);
+    half_t* dz16 = reinterpret_cast<half_t*>(ws);
+    float* dw64 = reinterpret_cast<float*>(ws + al256((size_t)P * 64 * 2));
+    char* slabs = ws + al256((size_t)P * 64 * 2) + al256((size_t)cin * 64 * 4);
+    hipLaunchKernelGGL(pad_dz_kernel, dim3(sgrid((size_t)P * 8)), dim3(256), 0, st,
+                       static_cast<const float*>(dz_f32), P, cout, dz16);
+    ocr_conv_desc d = small_wgrad_desc(P, cin);
+    int rc = ocr_conv2d_wgrad_f16(&d, x, dz16, dw64, slabs, ocr_conv2d_wgrad_workspace(&d), stream);
+    if (rc != OCR_OK) return rc;
+    hipLaunchKernelGGL(take_cols_kernel, dim3(ocr_cdiv(cin * cout, 256)), dim3(256), 0, st, dw64, cin,
+                       cout, static_cast<float*>(dw_f32));
+    return ocr_launch_status();
+  }
   const int S = small_wgrad_strips(P);
   const int strip = ocr_cdiv(P, S);
   dim3 grid(S, ocr_cdiv(cin, 256));

@@ -99,6 +99,11 @@ __global__ void scale_kernel(float* __restrict__ x, long long n, float s) {
     x[i] *= s;
 }
 
+__global__ void fill_kernel(float* __restrict__ x, long long n, float v) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    x[i] = v;
+}
+
 unsigned ogrid(long long n) {
   long long b = (n + 255) / 256;
   if (b > 4096) b = 4096;
@@ -155,5 +160,12 @@ extern "C" int ocr_scale_f32(void* x, int64_t n, float s, void* stream) {
   OCR_CHECK_ARG(x && n > 0);
   hipLaunchKernelGGL(scale_kernel, dim3(ogrid(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<float*>(x), (long long)n, s);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_fill_f32(void* x, int64_t n, float value, void* stream) {
+  OCR_CHECK_ARG(x && n > 0);
+  hipLaunchKernelGGL(fill_kernel, dim3(ogrid(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<float*>(x), (long long)n, value);
   return ocr_launch_status();
 }

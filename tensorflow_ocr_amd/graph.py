@@ -147,7 +147,7 @@ class Graph:
         self.ws = None
         self.ws_small = None
         self.collections = {"losses": [], "update_ops": []}
-        self.building = True
+        self.keepalive = None        # list while a step is being recorded (train.TrainStep)
 
     # --- scopes / variables (tf.variable_scope, tf.get_variable) ---
     @contextlib.contextmanager
@@ -174,10 +174,18 @@ class Graph:
         return self.ws
 
     def empty(self, shape, dtype=F16):
-        return torch.empty(shape, dtype=dtype, device=self.device)
+        t = torch.empty(shape, dtype=dtype, device=self.device)
+        if self.keepalive is not None:
+            self.keepalive.append(t)
+        return t
 
     def zeros(self, shape, dtype=F32):
-        return torch.zeros(shape, dtype=dtype, device=self.device)
+        """Zero-filled scratch.  NOT replay-safe inside a recorded step (the fill is a torch op):
+        ops that need zeros on every step must clear through a recorded kernel."""
+        t = torch.zeros(shape, dtype=dtype, device=self.device)
+        if self.keepalive is not None:
+            self.keepalive.append(t)
+        return t
 
     def ensure_materialised(self):
         self.store.materialise()
@@ -200,10 +208,13 @@ class Graph:
         """Run the tape in reverse (the loss op seeds its own gradient).  `on_grads_ready(vars)` is
         called as soon as a closure has finished a set of parameter gradients — the hook the
         data-parallel all-reduce uses to overlap communication with the rest of backward."""
+        from . import _lib
         for fn, produces in reversed(self.tape):
             fn()
             if on_grads_ready is not None and produces:
                 on_grads_ready(produces)
+                if _lib.RECORDER is not None:
+                    _lib.RECORDER.py(lambda pr=produces: on_grads_ready(pr))
         self.tape.clear()
 
     def reset_tape(self):

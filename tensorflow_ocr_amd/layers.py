@@ -112,7 +112,8 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
             if da_full is None and da_pool is None:
                 return
             if pool and da_pool is None:
-                da_pool = torch.zeros_like(a_pool.data)
+                da_pool = g.empty(a_pool.data.shape)
+                ops.fill_(da_pool, 0.0)
             if not pool and da_full is None:
                 return
             dy = g.empty(y.shape)
@@ -331,7 +332,8 @@ def pointwise_bn(g, x, xo, c, scope, is_training=True, relu=True):
         ops.sc_bn_bwd(z, scale, shift, mean, invstd, out.grad, relu, gamma.grad, beta.grad, dz, ws)
         ops.sc_pointwise_wgrad(x.data, xo, c, dz, 0, c, wv.grad, None, ws)
         if x.grad is None:
-            x.grad = g.zeros(x.data.shape, F32)
+            x.grad = g.empty(x.data.shape, F32)
+            ops.fill_(x.grad, 0.0)
         ops.sc_pointwise_dgrad(dz, 0, c, wv.data, x.grad, xo, c)
         out.grad = None
     g.record(backward, (wv, gamma, beta))

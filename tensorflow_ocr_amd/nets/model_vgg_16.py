@@ -86,7 +86,7 @@ def loss(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mask, gr
     1-channel labels against 2-/16-channel predictions included.  Records the backward seed."""
     g = graph or get_default_graph()
     ytp, ytl, m = _to_device(g, y_true_pixel), _to_device(g, y_true_link), _to_device(g, training_mask)
-    sums, out = g.zeros((27,)), g.zeros((10,))
+    sums, out = g.empty((27,), F32), g.empty((10,), F32)      # fully written by the finalize kernel
     ops.dice_loss_fwd(ytp, y_pred_pixel.data, ytl, y_pred_link.data, m, sums, out, g.workspace())
 
     def backward():

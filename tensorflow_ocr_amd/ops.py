@@ -81,15 +81,17 @@ def conv2d_variant(d):
 
 
 def conv2d(d, x, w_kc, y, bias=None, stats=None):
+    flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
     if KERNEL_TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.call("ocr_conv2d_f16", byref(d), ptr(x), ptr(w_kc), ptr(bias), ptr(y), ptr(stats), _st())
         e1.record()
-        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
         KERNEL_TIMING.append((conv2d_variant(d), flops, e0, e1))
-        return
-    L.call("ocr_conv2d_f16", byref(d), ptr(x), ptr(w_kc), ptr(bias), ptr(y), ptr(stats), _st())
+    else:
+        L.call("ocr_conv2d_f16", byref(d), ptr(x), ptr(w_kc), ptr(bias), ptr(y), ptr(stats), _st())
+    if L.RECORDER is not None:
+        L.RECORDER.tag_last((conv2d_variant(d), flops))
 
 
 def conv2d_wgrad(d, x, dy, dw, ws):
@@ -303,3 +305,10 @@ def momentum_step(w, g, acc, ema, n_reg, lr, momentum, wd, inv_scale, ema_decay)
 
 def scale_(x, s):
     L.call("ocr_scale_f32", ptr(x), c_int64(x.numel()), c_float(s), _st())
+
+
+def fill_(x, value=0.0):
+    """Fill a 4-byte-element tensor (or an even-length f16 tensor, value 0 only) with `value`."""
+    nbytes = x.numel() * x.element_size()
+    assert nbytes % 4 == 0 and (x.element_size() == 4 or value == 0.0)
+    L.call("ocr_fill_f32", ptr(x), c_int64(nbytes // 4), c_float(value), _st())

@@ -102,9 +102,17 @@ class MomentumOptimizer:
 class TrainStep:
     """One data-parallel training step of `multigpu_train.py`'s hot loop (:118-142,171-174) for
     this process's tower: forward -> loss -> backward (gradient buckets all-reduced while the rest
-    of backward runs) -> optimiser + EMA.  `model_fn(images) -> preds`, `loss_fn(labels..., preds)`."""
+    of backward runs) -> optimiser + EMA.
 
-    def __init__(self, graph, forward_loss, optimizer_factory, world_size=1, bucket_bytes=32 << 20):
+    `forward_loss(graph, *batch) -> loss`.  The step has static shapes, buffers and launch order,
+    so after two eager steps (variable creation, optimiser creation) the third is RECORDED as a
+    flat list of C-ABI calls (`_lib.Recorder`) and every later step REPLAYS that list: the Python
+    graph/tape logic, ~700 ctypes marshalling round trips and all per-step allocations disappear
+    from the hot loop (the host was the bottleneck at ~40 ms/step).  New input data is copied into
+    the recorded input buffers; `replay=False` keeps every step eager."""
+
+    def __init__(self, graph, forward_loss, optimizer_factory, world_size=1, bucket_bytes=32 << 20,
+                 replay=True):
         self.g = graph
         self.forward_loss = forward_loss
         self.optimizer_factory = optimizer_factory
@@ -112,16 +120,75 @@ class TrainStep:
         self.bucket_bytes = bucket_bytes
         self.opt = None
         self.reducer = None
+        self.replay = replay
+        self.steps = 0
+        self.plan = None
+        self.static_batch = None
+        self.loss = None
 
-    def __call__(self, *batch):
+    # -- eager / recording path --------------------------------------------------------------
+    def _eager(self, batch, record):
+        from . import _lib
         g = self.g
         g.reset_tape()
-        loss = self.forward_loss(g, *batch)
-        if self.opt is None:
-            from .dist import GradientAllReduce
-            self.opt = self.optimizer_factory(g)           # materialises the flat buffers
-            self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, fold_mean=True)
-        g.backward(self.reducer.on_grads_ready if self.world > 1 else None)
+        if record:
+            rec = _lib.Recorder()
+            _lib.RECORDER = rec
+            g.keepalive = []
+        try:
+            loss = self.forward_loss(g, *batch)
+            if self.opt is None:
+                from .dist import GradientAllReduce
+                self.opt = self.optimizer_factory(g)           # materialises the flat buffers
+                self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, fold_mean=True)
+            g.backward(self.reducer.on_grads_ready if self.world > 1 else None)
+        finally:
+            _lib.RECORDER = None
         self.reducer.finish()
         self.opt.apply_gradients(self.reducer.grad_scale)
+        if record:
+            rec.py(self.reducer.finish)
+            rec.py(lambda: self.opt.apply_gradients(self.reducer.grad_scale))
+            self.plan = rec.entries
+            self.static_batch = list(batch)
+            self.keepalive, g.keepalive = g.keepalive, None
+            g.reset_tape()
+        self.loss = loss
         return loss
+
+    def _replay(self, batch):
+        from . import ops
+        for dst, src in zip(self.static_batch, batch):
+            if src is not dst:
+                dst.copy_(src, non_blocking=True)
+        timing = ops.KERNEL_TIMING
+        if timing is None:
+            for e in self.plan:
+                if e[0] == "c":
+                    rc = e[1](*e[2])
+                    if rc != 0:
+                        from . import _lib
+                        _lib.check(rc, e[3])
+                else:
+                    e[1]()
+        else:
+            for e in self.plan:
+                if e[0] == "c":
+                    if e[4] is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        e[1](*e[2])
+                        e1.record()
+                        timing.append((e[4][0], e[4][1], e0, e1))
+                    else:
+                        e[1](*e[2])
+                else:
+                    e[1]()
+        return self.loss
+
+    def __call__(self, *batch):
+        self.steps += 1
+        if self.plan is not None:
+            return self._replay(batch)
+        # step 1 creates variables, step 2 runs with the flat buffers; step 3 is steady state
+        return self._eager(batch, record=self.replay and self.steps >= 3)

@@ -139,7 +139,7 @@ def test_heads_and_dice(device):
     from tensorflow_ocr_amd.graph import Act, Graph
     from tensorflow_ocr_amd.nets import model_vgg_16 as M
     rng = np.random.default_rng(4)
-    n, h = 2, 6
+    n, h = 2, 8       # fc7..conv4_3 take the MFMA weight-gradient route, conv3_3 (cin 32) the VALU one
     chans = {"fc7": 128, "conv5_3": 64, "conv4_3": 64, "conv3_3": 32}
     sizes = {"fc7": h, "conv5_3": h, "conv4_3": 2 * h, "conv3_3": 4 * h}
     feats = {k: _h(np.abs(rng.standard_normal((n, sizes[k], sizes[k], c)))) for k, c in chans.items()}
