@@ -13,3 +13,4 @@ extern "C" const char* ocr_status_string(int status) {
     default: return "unknown status";
   }
 }
+

@@ -41,3 +41,17 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// out[i] = scale * sum_{s<S} partial[s*elems + i]: one wave per output element (64 row lanes),
+// fixed summation order -> reproducible.  Launch with sum_rows_grid(elems) blocks of 256.
+static __global__ void ocr_sum_rows_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                           int elems, int S, float scale) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= elems) return;
+  float a = 0.f;
+  for (int s = lane; s < S; s += 64) a += partial[(size_t)s * elems + i];
+  a = wave_sum(a);
+  if (lane == 0) out[i] = a * scale;
+}
+static inline unsigned sum_rows_grid(int elems) { return (unsigned)((elems + 3) / 4); }

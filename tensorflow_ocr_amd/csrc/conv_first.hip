@@ -89,17 +89,40 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstP p, const half_t*
 }
 
 // ---- weight gradient -------------------------------------------------------
+// MFMA form: M = 32 patch rows (27 used: (ky*3+kx)*3+c), N = 64 couts, K = pixels.  Per 8x32
+// tile the 256 patch rows are built in LDS from the halo ([px][32] f16, row stride padded to
+// 128 B so the transposing reads are conflict-free) next to the dy tile; both MFMA operands come
+// from ds_read_b64_tr_b16.  The kernel is bound by streaming dy (128 B per pixel).
+typedef short short4v_f __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) short4v_f* lds_s4_ptr_f;
+
+__device__ __forceinline__ half8_t tr_pair_f(const char* base, int second_off) {
+  short4v_f lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr_f)(base));
+  short4v_f hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr_f)(base + second_off));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  short8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(half8_t, v);
+}
+
+constexpr int PSTRF = 64;        // bytes per im2col row (32 f16): 16 dwords -> tr reads conflict-free
+constexpr int DSTRF = 64 * 2 + 64;  // bytes per dy row
+
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const half_t* __restrict__ x4,
                                                                const half_t* __restrict__ dy,
                                                                float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) char halo[10 * HW * 8];
-  __shared__ __attribute__((aligned(16))) half_t dyt[256 * 64];
-  __shared__ float red[4 * 27 * 64];
-  const int tid = threadIdx.x, co = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) char patch[256 * PSTRF];
+  __shared__ __attribute__((aligned(16))) char dyt[256 * DSTRF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int q = li >> 2, pp = li & 3, hh = g >> 1, gc = g & 1;
   const int co0 = blockIdx.y * 64;
-  float acc[27];
+  const int cow = wave & 1, kw = wave >> 1;   // 2 co tiles x 2 K halves
+  f32x16 acc;
 #pragma unroll
-  for (int j = 0; j < 27; ++j) acc[j] = 0.f;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int a_lane = (8 * hh + q) * PSTRF + (16 * gc + 4 * pp) * 2;
+  const int b_lane = (8 * hh + q) * DSTRF + (cow * 32 + 16 * gc + 4 * pp) * 2;
 
   for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
     const int txi = mt % p.tiles_x;
@@ -116,31 +139,46 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
       u32x4 v = {0u, 0u, 0u, 0u};
       if (oy < p.h && ox < p.w)
         v = *reinterpret_cast<const u32x4*>(dy + (((size_t)img * p.h + oy) * p.w + ox) * p.cout + co0 + c * 8);
-      *reinterpret_cast<u32x4*>(dyt + px * 64 + c * 8) = v;
+      *reinterpret_cast<u32x4*>(dyt + px * DSTRF + c * 16) = v;
     }
     __syncthreads();
-    for (int pl = 0; pl < 64; ++pl) {
-      const int px = wave * 64 + pl;
-      const int ty = px >> 5, tx = px & 31;
-      const float d = (float)dyt[px * 64 + co];
+    {  // im2col row of this thread's pixel: 27 values, k = (ky*3+kx)*3 + c, zero padded to 32
+      const int ty = tid >> 5, tx = tid & 31;
+      half_t row[32];
+#pragma unroll
+      for (int k = 27; k < 32; ++k) row[k] = (half_t)0.f;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           half4_t xv = *reinterpret_cast<const half4_t*>(halo + ((ty + ky) * HW + tx + kx) * 8);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) acc[(ky * 3 + kx) * 3 + c] += (float)xv[c] * d;
+          for (int c = 0; c < 3; ++c) row[(ky * 3 + kx) * 3 + c] = xv[c];
         }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        half8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = row[k * 8 + e];
+        *reinterpret_cast<half8_t*>(patch + tid * PSTRF + k * 16) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k0 = (kw * 8 + s) * 16;     // this wave's 16-pixel k-step
+      half8_t a = tr_pair_f(patch + a_lane + k0 * PSTRF, 4 * PSTRF);
+      half8_t b = tr_pair_f(dyt + b_lane + k0 * DSTRF, 4 * DSTRF);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
     }
   }
+  // partial[blk][kw][27][cout]: the two K halves are separate partial rows
+  const int r = lane & 31, h2 = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < 27; ++j) red[(wave * 27 + j) * 64 + co] = acc[j];
-  __syncthreads();
-  for (int i = tid; i < 27 * 64; i += 256) {
-    const int j = i >> 6, c2 = i & 63;
-    float v = red[(0 * 27 + j) * 64 + c2] + red[(1 * 27 + j) * 64 + c2] +
-              red[(2 * 27 + j) * 64 + c2] + red[(3 * 27 + j) * 64 + c2];
-    partial[((size_t)blockIdx.x * 27 + j) * p.cout + co0 + c2] = v;
+  for (int e = 0; e < 16; ++e) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * h2;
+    if (row < 27)
+      partial[(((size_t)blockIdx.x * 2 + kw) * 27 + row) * p.cout + co0 + cow * 32 + r] = acc[e];
   }
 }
 
@@ -163,7 +201,7 @@ __global__ void pack_first_kernel(const float* __restrict__ w, half_t* __restric
   out[i] = (half_t)v;
 }
 
-int wgrad_blocks(int m_tiles) { return m_tiles < 1024 ? m_tiles : 1024; }
+int wgrad_blocks(int m_tiles) { return m_tiles < 256 ? m_tiles : 256; }
 
 int fill(FirstP* p, int n, int h, int w, int cout, int flags) {
   OCR_CHECK_ARG(n > 0 && h > 0 && w > 0);
@@ -209,7 +247,7 @@ extern "C" int ocr_conv2d_first_f16(int n, int h, int w, int cout, const void* x
 
 extern "C" size_t ocr_conv2d_first_wgrad_workspace(int n, int h, int w, int cout) {
   const int mt = ocr_conv2d_first_num_mtiles(n, h, w);
-  return (size_t)wgrad_blocks(mt) * 27 * cout * sizeof(float);
+  return (size_t)wgrad_blocks(mt) * 2 * 27 * cout * sizeof(float);
 }
 
 extern "C" int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const void* x4,
@@ -226,7 +264,7 @@ extern "C" int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const v
                      static_cast<const half_t*>(x4), static_cast<const half_t*>(dy),
                      static_cast<float*>(workspace));
   const int elems = 27 * cout;
-  hipLaunchKernelGGL(first_reduce_kernel, dim3(ocr_cdiv(elems, 256)), dim3(256), 0, st,
-                     static_cast<const float*>(workspace), static_cast<float*>(dw), elems, blocks);
+  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(elems)), dim3(256), 0, st,
+                     static_cast<const float*>(workspace), static_cast<float*>(dw), elems, blocks * 2, 1.f);
   return ocr_launch_status();
 }

@@ -467,7 +467,7 @@ extern "C" int ocr_conv1x1_small_wgrad_f16(const void* x, const void* dz_f32, in
     default: return OCR_ERR_UNSUPPORTED;
   }
   const int elems = cin * cout;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(ocr_cdiv(elems, 256)), dim3(256), 0, st, ws,
+  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(elems)), dim3(256), 0, st, ws,
                      static_cast<float*>(dw_f32), elems, S, 1.f);
   return ocr_launch_status();
 }
@@ -528,7 +528,7 @@ extern "C" int ocr_sc_bn_bwd(const void* z, const void* scale, const void* shift
                      P, C, relu, 0.f, static_cast<float*>(partial), (float*)nullptr);
   // partial [T][2][C]: sum rows into dbeta / dgamma (T <= 1024, tiny)
   float* part = static_cast<float*>(partial);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, part,
+  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(2 * C)), dim3(256), 0, st, part,
                      part + (size_t)T * 2 * C, 2 * C, T, 1.f);
   if (hipMemcpyAsync(dbeta, part + (size_t)T * 2 * C, C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
       hipMemcpyAsync(dgamma, part + (size_t)T * 2 * C + C, C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -581,7 +581,7 @@ extern "C" int ocr_sc_pointwise_wgrad(const void* x, int ldx, int xo, int cin, c
   hipLaunchKernelGGL(sc_pointwise_wgrad_kernel, dim3(B), dim3(256), 0, st,
                      static_cast<const float*>(x), ldx, xo, cin, static_cast<const float*>(dout),
                      ldo, oo, cout, P, ocr_cdiv(P, B), ws);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(ocr_cdiv(pairs, 256)), dim3(256), 0, st, ws, tot,
+  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(pairs)), dim3(256), 0, st, ws, tot,
                      pairs, B, 1.f);
   if (hipMemcpyAsync(dw, tot, (size_t)cin * cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
     return OCR_ERR_HIP;
