@@ -143,6 +143,12 @@ int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void* shift, con
                         int h, int w, int c, int relu, int pool, void* dgamma, void* dbeta, void* dy,
                         void* partial, void* workspace, size_t ws_bytes, void* stream);
 
+/* Backward of slim.conv2d's bias + ReLU (nets/pixellink.py:41-48): dz = da * [a > 0] (a = stored
+ * conv output), dbias [c] = column sums.  partial: f32 [ocr_bias_relu_bwd_num_partials][c]. */
+int ocr_bias_relu_bwd_num_partials(int64_t npix, int c);
+int ocr_bias_relu_bwd_f16(const void* a, const void* da, int64_t npix, int c, int relu, void* dz,
+                          void* dbias, void* partial, void* stream);
+
 /* slim.max_pool2d k x k / stride SAME as a standalone op (pool5 3x3/1 nets/vgg.py:32; ResNet
  * pool1 3x3/2 nets/resnet_v1.py:194; subsample 1x1/s nets/resnet_utils.py:74), f16 NHWC. */
 int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k, int stride, int pad_top,
@@ -176,6 +182,8 @@ int ocr_sc_unpool_bwd(const void* dout, int n, int lh, int lw, int C, void* dpre
 int ocr_sc_bn_bwd(const void* z, const void* scale, const void* shift, const void* save_mean,
                   const void* save_invstd, const void* dout, int P, int C, int relu, void* dgamma,
                   void* dbeta, void* dz, void* partial, void* stream);
+/* out[c] = sum_p x[p][c]; partial: (ocr_sc_num_partials + 1) * 2 * C floats */
+int ocr_sc_colsum(const void* x, int P, int C, void* out, void* partial, void* stream);
 /* pointwise f32 conv on channel slices: out[p][oo+co] = b[co] + sum_ci x[p][xo+ci] w[ci][co] */
 int ocr_sc_pointwise_fwd(const void* x, int ldx, int xo, int cin, const void* w, const void* bias,
                          int P, void* out, int ldo, int oo, int cout, void* stream);
@@ -200,6 +208,58 @@ int ocr_dice_loss_fwd(const void* y_true_pixel, const void* y_pred_pixel, int pc
 int ocr_dice_loss_bwd(const void* y_true_pixel, int pc, const void* y_true_link, int G,
                       const void* training_mask, int P, const void* sums27, float grad_scale,
                       void* d_pred_pixel, void* d_pred_link, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Softmax cross-entropy losses with online hard negative mining / focal links.
+ *   pixel_rule 0: nets/model.py:204-261 `loss` (OHNM: per image the k = min(neg_ratio*n_pos,
+ *                 n_neg) negatives with the smallest P(neg), tie-inclusive; pixel term
+ *                 sum(CE*selected)/n_pos_batch, 0 without positives)
+ *   pixel_rule 1: nets/model_vgg_16.py:243-282 `ohem_loss` (positives only)
+ *   pixel_rule 2: nets/pixellink.py:88-263 `PixelLinkNet.build_loss` (mean over all pixels)
+ *   label_rule 0: pos = (label == 1), neg = (label == 0);  1: pos = (label > 0), neg = !pos
+ *   link_gate  1: link weights times the selected pixel mask, unguarded division (model.py);
+ *              0: ungated, zero-guarded (pixellink.py:198-212)
+ *   focal      1: link CE -> -alpha_t (1-p_t)^gamma log p_t (build-defined)
+ * total = sum_8 link_i + 2*pixel.  Tensors f32: pixel_logits [n][hw][2], link_logits
+ * [n][hw][16], pixel_labels [n][hw], link_labels [n][hw][8].  Outputs: ohnm_threshold [n],
+ * sums34, loss10 = [total, pixel, link_0..7].
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n, hw;
+  int32_t pixel_rule, label_rule, link_gate, focal;
+  float neg_ratio, alpha, gamma;
+} ocr_softmax_loss_desc;
+size_t ocr_softmax_loss_workspace(const ocr_softmax_loss_desc* d);
+int ocr_softmax_loss_fwd(const ocr_softmax_loss_desc* d, const void* pixel_logits,
+                         const void* link_logits, const void* pixel_labels, const void* link_labels,
+                         void* ohnm_threshold, void* sums34, void* loss10, void* workspace,
+                         size_t ws_bytes, void* stream);
+int ocr_softmax_loss_bwd(const ocr_softmax_loss_desc* d, const void* pixel_logits,
+                         const void* link_logits, const void* pixel_labels, const void* link_labels,
+                         const void* ohnm_threshold, const void* sums34, float grad_scale,
+                         void* d_pixel_logits, void* d_link_logits, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * PixelLink decode (test_pixellink_fast.py:53-64,110-178; tool/pixellink_fn.py:120-158).
+ * ------------------------------------------------------------------------- */
+/* softmax over [pairs][2] (slim.softmax(pixel_cls), nets/pixellink.py:71) */
+int ocr_softmax_pairs(const void* logits, int64_t pairs, void* probs, void* stream);
+/* link_logits [m][16] -> [8][m][2]: tf.stack of the eight per-direction softmaxes */
+int ocr_link_softmax_stack(const void* link_logits, int64_t m, void* out, void* stream);
+/* pixel_detect: score_map [n,h,w,1], link_scores [8,n,h,w,2] -> uint8 [h,w] for batch element 0:
+ * score > score_map_thresh and every link[i,0,y,x,1] >= link_thresh */
+int ocr_pixel_detect(const void* score_map, const void* link_scores, int n, int h, int w,
+                     float score_map_thresh, float link_thresh, void* mask_u8, void* stream);
+/* Link-gated connected components, batched.  pixel_score [n,h,w]; link_score element
+ * (d, img, y, x) at ((d*n+img)*h*w + y*w+x)*link_elem_stride + link_elem_offset.  Outputs: labels
+ * int32 [n,h,w] (0 = background, dense ids 1..K in ascending order of each component's smallest
+ * pixel index, only components with more than min_size pixels), ncomp [n], comps
+ * [n][max_comps][2] = (smallest pixel index, size). */
+size_t ocr_link_cc_workspace(int n, int h, int w);
+int ocr_link_cc(const void* pixel_score, const void* link_score, int link_elem_stride,
+                int link_elem_offset, int n, int h, int w, float pixel_thresh, float link_thresh,
+                int min_size, void* labels_i32, void* ncomp_i32, void* comps_i32, int max_comps,
+                void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Optimisers over the flat parameter buffer: elements [0, n_regularized) also get

@@ -380,3 +380,238 @@ def synthetic_batch(rng, n, size, rects=8):
         link[..., d] = ((ids > 0) & same).astype(np.float32)
     mask = np.ones((n, q4, q4, 1), np.float32)
     return images, pixel, link, mask
+
+
+# ------------------------------------------------------- softmax / OHNM / focal losses
+def _ce2(logits, labels):
+    """tf.nn.sparse_softmax_cross_entropy_with_logits for 2 classes; logits [..., 2], labels int."""
+    lse = torch.logsumexp(logits, dim=-1)
+    return lse - torch.gather(logits, -1, labels.long().unsqueeze(-1)).squeeze(-1)
+
+
+def ohnm_single_image(scores, n_pos, neg_mask, ratio=3):
+    """nets/model.py:161-184.  scores: P(neg) per pixel (numpy 1-D), neg_mask bool.
+    Returns the selected-negative mask (float).  n_pos > 0 with no negatives raises in TF
+    (vals[-1] of an empty top_k); the build returns an empty selection."""
+    if n_pos <= 0:
+        return np.zeros_like(scores, dtype=np.float32)
+    n_neg = int(min(n_pos * ratio, int(neg_mask.sum())))
+    if n_neg <= 0:
+        return np.zeros_like(scores, dtype=np.float32)
+    neg_conf = scores[neg_mask]
+    vals = np.sort(-neg_conf)[::-1][:n_neg]          # tf.nn.top_k(-neg_conf, k): descending
+    threshold = vals[-1]
+    return (neg_mask & (scores <= -threshold)).astype(np.float32)
+
+
+def ohnm_batch(neg_scores, pos_mask, neg_mask, ratio=3):
+    """nets/model.py:186-197 (batch size from the tensor, not the constant 14)."""
+    sel = [ohnm_single_image(neg_scores[b], int(pos_mask[b].sum()), neg_mask[b], ratio)
+           for b in range(neg_scores.shape[0])]
+    return pos_mask.astype(np.float32) + np.stack(sel)
+
+
+def model_loss_ohnm(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mask=None):
+    """nets/model.py:204-261 (`loss`, the one multigpu_train.py:32 calls).  training_mask is unused
+    by the reference.  Returns (total, pixel_term, link_terms[8], selected_mask)."""
+    n = y_pred_pixel.shape[0]
+    label = y_true_pixel.reshape(n, -1)
+    pred = y_pred_pixel.reshape(n, -1, 2)
+    scores = torch.softmax(pred, dim=-1)[..., 0].detach().numpy()
+    pos = (label == 1).numpy()
+    neg = (label == 0).numpy()
+    sel = torch.from_numpy(ohnm_batch(scores, pos, neg))
+    n_seg_pos = float(pos.sum())
+    ce = _ce2(pred, label)
+    cls = (ce * sel).sum() / n_seg_pos if n_seg_pos > 0 else torch.tensor(0.0)
+    w_pixel = sel.reshape(-1)
+    links = []
+    for i in range(8):
+        ll = y_true_link[..., i].reshape(-1)
+        lp = y_pred_link[..., 2 * i:2 * i + 2].reshape(-1, 2)
+        lce = _ce2(lp, ll)
+        wp = (ll == 1).float() * w_pixel
+        wn = (ll == 0).float() * w_pixel
+        links.append((lce * wp).sum() / wp.sum() + (lce * wn).sum() / wn.sum())
+    total = sum(links) + 2 * cls
+    return total, cls, links, sel
+
+
+def ohem_loss(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mask=None):
+    """nets/model_vgg_16.py:243-282 (+ cal_link_loss :227-241): positives-only weights."""
+    label = y_true_pixel.reshape(-1)
+    pred = y_pred_pixel.reshape(-1, 2)
+    w = (label == 1).float()
+    l_pixel = (_ce2(pred, label) * w).sum() / w.sum()
+    links = []
+    for i in range(8):
+        ll = y_true_link[..., i].reshape(-1)
+        lp = y_pred_link[..., 2 * i:2 * i + 2].reshape(-1, 2)
+        lce = _ce2(lp, ll)
+        wp = (ll == 1).float() * w
+        wn = (ll == 0).float() * w
+        links.append((lce * wp).sum() / wp.sum() + (lce * wn).sum() / wn.sum())
+    return l_pixel * 2 + sum(links), l_pixel, links
+
+
+def pixellink_build_loss(pixel_cls, link_cls, pixel_labels, link_labels, focal=None):
+    """nets/pixellink.py:88-263: the two LOSSES entries (2*mean pixel CE, link total).
+    focal=(alpha, gamma) swaps the link CE for the focal loss (build-defined)."""
+    seg_pos = (pixel_labels > 0)
+    pixel_cls_loss = _ce2(pixel_cls.reshape(-1, 2), seg_pos.reshape(-1)).mean()
+    links = []
+    for i in range(8):
+        logits = link_cls[..., 2 * i:2 * i + 2].reshape(-1, 2)
+        lab = (link_labels[..., i] > 0).reshape(-1)
+        if focal is None:
+            l = _ce2(logits, lab)
+        else:
+            alpha, gamma = focal
+            logp = torch.log_softmax(logits, dim=-1).gather(-1, lab.long().unsqueeze(-1)).squeeze(-1)
+            p = logp.exp()
+            a = torch.where(lab, torch.tensor(alpha), torch.tensor(1.0 - alpha))
+            l = -a * (1 - p) ** gamma * logp
+        pw, nw = lab.float(), (~lab).float()
+        pn, nn = pw.sum(), nw.sum()
+        pos_l = (l * pw).sum() / pn if pn > 0 else torch.tensor(0.0)
+        neg_l = (l * nw).sum() / nn if nn > 0 else torch.tensor(0.0)
+        links.append(pos_l + neg_l)
+    return pixel_cls_loss * 2, sum(links), links
+
+
+# ------------------------------------------------------------------------------ decode
+LINK_OFFSETS = [(-1, 0), (-1, 1), (-1, -1), (1, 0), (1, 1), (1, -1), (0, -1), (0, 1)]   # (dx, dy), §3.4
+
+
+def pixel_detect(score_map, geo_map, score_map_thresh=0.8, link_thresh=0.8):
+    """tool/pixellink_fn.py:120-154.  score_map [N,h,w,1], geo_map [8,N,h,w,2] -> uint8 [h,w] of batch
+    element 0: score > thr and, for every direction, NOT (link[...,1] < link_thresh)."""
+    score = np.asarray(score_map)
+    geo = np.asarray(geo_map)
+    if score.ndim == 4:
+        score = score[0, :, :, 0]
+        geo = geo[:, 0]
+    res = (score > score_map_thresh).astype(np.uint8)
+    for i in range(8):
+        res[geo[i, :, :, 1] < link_thresh] = 0
+    return res
+
+
+def link_cc_reference_dfs(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, min_size=10):
+    """Literal restatement of test_pixellink_fast.py:110-178 for one map: neighbour graph of the
+    INTERIOR pixels, directed-edge DFS, keep components with len > min_size.  Python-2 dict order is
+    replaced by ascending key order.  Returns int32 labels [h,w] (gid from 1)."""
+    h, w = pixel_score.shape
+    seg = pixel_score > pixel_thresh
+    graph = {}
+    for x in range(1, w - 1):
+        for y in range(1, h - 1):
+            if seg[y, x]:
+                nb = []
+                for d, (dx, dy) in enumerate(LINK_OFFSETS):
+                    if link_scores[d][y, x] > link_thresh and seg[y + dy, x + dx]:
+                        nb.append((y + dy) * w + x + dx)
+                graph[y * w + x] = nb
+    group = np.zeros(h * w, np.int32)
+    gid = 1
+    for key in sorted(graph.keys()):
+        if group[key] != 0:
+            continue
+        stack, label, seen = [key], [], set()
+        while stack:
+            v = stack.pop()
+            if v not in seen:
+                seen.add(v)
+                label.append(v)
+                for e in graph.get(v, []):
+                    if group[e] == 0:
+                        stack.append(e)
+        if len(label) > min_size:
+            group[label] = gid
+            gid += 1
+    return group.reshape(h, w)
+
+
+def link_cc_union(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, min_size=10):
+    """Weakly-connected components of the same graph (every directed edge joins its two pixels),
+    dense ids in ascending order of each component's smallest pixel index — what the HIP kernel
+    computes.  Equals link_cc_reference_dfs whenever the link predictions are symmetric."""
+    h, w = pixel_score.shape
+    seg = pixel_score > pixel_thresh
+    parent = np.arange(h * w)
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+    for y in range(1, h - 1):
+        for x in range(1, w - 1):
+            if not seg[y, x]:
+                continue
+            for d, (dx, dy) in enumerate(LINK_OFFSETS):
+                if link_scores[d][y, x] > link_thresh and seg[y + dy, x + dx]:
+                    a, b = find(y * w + x), find((y + dy) * w + x + dx)
+                    if a != b:
+                        parent[max(a, b)] = min(a, b)
+    roots = np.array([find(i) if seg.flat[i] else -1 for i in range(h * w)])
+    labels = np.zeros(h * w, np.int32)
+    comps = []
+    for r in sorted(set(roots[roots >= 0])):
+        members = np.nonzero(roots == r)[0]
+        if len(members) > min_size:
+            comps.append((int(r), len(members)))
+            labels[members] = len(comps)
+    return labels.reshape(h, w), comps
+
+
+def synthetic_decode_maps(rng, n, q4, strength=3.0):
+    """SURVEY §8d decode inputs: logits = N(0,1) + 2*(label-0.5)*strength from rectangle labels."""
+    _, pixel, link, _ = synthetic_batch(rng, n, q4 * 4)
+    pl = np.zeros((n, q4, q4, 2), np.float32)
+    pl[..., 1] = rng.standard_normal((n, q4, q4)) + 2 * (pixel[..., 0] - 0.5) * strength
+    pl[..., 0] = rng.standard_normal((n, q4, q4)) - 2 * (pixel[..., 0] - 0.5) * strength
+    ll = np.zeros((n, q4, q4, 16), np.float32)
+    for d in range(8):
+        ll[..., 2 * d + 1] = rng.standard_normal((n, q4, q4)) + 2 * (link[..., d] - 0.5) * strength
+        ll[..., 2 * d] = rng.standard_normal((n, q4, q4)) - 2 * (link[..., d] - 0.5) * strength
+    return pl, ll
+
+
+# -------------------------------------------------------------------- PixelLinkNet (bias VGG)
+PL_STAGES = [("fc7", "stage_6"), ("conv5_3", "stage_5"), ("conv4_3", "stage_4"), ("conv3_3", "stage_3")]
+
+
+def init_pixellink_params(rng, width_div=1):
+    """Variables of nets/pixellink.py: `vgg/...` trunk with biases, `pixellink_layers/...` heads."""
+    p = init_vgg_params(rng, "vgg/", None, width_div)
+    for k in list(p):
+        if k.endswith("biases"):
+            p[k] = (0.05 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    chans = {"fc7": max(1024 // width_div, 8), "conv5_3": max(512 // width_div, 8),
+             "conv4_3": max(512 // width_div, 8), "conv3_3": max(256 // width_div, 8)}
+    for kind, c in (("pixel", 2), ("link", 16)):
+        for key, st in PL_STAGES:
+            nm = "pixellink_layers/%s_%s_fuse" % (st, kind)
+            p[nm + "/weights"] = (rng.standard_normal((1, 1, chans[key], c)) * math.sqrt(1.0 / chans[key])).astype(np.float32)
+            p[nm + "/biases"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+        nm = "pixellink_layers/%s_predication" % ("text" if kind == "pixel" else "link")
+        p[nm + "/weights"] = (rng.standard_normal((1, 1, c, c)) * math.sqrt(1.0 / c)).astype(np.float32)
+        p[nm + "/biases"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+    return p
+
+
+def pixellink_net(inputs, p, mixed=False):
+    """nets/pixellink.py:40-86.  inputs: preprocessed NHWC image.  Returns (pixel_cls, link_cls, end_points)."""
+    _, ep = vgg_basenet(inputs, p, "vgg/", None, mixed)
+    outs = []
+    for kind, c in (("pixel", 2), ("link", 16)):
+        def conv(key, st):
+            nm = "pixellink_layers/%s_%s_fuse" % (st, kind)
+            return conv2d(q(qg(ep[key], mixed), mixed), q(p[nm + "/weights"], mixed), 1, 1) + p[nm + "/biases"]
+        s1 = conv("fc7", "stage_6") + conv("conv5_3", "stage_5")
+        s2 = resize_bilinear_x2(s1) + conv("conv4_3", "stage_4")
+        s3 = resize_bilinear_x2(s2) + conv("conv3_3", "stage_3")
+        nm = "pixellink_layers/%s_predication" % ("text" if kind == "pixel" else "link")
+        outs.append(conv2d(s3, p[nm + "/weights"], 1, 1) + p[nm + "/biases"])
+    return outs[0], outs[1], ep

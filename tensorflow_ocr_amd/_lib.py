@@ -24,6 +24,12 @@ class ConvDesc(ctypes.Structure):
 
 CONV_BIAS, CONV_RELU, CONV_STATS, CONV_ACCUM_F16 = 1, 2, 4, 8
 
+
+class SoftmaxLossDesc(ctypes.Structure):
+    """ocr_softmax_loss_desc (include/ocr_hip.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("n", "hw", "pixel_rule", "label_rule", "link_gate", "focal")] + \
+               [(n, ctypes.c_float) for n in ("neg_ratio", "alpha", "gamma")]
+
 _lib = None
 
 

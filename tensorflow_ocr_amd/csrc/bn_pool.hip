@@ -315,6 +315,44 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
   }
 }
 
+// -------------------------------------------------- bias + ReLU backward
+// dz = da * [a > 0] (a = the stored conv output after bias+ReLU); per-block column sums of dz
+// for the bias gradient.  nets/pixellink.py:41-48 (slim.conv2d with biases, ReLU).
+__global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const half_t* __restrict__ a,
+                                                            const half_t* __restrict__ da,
+                                                            size_t npix, int c, int relu,
+                                                            half_t* __restrict__ dz,
+                                                            float* __restrict__ partial) {
+  __shared__ float red[256 * 8];
+  const int chunks = c >> 3;
+  const int lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  for (size_t u = (size_t)blockIdx.x * lanes + ul; u < npix; u += (size_t)gridDim.x * lanes) {
+    const size_t off = u * c + ch * 8;
+    half8_t av = *reinterpret_cast<const half8_t*>(a + off);
+    half8_t g = *reinterpret_cast<const half8_t*>(da + off);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = (!relu || (float)av[e] > 0.f) ? (float)g[e] : 0.f;
+      o[e] = (half_t)d;
+      s[e] += d;
+    }
+    *reinterpret_cast<half8_t*>(dz + off) = o;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[(ul * chunks + ch) * 8 + e] = s[e];
+  __syncthreads();
+  for (int cc = threadIdx.x; cc < c; cc += 256) {
+    float tot = 0.f;
+    for (int l = 0; l < lanes; ++l) tot += red[(l * chunks + (cc >> 3)) * 8 + (cc & 7)];
+    partial[(size_t)blockIdx.x * c + cc] = tot;
+  }
+}
+
 // --------------------------------------------------------- general max-pool
 struct PoolP {
   int n, h, w, c, oh, ow, k, stride, pt, pl;
@@ -565,5 +603,27 @@ extern "C" int ocr_maxpool_bwd_f16(const void* x, const void* dy, int n, int h, 
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(dy), static_cast<half_t*>(dx), accumulate);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bias_relu_bwd_num_partials(int64_t npix, int c) {
+  if (npix <= 0 || c % 8 || !pow2(c / 8) || c / 8 > 256) return OCR_ERR_UNSUPPORTED;
+  const int lanes = 256 / (c / 8);
+  int64_t b = (npix + lanes - 1) / lanes;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+extern "C" int ocr_bias_relu_bwd_f16(const void* a, const void* da, int64_t npix, int c, int relu,
+                                     void* dz, void* dbias, void* partial, void* stream) {
+  OCR_CHECK_ARG(a && da && dz && dbias && partial);
+  const int T = ocr_bias_relu_bwd_num_partials(npix, c);
+  if (T < 0) return T;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3(T), dim3(256), 0, st, static_cast<const half_t*>(a),
+                     static_cast<const half_t*>(da), (size_t)npix, c, relu, static_cast<half_t*>(dz),
+                     static_cast<float*>(partial));
+  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(c)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<float*>(dbias), c, T, 1.f);
   return ocr_launch_status();
 }

@@ -1,0 +1,251 @@
+// PixelLink decode: per-direction softmax, the threshold mask of pixel_detect, and the
+// link-gated connected-component labelling that the reference does with a Python neighbour
+// graph + DFS.
+//
+//   ocr_softmax_pairs   slim.softmax / tf.nn.softmax over [.., 2] pairs (nets/pixellink.py:71,
+//                       test_pixellink_fast.py:53-64)
+//   ocr_pixel_detect    tool/pixellink_fn.py:120-154: mask = score[0,y,x,0] > t_s and, for all 8
+//                       directions, link[i,0,y,x,1] >= t_l   (batch element 0, like the reference)
+//   ocr_link_cc         test_pixellink_fast.py:110-178: pixel_seg = score > t_p; for INTERIOR pixels
+//                       (1 <= x <= w-2, 1 <= y <= h-2) an edge to neighbour d exists iff
+//                       link_score[d][y][x] > t_l and the neighbour is in pixel_seg; components of
+//                       that graph with more than `min_size` pixels get a label.
+//                       Direction order: left, left_down, left_up, right, right_down, right_up,
+//                       up, down.  The reference walks DIRECTED edges in dict order (order
+//                       dependent); the kernel labels the weakly-connected components with a
+//                       lock-free union-find whose result is order independent: the root of a
+//                       component is its smallest pixel index, ids are dense in ascending root
+//                       order, so labels are bit-reproducible.
+#include "common.h"
+
+namespace {
+
+__global__ void softmax_pairs_kernel(const float* __restrict__ x, float* __restrict__ y, size_t m) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const float mx = fmaxf(a, b);
+    const float ea = expf(a - mx), eb = expf(b - mx);
+    const float s = ea + eb;
+    y[2 * i] = ea / s;
+    y[2 * i + 1] = eb / s;
+  }
+}
+
+__global__ void pixel_detect_kernel(const float* __restrict__ score, const float* __restrict__ link,
+                                    int n, int h, int w, float ts, float tl,
+                                    unsigned char* __restrict__ mask) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= h * w) return;
+  bool ok = score[i] > ts;                      // score [n,h,w,1], batch element 0
+  const size_t dir_stride = (size_t)n * h * w * 2;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) ok = ok && !(link[d * dir_stride + (size_t)i * 2 + 1] < tl);
+  mask[i] = ok ? 1 : 0;
+}
+
+// ---- union-find on pixel indices (roots = smallest index of the set) -----------------------
+__device__ __forceinline__ int uf_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(int* parent, int i) {
+  for (;;) {
+    const int p = uf_load(parent + i);
+    if (p == i) return i;
+    i = p;
+  }
+}
+__device__ __forceinline__ void uf_unite(int* parent, int a, int b) {
+  for (int guard = 0; guard < (1 << 22); ++guard) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }       // attach the larger root under the smaller
+    const int old = atomicMin(parent + a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+struct CcP {
+  int n, h, w, min_size;
+  float tp, tl;
+  int ls, lo;   // element stride / offset inside link_score (1,0: [8][n][h][w]; 2,1: [8][n][h][w][2])
+};
+
+// link_logits [m][16] -> out [8][m][2]: tf.stack([softmax(link_cls[..., 2i:2i+2]) for i in 0..7])
+__global__ void link_softmax_stack_kernel(const float* __restrict__ x, float* __restrict__ y, size_t m) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m * 8; i += (size_t)gridDim.x * 256) {
+    const size_t px = i >> 3;
+    const int d = (int)(i & 7);
+    const float a = x[px * 16 + 2 * d], b = x[px * 16 + 2 * d + 1];
+    const float mx = fmaxf(a, b);
+    const float ea = expf(a - mx), eb = expf(b - mx);
+    const float s = ea + eb;
+    y[((size_t)d * m + px) * 2] = ea / s;
+    y[((size_t)d * m + px) * 2 + 1] = eb / s;
+  }
+}
+
+__device__ __constant__ int kDx[8] = {-1, -1, -1, 1, 1, 1, 0, 0};
+__device__ __constant__ int kDy[8] = {0, 1, -1, 0, 1, -1, -1, 1};
+
+__global__ void cc_init_kernel(CcP p, const float* __restrict__ score, int* __restrict__ parent,
+                               int* __restrict__ size) {
+  const size_t total = (size_t)p.n * p.h * p.w;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int local = (int)(i % ((size_t)p.h * p.w));
+    parent[i] = score[i] > p.tp ? local : -1;
+    size[i] = 0;
+  }
+}
+
+__global__ void cc_union_kernel(CcP p, const float* __restrict__ link, int* __restrict__ parent) {
+  const size_t hw = (size_t)p.h * p.w, total = (size_t)p.n * hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int img = (int)(i / hw), local = (int)(i % hw);
+    const int y = local / p.w, x = local - y * p.w;
+    if (x < 1 || x > p.w - 2 || y < 1 || y > p.h - 2) continue;
+    int* par = parent + (size_t)img * hw;
+    if (par[local] < 0) continue;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      if (!(link[(((size_t)d * p.n + img) * hw + local) * p.ls + p.lo] > p.tl)) continue;
+      const int q = (y + kDy[d]) * p.w + (x + kDx[d]);
+      if (par[q] < 0) continue;
+      uf_unite(par, local, q);
+    }
+  }
+}
+
+__global__ void cc_root_kernel(CcP p, int* __restrict__ parent, int* __restrict__ root,
+                               int* __restrict__ size) {
+  const size_t hw = (size_t)p.h * p.w, total = (size_t)p.n * hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int img = (int)(i / hw), local = (int)(i % hw);
+    int* par = parent + (size_t)img * hw;
+    int r = -1;
+    if (par[local] >= 0) {
+      r = uf_find(par, local);
+      atomicAdd(size + (size_t)img * hw + r, 1);
+    }
+    root[i] = r;
+  }
+}
+
+// one workgroup per image: dense ids (ascending root index) for roots with size > min_size,
+// component table [id] = {root, size}, then labels.
+__global__ __launch_bounds__(1024) void cc_label_kernel(CcP p, const int* __restrict__ root,
+                                                        const int* __restrict__ size,
+                                                        int* __restrict__ ids, int* __restrict__ label,
+                                                        int* __restrict__ ncomp, int* __restrict__ comps,
+                                                        int max_comps) {
+  __shared__ int wsum[16];
+  __shared__ int s_carry;
+  const int img = blockIdx.x;
+  const int hw = p.h * p.w;
+  const int* rt = root + (size_t)img * hw;
+  const int* sz = size + (size_t)img * hw;
+  int* id = ids + (size_t)img * hw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < hw; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int flag = (i < hw && rt[i] == i && sz[i] > p.min_size) ? 1 : 0;
+    // inclusive scan inside the wave, then across the 16 waves
+    int v = flag;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(v, o, 64);
+      if (lane >= o) v += t;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int off = s_carry;
+    for (int k = 0; k < wave; ++k) off += wsum[k];
+    if (i < hw) {
+      const int myid = flag ? off + v : 0;       // 1-based dense id
+      id[i] = myid;
+      if (flag && myid <= max_comps) {
+        comps[((size_t)img * max_comps + myid - 1) * 2 + 0] = i;
+        comps[((size_t)img * max_comps + myid - 1) * 2 + 1] = sz[i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = off + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ncomp[img] = s_carry;
+  __syncthreads();
+  for (int i = threadIdx.x; i < hw; i += 1024) {
+    const int r = rt[i];
+    label[(size_t)img * hw + i] = r >= 0 ? id[r] : 0;
+  }
+}
+
+unsigned dgrid(size_t items) {
+  size_t b = (items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int ocr_softmax_pairs(const void* logits, int64_t pairs, void* probs, void* stream) {
+  OCR_CHECK_ARG(logits && probs && pairs > 0);
+  hipLaunchKernelGGL(softmax_pairs_kernel, dim3(dgrid((size_t)pairs)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(logits),
+                     static_cast<float*>(probs), (size_t)pairs);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_pixel_detect(const void* score_map, const void* link_scores, int n, int h, int w,
+                                float score_map_thresh, float link_thresh, void* mask_u8,
+                                void* stream) {
+  OCR_CHECK_ARG(score_map && link_scores && mask_u8 && n > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(pixel_detect_kernel, dim3(ocr_cdiv(h * w, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(score_map),
+                     static_cast<const float*>(link_scores), n, h, w, score_map_thresh, link_thresh,
+                     static_cast<unsigned char*>(mask_u8));
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_link_cc_workspace(int n, int h, int w) {
+  return (size_t)n * h * w * sizeof(int) * 4;   // parent, size, root, ids
+}
+
+extern "C" int ocr_link_softmax_stack(const void* link_logits, int64_t m, void* out, void* stream) {
+  OCR_CHECK_ARG(link_logits && out && m > 0);
+  hipLaunchKernelGGL(link_softmax_stack_kernel, dim3(dgrid((size_t)m * 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(link_logits),
+                     static_cast<float*>(out), (size_t)m);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_link_cc(const void* pixel_score, const void* link_score, int link_elem_stride,
+                           int link_elem_offset, int n, int h, int w,
+                           float pixel_thresh, float link_thresh, int min_size, void* labels_i32,
+                           void* ncomp_i32, void* comps_i32, int max_comps, void* workspace,
+                           size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(pixel_score && link_score && labels_i32 && ncomp_i32 && comps_i32 && workspace);
+  OCR_CHECK_ARG(n > 0 && h > 2 && w > 2 && max_comps > 0);
+  if (ws_bytes < ocr_link_cc_workspace(n, h, w)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t total = (size_t)n * h * w;
+  int* parent = static_cast<int*>(workspace);
+  int* size = parent + total;
+  int* root = size + total;
+  int* ids = root + total;
+  OCR_CHECK_ARG(link_elem_stride >= 1 && link_elem_offset >= 0 && link_elem_offset < link_elem_stride);
+  CcP p{n, h, w, min_size, pixel_thresh, link_thresh, link_elem_stride, link_elem_offset};
+  hipLaunchKernelGGL(cc_init_kernel, dim3(dgrid(total)), dim3(256), 0, st, p,
+                     static_cast<const float*>(pixel_score), parent, size);
+  hipLaunchKernelGGL(cc_union_kernel, dim3(dgrid(total)), dim3(256), 0, st, p,
+                     static_cast<const float*>(link_score), parent);
+  hipLaunchKernelGGL(cc_root_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, parent, root, size);
+  hipLaunchKernelGGL(cc_label_kernel, dim3(n), dim3(1024), 0, st, p, root, size, ids,
+                     static_cast<int*>(labels_i32), static_cast<int*>(ncomp_i32),
+                     static_cast<int*>(comps_i32), max_comps);
+  return ocr_launch_status();
+}

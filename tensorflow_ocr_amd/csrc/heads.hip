@@ -589,3 +589,19 @@ extern "C" int ocr_sc_pointwise_wgrad(const void* x, int ldx, int xo, int cin, c
     return OCR_ERR_HIP;
   return ocr_launch_status();
 }
+
+// out[c] = sum_p x[p][c]   (bias gradient of the un-normalised PixelLink heads);
+// partial must hold (ocr_sc_num_partials + 1) * 2 * C floats
+extern "C" int ocr_sc_colsum(const void* x, int P, int C, void* out, void* partial, void* stream) {
+  OCR_CHECK_ARG(x && out && partial && P > 0);
+  OCR_CHECK_SHAPE(C > 0 && C <= 128);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int T = sc_blocks(P, C);
+  float* part = static_cast<float*>(partial);
+  hipLaunchKernelGGL(sc_stats_kernel, dim3(T), dim3(256), 0, st, static_cast<const float*>(x), P, C, part);
+  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(2 * C)), dim3(256), 0, st, part,
+                     part + (size_t)T * 2 * C, 2 * C, T, 1.f);
+  if (hipMemcpyAsync(out, part + (size_t)T * 2 * C, C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return OCR_ERR_HIP;
+  return ocr_launch_status();
+}

@@ -1,0 +1,332 @@
+// Softmax cross-entropy losses of the PixelLink-style heads, with online hard negative
+// mining (OHNM) and the focal variant.
+//
+//   pixel_rule 0  nets/model.py:204-261       OHNM per image: k = min(3*n_pos, n_neg) hardest
+//                                             negatives (tf.nn.top_k on -P(neg), tie-inclusive);
+//                                             pixel = sum(CE*sel)/n_pos_batch, 0 if no positives
+//   pixel_rule 1  nets/model_vgg_16.py:243-282 `ohem_loss`: weights = positives only
+//   pixel_rule 2  nets/pixellink.py:88-263     `PixelLinkNet.build_loss`: mean CE over all pixels
+//   link_gate 1   link weights W_pos/W_neg multiplied by the selected pixel mask, NO zero guard
+//                 (model.py:238-254 -> NaN when a direction has no positive or no negative link)
+//   link_gate 0   ungated, zero-guarded (pixellink.py:198-212)
+//   focal 1       link CE replaced by FL = -alpha_t (1-p_t)^gamma log p_t (Lin et al. 2017;
+//                 absent from the reference tree, SURVEY D1: build-defined, parity unpinned)
+//
+// total = sum_i link_i + 2 * pixel.  The mined mask is a constant w.r.t. the gradient.
+//
+// OHNM threshold: exact k-th smallest P(neg) among an image's negatives by a 4-pass 8-bit radix
+// select on the float bits (one workgroup per image, integer LDS histograms: deterministic),
+// then `score <= threshold` — the same float expression in every pass.
+#include "common.h"
+
+namespace {
+
+struct SlP {
+  int n, hw, pixel_rule, label_rule, link_gate, focal;
+  float neg_ratio, alpha, gamma;
+};
+
+__device__ __forceinline__ bool is_pos(float label, int rule) { return rule ? label > 0.f : label == 1.f; }
+__device__ __forceinline__ bool is_neg(float label, int rule) { return rule ? !(label > 0.f) : label == 0.f; }
+
+// P(class 0) of a 2-way softmax
+__device__ __forceinline__ float neg_score(float l0, float l1) { return 1.f / (1.f + expf(l1 - l0)); }
+
+// 2-class CE and softmax of logits (l0, l1) for class t
+__device__ __forceinline__ float ce2(float l0, float l1, int t, float* p1) {
+  const float m = fmaxf(l0, l1);
+  const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+  const float s = e0 + e1;
+  *p1 = e1 / s;
+  return logf(s) + m - (t ? l1 : l0);
+}
+
+__device__ __forceinline__ float focal2(float l0, float l1, int t, float alpha, float gamma, float* dz1) {
+  // L = -a_t (1-p)^g log p,  p = softmax prob of the true class; dz1 = dL/d(l1)
+  const float m = fmaxf(l0, l1);
+  const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+  const float s = e0 + e1;
+  const float p = (t ? e1 : e0) / s;
+  const float logp = (t ? l1 : l0) - m - logf(s);
+  const float a = t ? alpha : 1.f - alpha;
+  const float om = 1.f - p;
+  const float omg = powf(fmaxf(om, 1e-30f), gamma);
+  const float dzt = a * (gamma * omg * p * logp - omg * om);   // dL/dz_true
+  *dz1 = t ? dzt : -dzt;
+  return -a * omg * logp;
+}
+
+// ------------------------------------------------------------- OHNM threshold per image
+__global__ __launch_bounds__(1024) void ohnm_threshold_kernel(SlP p, const float* __restrict__ pl,
+                                                              const float* __restrict__ lab,
+                                                              float* __restrict__ thr) {
+  __shared__ int hist[256];
+  __shared__ int s_cnt[2];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_k;
+  const int img = blockIdx.x;
+  const float* l = pl + (size_t)img * p.hw * 2;
+  const float* y = lab + (size_t)img * p.hw;
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int np = 0, nn = 0;
+  for (int i = threadIdx.x; i < p.hw; i += 1024) {
+    np += is_pos(y[i], p.label_rule) ? 1 : 0;
+    nn += is_neg(y[i], p.label_rule) ? 1 : 0;
+  }
+  atomicAdd(&s_cnt[0], np);
+  atomicAdd(&s_cnt[1], nn);
+  __syncthreads();
+  const int n_pos = s_cnt[0], n_neg = s_cnt[1];
+  int k = (int)fminf((float)n_pos * p.neg_ratio, (float)n_neg);
+  if (n_pos == 0 || k <= 0) {
+    if (threadIdx.x == 0) thr[img] = -1.f;   // nothing is selected (scores are >= 0)
+    return;
+  }
+  if (threadIdx.x == 0) { s_prefix = 0u; s_k = k; }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = threadIdx.x; i < p.hw; i += 1024) {
+      if (!is_neg(y[i], p.label_rule)) continue;
+      const unsigned u = __float_as_uint(neg_score(l[2 * i], l[2 * i + 1]));
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int kk = s_k, cum = 0, d = 0;
+      for (; d < 256; ++d) {
+        if (cum + hist[d] >= kk) break;
+        cum += hist[d];
+      }
+      s_prefix = prefix | ((unsigned)d << shift);
+      s_k = kk - cum;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) thr[img] = __uint_as_float(s_prefix);
+}
+
+// per-pixel weight of the pixel CE term
+__device__ __forceinline__ float pixel_weight(const SlP& p, float label, float l0, float l1, float thr) {
+  if (p.pixel_rule == 2) return 1.f;
+  if (is_pos(label, p.label_rule)) return 1.f;
+  if (p.pixel_rule == 0 && is_neg(label, p.label_rule) && neg_score(l0, l1) <= thr) return 1.f;
+  return 0.f;
+}
+
+// sums: [0] sum CE*W  [1] n_pos (batch)  then per direction i: [2+4i] sum L*Wp [3+4i] sum Wp
+// [4+4i] sum L*Wn [5+4i] sum Wn
+constexpr int NS = 34;
+
+__global__ __launch_bounds__(256) void sl_reduce_kernel(SlP p, const float* __restrict__ pl,
+                                                        const float* __restrict__ ll,
+                                                        const float* __restrict__ plab,
+                                                        const float* __restrict__ llab,
+                                                        const float* __restrict__ thr,
+                                                        float* __restrict__ partial) {
+  __shared__ float red[4][NS];
+  float s[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) s[j] = 0.f;
+  const size_t total = (size_t)p.n * p.hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int img = (int)(i / p.hw);
+    const float y = plab[i], l0 = pl[2 * i], l1 = pl[2 * i + 1];
+    const bool pos = is_pos(y, p.label_rule);
+    const float W = pixel_weight(p, y, l0, l1, p.pixel_rule == 0 ? thr[img] : 0.f);
+    float p1;
+    const float ce = ce2(l0, l1, pos ? 1 : 0, &p1);
+    s[0] += ce * W;
+    s[1] += pos ? 1.f : 0.f;
+    const float G = p.link_gate ? W : 1.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float yl = llab[i * 8 + d];
+      const float a0 = ll[i * 16 + 2 * d], a1 = ll[i * 16 + 2 * d + 1];
+      const bool lp = is_pos(yl, p.label_rule), ln = is_neg(yl, p.label_rule);
+      float dummy;
+      const float L = p.focal ? focal2(a0, a1, lp ? 1 : 0, p.alpha, p.gamma, &dummy)
+                              : ce2(a0, a1, lp ? 1 : 0, &dummy);
+      const float wp = lp ? G : 0.f, wn = ln ? G : 0.f;
+      s[2 + 4 * d] += L * wp;
+      s[3 + 4 * d] += wp;
+      s[4 + 4 * d] += L * wn;
+      s[5 + 4 * d] += wn;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const float v = wave_sum(s[j]);
+    if (lane == 0) red[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS)
+    partial[(size_t)blockIdx.x * NS + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// sums[34]; loss[0] total, loss[1] pixel term (before the factor 2), loss[2..9] link terms
+__global__ void sl_finalize_kernel(SlP p, const float* __restrict__ partial, int T,
+                                   float* __restrict__ sums, float* __restrict__ loss) {
+  __shared__ double part[4][64];
+  __shared__ float tot[NS];
+  const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+  double a = 0.0;
+  if (j < NS)
+    for (int t = g; t < T; t += 4) a += (double)partial[(size_t)t * NS + j];
+  part[g][j] = a;
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    const float v = (float)(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    tot[threadIdx.x] = v;
+    sums[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float pixel;
+    if (p.pixel_rule == 2) pixel = tot[0] / ((float)p.n * (float)p.hw);
+    else if (p.pixel_rule == 0) pixel = tot[1] > 0.f ? tot[0] / tot[1] : 0.f;
+    else pixel = tot[0] / tot[1];                      // ohem_loss: no guard in the reference
+    float total = 2.f * pixel;
+    loss[1] = pixel;
+    for (int d = 0; d < 8; ++d) {
+      const float lp = tot[2 + 4 * d], wp = tot[3 + 4 * d], ln = tot[4 + 4 * d], wn = tot[5 + 4 * d];
+      float v;
+      if (p.link_gate) v = lp / wp + ln / wn;           // model.py:249-254: unguarded
+      else v = (wp == 0.f ? 0.f : lp / wp) + (wn == 0.f ? 0.f : ln / wn);
+      loss[2 + d] = v;
+      total += v;
+    }
+    loss[0] = total;
+  }
+}
+
+__global__ __launch_bounds__(256) void sl_bwd_kernel(SlP p, const float* __restrict__ pl,
+                                                     const float* __restrict__ ll,
+                                                     const float* __restrict__ plab,
+                                                     const float* __restrict__ llab,
+                                                     const float* __restrict__ thr,
+                                                     const float* __restrict__ sums, float gscale,
+                                                     float* __restrict__ dpl, float* __restrict__ dll) {
+  __shared__ float c_pix, c_pos[8], c_neg[8];
+  if (threadIdx.x == 0) {
+    if (p.pixel_rule == 2) c_pix = 2.f * gscale / ((float)p.n * (float)p.hw);
+    else if (p.pixel_rule == 0) c_pix = sums[1] > 0.f ? 2.f * gscale / sums[1] : 0.f;
+    else c_pix = 2.f * gscale / sums[1];
+  }
+  if (threadIdx.x < 8) {
+    const float wp = sums[3 + 4 * threadIdx.x], wn = sums[5 + 4 * threadIdx.x];
+    c_pos[threadIdx.x] = (!p.link_gate && wp == 0.f) ? 0.f : gscale / wp;
+    c_neg[threadIdx.x] = (!p.link_gate && wn == 0.f) ? 0.f : gscale / wn;
+  }
+  __syncthreads();
+  const size_t total = (size_t)p.n * p.hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int img = (int)(i / p.hw);
+    const float y = plab[i], l0 = pl[2 * i], l1 = pl[2 * i + 1];
+    const bool pos = is_pos(y, p.label_rule);
+    const float W = pixel_weight(p, y, l0, l1, p.pixel_rule == 0 ? thr[img] : 0.f);
+    float p1;
+    ce2(l0, l1, pos ? 1 : 0, &p1);
+    const float g1 = (p1 - (pos ? 1.f : 0.f)) * W * c_pix;   // d/dl1 ; d/dl0 = -g1
+    dpl[2 * i] = -g1;
+    dpl[2 * i + 1] = g1;
+    const float G = p.link_gate ? W : 1.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float yl = llab[i * 8 + d];
+      const float a0 = ll[i * 16 + 2 * d], a1 = ll[i * 16 + 2 * d + 1];
+      const bool lp = is_pos(yl, p.label_rule), ln = is_neg(yl, p.label_rule);
+      float dz1;
+      if (p.focal) {
+        focal2(a0, a1, lp ? 1 : 0, p.alpha, p.gamma, &dz1);
+      } else {
+        float q1;
+        ce2(a0, a1, lp ? 1 : 0, &q1);
+        dz1 = q1 - (lp ? 1.f : 0.f);
+      }
+      // weights that are exactly zero contribute nothing even when the normaliser is 0/0
+      float coef = 0.f;
+      if (lp && G != 0.f) coef += G * c_pos[d];
+      if (ln && G != 0.f) coef += G * c_neg[d];
+      const float gl = dz1 * coef;
+      dll[i * 16 + 2 * d] = -gl;
+      dll[i * 16 + 2 * d + 1] = gl;
+    }
+  }
+}
+
+int sl_blocks(size_t total) {
+  size_t b = (total + 256 * 4 - 1) / (256 * 4);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int fill(const ocr_softmax_loss_desc* d, SlP* p) {
+  OCR_CHECK_ARG(d != nullptr && d->n > 0 && d->hw > 0);
+  OCR_CHECK_ARG(d->pixel_rule >= 0 && d->pixel_rule <= 2);
+  p->n = d->n; p->hw = d->hw; p->pixel_rule = d->pixel_rule; p->label_rule = d->label_rule;
+  p->link_gate = d->link_gate; p->focal = d->focal;
+  p->neg_ratio = d->neg_ratio; p->alpha = d->alpha; p->gamma = d->gamma;
+  return OCR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ocr_softmax_loss_workspace(const ocr_softmax_loss_desc* d) {
+  if (!d) return 0;
+  return (size_t)sl_blocks((size_t)d->n * d->hw) * NS * sizeof(float);
+}
+
+extern "C" int ocr_softmax_loss_fwd(const ocr_softmax_loss_desc* d, const void* pixel_logits,
+                                    const void* link_logits, const void* pixel_labels,
+                                    const void* link_labels, void* ohnm_threshold, void* sums34,
+                                    void* loss10, void* workspace, size_t ws_bytes, void* stream) {
+  SlP p;
+  int rc = fill(d, &p);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(pixel_logits && link_logits && pixel_labels && link_labels && ohnm_threshold);
+  OCR_CHECK_ARG(sums34 && loss10 && workspace);
+  if (ws_bytes < ocr_softmax_loss_workspace(d)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float* pl = static_cast<const float*>(pixel_logits);
+  const float* plab = static_cast<const float*>(pixel_labels);
+  if (p.pixel_rule == 0)
+    hipLaunchKernelGGL(ohnm_threshold_kernel, dim3(p.n), dim3(1024), 0, st, p, pl, plab,
+                       static_cast<float*>(ohnm_threshold));
+  const int T = sl_blocks((size_t)p.n * p.hw);
+  hipLaunchKernelGGL(sl_reduce_kernel, dim3(T), dim3(256), 0, st, p, pl,
+                     static_cast<const float*>(link_logits), plab,
+                     static_cast<const float*>(link_labels),
+                     static_cast<const float*>(ohnm_threshold), static_cast<float*>(workspace));
+  hipLaunchKernelGGL(sl_finalize_kernel, dim3(1), dim3(256), 0, st, p,
+                     static_cast<const float*>(workspace), T, static_cast<float*>(sums34),
+                     static_cast<float*>(loss10));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_softmax_loss_bwd(const ocr_softmax_loss_desc* d, const void* pixel_logits,
+                                    const void* link_logits, const void* pixel_labels,
+                                    const void* link_labels, const void* ohnm_threshold,
+                                    const void* sums34, float grad_scale, void* d_pixel_logits,
+                                    void* d_link_logits, void* stream) {
+  SlP p;
+  int rc = fill(d, &p);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(pixel_logits && link_logits && pixel_labels && link_labels && ohnm_threshold);
+  OCR_CHECK_ARG(sums34 && d_pixel_logits && d_link_logits);
+  const int T = sl_blocks((size_t)p.n * p.hw) * 2;
+  hipLaunchKernelGGL(sl_bwd_kernel, dim3(T), dim3(256), 0, static_cast<hipStream_t>(stream), p,
+                     static_cast<const float*>(pixel_logits), static_cast<const float*>(link_logits),
+                     static_cast<const float*>(pixel_labels), static_cast<const float*>(link_labels),
+                     static_cast<const float*>(ohnm_threshold), static_cast<const float*>(sums34),
+                     grad_scale, static_cast<float*>(d_pixel_logits),
+                     static_cast<float*>(d_link_logits));
+  return ocr_launch_status();
+}

@@ -135,17 +135,16 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         d.flags = flags
         ops.conv2d(d, x.data, w_fwd, y, bias.data, None)
     a_full = Act(y, name=scope)
-    a_pool = None
-    if pool:
-        _, pt = ops.same_pad(oh, 2, 2)
-        _, pl = ops.same_pad(ow, 2, 2)
-        pooled = g.empty((n, (oh + 1) // 2, (ow + 1) // 2, cout))
-        ops.maxpool(y, 2, 2, (pt, pl), pooled)
-        a_pool = Act(pooled, name=scope + "/pool")
 
     def backward_bias():
-        raise NotImplementedError("bias-path backward is wired in layers_bias (PixelLinkNet)")
-    g.record(backward_bias)
+        if a_full.grad is None:
+            return
+        dz = g.empty(y.shape)
+        ops.bias_relu_bwd(y, a_full.grad, relu, dz, bias.grad, ws)
+        _conv_backward(g, x, wv, w_dg, d, dz, first)
+        a_full.grad = None
+    g.record(backward_bias, (wv, bias))
+    a_pool = max_pool2d(g, a_full, 2, 2, scope=scope + "/pool") if pool else None
     return a_full, a_pool
 
 
@@ -196,13 +195,13 @@ def max_pool2d(g, x, k, stride, scope="pool"):
     return out
 
 
-def prep_images(g, images):
+def prep_images(g, images, means=(123.68, 116.78, 103.94)):
     """mean_image_subtraction (nets/model.py:18-31) + f16 cast into the [n,h,w,4] layout."""
-    if images.shape[-1] != 3:
+    if images.shape[-1] != len(means):
         raise ValueError("len(means) must match the number of channels")
     n, h, w, _ = images.shape
     x4 = g.empty((n, h, w, 4))
-    ops.prep_images(images, x4)
+    ops.prep_images(images, x4, means)
     return Act(x4, requires_grad=False, name="images")
 
 
@@ -265,10 +264,73 @@ def head_conv_bn(g, feat, names, couts, is_training=True, relu=True):
     return out, scale, shift
 
 
-def _merged_init(g, cin, couts):
+def head_conv_bias(g, feat, names, couts, initializer=None):
+    """PixelLinkNet's fuse convs on one feature map — slim.conv2d(feat, c, [1,1], activation_fn=None)
+    with biases, no normaliser (nets/pixellink.py:58-67) — merged into one pass over the feature.
+    Returns (z, None, None) in the triple form `fuse` consumes."""
+    n, h, w, cin = feat.shape
+    C = sum(couts)
+    ws = g.workspace()
+    with g.variable_scope("+".join(names)):
+        init = _merged_init(g, cin, couts, initializer or xavier_uniform)
+        wv = g.get_variable("weights", (cin, C), init, regularized=True)
+        bias = g.get_variable("biases", (C,), constant(0.0))
+
+    def mk(old):
+        if old is None:
+            old = (g.empty((32, cin)), g.empty((cin, 32)))
+        ops.pack_weights_small(wv.data, old[0], old[1])
+        return old
+    w_kc32, w_ck32 = g.packed(wv, "small", mk)
+    z = g.empty((n, h, w, C), F32)
+    ops.conv1x1_small(feat.data, w_kc32, C, z, bias.data)
+    out = SmallAct(z)
+
+    def backward():
+        if out.grad is None:
+            return
+        ops.sc_colsum(out.grad, C, bias.grad, ws)
+        ops.conv1x1_small_wgrad(feat.data, out.grad, C, wv.grad, ws)
+        if feat.requires_grad:
+            acc = feat.grad is not None
+            if not acc:
+                feat.grad = g.empty(feat.shape)
+            ops.conv1x1_small_dgrad(out.grad, w_ck32, C, feat.grad, acc)
+        out.grad = None
+    g.record(backward, (wv, bias))
+    return out, None, None
+
+
+def pointwise_bias(g, x, xo, c, scope, initializer=None):
+    """text_predication / link_predication: 1x1 conv with biases and no activation on a channel
+    slice of the fused head tensor (nets/pixellink.py:61,67).  Returns contiguous logits."""
+    n, h, w, C = x.data.shape
+    ws = g.workspace()
+    with g.variable_scope(scope):
+        wv = g.get_variable("weights", (1, 1, c, c), (initializer or xavier_uniform)(g.rng), regularized=True)
+        bias = g.get_variable("biases", (c,), constant(0.0))
+    out = SmallAct(g.empty((n, h, w, c), F32))
+    ops.sc_pointwise_fwd(x.data, xo, c, wv.data, out.data, 0, c, bias.data)
+
+    def backward():
+        if out.grad is None:
+            return
+        ops.sc_pointwise_wgrad(x.data, xo, c, out.grad, 0, c, wv.grad, bias.grad, ws)
+        if x.grad is None:
+            x.grad = g.empty(x.data.shape, F32)
+            ops.fill_(x.grad, 0.0)
+        ops.sc_pointwise_dgrad(out.grad, 0, c, wv.data, x.grad, xo, c)
+        out.grad = None
+    g.record(backward, (wv, bias))
+    return out
+
+
+def _merged_init(g, cin, couts, base=None):
+    base = base or variance_scaling
+
     def init(shape):
         import numpy as np
-        cols = [variance_scaling(g.rng)((1, 1, cin, c)).reshape(cin, c) for c in couts]
+        cols = [base(g.rng)((1, 1, cin, c)).reshape(cin, c) for c in couts]
         return np.concatenate(cols, axis=1)
     return init
 

@@ -97,3 +97,12 @@ def loss(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mask, gr
     res = Scalar(out)
     g.collections["losses"].append(res)
     return res
+
+
+def ohem_loss(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mask, graph=None):
+    """nets/model_vgg_16.py:243-282 (with cal_link_loss :227-241): despite the name no mining —
+    pixel CE over positives / n_pos, link CEs weighted by the positive-pixel mask, L_pixel*2 + L_link."""
+    from .. import losses
+    g = graph or get_default_graph()
+    return losses.softmax_loss(g, y_pred_pixel, y_pred_link, y_true_pixel, y_true_link,
+                               pixel_rule=1, label_rule=0, link_gate=True)

@@ -183,6 +183,22 @@ def bn_relu_bwd(y, scale, shift, save_mean, save_invstd, da_full, da_pool, relu,
            c_size_t(stage.numel()), _st())
 
 
+def bias_relu_bwd(a, da, relu, dz, dbias, ws):
+    c = a.shape[-1]
+    npix = a.numel() // c
+    T = L.call_int("ocr_bias_relu_bwd_num_partials", c_int64(npix), c_int(c))
+    buf = ws.get(T * c * 4)
+    L.call("ocr_bias_relu_bwd_f16", ptr(a), ptr(da), c_int64(npix), c_int(c), c_int(int(relu)), ptr(dz),
+           ptr(dbias), ptr(buf), _st())
+
+
+def sc_colsum(x, C, out, ws):
+    P = x.numel() // C
+    T = sc_num_partials(P, C)
+    buf = ws.get((T + 1) * 2 * C * 4)
+    L.call("ocr_sc_colsum", ptr(x), c_int(P), c_int(C), ptr(out), ptr(buf), _st())
+
+
 def maxpool(x, k, stride, pad, y):
     n, h, w, c = x.shape
     _, oh, ow, _ = y.shape
@@ -289,6 +305,42 @@ def dice_loss_bwd(yt_pixel, yt_link, mask, sums27, grad_scale, d_pixel, d_link):
     G = d_link.numel() // (8 * P)
     L.call("ocr_dice_loss_bwd", ptr(yt_pixel), c_int(pc), ptr(yt_link), c_int(G), ptr(mask), c_int(P),
            ptr(sums27), c_float(grad_scale), ptr(d_pixel), ptr(d_link), _st())
+
+
+def softmax_loss_fwd(desc, pixel_logits, link_logits, pixel_labels, link_labels, thr, sums34, loss10, ws):
+    nbytes = L.call_size("ocr_softmax_loss_workspace", byref(desc))
+    buf = ws.get(nbytes)
+    L.call("ocr_softmax_loss_fwd", byref(desc), ptr(pixel_logits), ptr(link_logits), ptr(pixel_labels),
+           ptr(link_labels), ptr(thr), ptr(sums34), ptr(loss10), ptr(buf), c_size_t(nbytes), _st())
+
+
+def softmax_loss_bwd(desc, pixel_logits, link_logits, pixel_labels, link_labels, thr, sums34, grad_scale,
+                     d_pixel, d_link):
+    L.call("ocr_softmax_loss_bwd", byref(desc), ptr(pixel_logits), ptr(link_logits), ptr(pixel_labels),
+           ptr(link_labels), ptr(thr), ptr(sums34), c_float(grad_scale), ptr(d_pixel), ptr(d_link), _st())
+
+
+# ----------------------------------------------------------------------------- decode
+def softmax_pairs(logits, probs):
+    L.call("ocr_softmax_pairs", ptr(logits), c_int64(logits.numel() // 2), ptr(probs), _st())
+
+
+def link_softmax_stack(link_logits, out):
+    L.call("ocr_link_softmax_stack", ptr(link_logits), c_int64(link_logits.numel() // 16), ptr(out), _st())
+
+
+def pixel_detect(score_map, link_scores, n, h, w, score_thresh, link_thresh, mask):
+    L.call("ocr_pixel_detect", ptr(score_map), ptr(link_scores), c_int(n), c_int(h), c_int(w),
+           c_float(score_thresh), c_float(link_thresh), ptr(mask), _st())
+
+
+def link_cc(pixel_score, link_score, stride, offset, n, h, w, pixel_thresh, link_thresh, min_size, labels,
+            ncomp, comps, ws):
+    nbytes = L.call_size("ocr_link_cc_workspace", c_int(n), c_int(h), c_int(w))
+    buf = ws.get(nbytes)
+    L.call("ocr_link_cc", ptr(pixel_score), ptr(link_score), c_int(stride), c_int(offset), c_int(n), c_int(h),
+           c_int(w), c_float(pixel_thresh), c_float(link_thresh), c_int(min_size), ptr(labels), ptr(ncomp),
+           ptr(comps), c_int(comps.shape[1]), ptr(buf), c_size_t(nbytes), _st())
 
 
 # -------------------------------------------------------------------------- optimiser
