@@ -95,6 +95,17 @@ int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const void* x4,
                                void* workspace, size_t ws_bytes, void* stream);
 size_t ocr_conv2d_first_wgrad_workspace(int n, int h, int w, int cout);
 
+/* ResNet root convolution: 7x7 stride 2, cin = 3 (image [n,h,w,4] f16), explicit (3,3) padding of
+ * resnet_utils.conv2d_same (nets/resnet_v1.py:193): y [n,(h-1)/2+1,(w-1)/2+1,cout].
+ * w_stem [7][2][cout][16] f16 from ocr_pack_weights_stem_f16; dw [7,7,3,cout] f32. */
+int ocr_conv2d_stem_num_mtiles(int n, int h, int w);
+int ocr_pack_weights_stem_f16(const void* w_hwio_f32, int cout, void* w_stem, void* stream);
+int ocr_conv2d_stem_f16(int n, int h, int w, int cout, const void* x4, const void* w_stem,
+                        const void* bias, int flags, void* y, void* stats, void* stream);
+size_t ocr_conv2d_stem_wgrad_workspace(int n, int h, int w, int cout);
+int ocr_conv2d_stem_wgrad_f16(int n, int h, int w, int cout, const void* x4, const void* dy,
+                              void* dw_hwio_f32, void* workspace, size_t ws_bytes, void* stream);
+
 /* f32 HWIO master weights -> the f16 operand layouts of the MFMA kernels (done once per optimiser
  * step).  w_kc [taps][cout][cin] feeds ocr_conv2d_f16 forward; w_ck [taps][cin][cout] (a plain
  * cast) feeds the input gradient: call ocr_conv2d_f16 on dy with cin/cout swapped, flip_taps = 1
@@ -142,6 +153,17 @@ int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void* shift, con
                         const void* save_invstd, const void* da_full, const void* da_pool, int n,
                         int h, int w, int c, int relu, int pool, void* dgamma, void* dbeta, void* dy,
                         void* partial, void* workspace, size_t ws_bytes, void* stream);
+
+/* Per-channel sum / sum of squares partials [ocr_channel_stats_num_partials][2][c] of an f16
+ * tensor [npix][c] (batch norm after a sub-sampled conv output). */
+int ocr_channel_stats_num_partials(int64_t npix, int c);
+int ocr_channel_stats_f16(const void* x, int64_t npix, int c, void* partial, void* stream);
+/* ResNet bottleneck tail (nets/resnet_v1.py:107): out = relu(bn(y) + shortcut); its ReLU
+ * backward dz = dout * [out > 0]; a += b on f16 gradients. */
+int ocr_bn_add_relu_f16(const void* y, const void* scale, const void* shift, const void* shortcut,
+                        int64_t npix, int c, void* out, void* stream);
+int ocr_relu_bwd_f16(const void* out, const void* dout, int64_t n, void* dz, void* stream);
+int ocr_add_inplace_f16(void* a, const void* b, int64_t n, void* stream);
 
 /* Backward of slim.conv2d's bias + ReLU (nets/pixellink.py:41-48): dz = da * [a > 0] (a = stored
  * conv output), dbias [c] = column sums.  partial: f32 [ocr_bias_relu_bwd_num_partials][c]. */

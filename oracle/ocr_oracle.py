@@ -615,3 +615,114 @@ def pixellink_net(inputs, p, mixed=False):
         nm = "pixellink_layers/%s_predication" % ("text" if kind == "pixel" else "link")
         outs.append(conv2d(s3, p[nm + "/weights"], 1, 1) + p[nm + "/biases"])
     return outs[0], outs[1], ep
+
+
+# ------------------------------------------------------------------------ ResNet-v1-50
+RESNET50_BLOCKS = [("block1", [(256, 64, 1)] * 2 + [(256, 64, 2)]),
+                   ("block2", [(512, 128, 1)] * 3 + [(512, 128, 2)]),
+                   ("block3", [(1024, 256, 1)] * 5 + [(1024, 256, 2)]),
+                   ("block4", [(2048, 512, 1)] * 3)]
+
+
+def _he(rng, shape):
+    fan_in = shape[0] * shape[1] * shape[2]
+    return (rng.standard_normal(shape) * math.sqrt(2.0 / fan_in)).astype(np.float32)
+
+
+def init_resnet50_params(rng, scope="resnet_v1_50", blocks=None):
+    blocks = blocks or RESNET50_BLOCKS
+    p = {}
+
+    def conv(name, k, cin, cout):
+        p[name + "/weights"] = _he(rng, (k, k, cin, cout))
+        _bn_init(p, name, cout)
+        p[name + "/BatchNorm/gamma"] = (1 + 0.1 * rng.standard_normal(cout)).astype(np.float32)
+        p[name + "/BatchNorm/beta"] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    conv(scope + "/conv1", 7, 3, 64)
+    cin = 64
+    for bname, units in blocks:
+        for i, (depth, db, stride) in enumerate(units):
+            u = "%s/%s/unit_%d/bottleneck_v1" % (scope, bname, i + 1)
+            if depth != cin:
+                conv(u + "/shortcut", 1, cin, depth)
+            conv(u + "/conv1", 1, cin, db)
+            conv(u + "/conv2", 3, db, db)
+            conv(u + "/conv3", 1, db, depth)
+            cin = depth
+    return p
+
+
+def _conv_bn(x, p, name, stride, relu, is_training, mixed, updates, k=None):
+    w = p[name + "/weights"]
+    y = conv2d_same(q(x, mixed), q(w, mixed), stride)
+    y = qg(q(y, mixed), mixed)
+    y, nm, nv = batch_norm(y, p[name + "/BatchNorm/gamma"], p[name + "/BatchNorm/beta"],
+                           p[name + "/BatchNorm/moving_mean"], p[name + "/BatchNorm/moving_variance"],
+                           is_training)
+    updates[name + "/BatchNorm/moving_mean"] = nm
+    updates[name + "/BatchNorm/moving_variance"] = nv
+    return torch.relu(y) if relu else y
+
+
+def bottleneck(x, p, u, depth, stride, is_training, mixed, updates):
+    """nets/resnet_v1.py:68-111."""
+    depth_in = x.shape[-1]
+    if depth == depth_in:
+        shortcut = x if stride == 1 else max_pool(x, 1, stride)
+    else:
+        shortcut = q(_conv_bn(qg(x, mixed), p, u + "/shortcut", stride, False, is_training, mixed, updates), mixed)
+    r = q(_conv_bn(qg(x, mixed), p, u + "/conv1", 1, True, is_training, mixed, updates), mixed)
+    r = q(_conv_bn(qg(r, mixed), p, u + "/conv2", stride, True, is_training, mixed, updates), mixed)
+    r = q(_conv_bn(qg(r, mixed), p, u + "/conv3", 1, False, is_training, mixed, updates), mixed)
+    return q(torch.relu(shortcut + r), mixed)
+
+
+def resnet_v1_50(x, p, is_training=True, scope="resnet_v1_50", mixed=False, updates=None, blocks=None):
+    """nets/resnet_v1.py:114-259 (root 7x7/2 + 3x3/2 max-pool, blocks, end points pool2..pool5)."""
+    updates = {} if updates is None else updates
+    blocks = blocks or RESNET50_BLOCKS
+    ep = {}
+    net = q(_conv_bn(q(x, mixed), p, scope + "/conv1", 2, True, is_training, mixed, updates), mixed)
+    net = max_pool(net, 3, 2)
+    ep["pool2"] = net
+    for bname, units in blocks:
+        for i, (depth, db, stride) in enumerate(units):
+            net = bottleneck(net, p, "%s/%s/unit_%d/bottleneck_v1" % (scope, bname, i + 1), depth, stride,
+                             is_training, mixed, updates)
+        ep[scope + "/" + bname] = net
+    ep["pool3"], ep["pool4"], ep["pool5"] = ep[scope + "/block1"], ep[scope + "/block2"], net
+    return net, ep
+
+
+def init_model_resnet_params(rng, blocks=None):
+    p = init_resnet50_params(rng, blocks=blocks)
+    blocks = blocks or RESNET50_BLOCKS
+    chans = [blocks[-1][1][-1][0], blocks[1][1][-1][0], blocks[0][1][-1][0], 64]   # pool5, pool4, pool3, pool2
+    for base, c in ((0, 2), (4, 16)):
+        for i, cin in enumerate(chans):
+            nm = "feature_fusion/Conv" + ("_%d" % (base + i) if base + i else "")
+            p[nm + "/weights"] = _he(rng, (1, 1, cin, c))
+            _bn_init(p, nm, c)
+            p[nm + "/BatchNorm/beta"] = (0.2 + 0.1 * rng.standard_normal(c)).astype(np.float32)
+    for nm, c in (("feature_fusion/Conv_8", 2), ("feature_fusion/Conv_9", 16)):
+        p[nm + "/weights"] = _he(rng, (1, 1, c, c))
+        p[nm + "/biases"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+    return p
+
+
+def model_resnet(images, p, is_training=True, mixed=False, updates=None, blocks=None):
+    """nets/model.py:84-143 -> (pixel_4, link_4, end_points)."""
+    updates = {} if updates is None else updates
+    x = mean_image_subtraction(images)
+    _, ep = resnet_v1_50(x, p, is_training, "resnet_v1_50", mixed, updates, blocks)
+    f = [ep["pool5"], ep["pool4"], ep["pool3"], ep["pool2"]]
+    outs = []
+    for base, c, last in ((0, 2, "Conv_8"), (4, 16, "Conv_9")):
+        def nm(i):
+            return "feature_fusion/Conv" + ("_%d" % (base + i) if base + i else "")
+        s = resize_bilinear_x2(_head(qg(f[0], mixed), p, nm(0), is_training, mixed, updates)) + \
+            _head(qg(f[1], mixed), p, nm(1), is_training, mixed, updates)
+        s = resize_bilinear_x2(s) + _head(qg(f[2], mixed), p, nm(2), is_training, mixed, updates)
+        s = resize_bilinear_x2(s) + _head(qg(f[3], mixed), p, nm(3), is_training, mixed, updates)
+        outs.append(conv2d(s, p["feature_fusion/%s/weights" % last], 1, 1) + p["feature_fusion/%s/biases" % last])
+    return outs[0], outs[1], ep

@@ -353,6 +353,86 @@ __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const half_t* __rest
   }
 }
 
+// ------------------------------------------- per-channel statistics of an f16 tensor
+// (batch norm after a sub-sampled / otherwise post-processed conv output, where the conv
+// epilogue's fused statistics do not apply): partial [blocks][2][C] like OCR_CONV_STATS.
+__global__ __launch_bounds__(256) void channel_stats_kernel(const half_t* __restrict__ x, size_t npix,
+                                                            int c, float* __restrict__ partial) {
+  __shared__ float red[256 * 16];
+  const int chunks = c >> 3;
+  const int lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  for (size_t u = (size_t)blockIdx.x * lanes + ul; u < npix; u += (size_t)gridDim.x * lanes) {
+    half8_t v = *reinterpret_cast<const half8_t*>(x + u * c + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)v[e];
+      s[e] += f;
+      q[e] += f * f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[(ul * chunks + ch) * 16 + e] = s[e];
+    red[(ul * chunks + ch) * 16 + 8 + e] = q[e];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * c; j += 256) {
+    const int which = j / c, cc = j % c;
+    float tot = 0.f;
+    for (int l = 0; l < lanes; ++l) tot += red[(l * chunks + (cc >> 3)) * 16 + (cc & 7) + which * 8];
+    partial[((size_t)blockIdx.x * 2 + which) * c + cc] = tot;
+  }
+}
+
+// ResNet bottleneck tail: out = relu(y*scale + shift + shortcut)   (nets/resnet_v1.py:107)
+__global__ void bn_add_relu_kernel(const half_t* __restrict__ y, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, const half_t* __restrict__ sc,
+                                   size_t npix, int c, half_t* __restrict__ out) {
+  const int chunks = c >> 3;
+  const size_t total = npix * chunks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    half8_t v = *reinterpret_cast<const half8_t*>(y + i * 8);
+    half8_t r = *reinterpret_cast<const half8_t*>(sc + i * 8);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // the normalised residual is rounded to f16 first (it is what BN backward differentiates)
+      const float z = (float)(half_t)((float)v[e] * scale[ch * 8 + e] + shift[ch * 8 + e]);
+      const float f = z + (float)r[e];
+      o[e] = (half_t)(f > 0.f ? f : 0.f);
+    }
+    *reinterpret_cast<half8_t*>(out + i * 8) = o;
+  }
+}
+
+// dz = dout * [out > 0]  (+ optionally accumulated into an existing gradient)
+__global__ void relu_bwd_kernel(const half_t* __restrict__ out, const half_t* __restrict__ dout,
+                                size_t n8, half_t* __restrict__ dz) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    half8_t o = *reinterpret_cast<const half8_t*>(out + i * 8);
+    half8_t g = *reinterpret_cast<const half8_t*>(dout + i * 8);
+    half8_t d;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = (float)o[e] > 0.f ? g[e] : (half_t)0.f;
+    *reinterpret_cast<half8_t*>(dz + i * 8) = d;
+  }
+}
+
+__global__ void add_inplace_kernel(half_t* __restrict__ a, const half_t* __restrict__ b, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    half8_t x = *reinterpret_cast<const half8_t*>(a + i * 8);
+    half8_t y = *reinterpret_cast<const half8_t*>(b + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (half_t)((float)x[e] + (float)y[e]);
+    *reinterpret_cast<half8_t*>(a + i * 8) = x;
+  }
+}
+
 // --------------------------------------------------------- general max-pool
 struct PoolP {
   int n, h, w, c, oh, ow, k, stride, pt, pl;
@@ -625,5 +705,45 @@ extern "C" int ocr_bias_relu_bwd_f16(const void* a, const void* da, int64_t npix
                      static_cast<float*>(partial));
   hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(c)), dim3(256), 0, st,
                      static_cast<const float*>(partial), static_cast<float*>(dbias), c, T, 1.f);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_channel_stats_num_partials(int64_t npix, int c) {
+  return ocr_bias_relu_bwd_num_partials(npix, c);
+}
+
+extern "C" int ocr_channel_stats_f16(const void* x, int64_t npix, int c, void* partial, void* stream) {
+  OCR_CHECK_ARG(x && partial);
+  const int T = ocr_channel_stats_num_partials(npix, c);
+  if (T < 0) return T;
+  hipLaunchKernelGGL(channel_stats_kernel, dim3(T), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const half_t*>(x), (size_t)npix, c, static_cast<float*>(partial));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_add_relu_f16(const void* y, const void* scale, const void* shift,
+                                   const void* shortcut, int64_t npix, int c, void* out, void* stream) {
+  OCR_CHECK_ARG(y && scale && shift && shortcut && out && npix > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0);
+  hipLaunchKernelGGL(bn_add_relu_kernel, dim3(stream_grid((size_t)npix * (c / 8))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(y),
+                     static_cast<const float*>(scale), static_cast<const float*>(shift),
+                     static_cast<const half_t*>(shortcut), (size_t)npix, c, static_cast<half_t*>(out));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_relu_bwd_f16(const void* out, const void* dout, int64_t n, void* dz, void* stream) {
+  OCR_CHECK_ARG(out && dout && dz && n > 0 && n % 8 == 0);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_grid((size_t)n / 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(out),
+                     static_cast<const half_t*>(dout), (size_t)n / 8, static_cast<half_t*>(dz));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_add_inplace_f16(void* a, const void* b, int64_t n, void* stream) {
+  OCR_CHECK_ARG(a && b && n > 0 && n % 8 == 0);
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(stream_grid((size_t)n / 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<half_t*>(a),
+                     static_cast<const half_t*>(b), (size_t)n / 8);
   return ocr_launch_status();
 }

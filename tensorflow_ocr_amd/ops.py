@@ -120,6 +120,29 @@ def conv2d_first_wgrad(x4, dy, dw, ws):
            ptr(dw), ptr(buf), c_size_t(nbytes), _st())
 
 
+def conv2d_stem_num_mtiles(n, h, w):
+    return L.call_int("ocr_conv2d_stem_num_mtiles", c_int(n), c_int(h), c_int(w))
+
+
+def conv2d_stem(x4, w_stem, y, flags=0, bias=None, stats=None):
+    n, h, w, _ = x4.shape
+    L.call("ocr_conv2d_stem_f16", c_int(n), c_int(h), c_int(w), c_int(y.shape[-1]), ptr(x4), ptr(w_stem),
+           ptr(bias), c_int(flags), ptr(y), ptr(stats), _st())
+
+
+def conv2d_stem_wgrad(x4, dy, dw, ws):
+    n, h, w, _ = x4.shape
+    cout = dy.shape[-1]
+    nbytes = L.call_size("ocr_conv2d_stem_wgrad_workspace", c_int(n), c_int(h), c_int(w), c_int(cout))
+    buf = ws.get(nbytes)
+    L.call("ocr_conv2d_stem_wgrad_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(dy), ptr(dw),
+           ptr(buf), c_size_t(nbytes), _st())
+
+
+def pack_weights_stem(w_hwio, w_stem):
+    L.call("ocr_pack_weights_stem_f16", ptr(w_hwio), c_int(w_hwio.shape[-1]), ptr(w_stem), _st())
+
+
 def pack_weights_first(w_hwio, w_first):
     L.call("ocr_pack_weights_first_f16", ptr(w_hwio), c_int(w_hwio.shape[-1]), ptr(w_first), _st())
 
@@ -181,6 +204,29 @@ def bn_relu_bwd(y, scale, shift, save_mean, save_invstd, da_full, da_pool, relu,
            ptr(da_full), ptr(da_pool), c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)),
            c_int(pool), ptr(dgamma), ptr(dbeta), ptr(dy), ptr(part), ptr(stage),
            c_size_t(stage.numel()), _st())
+
+
+def channel_stats_num_partials(npix, c):
+    return L.call_int("ocr_channel_stats_num_partials", c_int64(npix), c_int(c))
+
+
+def channel_stats(x, partial):
+    c = x.shape[-1]
+    L.call("ocr_channel_stats_f16", ptr(x), c_int64(x.numel() // c), c_int(c), ptr(partial), _st())
+
+
+def bn_add_relu(y, scale, shift, shortcut, out):
+    c = y.shape[-1]
+    L.call("ocr_bn_add_relu_f16", ptr(y), ptr(scale), ptr(shift), ptr(shortcut), c_int64(y.numel() // c),
+           c_int(c), ptr(out), _st())
+
+
+def relu_bwd(out, dout, dz):
+    L.call("ocr_relu_bwd_f16", ptr(out), ptr(dout), c_int64(out.numel()), ptr(dz), _st())
+
+
+def add_inplace(a, b):
+    L.call("ocr_add_inplace_f16", ptr(a), ptr(b), c_int64(a.numel()), _st())
 
 
 def bias_relu_bwd(a, da, relu, dz, dbias, ws):

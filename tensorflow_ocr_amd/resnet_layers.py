@@ -1,0 +1,183 @@
+"""ResNet-v1 building blocks on the HIP kernels: conv + slim.batch_norm (+ReLU), the 7x7/2 root
+convolution, and the bottleneck tail relu(shortcut + bn(conv3)) — reference nets/resnet_v1.py:68-111,
+181-196 and nets/resnet_utils.py:59-122.
+
+Strided 3x3 convolutions use the identity the reference's own docstring states
+(resnet_utils.py:85-93): conv2d_same(x, n, 3, stride=s) == subsample(conv2d(x, n, 3, stride=1,
+SAME), s).  The stride-1 MFMA kernels (forward, input gradient, weight gradient) are reused and the
+sub-sampling is the 1x1/s max-pool kernel; only 3 of ResNet-50's 53 convolutions are strided 3x3
+(+7 % forward FLOPs), so this costs little and keeps one tuned kernel family.
+"""
+from . import ops
+from .graph import Act, F32, constant, variance_scaling
+from .layers import BN_DECAY, BN_EPS, _bn_vars, _packs
+from ._lib import CONV_ACCUM_F16, CONV_STATS
+
+
+class ConvBN:
+    """Raw conv output + the batch-norm coefficients of one conv layer."""
+    __slots__ = ("y", "scale", "shift", "mean", "invstd", "gamma", "beta", "wv", "backward_from")
+
+
+def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, weight_decay=True):
+    """slim.conv2d(normalizer_fn=slim.batch_norm) up to (not including) the normalise step.
+    x: Act f16 [n,h,w,cin].  Returns ConvBN; `backward_from(dy)` propagates the gradient of the
+    conv output into the weights and into x."""
+    n, h, w, cin = x.shape
+    with g.variable_scope(scope):
+        wv = g.get_variable("weights", (k, k, cin, cout), variance_scaling(g.rng), regularized=weight_decay)
+        gamma, beta, mm, mv = _bn_vars(g, cout)
+    ws = g.workspace()
+    w_fwd, w_dg = _packs(g, wv, False)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, 1, rate)          # stride-1 SAME
+    strided = stride != 1
+    if strided and k == 1:
+        raise NotImplementedError("strided 1x1 conv (the slim variant in the reference has none)")
+    y_full = g.empty((n, d.oh, d.ow, cout))
+    mt = ops.conv2d_num_mtiles(d)
+    if strided:
+        d.flags = 0
+        ops.conv2d(d, x.data, w_fwd, y_full, None, None)
+        oh, ow = -(-h // stride), -(-w // stride)
+        y = g.empty((n, oh, ow, cout))
+        ops.maxpool(y_full, 1, stride, (0, 0), y)                   # subsample (resnet_utils.py:74)
+        T = ops.channel_stats_num_partials(n * oh * ow, cout)
+        part, stage = g.ws_small.two(T * 2 * cout * 4, ops.bn_reduce_workspace(T, cout))
+        if is_training:
+            ops.channel_stats(y, part)
+    else:
+        oh, ow = d.oh, d.ow
+        y = y_full
+        T = mt
+        part, stage = g.ws_small.two(T * 2 * cout * 4, ops.bn_reduce_workspace(T, cout))
+        d.flags = CONV_STATS if is_training else 0
+        ops.conv2d(d, x.data, w_fwd, y, None, part if is_training else None)
+    c = ConvBN()
+    c.y, c.gamma, c.beta, c.wv = y, gamma, beta, wv
+    c.scale, c.shift = g.empty((cout,), F32), g.empty((cout,), F32)
+    c.mean, c.invstd = g.empty((cout,), F32), g.empty((cout,), F32)
+    if is_training:
+        ops.bn_finalize(part, T, cout, float(n) * oh * ow, gamma.data, beta.data, BN_EPS, BN_DECAY, mm.data,
+                        mv.data, c.scale, c.shift, c.mean, c.invstd, stage)
+    else:
+        ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, c.scale, c.shift)
+
+    def backward_from(dy):
+        if strided:
+            dy_full = g.empty(y_full.shape)
+            ops.maxpool_bwd(y_full, dy, 1, stride, (0, 0), dy_full, False)   # zero insertion
+            dy = dy_full
+        dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, d.kh, d.kw, 1, d.dilation, d.pad_top,
+                          d.pad_left, 0, 0)
+        ops.conv2d_wgrad(dd, x.data, dy, wv.grad, ws)
+        if not x.requires_grad:
+            return
+        pt = d.dilation * (d.kh - 1) - d.pad_top
+        pl = d.dilation * (d.kw - 1) - d.pad_left
+        flags = 0
+        if x.grad is None:
+            x.grad = g.empty(x.shape)
+        else:
+            flags |= CONV_ACCUM_F16
+        dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, flags)
+        ops.conv2d(dg, dy, w_dg, x.grad, None, None)
+    c.backward_from = backward_from
+    return c
+
+
+def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_training=True):
+    """conv + batch_norm + (ReLU | identity) -> Act."""
+    c = conv_bn_raw(g, x, cout, k, scope, stride=stride, rate=rate, is_training=is_training)
+    a = Act(g.empty(c.y.shape), name=scope)
+    ops.bn_relu(c.y, c.scale, c.shift, relu, 0, a.data, None)
+    ws = g.workspace()
+
+    def backward():
+        if a.grad is None:
+            return
+        dy = g.empty(c.y.shape)
+        ops.bn_relu_bwd(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, None, relu, 0, c.gamma.grad,
+                        c.beta.grad, dy, ws)
+        c.backward_from(dy)
+        a.grad = None
+    g.record(backward, (c.wv, c.gamma, c.beta))
+    return a
+
+
+def root_block(g, x4, scope="conv1", cout=64, is_training=True):
+    """conv2d_same(inputs, 64, 7, stride=2) + BN + ReLU (nets/resnet_v1.py:193).  x4: prepared image."""
+    n, h, w, _ = x4.shape
+    with g.variable_scope(scope):
+        wv = g.get_variable("weights", (7, 7, 3, cout), variance_scaling(g.rng), regularized=True)
+        gamma, beta, mm, mv = _bn_vars(g, cout)
+    ws = g.workspace()
+
+    def mk(old):
+        t = old if old is not None else g.empty((7, 2, cout, 16))
+        ops.pack_weights_stem(wv.data, t)
+        return t
+    w_stem = g.packed(wv, "stem", mk)
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = g.empty((n, oh, ow, cout))
+    mt = ops.conv2d_stem_num_mtiles(n, h, w)
+    part, stage = g.ws_small.two(mt * 2 * cout * 4, ops.bn_reduce_workspace(mt, cout))
+    ops.conv2d_stem(x4.data, w_stem, y, CONV_STATS if is_training else 0, None, part if is_training else None)
+    scale, shift = g.empty((cout,), F32), g.empty((cout,), F32)
+    mean, invstd = g.empty((cout,), F32), g.empty((cout,), F32)
+    if is_training:
+        ops.bn_finalize(part, mt, cout, float(n) * oh * ow, gamma.data, beta.data, BN_EPS, BN_DECAY, mm.data,
+                        mv.data, scale, shift, mean, invstd, stage)
+    else:
+        ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
+    a = Act(g.empty(y.shape), name=scope)
+    ops.bn_relu(y, scale, shift, True, 0, a.data, None)
+
+    def backward():
+        if a.grad is None:
+            return
+        dy = g.empty(y.shape)
+        ops.bn_relu_bwd(y, scale, shift, mean, invstd, a.grad, None, True, 0, gamma.grad, beta.grad, dy, ws)
+        ops.conv2d_stem_wgrad(x4.data, dy, wv.grad, ws)
+        a.grad = None
+    g.record(backward, (wv, gamma, beta))
+    return a
+
+
+def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
+    """nets/resnet_v1.py:68-111: shortcut = subsample(x, stride) if depth == depth_in else
+    1x1 conv(stride) + BN;  residual = 1x1 -> 3x3(stride) -> 1x1 with BN (ReLU, ReLU, none);
+    output = relu(shortcut + residual)."""
+    from .layers import max_pool2d
+    depth_in = x.shape[-1]
+    ws = g.workspace()
+    with g.variable_scope(scope):
+        with g.variable_scope("bottleneck_v1"):
+            if depth == depth_in:
+                shortcut = x if stride == 1 else max_pool2d(g, x, 1, stride, scope="shortcut")
+            else:
+                if stride != 1:
+                    raise NotImplementedError("strided projection shortcut")
+                shortcut = conv_bn_act(g, x, depth, 1, "shortcut", relu=False, is_training=is_training)
+            r = conv_bn_act(g, x, depth_bottleneck, 1, "conv1", is_training=is_training)
+            r = conv_bn_act(g, r, depth_bottleneck, 3, "conv2", stride=stride, is_training=is_training)
+            c3 = conv_bn_raw(g, r, depth, 1, "conv3", is_training=is_training)
+    out = Act(g.empty(c3.y.shape), name=scope)
+    ops.bn_add_relu(c3.y, c3.scale, c3.shift, shortcut.data, out.data)
+
+    def backward():
+        if out.grad is None:
+            return
+        dz = g.empty(out.shape)
+        ops.relu_bwd(out.data, out.grad, dz)
+        dy = g.empty(c3.y.shape)
+        ops.bn_relu_bwd(c3.y, c3.scale, c3.shift, c3.mean, c3.invstd, dz, None, False, 0, c3.gamma.grad,
+                        c3.beta.grad, dy, ws)
+        c3.backward_from(dy)
+        if shortcut.requires_grad:
+            if shortcut.grad is None:
+                shortcut.grad = dz
+            else:
+                ops.add_inplace(shortcut.grad, dz)
+        out.grad = None
+    g.record(backward, (c3.wv, c3.gamma, c3.beta))
+    return out

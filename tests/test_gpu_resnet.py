@@ -1,0 +1,144 @@
+"""GPU parity of the ResNet-v1 pieces (root 7x7/2 conv, bottleneck units incl. the strided
+3x3 = stride-1 conv + subsample identity, projection / identity / subsample shortcuts) and of
+`model.model` (ResNet trunk + PixelLink fuse heads + OHNM loss) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ocr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _h(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-20))
+
+
+def _rel2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-20))
+
+
+def test_root_block(device):
+    from tensorflow_ocr_amd import layers, resnet_layers
+    from tensorflow_ocr_amd.graph import Graph
+    rng = np.random.default_rng(0)
+    n, h, w = 2, 38, 70
+    img = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    p = {}
+    p["conv1/weights"] = _h(rng.standard_normal((7, 7, 3, 64)) * 0.02)
+    O._bn_init(p, "conv1", 64)
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    gout = _h(rng.standard_normal((n, oh, ow, 64)) * 0.1)
+    g = Graph(device, loss_scale=1.0)
+    x4 = layers.prep_images(g, torch.from_numpy(img).to(device))
+    resnet_layers.root_block(g, x4)
+    g.reset_tape()
+    g.store.load_state_dict(p)
+    a = resnet_layers.root_block(g, x4)
+    assert a.shape == (n, oh, ow, 64)
+    a.grad = torch.from_numpy(gout).half().to(device)
+    g.backward()
+    torch.cuda.synchronize()
+    tp = O.to_torch_params(p)
+    xm = O.q(O.mean_image_subtraction(torch.from_numpy(img)), True)
+    o = O.q(O._conv_bn(xm, tp, "conv1", 2, True, True, True, {}), True)
+    (o * torch.from_numpy(gout)).sum().backward()
+    assert np.abs(a.data.float().cpu().numpy() - o.detach().numpy()).max() < 4e-3
+    assert _rel(g.store.vars["conv1/weights"].grad.cpu().numpy(), tp["conv1/weights"].grad.numpy()) < 1e-2
+    assert _rel(g.store.vars["conv1/BatchNorm/gamma"].grad.cpu().numpy(), tp["conv1/BatchNorm/gamma"].grad.numpy()) < 5e-3
+
+
+@pytest.mark.parametrize("cin,depth,db,stride,hw", [
+    (128, 128, 64, 1, 12),     # identity shortcut
+    (128, 128, 64, 2, 12),     # subsample shortcut + strided 3x3
+    (64, 128, 64, 1, 10),      # projection shortcut
+    (128, 128, 64, 2, 9),      # odd size: ceil(h/2)
+])
+def test_bottleneck(device, cin, depth, db, stride, hw):
+    from tensorflow_ocr_amd import resnet_layers
+    from tensorflow_ocr_amd.graph import Act, Graph
+    rng = np.random.default_rng(1)
+    n = 2
+    x = _h(np.abs(rng.standard_normal((n, hw, hw, cin))))
+    u = "u/bottleneck_v1"
+    p = {}
+    for name, k, ci, co in (("shortcut", 1, cin, depth), ("conv1", 1, cin, db), ("conv2", 3, db, db), ("conv3", 1, db, depth)):
+        if name == "shortcut" and cin == depth:
+            continue
+        p["%s/%s/weights" % (u, name)] = _h(rng.standard_normal((k, k, ci, co)) * np.sqrt(2.0 / (k * k * ci)))
+        O._bn_init(p, "%s/%s" % (u, name), co)
+        p["%s/%s/BatchNorm/gamma" % (u, name)] = (1 + 0.1 * rng.standard_normal(co)).astype(np.float32)
+        p["%s/%s/BatchNorm/beta" % (u, name)] = (0.1 * rng.standard_normal(co)).astype(np.float32)
+    oh = -(-hw // stride)
+    gout = _h(rng.standard_normal((n, oh, oh, depth)) * 0.1)
+    g = Graph(device, loss_scale=1.0)
+    xa = Act(torch.from_numpy(x).half().to(device))
+    resnet_layers.bottleneck(g, xa, depth, db, stride, "u")
+    g.reset_tape()
+    g.store.load_state_dict(p)
+    out = resnet_layers.bottleneck(g, xa, depth, db, stride, "u")
+    out.grad = torch.from_numpy(gout).half().to(device)
+    g.backward()
+    torch.cuda.synchronize()
+    tp = O.to_torch_params(p)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    o = O.bottleneck(xt, tp, u, depth, stride, True, True, {})
+    (o * torch.from_numpy(gout)).sum().backward()
+    assert out.shape == tuple(o.shape)
+    assert np.abs(out.data.float().cpu().numpy() - o.detach().numpy()).max() < 1e-2
+    # three BN'd convs deep with a few hundred samples per channel: relative L2 (max-norm of a
+    # single weight tensor is dominated by one or two cancellation-heavy entries)
+    assert _rel2(xa.grad.float().cpu().numpy(), xt.grad.numpy()) < 3e-2
+    for k in p:
+        if k.endswith("weights") or k.endswith("gamma") or k.endswith("beta"):
+            r = _rel2(g.store.vars[k].grad.cpu().numpy(), tp[k].grad.numpy())
+            assert r < 3e-2, (k, r)
+
+
+SMALL = [("block1", [(128, 64, 1), (128, 64, 2)]), ("block2", [(256, 64, 1), (256, 64, 2)]),
+         ("block3", [(256, 128, 1), (256, 128, 2)]), ("block4", [(512, 128, 1)])]
+
+
+def test_model_resnet_pixellink_heads_ohnm(device):
+    """nets/model.py `model` + `loss` end to end on a reduced block list (same code path as
+    resnet_v1_50).  End-to-end bars as in test_gpu_model_vgg.py (BN nets at random init are chaotic
+    under f16 storage)."""
+    from tensorflow_ocr_amd import checkpoint
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model as M
+    from tensorflow_ocr_amd.nets import resnet_model
+    S = 256.0
+    rng = np.random.default_rng(2)
+    p = O.init_model_resnet_params(rng, SMALL)
+    images, pixel, link, mask = O.synthetic_batch(rng, 2, 128)
+    g = Graph(device, loss_scale=S)
+    resnet_model.model_resnet50_pixellink(images, graph=g, blocks=SMALL)
+    g.reset_tape()
+    g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, p))
+    px, lk = resnet_model.model_resnet50_pixellink(images, graph=g, blocks=SMALL)
+    assert px.data.shape == (2, 32, 32, 2) and lk.data.shape == (2, 32, 32, 16)
+    L = M.loss(pixel, px, link, lk, mask, graph=g)
+    g.backward()
+    torch.cuda.synchronize()
+    grads = checkpoint.internal_to_tf({n: (v.grad / S).cpu().numpy() for n, v in g.store.vars.items() if v.trainable})
+    tp = O.to_torch_params(p)
+    opx, olk, _ = O.model_resnet(torch.from_numpy(images), tp, True, mixed=True, blocks=SMALL)
+    oL, _, _, _ = O.model_loss_ohnm(torch.from_numpy(pixel), opx, torch.from_numpy(link), olk)
+    (oL * S).backward()
+    dpx = px.data.cpu().numpy()
+    print("loss %.5f vs %.5f; pixel_4 Linf %.3e mean %.3e" % (L.item(), float(oL), np.abs(dpx - opx.detach().numpy()).max(),
+                                                          np.abs(dpx - opx.detach().numpy()).mean()))
+    assert abs(L.item() - float(oL)) < 2e-2 * max(1.0, abs(float(oL)))
+    assert np.abs(dpx - opx.detach().numpy()).mean() < 2e-2
+
+    def cos(a, b):
+        a, b = a.ravel().astype(np.float64), b.ravel().astype(np.float64)
+        return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    cs = sorted((cos(grads[k], (tp[k].grad / S).numpy()), k) for k in grads if grads[k].size >= 64)
+    print("lowest gradient cosines", cs[:3])
+    assert cs[0][0] > 0.9
