@@ -165,6 +165,11 @@ int ocr_bn_add_relu_f16(const void* y, const void* scale, const void* shift, con
 int ocr_relu_bwd_f16(const void* out, const void* dout, int64_t n, void* dz, void* stream);
 int ocr_add_inplace_f16(void* a, const void* b, int64_t n, void* stream);
 
+/* unpool = tf.image.resize_bilinear x2 with TF-1.4 legacy sampling on f16 NHWC maps (EAST merge
+ * branch, nets/model_vgg_16.py:15-16,121): x [n,lh,lw,c] -> y [n,2lh,2lw,c]; and its transpose. */
+int ocr_unpool_f16(const void* x, int n, int lh, int lw, int c, void* y, void* stream);
+int ocr_unpool_bwd_f16(const void* dy, int n, int lh, int lw, int c, void* dx, int accumulate, void* stream);
+
 /* Backward of slim.conv2d's bias + ReLU (nets/pixellink.py:41-48): dz = da * [a > 0] (a = stored
  * conv output), dbias [c] = column sums.  partial: f32 [ocr_bias_relu_bwd_num_partials][c]. */
 int ocr_bias_relu_bwd_num_partials(int64_t npix, int c);
@@ -206,6 +211,9 @@ int ocr_sc_bn_bwd(const void* z, const void* scale, const void* shift, const voi
                   void* dbeta, void* dz, void* partial, void* stream);
 /* out[c] = sum_p x[p][c]; partial: (ocr_sc_num_partials + 1) * 2 * C floats */
 int ocr_sc_colsum(const void* x, int P, int C, void* out, void* partial, void* stream);
+/* sigmoid heads (F_score / geo_map, nets/model_vgg_16.py:129-131) and their gradient, f32 */
+int ocr_sc_sigmoid(const void* z, int64_t n, void* out, void* stream);
+int ocr_sc_sigmoid_bwd(const void* out, const void* dout, int64_t n, void* dz, void* stream);
 /* pointwise f32 conv on channel slices: out[p][oo+co] = b[co] + sum_ci x[p][xo+ci] w[ci][co] */
 int ocr_sc_pointwise_fwd(const void* x, int ldx, int xo, int cin, const void* w, const void* bias,
                          int P, void* out, int ldo, int oo, int cout, void* stream);

@@ -726,3 +726,65 @@ def model_resnet(images, p, is_training=True, mixed=False, updates=None, blocks=
         s = resize_bilinear_x2(s) + _head(qg(f[3], mixed), p, nm(3), is_training, mixed, updates)
         outs.append(conv2d(s, p["feature_fusion/%s/weights" % last], 1, 1) + p["feature_fusion/%s/biases" % last])
     return outs[0], outs[1], ep
+
+
+# --------------------------------------------------------------- EAST merge branch (ResNet)
+def init_model_east_params(rng, blocks=None):
+    """nets/model_vgg_16.py:85-136 variables: resnet_v1_50/... + feature_fusion/Conv..Conv_8."""
+    blocks = blocks or RESNET50_BLOCKS
+    p = init_resnet50_params(rng, blocks=blocks)
+    f = [blocks[-1][1][-1][0], blocks[1][1][-1][0], blocks[0][1][-1][0], 64]
+    outs = [None, 128, 64, 32]
+    idx = 0
+
+    def nm():
+        nonlocal idx
+        s = "feature_fusion/Conv" + ("_%d" % idx if idx else "")
+        idx += 1
+        return s
+
+    def conv(name, k, cin, cout):
+        p[name + "/weights"] = _he(rng, (k, k, cin, cout))
+        _bn_init(p, name, cout)
+        p[name + "/BatchNorm/beta"] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    cg = f[0]
+    for i in range(1, 4):
+        conv(nm(), 1, cg + f[i], outs[i])
+        conv(nm(), 3, outs[i], outs[i])
+        cg = outs[i]
+    conv(nm(), 3, 32, 32)
+    for c in (1, 8):
+        n_ = nm()
+        p[n_ + "/weights"] = _he(rng, (1, 1, 32, c))
+        p[n_ + "/biases"] = (0.05 * rng.standard_normal(c)).astype(np.float32)
+    return p
+
+
+def model_east(images, p, is_training=True, mixed=False, updates=None, blocks=None):
+    """nets/model_vgg_16.py:85-136 -> (F_score [N,H/4,W/4,1], geo_map [N,H/4,W/4,8], end_points)."""
+    updates = {} if updates is None else updates
+    x = mean_image_subtraction(images)
+    _, ep = resnet_v1_50(x, p, is_training, "resnet_v1_50", mixed, updates, blocks)
+    f = [ep["pool5"], ep["pool4"], ep["pool3"], ep["pool2"]]
+    idx = [0]
+
+    def nm():
+        s = "feature_fusion/Conv" + ("_%d" % idx[0] if idx[0] else "")
+        idx[0] += 1
+        return s
+    h = f[0]
+    g = q(resize_bilinear_x2(qg(h, mixed)), mixed)
+    for i in range(1, 4):
+        cat = torch.cat([qg(g, mixed), qg(f[i], mixed)], dim=-1)
+        c1 = q(_conv_bn(cat, p, nm(), 1, True, is_training, mixed, updates), mixed)
+        h = q(_conv_bn(qg(c1, mixed), p, nm(), 1, True, is_training, mixed, updates), mixed)
+        if i <= 2:
+            g = q(resize_bilinear_x2(qg(h, mixed)), mixed)
+        else:
+            g = q(_conv_bn(qg(h, mixed), p, nm(), 1, True, is_training, mixed, updates), mixed)
+    outs = []
+    for _ in range(2):
+        n_ = nm()
+        z = conv2d(q(qg(g, mixed), mixed), q(p[n_ + "/weights"], mixed), 1, 1) + p[n_ + "/biases"]
+        outs.append(torch.sigmoid(z))
+    return outs[0], outs[1], ep

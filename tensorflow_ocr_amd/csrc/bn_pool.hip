@@ -433,6 +433,82 @@ __global__ void add_inplace_kernel(half_t* __restrict__ a, const half_t* __restr
   }
 }
 
+// -------------------------------- legacy bilinear x2 on wide f16 maps (EAST merge branch)
+// tf.image.resize_bilinear(size = 2x, align_corners=False) of TF 1.4: out[2i] = in[i],
+// out[2i+1] = (in[i] + in[min(i+1, H-1)]) / 2, separably (nets/model_vgg_16.py:15-16,121).
+__global__ void unpool_f16_kernel(const half_t* __restrict__ x, int n, int lh, int lw, int c,
+                                  half_t* __restrict__ y) {
+  const int chunks = c >> 3, H = 2 * lh, W = 2 * lw;
+  const size_t total = (size_t)n * H * W * chunks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    size_t u = i / chunks;
+    const int ox = (int)(u % W);
+    u /= W;
+    const int oy = (int)(u % H);
+    const int img = (int)(u / H);
+    const int y0 = oy >> 1, x0 = ox >> 1;
+    const int y1 = (oy & 1) ? (y0 + 1 < lh ? y0 + 1 : lh - 1) : y0;
+    const int x1 = (ox & 1) ? (x0 + 1 < lw ? x0 + 1 : lw - 1) : x0;
+    const float wy = (oy & 1) ? 0.5f : 0.f, wx = (ox & 1) ? 0.5f : 0.f;
+    const half_t* b = x + (size_t)img * lh * lw * c + ch * 8;
+    half8_t v00 = *reinterpret_cast<const half8_t*>(b + ((size_t)y0 * lw + x0) * c);
+    half8_t v01 = *reinterpret_cast<const half8_t*>(b + ((size_t)y0 * lw + x1) * c);
+    half8_t v10 = *reinterpret_cast<const half8_t*>(b + ((size_t)y1 * lw + x0) * c);
+    half8_t v11 = *reinterpret_cast<const half8_t*>(b + ((size_t)y1 * lw + x1) * c);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float top = (float)v00[e] + ((float)v01[e] - (float)v00[e]) * wx;
+      const float bot = (float)v10[e] + ((float)v11[e] - (float)v10[e]) * wx;
+      o[e] = (half_t)(top + (bot - top) * wy);
+    }
+    *reinterpret_cast<half8_t*>(y + i * 8) = o;
+  }
+}
+
+__global__ void unpool_bwd_f16_kernel(const half_t* __restrict__ dy, int n, int lh, int lw, int c,
+                                      half_t* __restrict__ dx, int accumulate) {
+  const int chunks = c >> 3, H = 2 * lh, W = 2 * lw;
+  const size_t total = (size_t)n * lh * lw * chunks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    size_t u = i / chunks;
+    const int x = (int)(u % lw);
+    u /= lw;
+    const int y = (int)(u % lh);
+    const int img = (int)(u / lh);
+    const half_t* b = dy + (size_t)img * H * W * c + ch * 8;
+    int ry[3] = {2 * y, 2 * y + 1, 2 * y - 1}, rx[3] = {2 * x, 2 * x + 1, 2 * x - 1};
+    float wy[3] = {1.f, (y == lh - 1) ? 1.f : 0.5f, (y > 0) ? 0.5f : 0.f};
+    float wx[3] = {1.f, (x == lw - 1) ? 1.f : 0.5f, (x > 0) ? 0.5f : 0.f};
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (wy[a] == 0.f) continue;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (wx[d] == 0.f) continue;
+        half8_t v = *reinterpret_cast<const half8_t*>(b + ((size_t)ry[a] * W + rx[d]) * c);
+        const float wgt = wy[a] * wx[d];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += wgt * (float)v[e];
+      }
+    }
+    half8_t o;
+    if (accumulate) {
+      half8_t old = *reinterpret_cast<const half8_t*>(dx + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] += (float)old[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)g[e];
+    *reinterpret_cast<half8_t*>(dx + i * 8) = o;
+  }
+}
+
 // --------------------------------------------------------- general max-pool
 struct PoolP {
   int n, h, w, c, oh, ow, k, stride, pt, pl;
@@ -745,5 +821,24 @@ extern "C" int ocr_add_inplace_f16(void* a, const void* b, int64_t n, void* stre
   hipLaunchKernelGGL(add_inplace_kernel, dim3(stream_grid((size_t)n / 8)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<half_t*>(a),
                      static_cast<const half_t*>(b), (size_t)n / 8);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_unpool_f16(const void* x, int n, int lh, int lw, int c, void* y, void* stream) {
+  OCR_CHECK_ARG(x && y && n > 0 && lh > 0 && lw > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0);
+  hipLaunchKernelGGL(unpool_f16_kernel, dim3(stream_grid((size_t)n * lh * lw * 4 * (c / 8))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(x), n, lh, lw, c,
+                     static_cast<half_t*>(y));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_unpool_bwd_f16(const void* dy, int n, int lh, int lw, int c, void* dx, int accumulate,
+                                  void* stream) {
+  OCR_CHECK_ARG(dy && dx && n > 0 && lh > 0 && lw > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0);
+  hipLaunchKernelGGL(unpool_bwd_f16_kernel, dim3(stream_grid((size_t)n * lh * lw * (c / 8))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(dy), n, lh, lw, c,
+                     static_cast<half_t*>(dx), accumulate);
   return ocr_launch_status();
 }

@@ -219,7 +219,7 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, int* bn, int* ck) {
   OCR_CHECK_ARG(d != nullptr);
   OCR_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0);
   OCR_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dilation > 0);
-  OCR_CHECK_SHAPE(d->cin % 32 == 0 && d->cout % 64 == 0);
+  OCR_CHECK_SHAPE(d->cin % 32 == 0 && d->cout % 32 == 0);
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
   p->kh = d->kh; p->kw = d->kw; p->stride = d->stride; p->dil = d->dilation;
@@ -228,7 +228,7 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, int* bn, int* ck) {
   p->tiles_y = ocr_cdiv(d->oh, TILE_H);
   p->HT = (TILE_H - 1) * d->stride + (d->kh - 1) * d->dilation + 1;
   p->WT = (TILE_W - 1) * d->stride + (d->kw - 1) * d->dilation + 1;
-  *bn = (d->cout % 256 == 0) ? 256 : (d->cout % 128 == 0) ? 128 : 64;
+  *bn = (d->cout % 256 == 0) ? 256 : (d->cout % 128 == 0) ? 128 : (d->cout % 64 == 0) ? 64 : 32;
   if (const char* e = getenv("OCR_CONV_BN")) { int v = atoi(e); if (v == 128 && *bn == 256) *bn = 128; }
   int c = (d->cin % 64 == 0) ? 64 : 32;
   if (const char* e = getenv("OCR_CONV_CK")) { if (atoi(e) == 32) c = 32; }
@@ -266,5 +266,7 @@ extern "C" int ocr_conv2d_f16(const ocr_conv_desc* d, const void* x, const void*
   if (bn == 128 && ck == 64) return launch<128, 64, 2>(p, x, w_kc, bias, y, stats, st);
   if (bn == 128 && ck == 32) return launch<128, 32, 2>(p, x, w_kc, bias, y, stats, st);
   if (bn == 64 && ck == 64) return launch<64, 64, 2>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 32 && ck == 64) return launch<32, 64, 1>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 32) return launch<32, 32, 1>(p, x, w_kc, bias, y, stats, st);
   return launch<64, 32, 2>(p, x, w_kc, bias, y, stats, st);
 }

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(COB2 * 4) void wgrad2_kernel(Wg2P p, const half_t* 
       xr[u] = u32x4{0u, 0u, 0u, 0u};
       if (xpos[u] >= 0) {
         const int iy = iy0 + (xpos[u] >> 16), ix = ix0 + (xpos[u] & 0xffff);
-        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w && ci0 + xc * 8 < p.cin)
           xr[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin);
       }
     }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(COB2 * 4) void wgrad2_kernel(Wg2P p, const half_t* 
       const int px = idx / DCH, c = idx % DCH;
       const int oy = tyi * T2_H + (px >> 5), ox = txi * TILE_W + (px & 31);
       dr[u] = u32x4{0u, 0u, 0u, 0u};
-      if (oy < p.oh && ox < p.ow)
+      if (oy < p.oh && ox < p.ow && co0 + c * 8 < p.cout)
         dr[u] = *reinterpret_cast<const u32x4*>(db + ((size_t)oy * p.ow + ox) * p.cout + c * 8);
     }
   };
@@ -337,10 +337,12 @@ __global__ __launch_bounds__(COB2 * 4) void wgrad2_kernel(Wg2P p, const half_t* 
     if (t < ntaps) {
       float* dst = slab + (((size_t)split * ntaps + t) * p.cin + ci0 + ciw * 32) * p.cout + co0 +
                    cow * 32 + r;
+      if (ci0 + ciw * 32 < p.cin && co0 + cow * 32 < p.cout) {   // 32-wide partial blocks
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h2;
-        dst[(size_t)row * p.cout] = acc[t][e];
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h2;
+          dst[(size_t)row * p.cout] = acc[t][e];
+        }
       }
     }
   }
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(COB2 * 4) void wgrad2_kernel(Wg2P p, const half_t* 
 
 // returns OCR_OK when v2 applies (and fills p / cob), OCR_ERR_UNSUPPORTED otherwise
 int fill2(const ocr_conv_desc* d, Wg2P* p, int* cob) {
-  if (d->cin % 64 || d->cout % 64 || d->kh * d->kw > 9) return OCR_ERR_UNSUPPORTED;
+  if (d->cin % 32 || d->cout % 32 || d->kh * d->kw > 9) return OCR_ERR_UNSUPPORTED;
   *cob = (d->cout % 128 == 0) ? 128 : 64;
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
@@ -362,8 +364,8 @@ int fill2(const ocr_conv_desc* d, Wg2P* p, int* cob) {
   if (p->HT * p->WT > 7 * 32) return OCR_ERR_UNSUPPORTED;
   const size_t stage = (size_t)p->HT * p->WT * X2STR + 128 * (*cob * 2 + 64);
   if (2 * stage > 160 * 1024) return OCR_ERR_UNSUPPORTED;
-  p->nci = d->cin / CIB;
-  p->nco = d->cout / *cob;
+  p->nci = ocr_cdiv(d->cin, CIB);
+  p->nco = ocr_cdiv(d->cout, *cob);
   const int blocks = p->nci * p->nco;
   int want = ocr_cdiv(256, blocks);            // one resident workgroup per CU
   if (want > p->m_tiles) want = p->m_tiles;

@@ -605,3 +605,34 @@ extern "C" int ocr_sc_colsum(const void* x, int P, int C, void* out, void* parti
     return OCR_ERR_HIP;
   return ocr_launch_status();
 }
+
+// sigmoid heads of the EAST branch (F_score / geo_map, nets/model_vgg_16.py:129-131) on f32 [n] maps
+namespace {
+__global__ void sc_sigmoid_kernel(const float* __restrict__ z, size_t n, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = 1.f / (1.f + expf(-z[i]));
+}
+__global__ void sc_sigmoid_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                      size_t n, float* __restrict__ dz) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float s = out[i];
+    dz[i] = dout[i] * s * (1.f - s);
+  }
+}
+}  // namespace
+
+extern "C" int ocr_sc_sigmoid(const void* z, int64_t n, void* out, void* stream) {
+  OCR_CHECK_ARG(z && out && n > 0);
+  hipLaunchKernelGGL(sc_sigmoid_kernel, dim3(sgrid((size_t)n)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(z), (size_t)n,
+                     static_cast<float*>(out));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_sc_sigmoid_bwd(const void* out, const void* dout, int64_t n, void* dz, void* stream) {
+  OCR_CHECK_ARG(out && dout && dz && n > 0);
+  hipLaunchKernelGGL(sc_sigmoid_bwd_kernel, dim3(sgrid((size_t)n)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(out),
+                     static_cast<const float*>(dout), (size_t)n, static_cast<float*>(dz));
+  return ocr_launch_status();
+}

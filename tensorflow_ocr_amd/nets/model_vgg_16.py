@@ -31,6 +31,38 @@ def _to_device(g, arr, dtype=F32):
     return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(g.device)
 
 
+def model(images, weight_decay=1e-5, is_training=True, graph=None, blocks=None):
+    """nets/model_vgg_16.py:85-136: ResNet-v1-50 + the EAST feature-merging branch
+    h_i = conv3x3(conv1x1(concat(unpool(h_{i-1}), f_i))), widths 128/64/32, one more 3x3, then
+    F_score = sigmoid(conv1x1 -> 1), geo_map = sigmoid(conv1x1 -> 8)."""
+    from .. import resnet_layers as R
+    from . import resnet_v1
+    g = graph or get_default_graph()
+    g.weight_decay = weight_decay
+    x4 = mean_image_subtraction(images, graph=g)
+    if blocks is None:
+        _, end_points = resnet_v1.resnet_v1_50(x4, is_training=is_training, scope='resnet_v1_50', graph=g)
+    else:
+        _, end_points = resnet_v1.resnet_v1(x4, blocks, is_training=is_training, scope='resnet_v1_50', graph=g)
+    g.end_points = end_points
+    f = [end_points['pool5'], end_points['pool4'], end_points['pool3'], end_points['pool2']]
+    num_outputs = [None, 128, 64, 32]
+    names = iter(['Conv'] + ['Conv_%d' % i for i in range(1, 9)])
+    with g.variable_scope('feature_fusion'):
+        h = f[0]
+        gi = R.unpool(g, h)
+        for i in range(1, 4):
+            c1_1 = R.concat_conv_bn_relu(g, gi, f[i], num_outputs[i], next(names), is_training)
+            h = R.conv_bn_act(g, c1_1, num_outputs[i], 3, next(names), is_training=is_training)
+            if i <= 2:
+                gi = R.unpool(g, h)
+            else:
+                gi = R.conv_bn_act(g, h, num_outputs[i], 3, next(names), is_training=is_training)
+        F_score = R.sigmoid_head(g, gi, 1, next(names))
+        geo_map = R.sigmoid_head(g, gi, 8, next(names))
+    return F_score, geo_map
+
+
 def model_vgg(images, weight_decay=1e-5, is_training=True, graph=None):
     """nets/model_vgg_16.py:138-177.  images: [N,H,W,3] float (0..255).  Returns (pixel_cls, link_cls)."""
     g = graph or get_default_graph()

@@ -229,6 +229,25 @@ def add_inplace(a, b):
     L.call("ocr_add_inplace_f16", ptr(a), ptr(b), c_int64(a.numel()), _st())
 
 
+def unpool_f16(x, y):
+    n, lh, lw, c = x.shape
+    L.call("ocr_unpool_f16", ptr(x), c_int(n), c_int(lh), c_int(lw), c_int(c), ptr(y), _st())
+
+
+def unpool_bwd_f16(dy, dx, accumulate):
+    n, lh, lw, c = dx.shape
+    L.call("ocr_unpool_bwd_f16", ptr(dy), c_int(n), c_int(lh), c_int(lw), c_int(c), ptr(dx),
+           c_int(int(accumulate)), _st())
+
+
+def sc_sigmoid(z, out):
+    L.call("ocr_sc_sigmoid", ptr(z), c_int64(z.numel()), ptr(out), _st())
+
+
+def sc_sigmoid_bwd(out, dout, dz):
+    L.call("ocr_sc_sigmoid_bwd", ptr(out), ptr(dout), c_int64(out.numel()), ptr(dz), _st())
+
+
 def bias_relu_bwd(a, da, relu, dz, dbias, ws):
     c = a.shape[-1]
     npix = a.numel() // c

@@ -181,3 +181,97 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
         out.grad = None
     g.record(backward, (c3.wv, c3.gamma, c3.beta))
     return out
+
+
+# ----------------------------------------------------------------- EAST feature-merging branch
+def unpool(g, x):
+    """tf.image.resize_bilinear x2 (legacy sampling) on an f16 feature map (nets/model_vgg_16.py:15-16)."""
+    n, h, w, c = x.shape
+    out = Act(g.empty((n, 2 * h, 2 * w, c)), name="unpool")
+    ops.unpool_f16(x.data, out.data)
+
+    def backward():
+        if out.grad is None or not x.requires_grad:
+            return
+        acc = x.grad is not None
+        if not acc:
+            x.grad = g.empty(x.shape)
+        ops.unpool_bwd_f16(out.grad, x.grad, acc)
+        out.grad = None
+    g.record(backward)
+    return out
+
+
+def concat_conv_bn_relu(g, xa, xb, cout, scope, is_training=True):
+    """slim.conv2d(tf.concat([xa, xb], axis=-1), cout, 1) + BN + ReLU (nets/model_vgg_16.py:118) without
+    materialising the concatenation: conv(xa, W[:ca]) + conv(xb, W[ca:]) through the accumulating
+    epilogue; ONE variable `<scope>/weights` [1,1,ca+cb,cout] as in the reference."""
+    n, h, w, ca = xa.shape
+    cb = xb.shape[-1]
+    with g.variable_scope(scope):
+        wv = g.get_variable("weights", (1, 1, ca + cb, cout), variance_scaling(g.rng), regularized=True)
+        gamma, beta, mm, mv = _bn_vars(g, cout)
+    ws = g.workspace()
+
+    def mk(old):
+        if old is None:
+            old = [g.empty((1, cout, ca)), g.empty((1, ca, cout)), g.empty((1, cout, cb)), g.empty((1, cb, cout))]
+        ops.pack_weights(wv.data[:, :, :ca, :], old[0], old[1])
+        ops.pack_weights(wv.data[:, :, ca:, :], old[2], old[3])
+        return old
+    wa_kc, wa_ck, wb_kc, wb_ck = g.packed(wv, "cat", mk)
+    da = ops.conv_desc((n, h, w, ca), cout, 1, 1)
+    db = ops.conv_desc((n, h, w, cb), cout, 1, 1)
+    y = g.empty((n, h, w, cout))
+    mt = ops.conv2d_num_mtiles(da)
+    part, stage = g.ws_small.two(mt * 2 * cout * 4, ops.bn_reduce_workspace(mt, cout))
+    da.flags = 0
+    ops.conv2d(da, xa.data, wa_kc, y, None, None)
+    db.flags = CONV_ACCUM_F16 | (CONV_STATS if is_training else 0)
+    ops.conv2d(db, xb.data, wb_kc, y, None, part if is_training else None)
+    scale, shift = g.empty((cout,), F32), g.empty((cout,), F32)
+    mean, invstd = g.empty((cout,), F32), g.empty((cout,), F32)
+    if is_training:
+        ops.bn_finalize(part, mt, cout, float(n) * h * w, gamma.data, beta.data, BN_EPS, BN_DECAY, mm.data,
+                        mv.data, scale, shift, mean, invstd, stage)
+    else:
+        ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
+    a = Act(g.empty(y.shape), name=scope)
+    ops.bn_relu(y, scale, shift, True, 0, a.data, None)
+
+    def backward():
+        if a.grad is None:
+            return
+        dy = g.empty(y.shape)
+        ops.bn_relu_bwd(y, scale, shift, mean, invstd, a.grad, None, True, 0, gamma.grad, beta.grad, dy, ws)
+        for x, c, w_ck, sl in ((xa, ca, wa_ck, slice(0, ca)), (xb, cb, wb_ck, slice(ca, ca + cb))):
+            dd = ops.conv_desc((n, h, w, c), cout, 1, 1)
+            ops.conv2d_wgrad(dd, x.data, dy, wv.grad[:, :, sl, :], ws)
+            if x.requires_grad:
+                flags = 0
+                if x.grad is None:
+                    x.grad = g.empty(x.shape)
+                else:
+                    flags = CONV_ACCUM_F16
+                dg = ops.ConvDesc(n, h, w, cout, h, w, c, 1, 1, 1, 1, 0, 0, 1, flags)
+                ops.conv2d(dg, dy, w_ck, x.grad, None, None)
+        a.grad = None
+    g.record(backward, (wv, gamma, beta))
+    return a
+
+
+def sigmoid_head(g, feat, cout, scope):
+    """slim.conv2d(feat, cout, 1, activation_fn=tf.nn.sigmoid, normalizer_fn=None) (model_vgg_16.py:129-131)."""
+    from .layers import SmallAct, head_conv_bias
+    z, _, _ = head_conv_bias(g, feat, (scope,), (cout,))
+    out = SmallAct(g.empty(z.data.shape, F32))
+    ops.sc_sigmoid(z.data, out.data)
+
+    def backward():
+        if out.grad is None:
+            return
+        z.grad = g.empty(z.data.shape, F32)
+        ops.sc_sigmoid_bwd(out.data, out.grad, z.grad)
+        out.grad = None
+    g.record(backward)
+    return out

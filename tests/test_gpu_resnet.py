@@ -142,3 +142,39 @@ def test_model_resnet_pixellink_heads_ohnm(device):
     cs = sorted((cos(grads[k], (tp[k].grad / S).numpy()), k) for k in grads if grads[k].size >= 64)
     print("lowest gradient cosines", cs[:3])
     assert cs[0][0] > 0.9
+
+
+def test_model_east_merge_branch_dice(device):
+    """nets/model_vgg_16.py `model` (ResNet + EAST feature-merging branch, sigmoid score/geometry) with
+    the dice `loss` of the same file, reduced block list."""
+    from tensorflow_ocr_amd import checkpoint
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model_vgg_16 as M
+    S = 1024.0
+    rng = np.random.default_rng(4)
+    p = O.init_model_east_params(rng, SMALL)
+    images, pixel, link, mask = O.synthetic_batch(rng, 2, 128)
+    g = Graph(device, loss_scale=S)
+    M.model(images, graph=g, blocks=SMALL)
+    g.reset_tape()
+    g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, p))
+    fs, geo = M.model(images, graph=g, blocks=SMALL)
+    assert fs.data.shape == (2, 32, 32, 1) and geo.data.shape == (2, 32, 32, 8)
+    L = M.loss(pixel, fs, link, geo, mask, graph=g)
+    g.backward()
+    torch.cuda.synchronize()
+    grads = checkpoint.internal_to_tf({n: (v.grad / S).cpu().numpy() for n, v in g.store.vars.items() if v.trainable})
+    tp = O.to_torch_params(p)
+    ofs, ogeo, _ = O.model_east(torch.from_numpy(images), tp, True, mixed=True, blocks=SMALL)
+    oL = O.dice_loss(torch.from_numpy(pixel), ofs, torch.from_numpy(link), ogeo, torch.from_numpy(mask))
+    (oL * S).backward()
+    d = np.abs(fs.data.cpu().numpy() - ofs.detach().numpy())
+    print("loss %.5f vs %.5f; F_score Linf %.3e mean %.3e" % (L.item(), float(oL), d.max(), d.mean()))
+    assert abs(L.item() - float(oL)) < 5e-3 and d.mean() < 5e-3
+
+    def cos(a, b):
+        a, b = a.ravel().astype(np.float64), b.ravel().astype(np.float64)
+        return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    cs = sorted((cos(grads[k], (tp[k].grad / S).numpy()), k) for k in grads if grads[k].size >= 64)
+    print("lowest gradient cosines", cs[:3])
+    assert cs[0][0] > 0.9
