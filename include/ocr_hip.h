@@ -292,6 +292,18 @@ int ocr_link_cc(const void* pixel_score, const void* link_score, int link_elem_s
                 void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Locality-aware NMS (EAST, Zhou et al. CVPR 2017, Algorithm 1).  ABSENT from the reference tree
+ * (SURVEY.md D2); build-defined, pinned bit for bit against oracle/lanms_oracle.c.
+ * boxes f32 [n_images][max_k][9] (x1,y1,..,x4,y4,score; row-major scan order), counts i32
+ * [n_images].  Outputs: merged [n_images][max_k][9], n_merged [n_images], keep_idx
+ * [n_images][max_k] (indices into merged, in keep order), n_keep [n_images].
+ * ------------------------------------------------------------------------- */
+size_t ocr_lanms_workspace(int n_images, int max_k);
+int ocr_lanms(const void* boxes, const void* counts, int n_images, int max_k, float iou_thresh,
+              void* merged, void* n_merged, void* keep_idx, void* n_keep, void* workspace,
+              size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Optimisers over the flat parameter buffer: elements [0, n_regularized) also get
  * the slim.l2_regularizer gradient weight_decay*w.  g is multiplied by
  * inv_loss_scale first.  ema (may be NULL) follows ExponentialMovingAverage.

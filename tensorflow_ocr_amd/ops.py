@@ -408,6 +408,14 @@ def link_cc(pixel_score, link_score, stride, offset, n, h, w, pixel_thresh, link
            ptr(comps), c_int(comps.shape[1]), ptr(buf), c_size_t(nbytes), _st())
 
 
+def lanms(boxes, counts, iou_thresh, merged, n_merged, keep_idx, n_keep, ws):
+    n_images, max_k, _ = boxes.shape
+    nbytes = L.call_size("ocr_lanms_workspace", c_int(n_images), c_int(max_k))
+    buf = ws.get(nbytes)
+    L.call("ocr_lanms", ptr(boxes), ptr(counts), c_int(n_images), c_int(max_k), c_float(iou_thresh),
+           ptr(merged), ptr(n_merged), ptr(keep_idx), ptr(n_keep), ptr(buf), c_size_t(nbytes), _st())
+
+
 # -------------------------------------------------------------------------- optimiser
 def adam_step(w, g, m, v, ema, n_reg, lr_t, beta1, beta2, eps, wd, inv_scale, ema_decay):
     L.call("ocr_adam_step", ptr(w), ptr(g), ptr(m), ptr(v), ptr(ema), c_int64(w.numel()),

@@ -1,0 +1,50 @@
+"""GPU: locality-aware NMS kernel vs the plain-C oracle — merged quads and kept INDICES bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lanms as OL
+
+pytestmark = pytest.mark.gpu
+
+
+def _quads(rng, k, span=400.0):
+    """Row-major stream of noisy, rotated text-like quads clustered around a few true boxes."""
+    out = []
+    centers = rng.uniform(40, span, size=(max(k // 12, 1), 2))
+    for i in range(k):
+        c = centers[rng.integers(len(centers))] + rng.normal(0, 1.5, 2)
+        w, h = rng.uniform(40, 90), rng.uniform(12, 24)
+        ang = rng.uniform(-0.3, 0.3)
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        pts = (np.array([[-w, -h], [w, -h], [w, h], [-w, h]]) / 2) @ R.T + c
+        if rng.uniform() < 0.3:
+            pts = pts[::-1]                      # clockwise input must not matter
+        out.append(np.concatenate([pts.ravel(), [rng.uniform(0.5, 1.0)]]))
+    a = np.array(out, np.float32)
+    return a[np.lexsort((a[:, 0], a[:, 1].round(-1)))]       # roughly row-major
+
+
+@pytest.mark.parametrize("k", [1, 7, 200, 1500])
+def test_lanms_bit_exact(device, k):
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.tool import lanms
+    g = Graph(device)
+    rng = np.random.default_rng(k)
+    n_img = 3
+    max_k = k
+    boxes = np.zeros((n_img, max_k, 9), np.float32)
+    counts = np.array([k, max(k // 2, 1), 0], np.int32)
+    for b in range(n_img):
+        if counts[b]:
+            boxes[b, :counts[b]] = _quads(rng, int(counts[b]))
+    merged, n_merged, keep, n_keep = lanms.lanms_batch(boxes, counts, 0.2, graph=g)
+    merged, n_merged, keep, n_keep = [t.cpu().numpy() for t in (merged, n_merged, keep, n_keep)]
+    for b in range(n_img):
+        om, ok = OL.lanms(boxes[b, :counts[b]], 0.2)
+        assert n_merged[b] == len(om) and n_keep[b] == len(ok)
+        assert np.array_equal(merged[b, :len(om)], om)            # bit-exact merged quads
+        assert np.array_equal(keep[b, :len(ok)], ok)              # bit-exact kept indices
+    one = lanms.merge_quadrangle_n9(boxes[0, :counts[0]], 0.2, graph=g)
+    om, ok = OL.lanms(boxes[0, :counts[0]], 0.2)
+    assert np.array_equal(one, om[ok])
