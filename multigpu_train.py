@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's multigpu_train.py (flags :6-17, tower/step assembly :27-142, hot
+loop :169-194) on the MI355X path: one process per GPU
+
+    python multigpu_train.py --gpu_list 0 --batch_size_per_gpu 14 --input_size 512
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 multigpu_train.py --gpu_list 0,1
+
+Same flag names and defaults; `--net` selects the graph (`model` = nets/model.py ResNet-50 +
+PixelLink heads + OHNM loss, the one the reference script imports; `model_vgg` / `east` /
+`pixellink` the others).  Data: the icdar generator is outside this round's scope,
+so batches are synthetic (`tensorflow_ocr_amd.synthetic`).  The stdout line format is the
+reference's (:183-184)."""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--input_size', type=int, default=512)
+    ap.add_argument('--batch_size_per_gpu', type=int, default=14)
+    ap.add_argument('--num_readers', type=int, default=16)
+    ap.add_argument('--learning_rate', type=float, default=0.0001)
+    ap.add_argument('--max_steps', type=int, default=100000)
+    ap.add_argument('--moving_average_decay', type=float, default=0.997)
+    ap.add_argument('--gpu_list', type=str, default='1')
+    ap.add_argument('--checkpoint_path', type=str, default='/tmp/east_resnet_v1_50_rbox/')
+    ap.add_argument('--restore', action='store_true')
+    ap.add_argument('--save_checkpoint_steps', type=int, default=1000)
+    ap.add_argument('--save_summary_steps', type=int, default=20)
+    ap.add_argument('--pretrained_model_path', type=str, default=None)
+    ap.add_argument('--net', choices=['model', 'model_vgg', 'east', 'pixellink'], default='model')
+    return ap.parse_args()
+
+
+def build_forward_loss(net):
+    from tensorflow_ocr_amd.nets import model, model_vgg_16, pixellink
+    if net == 'model':
+        def f(g, im, sm, gm, tm):
+            a, b = model.model(im, is_training=True, graph=g)
+            return model.loss(sm, a, gm, b, tm, graph=g)
+    elif net == 'model_vgg':
+        def f(g, im, sm, gm, tm):
+            a, b = model_vgg_16.model_vgg(im, is_training=True, graph=g)
+            return model_vgg_16.loss(sm, a, gm, b, tm, graph=g)
+    elif net == 'east':
+        def f(g, im, sm, gm, tm):
+            a, b = model_vgg_16.model(im, is_training=True, graph=g)
+            return model_vgg_16.loss(sm, a, gm, b, tm, graph=g)
+    else:
+        def f(g, im, sm, gm, tm):
+            n = pixellink.PixelLinkNet((im - 120.0) / 60.0, graph=g)
+            return n.build_loss(sm[..., 0], gm)
+    return f
+
+
+def main():
+    FLAGS = parse()
+    from tensorflow_ocr_amd import checkpoint, dist, synthetic
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.train import AdamOptimizer, TrainStep
+    gpus = FLAGS.gpu_list.split(',')
+    rank, world, local = dist.init_process_group_from_env()
+    if world not in (1, len(gpus)):
+        raise SystemExit("gpu_list has %d entries but WORLD_SIZE=%d" % (len(gpus), world))
+    device = torch.device('cuda', local)     # the launcher maps LOCAL_RANK -> visible GPU
+    torch.cuda.set_device(device)
+    if rank == 0:
+        os.makedirs(FLAGS.checkpoint_path, exist_ok=True)
+
+    g = Graph(device, seed=1)
+    step = TrainStep(g, build_forward_loss(FLAGS.net),
+                     lambda gr: AdamOptimizer(gr, learning_rate=FLAGS.learning_rate,
+                                              moving_average_decay=FLAGS.moving_average_decay),
+                     world_size=world)
+    rng = np.random.default_rng(1000 + rank)
+    start = time.time()
+    for it in range(FLAGS.max_steps):
+        data = synthetic.make_batch(rng, FLAGS.batch_size_per_gpu, FLAGS.input_size)
+        batch = [torch.from_numpy(a).to(device, non_blocking=True) for a in data]
+        loss = step(*batch)
+        if it == 0 and FLAGS.restore:
+            path = os.path.join(FLAGS.checkpoint_path, 'latest.npz')
+            if os.path.exists(path):
+                g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, dict(np.load(path))), strict=False)
+        if it % 10 == 0:
+            ml = loss.item()
+            if np.isnan(ml):
+                print('Loss diverged, stop training')
+                break
+            avg_time_per_step = (time.time() - start) / 10
+            avg_examples_per_second = (10 * FLAGS.batch_size_per_gpu * world) / (time.time() - start)
+            start = time.time()
+            if rank == 0:
+                tl = ml        # the L2 regulariser enters through the optimiser, not the reported loss
+                print('Step {:06d}, model loss {:.4f}, total loss {:.4f}, {:.2f} seconds/step, {:.2f} examples/second'.format(
+                    it, ml, tl, avg_time_per_step, avg_examples_per_second), flush=True)
+        if rank == 0 and it % FLAGS.save_checkpoint_steps == 0 and it > 0:
+            sd = checkpoint.internal_to_tf(g.store.state_dict())
+            np.savez(os.path.join(FLAGS.checkpoint_path, 'model.ckpt-%d.npz' % it), **sd)
+            np.savez(os.path.join(FLAGS.checkpoint_path, 'latest.npz'), **sd)
+
+
+if __name__ == '__main__':
+    main()

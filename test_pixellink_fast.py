@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's test_pixellink_fast.py (eval :44-217): PixelLinkNet forward,
+per-direction softmax, pixel_detect mask, link-gated connected components at 1/4 resolution, one
+box per component, `res_<name>.txt` lines `x1,y1,x2,y2,x3,y3,x4,y4\\r\\n` (:215-217).
+
+Flag names follow the reference (:12-19).  Differences, all forced by the container:
+images are read with NumPy-decodable formats only (.npy arrays [H,W,3] RGB; no cv2), and the box of
+a component is its axis-aligned bounding rectangle (cv2.minAreaRect is §8f "next"), scaled x4 like
+the reference's `show_xy` mapping."""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--checkpoint_path', type=str, default=None)
+    ap.add_argument('--test_data_path', type=str, default='/tmp/images/')
+    ap.add_argument('--output_dir', type=str, default='/tmp/output/')
+    ap.add_argument('--gpu_memory_fraction', type=float, default=-1)
+    ap.add_argument('--pixel_conf_threshold', type=float, default=0.8)
+    ap.add_argument('--link_conf_threshold', type=float, default=0.9)
+    ap.add_argument('--eval_image_width', type=int, default=1280)
+    ap.add_argument('--eval_image_height', type=int, default=768)
+    ap.add_argument('--synthetic', type=int, default=0, help='decode N synthetic images instead of files')
+    return ap.parse_args()
+
+
+def get_images(path):
+    files = []
+    for parent, _, filenames in os.walk(path):
+        for f in sorted(filenames):
+            if f.endswith('.npy'):
+                files.append(os.path.join(parent, f))
+    print('Find {} images'.format(len(files)))
+    return files
+
+
+def main():
+    FLAGS = parse()
+    from tensorflow_ocr_amd import checkpoint
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import pixellink
+    from tensorflow_ocr_amd.tool import pixellink_fn
+    g = Graph('cuda:0')
+    os.makedirs(FLAGS.output_dir, exist_ok=True)
+    H, W = FLAGS.eval_image_height, FLAGS.eval_image_width
+    if FLAGS.synthetic:
+        rng = np.random.default_rng(0)
+        items = [('synthetic_%d' % i, rng.uniform(0, 255, (H, W, 3)).astype(np.float32)) for i in range(FLAGS.synthetic)]
+    else:
+        items = [(os.path.basename(f).split('.')[0], np.load(f).astype(np.float32)) for f in get_images(FLAGS.test_data_path)]
+    loaded = False
+    for name, im in items:
+        if im.shape[:2] != (H, W):
+            raise SystemExit('%s: expected %dx%d input (resize is a cv2 step, out of scope)' % (name, H, W))
+        x = ((im - 120.0) / 60.0)[None]
+        t0 = time.time()
+        net = pixellink.PixelLinkNet(x, graph=g)
+        g.reset_tape()
+        if FLAGS.checkpoint_path and not loaded:
+            g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, dict(np.load(FLAGS.checkpoint_path))), strict=False)
+            loaded = True
+            net = pixellink.PixelLinkNet(x, graph=g)
+            g.reset_tape()
+        pixel_score = net.pixel_scores                                  # [1,h,w,2]
+        link_score = pixellink_fn.link_scores(net.link_cls, graph=g)    # [8,1,h,w,2]
+        score_res = pixellink_fn.tf_pixel_detect(pixel_score[..., 1:2].contiguous(), link_score,
+                                                 FLAGS.pixel_conf_threshold, FLAGS.link_conf_threshold, graph=g)
+        labels, ncomp, comps = pixellink_fn.link_cc_decode(pixel_score[..., 1].contiguous(), link_score,
+                                                           FLAGS.pixel_conf_threshold, FLAGS.link_conf_threshold,
+                                                           min_size=10, graph=g)
+        lab = labels[0].cpu().numpy()
+        k = int(ncomp[0].item())
+        print('%s: net+decode %.0f ms, %d components, mask pixels %d' % (
+            name, (time.time() - t0) * 1e3, k, int(score_res.sum().item())))
+        h4, w4 = lab.shape
+        boxes = []
+        for i in range(1, k + 1):
+            ys, xs = np.nonzero(lab == i)
+            x0, x1 = xs.min() * (W / w4), xs.max() * (W / w4)
+            y0, y1 = ys.min() * (H / h4), ys.max() * (H / h4)
+            boxes.append(np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]]).astype(np.int64))
+        with open(os.path.join(FLAGS.output_dir, 'res_{}.txt'.format(name)), 'w') as f:
+            for box in boxes:
+                f.write('{},{},{},{},{},{},{},{}\r\n'.format(box[0, 0], box[0, 1], box[1, 0], box[1, 1],
+                                                            box[2, 0], box[2, 1], box[3, 0], box[3, 1]))
+
+
+if __name__ == '__main__':
+    main()
