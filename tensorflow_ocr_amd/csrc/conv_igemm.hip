@@ -108,12 +108,46 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
     }
   };
 
+  // halo staging split into issue-early (global -> registers, right after the previous chunk's
+  // halo has been handed to LDS) and write-late (registers -> LDS at the chunk boundary), so the
+  // global latency of chunk cc+1 hides under the kh*kw taps of chunk cc.
+  constexpr int NH = BN >= 128 ? 7 : 1;   // narrow tiles keep their registers for occupancy
+  const int halo_total = halo_px * CPP;
+  const bool prefetch = BN >= 128 && halo_total <= NH * NT && nchunks > 1;
+  u32x4 hreg[NH];
+  auto halo_load = [&](int cc) {
+    const half_t* xb = x + (size_t)img * p.h * p.w * p.cin + cc * CK;
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int idx = u * NT + tid;
+      hreg[u] = u32x4{0u, 0u, 0u, 0u};
+      if (idx < halo_total) {
+        const int hp = idx / CPP, c = idx % CPP;
+        const int hy = hp / WT, hx = hp - hy * WT;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+          hreg[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin + c * 8);
+      }
+    }
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int idx = u * NT + tid;
+      if (idx < halo_total)
+        *reinterpret_cast<u32x4*>(halo + (idx / CPP) * PSTR + (idx % CPP) * 16) = hreg[u];
+    }
+  };
+
   int wb = 0;
+  if (prefetch) halo_load(0);
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();  // previous chunk's halo fully consumed
     // ---- stage the halo tile of this channel chunk ----
-    {
-      const int total = halo_px * CPP;
+    if (prefetch) {
+      halo_store();
+    } else {
+      const int total = halo_total;
       const half_t* xb = x + (size_t)img * p.h * p.w * p.cin + cc * CK;
       for (int base = 0; base < total; base += NT * 4) {
         u32x4 v[4];
@@ -141,6 +175,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
     load_w(0, cc);
     store_w(wb);
     if (ntaps > 1) load_w(1, cc);
+    if (prefetch && cc + 1 < nchunks) halo_load(cc + 1);
     for (int tap = 0; tap < ntaps; ++tap) {
       // after this barrier: buf[wb] (this tap, and at tap 0 the halo) is visible and
       // buf[wb^1] is free (its readers finished tap-1)
@@ -153,20 +188,63 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
       const char* ab = wbuf + wb * (BN * PSTR) + a_lane;
       const char* bb = halo + b_lane + ((ky * p.dil) * WT + kx * p.dil) * PSTR +
                        (wpx * TPX) * b_row;
+      if constexpr (BN == 128) {
+      // software-pipelined k-steps: the LDS reads of step ks+1 are issued before the MFMAs of
+      // step ks (two named fragment sets; sched_barrier keeps hipcc from sinking the reads)
+      half8_t a0[TCO], b0[TPX], a1[TCO], b1[TPX];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        half8_t a[TCO], b[TPX];
+      for (int i = 0; i < TCO; ++i) a0[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * PSTR);
 #pragma unroll
-        for (int i = 0; i < TCO; ++i)
-          a[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * PSTR + ks * 32);
+      for (int t = 0; t < TPX; ++t) b0[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row);
 #pragma unroll
-        for (int t = 0; t < TPX; ++t)
-          b[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row + ks * 32);
+      for (int ks = 0; ks < KSTEPS; ks += 2) {
+        if (ks + 1 < KSTEPS) {
+#pragma unroll
+          for (int i = 0; i < TCO; ++i)
+            a1[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * PSTR + (ks + 1) * 32);
+#pragma unroll
+          for (int t = 0; t < TPX; ++t)
+            b1[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row + (ks + 1) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TCO; ++i)
 #pragma unroll
           for (int t = 0; t < TPX; ++t)
-            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[t], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[i], b0[t], acc[i][t], 0, 0, 0);
+        if (ks + 1 < KSTEPS) {
+          if (ks + 2 < KSTEPS) {
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+              a0[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * PSTR + (ks + 2) * 32);
+#pragma unroll
+            for (int t = 0; t < TPX; ++t)
+              b0[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row + (ks + 2) * 32);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int t = 0; t < TPX; ++t)
+              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b1[t], acc[i][t], 0, 0, 0);
+        }
+      }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          half8_t a[TCO], b[TPX];
+#pragma unroll
+          for (int i = 0; i < TCO; ++i)
+            a[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * PSTR + ks * 32);
+#pragma unroll
+          for (int t = 0; t < TPX; ++t)
+            b[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row + ks * 32);
+#pragma unroll
+          for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int t = 0; t < TPX; ++t)
+              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[t], acc[i][t], 0, 0, 0);
+        }
       }
       wb ^= 1;
     }
