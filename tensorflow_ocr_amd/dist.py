@@ -81,6 +81,7 @@ class GradientAllReduce:
                     break
         self.cuda = store.flat.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        self.extra_streams = []       # streams that also produce gradients (side-stream wgrad)
         self.reset()
 
     def reset(self):
@@ -108,6 +109,8 @@ class GradientAllReduce:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                for es in self.extra_streams:
+                    self.comm_stream.wait_stream(es)
                 h = td.all_reduce(buf, op=td.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             h = td.all_reduce(buf, op=td.ReduceOp.SUM, group=self.group, async_op=True)

@@ -146,6 +146,7 @@ class Graph:
         self.rng = np.random.default_rng(seed)
         self.ws = None
         self.ws_small = None
+        self.ws_wgrad = None
         self.collections = {"losses": [], "update_ops": []}
         self.keepalive = None        # list while a step is being recorded (train.TrainStep)
 
@@ -171,6 +172,7 @@ class Graph:
         if self.ws is None:
             self.ws = ops.Workspace(self.device, 256 << 20)
             self.ws_small = ops.Workspace(self.device, 8 << 20)
+            self.ws_wgrad = ops.Workspace(self.device, 160 << 20)   # weight-gradient slabs (side stream)
         return self.ws
 
     def empty(self, shape, dtype=F16):

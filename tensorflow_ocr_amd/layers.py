@@ -156,7 +156,7 @@ def _conv_backward(g, x, wv, w_dg, d, dy, first):
         return
     dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, d.kh, d.kw, d.stride, d.dilation,
                       d.pad_top, d.pad_left, 0, 0)
-    ops.conv2d_wgrad(dd, x.data, dy, wv.grad, ws)
+    ops.conv2d_wgrad(dd, x.data, dy, wv.grad, g.ws_wgrad)
     if not x.requires_grad:
         return
     if d.stride != 1:

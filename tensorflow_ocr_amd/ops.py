@@ -98,6 +98,10 @@ def conv2d_wgrad(d, x, dy, dw, ws):
     nbytes = L.call_size("ocr_conv2d_wgrad_workspace", byref(d))
     buf = ws.get(nbytes)
     L.call("ocr_conv2d_wgrad_f16", byref(d), ptr(x), ptr(dy), ptr(dw), ptr(buf), c_size_t(nbytes), _st())
+    if L.RECORDER is not None:
+        # independent of the rest of backward (only the optimiser reads dw): replayed on a side
+        # stream so it overlaps the HBM-bound batch-norm passes of the layers below
+        L.RECORDER.tag_last(("side",))
 
 
 def conv2d_first_num_mtiles(n, h, w):

@@ -69,7 +69,7 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             dy = dy_full
         dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, d.kh, d.kw, 1, d.dilation, d.pad_top,
                           d.pad_left, 0, 0)
-        ops.conv2d_wgrad(dd, x.data, dy, wv.grad, ws)
+        ops.conv2d_wgrad(dd, x.data, dy, wv.grad, g.ws_wgrad)
         if not x.requires_grad:
             return
         pt = d.dilation * (d.kh - 1) - d.pad_top
@@ -246,7 +246,7 @@ def concat_conv_bn_relu(g, xa, xb, cout, scope, is_training=True):
         ops.bn_relu_bwd(y, scale, shift, mean, invstd, a.grad, None, True, 0, gamma.grad, beta.grad, dy, ws)
         for x, c, w_ck, sl in ((xa, ca, wa_ck, slice(0, ca)), (xb, cb, wb_ck, slice(ca, ca + cb))):
             dd = ops.conv_desc((n, h, w, c), cout, 1, 1)
-            ops.conv2d_wgrad(dd, x.data, dy, wv.grad[:, :, sl, :], ws)
+            ops.conv2d_wgrad(dd, x.data, dy, wv.grad[:, :, sl, :], g.ws_wgrad)
             if x.requires_grad:
                 flags = 0
                 if x.grad is None:

@@ -125,6 +125,9 @@ class TrainStep:
         self.plan = None
         self.static_batch = None
         self.loss = None
+        self.side_stream = None
+        self.side_ptr = None
+        self.use_side_stream = True
 
     # -- eager / recording path --------------------------------------------------------------
     def _eager(self, batch, record):
@@ -157,33 +160,44 @@ class TrainStep:
         return loss
 
     def _replay(self, batch):
-        from . import ops
+        import ctypes
+        from . import _lib, ops
         for dst, src in zip(self.static_batch, batch):
             if src is not dst:
                 dst.copy_(src, non_blocking=True)
         timing = ops.KERNEL_TIMING
-        if timing is None:
-            for e in self.plan:
-                if e[0] == "c":
+        main = torch.cuda.current_stream()
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream()
+            self.side_ptr = ctypes.c_void_p(self.side_stream.cuda_stream)
+            if self.reducer is not None:
+                self.reducer.extra_streams = [self.side_stream]
+        side, side_ptr, side_used = self.side_stream, self.side_ptr, False
+        for e in self.plan:
+            if e[0] == "c":
+                tag = e[4]
+                if tag is not None and tag[0] == "side" and self.use_side_stream:
+                    # weight gradient: only the optimiser (and the all-reduce) consumes it
+                    side.wait_stream(main)
+                    rc = e[1](*(e[2][:-1] + (side_ptr,)))
+                    side_used = True
+                elif timing is not None and tag is not None and tag[0] != "side":
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                     rc = e[1](*e[2])
-                    if rc != 0:
-                        from . import _lib
-                        _lib.check(rc, e[3])
+                    e1.record()
+                    timing.append((tag[0], tag[1], e0, e1))
                 else:
-                    e[1]()
-        else:
-            for e in self.plan:
-                if e[0] == "c":
-                    if e[4] is not None:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        e[1](*e[2])
-                        e1.record()
-                        timing.append((e[4][0], e[4][1], e0, e1))
-                    else:
-                        e[1](*e[2])
-                else:
-                    e[1]()
+                    rc = e[1](*e[2])
+                if rc != 0:
+                    _lib.check(rc, e[3])
+            else:
+                if side_used and (self.world == 1 or e[1] == self.reducer.finish):
+                    main.wait_stream(side)       # optimiser / end of step: weight gradients done
+                    side_used = False
+                e[1]()
+        if side_used:
+            main.wait_stream(side)
         return self.loss
 
     def __call__(self, *batch):
