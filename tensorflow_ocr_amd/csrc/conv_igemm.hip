@@ -180,10 +180,13 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
       // after this barrier: buf[wb] (this tap, and at tap 0 the halo) is visible and
       // buf[wb^1] is free (its readers finished tap-1)
       __syncthreads();
-      if (tap + 1 < ntaps) {
-        store_w(wb ^ 1);
-        if (tap + 2 < ntaps) load_w(tap + 2, cc);
-      }
+      auto restage = [&]() {
+        if (tap + 1 < ntaps) {
+          store_w(wb ^ 1);
+          if (tap + 2 < ntaps) load_w(tap + 2, cc);
+        }
+      };
+      if constexpr (BN == 128) restage();
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
       const char* ab = wbuf + wb * (BN * PSTR) + a_lane;
       const char* bb = halo + b_lane + ((ky * p.dil) * WT + kx * p.dil) * PSTR +
@@ -239,6 +242,13 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
 #pragma unroll
           for (int t = 0; t < TPX; ++t)
             b[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row + ks * 32);
+          if (ks == 0) {
+            // the next tap's weight slice goes to the other LDS buffer while the first
+            // fragments are in flight (not between the barrier and the first reads)
+            __builtin_amdgcn_sched_barrier(0);
+            restage();
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int i = 0; i < TCO; ++i)
 #pragma unroll
