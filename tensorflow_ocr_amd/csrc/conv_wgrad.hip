@@ -45,7 +45,7 @@ __device__ __forceinline__ half8_t tr_pair(const char* base, int second_off) {
 }
 
 template <int MAXTAPS>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgP p, const half_t* __restrict__ x,
+__global__ __launch_bounds__(512) void wgrad_kernel(WgP p, const half_t* __restrict__ x,
                                                     const half_t* __restrict__ dy,
                                                     float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p, const half_t* __restr
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int ciw = wave >> 1, cow = wave & 1;
+  // 8 waves = 2 (pixel halves of every tile) x 2 (ci) x 2 (co); the two pixel groups leave as
+  // separate slab rows
+  const int kgrp = wave >> 2;
+  const int ciw = (wave >> 1) & 1, cow = wave & 1;
   const int li = lane & 15, g = lane >> 4;
   const int q = li >> 2, pp = li & 3, hh = g >> 1, gc = g & 1;
 
@@ -93,12 +96,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p, const half_t* __restr
     {  // x halo tile, channels ci0..ci0+63
       const int total = halo_px * (CIB / 8);
       const half_t* xb = x + (size_t)img * p.h * p.w * p.cin + ci0;
-      for (int base = 0; base < total; base += 256 * 4) {
+      for (int base = 0; base < total; base += 512 * 4) {
         u32x4 v[4];
         int off[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          int idx = base + u * 256 + tid;
+          int idx = base + u * 512 + tid;
           v[u] = u32x4{0u, 0u, 0u, 0u};
           off[u] = -1;
           if (idx < total) {
@@ -117,10 +120,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p, const half_t* __restr
     }
     {  // dy tile [256][64], zero outside the output
       const half_t* db = dy + (size_t)img * p.oh * p.ow * p.cout + co0;
-      u32x4 v[8];
+      u32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        int idx = u * 256 + tid;
+      for (int u = 0; u < 4; ++u) {
+        int idx = u * 512 + tid;
         int px = idx >> 3, c = idx & 7;
         int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
         v[u] = u32x4{0u, 0u, 0u, 0u};
@@ -128,15 +131,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p, const half_t* __restr
           v[u] = *reinterpret_cast<const u32x4*>(db + ((size_t)oy * p.ow + ox) * p.cout + c * 8);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        int idx = u * 256 + tid;
+      for (int u = 0; u < 4; ++u) {
+        int idx = u * 512 + tid;
         int px = idx >> 3, c = idx & 7;
         *reinterpret_cast<u32x4*>(dyt + px * DSTR + c * 16) = v[u];
       }
     }
     __syncthreads();
-#pragma unroll 2
-    for (int s = 0; s < 16; ++s) {
+#pragma unroll 1
+    for (int s = kgrp * 8; s < kgrp * 8 + 8; ++s) {
       const int ty = s >> 1, tx0 = (s & 1) * 16;
       half8_t b = tr_pair(dyt + b_lane + (ty * 32 + tx0) * DSTR, b_half);
       const char* abase = xh + a_lane + ((ty * p.stride) * p.WT + tx0 * p.stride) * XSTR;
@@ -156,8 +159,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p, const half_t* __restr
 #pragma unroll
   for (int t = 0; t < MAXTAPS; ++t) {
     if (t < ntaps) {
-      float* dst = slab + (((size_t)split * ntaps + t) * p.cin + ci0 + ciw * 32) * p.cout + co0 +
-                   cow * 32 + r;
+      float* dst = slab + (((size_t)(split * 2 + kgrp) * ntaps + t) * p.cin + ci0 + ciw * 32) * p.cout +
+                   co0 + cow * 32 + r;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h2;
@@ -202,11 +205,15 @@ constexpr int X2STR = CIB * 2 + 64;   // 192 B: row stride = 16 dwords mod 64 ->
                                        // transposing read land in 4 disjoint bank quarters
 
 template <int COB2, int MAXTAPS>
-__global__ __launch_bounds__(COB2 * 4) void wgrad2_kernel(Wg2P p, const half_t* __restrict__ x,
+__global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __restrict__ x,
                                                           const half_t* __restrict__ dy,
                                                           float* __restrict__ slab) {
-  constexpr int NT = COB2 * 4;             // threads: 2 (ci) x COB2/32 (co) waves, 32x32 each
+  // 8 waves: 2 (ci) x COB2/32 (co) x KG (pixel halves); every wave owns a 32x32 block per tap.
+  // COB2 = 64 splits the tile's 8 k-steps over KG = 2 wave groups whose partial blocks leave as
+  // two separate slab rows (split index 2*split + kgrp).
+  constexpr int NT = 512;
   constexpr int NWCO = COB2 / 32;
+  constexpr int KG = 8 / (2 * NWCO);
   constexpr int DSTR2 = COB2 * 2 + 64;     // bytes per dy pixel in LDS (same bank rule)
   constexpr int DCH = COB2 / 8;            // 16-byte chunks per dy pixel
   constexpr int NDY = 128 * DCH / NT;      // dy loads per thread per tile
@@ -219,7 +226,8 @@ __global__ __launch_bounds__(COB2 * 4) void wgrad2_kernel(Wg2P p, const half_t* 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int ciw = wave / NWCO, cow = wave % NWCO;
+  const int kgrp = wave / (2 * NWCO);
+  const int ciw = (wave / NWCO) & 1, cow = wave % NWCO;
   const int li = lane & 15, g = lane >> 4;
   const int q = li >> 2, pp = li & 3, hh = g >> 1, gc = g & 1;
 
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(COB2 * 4) void wgrad2_kernel(Wg2P p, const half_t* 
     const char* xh = smem + buf * stage_bytes;
     const char* dyt = xh + halo_bytes;
 #pragma unroll 1
-    for (int s = 0; s < 8; ++s) {
+    for (int s = kgrp * (8 / KG); s < (kgrp + 1) * (8 / KG); ++s) {
       const int ty = s >> 1, tx0 = (s & 1) * 16;
       half8_t b = tr_pair(dyt + b_lane + (ty * 32 + tx0) * DSTR2, b_half);
       const char* abase = xh + a_lane + ((ty * p.stride) * p.WT + tx0 * p.stride) * X2STR;
@@ -335,8 +343,8 @@ __global__ __launch_bounds__(COB2 * 4) void wgrad2_kernel(Wg2P p, const half_t* 
 #pragma unroll
   for (int t = 0; t < MAXTAPS; ++t) {
     if (t < ntaps) {
-      float* dst = slab + (((size_t)split * ntaps + t) * p.cin + ci0 + ciw * 32) * p.cout + co0 +
-                   cow * 32 + r;
+      float* dst = slab + (((size_t)(split * KG + kgrp) * ntaps + t) * p.cin + ci0 + ciw * 32) * p.cout +
+                   co0 + cow * 32 + r;
       if (ci0 + ciw * 32 < p.cin && co0 + cow * 32 < p.cout) {   // 32-wide partial blocks
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -409,10 +417,10 @@ extern "C" size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d) {
   Wg2P p2;
   int cob = 0;
   if (fill2(d, &p2, &cob) == OCR_OK)
-    return (size_t)p2.splits * d->kh * d->kw * d->cin * d->cout * sizeof(float);
+    return (size_t)p2.splits * (cob == 64 ? 2 : 1) * d->kh * d->kw * d->cin * d->cout * sizeof(float);
   WgP p;
   if (fill(d, &p) != OCR_OK) return 0;
-  return (size_t)p.splits * d->kh * d->kw * d->cin * d->cout * sizeof(float);
+  return (size_t)p.splits * 2 * d->kh * d->kw * d->cin * d->cout * sizeof(float);
 }
 
 template <typename K, typename P>
@@ -438,7 +446,7 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
   Wg2P p2;
   int cob = 0;
   if (fill2(d, &p2, &cob) == OCR_OK) {
-    splits = p2.splits;
+    splits = p2.splits * (cob == 64 ? 2 : 1);
     if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
     const size_t lds = 2 * ((size_t)p2.HT * p2.WT * X2STR + 128 * (cob * 2 + 64));
     const unsigned grid = (unsigned)(p2.splits * p2.nci * p2.nco);
@@ -446,18 +454,18 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
       rc = ntaps == 1 ? launch_wg(wgrad2_kernel<128, 1>, p2, grid, lds, x, dy, workspace, st, 512)
                       : launch_wg(wgrad2_kernel<128, 9>, p2, grid, lds, x, dy, workspace, st, 512);
     else
-      rc = ntaps == 1 ? launch_wg(wgrad2_kernel<64, 1>, p2, grid, lds, x, dy, workspace, st)
-                      : launch_wg(wgrad2_kernel<64, 9>, p2, grid, lds, x, dy, workspace, st);
+      rc = ntaps == 1 ? launch_wg(wgrad2_kernel<64, 1>, p2, grid, lds, x, dy, workspace, st, 512)
+                      : launch_wg(wgrad2_kernel<64, 9>, p2, grid, lds, x, dy, workspace, st, 512);
   } else {
     WgP p;
     rc = fill(d, &p);
     if (rc != OCR_OK) return rc;
-    splits = p.splits;
+    splits = p.splits * 2;
     if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
     const size_t lds = (size_t)p.HT * p.WT * XSTR + 256 * DSTR;
     const unsigned grid = (unsigned)(p.splits * p.nci * p.nco);
-    rc = ntaps == 1 ? launch_wg(wgrad_kernel<1>, p, grid, lds, x, dy, workspace, st)
-                    : launch_wg(wgrad_kernel<9>, p, grid, lds, x, dy, workspace, st);
+    rc = ntaps == 1 ? launch_wg(wgrad_kernel<1>, p, grid, lds, x, dy, workspace, st, 512)
+                    : launch_wg(wgrad_kernel<9>, p, grid, lds, x, dy, workspace, st, 512);
   }
   if (rc != OCR_OK) return rc;
   const size_t elems4 = elems / 4;
