@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loss-scale", type=float, default=1024.0)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
+                    "gloo lets several ranks share one GPU for a functional check")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (functional check only)")
     args = ap.parse_args()
 
     from tensorflow_ocr_amd import dist, ops, synthetic
@@ -65,7 +68,9 @@ def main():
     from tensorflow_ocr_amd.train import AdamOptimizer, TrainStep
     import torch.distributed as td
 
-    rank, world, local = dist.init_process_group_from_env()
+    if args.share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = dist.init_process_group_from_env(args.backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     device = torch.device("cuda", local)

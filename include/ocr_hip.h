@@ -71,6 +71,14 @@ int ocr_conv2d_f16(const ocr_conv_desc* d, const void* x, const void* w_kc,
                    const void* bias, void* y, void* stats, void* stream);
 int ocr_conv2d_num_mtiles(const ocr_conv_desc* d);
 
+/* Input-gradient convolution fused with the batch-norm BACKWARD reduction of the layer below:
+ * y (= gradient w.r.t. that layer's activation) is written as usual and `partial`
+ * [ocr_conv2d_num_mtiles][2][cout] receives (sum dz, sum dz*xhat) per tile, dz = y * [relu(bn(bn_y)) > 0],
+ * so ocr_bn_relu_bwd_apply_f16 can skip the reduction pass over the two tensors. */
+int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y, void* partial,
+                         const void* bn_y, const void* bn_scale, const void* bn_shift,
+                         const void* bn_mean, const void* bn_invstd, int bn_relu, void* stream);
+
 /* First-layer convolution (cin = 3, images [n,h,w,4] f16 with channel 3 zero,
  * produced by ocr_prep_images): 3x3 stride 1, pad 1.
  *   w_first [3][cout][16] f16: for tap row ky, k = kx*4 + c (kx<3, c<3), else 0.
@@ -175,6 +183,12 @@ int ocr_unpool_bwd_f16(const void* dy, int n, int lh, int lw, int c, void* dx, i
 int ocr_bias_relu_bwd_num_partials(int64_t npix, int c);
 int ocr_bias_relu_bwd_f16(const void* a, const void* da, int64_t npix, int c, int relu, void* dz,
                           void* dbias, void* partial, void* stream);
+
+/* ocr_bn_relu_bwd_f16 without its reduction pass (partials [T][2][c] from ocr_conv2d_bnred_f16) */
+int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const void* shift, const void* save_mean,
+                              const void* save_invstd, const void* da_full, int n, int h, int w, int c,
+                              int relu, const void* partial, int T, void* dgamma, void* dbeta, void* dy,
+                              void* workspace, size_t ws_bytes, void* stream);
 
 /* slim.max_pool2d k x k / stride SAME as a standalone op (pool5 3x3/1 nets/vgg.py:32; ResNet
  * pool1 3x3/2 nets/resnet_v1.py:194; subsample 1x1/s nets/resnet_utils.py:74), f16 NHWC. */

@@ -842,3 +842,32 @@ extern "C" int ocr_unpool_bwd_f16(const void* dy, int n, int lh, int lw, int c, 
                      static_cast<half_t*>(dx), accumulate);
   return ocr_launch_status();
 }
+
+// Second half of ocr_bn_relu_bwd_f16 when the (sum dz, sum dz*xhat) partials [T][2][c] already
+// exist (produced by ocr_conv2d_bnred_f16): finalise dgamma / dbeta, then the apply pass.
+extern "C" int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const void* shift,
+                                         const void* save_mean, const void* save_invstd,
+                                         const void* da_full, int n, int h, int w, int c, int relu,
+                                         const void* partial, int T, void* dgamma, void* dbeta,
+                                         void* dy, void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(y && scale && shift && save_mean && save_invstd && da_full && partial && dgamma && dbeta && dy);
+  OCR_CHECK_ARG(workspace && T > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
+  if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int R = ocr_cdiv(T, 256);
+  hipLaunchKernelGGL(reduce_stage1_kernel, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ocr_cdiv(c, 64)), dim3(64), 0, st,
+                     static_cast<const double*>(workspace), R, c, static_cast<float*>(dgamma),
+                     static_cast<float*>(dbeta));
+  BnBwdP p{n, h, w, c, relu, 0, (float)(1.0 / ((double)n * h * w))};
+  const int B = bwd_blocks(n, h, w, c, 0);
+  hipLaunchKernelGGL(bn_relu_bwd_kernel<1>, dim3(B), dim3(256), 0, st, p, static_cast<const half_t*>(y),
+                     static_cast<const float*>(scale), static_cast<const float*>(shift),
+                     static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                     static_cast<const float*>(dgamma), static_cast<const float*>(dbeta),
+                     static_cast<const half_t*>(da_full), (const half_t*)nullptr, (float*)nullptr,
+                     static_cast<half_t*>(dy));
+  return ocr_launch_status();
+}

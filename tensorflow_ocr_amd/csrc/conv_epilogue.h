@@ -8,6 +8,16 @@
 constexpr int TILE_H = 8;
 constexpr int TILE_W = 32;
 
+// Optional fusion of the batch-norm BACKWARD reduction of the layer that produced this conv's
+// output position (used by the input-gradient form): instead of (sum v, sum v^2) the per-tile
+// partials become (sum dz, sum dz*xhat) with dz = v * [relu(bn(y)) > 0], xhat = (y - mean)*invstd,
+// y = that layer's stored conv output (same [n,oh,ow,cout] geometry as the tensor being written).
+struct BnRed {
+  const half_t* y;
+  const float *scale, *shift, *mean, *invstd;
+  int relu;
+};
+
 // LDS needed by the epilogue for a BN-wide tile.
 constexpr size_t conv_epilogue_lds(int bn, int nt = 256) { return 256 * (bn * 2 + 16) + nt * 16 * sizeof(float); }
 
@@ -16,7 +26,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* sme
                                               const float* __restrict__ bias,
                                               half_t* __restrict__ y, float* __restrict__ stats,
                                               int img, int tyi, int txi, int mt, int co0, int oh,
-                                              int ow, int cout, int wco, int wpx, bool active) {
+                                              int ow, int cout, int wco, int wpx, bool active,
+                                              const BnRed* br = nullptr) {
   constexpr int OSTR = BN * 2 + 16;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -75,11 +86,25 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* sme
       }
       *reinterpret_cast<half8_t*>(dst) = v;
       if (do_stats) {
+        if (br != nullptr) {
+          const size_t off = (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
+          half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float f = (float)v[e];
-          s[e] += f;
-          q2[e] += f * f;
+          for (int e = 0; e < 8; ++e) {
+            const int cc = co0 + c * 8 + e;
+            const float yf = (float)yv[e];
+            const float z = (float)(half_t)(yf * br->scale[cc] + br->shift[cc]);
+            const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
+            s[e] += dz;
+            q2[e] += dz * ((yf - br->mean[cc]) * br->invstd[cc]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = (float)v[e];
+            s[e] += f;
+            q2[e] += f * f;
+          }
         }
       }
     }

@@ -29,6 +29,7 @@ namespace {
 struct ConvP {
   int n, h, w, cin, oh, ow, cout, kh, kw, stride, dil, pt, pl, flip, flags;
   int tiles_x, tiles_y, n_tiles, HT, WT, halo_bytes;
+  BnRed br;       // br.y != nullptr: fused BN-backward reduction (see conv_epilogue.h)
 };
 
 
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
   if constexpr (BN <= 128) {
     __syncthreads();
     conv_epilogue<BN, TCO, TPX, WCO, NT>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt, co0,
-                                         p.oh, p.ow, p.cout, wco, wpx, true);
+                                         p.oh, p.ow, p.cout, wco, wpx, true, p.br.y ? &p.br : nullptr);
   } else {
     // 256-wide tiles leave through LDS in two 128-cout halves (waves wco 0,1 then 2,3)
 #pragma unroll
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
       __syncthreads();
       conv_epilogue<128, TCO, TPX, 2, NT>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt,
                                           co0 + h * 128, p.oh, p.ow, p.cout, wco & 1, wpx,
-                                          (wco >> 1) == h);
+                                          (wco >> 1) == h, p.br.y ? &p.br : nullptr);
     }
   }
 }
@@ -329,6 +330,7 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, int* bn, int* ck) {
   *ck = c;
   p->halo_bytes = p->HT * p->WT * (c * 2 + 16);
   p->n_tiles = d->cout / *bn;
+  p->br = BnRed{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   return OCR_OK;
 }
 
@@ -337,6 +339,18 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, int* bn, int* ck) {
 extern "C" int ocr_conv2d_num_mtiles(const ocr_conv_desc* d) {
   if (!d) return OCR_ERR_INVALID_ARG;
   return d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
+}
+
+static int dispatch(ConvP& p, int bn, int ck, const void* x, const void* w_kc, const void* bias, void* y,
+                    void* stats, hipStream_t st) {
+  if (bn == 256 && ck == 64) return launch<256, 64, 4>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 256 && ck == 32) return launch<256, 32, 4>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 128 && ck == 64) return launch<128, 64, 2>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 128 && ck == 32) return launch<128, 32, 2>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 64 && ck == 64) return launch<64, 64, 2>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 32 && ck == 64) return launch<32, 64, 1>(p, x, w_kc, bias, y, stats, st);
+  if (bn == 32) return launch<32, 32, 1>(p, x, w_kc, bias, y, stats, st);
+  return launch<64, 32, 2>(p, x, w_kc, bias, y, stats, st);
 }
 
 extern "C" int ocr_conv2d_f16(const ocr_conv_desc* d, const void* x, const void* w_kc,
@@ -348,13 +362,22 @@ extern "C" int ocr_conv2d_f16(const ocr_conv_desc* d, const void* x, const void*
   OCR_CHECK_ARG(x && w_kc && y);
   OCR_CHECK_ARG(!(d->flags & OCR_CONV_BIAS) || bias);
   OCR_CHECK_ARG(!(d->flags & OCR_CONV_STATS) || stats);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (bn == 256 && ck == 64) return launch<256, 64, 4>(p, x, w_kc, bias, y, stats, st);
-  if (bn == 256 && ck == 32) return launch<256, 32, 4>(p, x, w_kc, bias, y, stats, st);
-  if (bn == 128 && ck == 64) return launch<128, 64, 2>(p, x, w_kc, bias, y, stats, st);
-  if (bn == 128 && ck == 32) return launch<128, 32, 2>(p, x, w_kc, bias, y, stats, st);
-  if (bn == 64 && ck == 64) return launch<64, 64, 2>(p, x, w_kc, bias, y, stats, st);
-  if (bn == 32 && ck == 64) return launch<32, 64, 1>(p, x, w_kc, bias, y, stats, st);
-  if (bn == 32) return launch<32, 32, 1>(p, x, w_kc, bias, y, stats, st);
-  return launch<64, 32, 2>(p, x, w_kc, bias, y, stats, st);
+  return dispatch(p, bn, ck, x, w_kc, bias, y, stats, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y,
+                                    void* partial, const void* bn_y, const void* bn_scale,
+                                    const void* bn_shift, const void* bn_mean, const void* bn_invstd,
+                                    int bn_relu, void* stream) {
+  ConvP p;
+  int bn = 0, ck = 0;
+  int rc = fill_params(d, &p, &bn, &ck);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x && w_kc && y && partial && bn_y && bn_scale && bn_shift && bn_mean && bn_invstd);
+  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_BIAS | OCR_CONV_RELU)));
+  p.flags |= OCR_CONV_STATS;
+  p.br = BnRed{static_cast<const half_t*>(bn_y), static_cast<const float*>(bn_scale),
+               static_cast<const float*>(bn_shift), static_cast<const float*>(bn_mean),
+               static_cast<const float*>(bn_invstd), bn_relu};
+  return dispatch(p, bn, ck, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }

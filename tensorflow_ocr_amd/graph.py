@@ -120,13 +120,15 @@ class VariableStore:
 class Act:
     """Activation handle: device tensor + (lazily created) gradient."""
 
-    __slots__ = ("data", "grad", "requires_grad", "name")
+    __slots__ = ("data", "grad", "requires_grad", "name", "bn_ctx", "bn_partial")
 
     def __init__(self, data, requires_grad=True, name=""):
         self.data = data
         self.grad = None
         self.requires_grad = requires_grad
         self.name = name
+        self.bn_ctx = None        # (y, scale, shift, mean, invstd, relu) of the conv+BN that made it
+        self.bn_partial = None    # (partial, T): BN-backward sums already reduced by the dgrad conv
 
     @property
     def shape(self):

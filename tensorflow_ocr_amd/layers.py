@@ -13,6 +13,7 @@ from ._lib import CONV_ACCUM_F16, CONV_BIAS, CONV_RELU, CONV_STATS
 
 BN_DECAY = 0.997
 BN_EPS = 1e-5
+FUSE_BN_REDUCE = __import__("os").environ.get("OCR_FUSE_BN", "1") == "1"   # BN-backward reduction inside the consumer's input-gradient kernel
 
 
 def _bn_vars(g, C):
@@ -103,6 +104,9 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
             ops.bn_relu(y, scale, shift, relu, 0, full, None)
         a_full = Act(full, name=scope) if full is not None else None
         a_pool = Act(pooled, name=scope + "/pool") if pooled is not None else None
+        if not pool and train_stats:
+            # lets the consumer conv's input-gradient kernel do this layer's BN-backward reduction
+            a_full.bn_ctx = (y, scale, shift, mean, invstd, relu)
 
         def backward():
             if not train_stats:
@@ -117,8 +121,14 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
             if not pool and da_full is None:
                 return
             dy = g.empty(y.shape)
-            ops.bn_relu_bwd(y, scale, shift, mean, invstd, da_full, da_pool, relu, 2 if pool else 0,
-                            gamma.grad, beta.grad, dy, ws)
+            if not pool and a_full.bn_partial is not None:
+                part_f, T_f = a_full.bn_partial
+                ops.bn_relu_bwd_apply(y, scale, shift, mean, invstd, da_full, relu, part_f, T_f,
+                                      gamma.grad, beta.grad, dy, ws)
+                a_full.bn_partial = None
+            else:
+                ops.bn_relu_bwd(y, scale, shift, mean, invstd, da_full, da_pool, relu, 2 if pool else 0,
+                                gamma.grad, beta.grad, dy, ws)
             _conv_backward(g, x, wv, w_dg, d, dy, first)
             if a_full is not None:
                 a_full.grad = None
@@ -171,7 +181,13 @@ def _conv_backward(g, x, wv, w_dg, d, dy, first):
         flags |= CONV_ACCUM_F16
     dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1,
                       flags)
-    ops.conv2d(dg, dy, w_dg, x.grad, None, None)
+    if x.bn_ctx is not None and not flags and FUSE_BN_REDUCE:
+        T = ops.conv2d_num_mtiles(dg)
+        partial = g.empty((T, 2, d.cin), F32)
+        ops.conv2d_bnred(dg, dy, w_dg, x.grad, partial, x.bn_ctx)
+        x.bn_partial = (partial, T)
+    else:
+        ops.conv2d(dg, dy, w_dg, x.grad, None, None)
 
 
 def max_pool2d(g, x, k, stride, scope="pool"):

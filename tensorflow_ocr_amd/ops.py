@@ -94,6 +94,24 @@ def conv2d(d, x, w_kc, y, bias=None, stats=None):
         L.RECORDER.tag_last((conv2d_variant(d), flops))
 
 
+def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx):
+    """Input-gradient conv fused with the BN-backward reduction of the layer below."""
+    by, sc, sh, mu, istd, relu = bn_ctx
+    L.call("ocr_conv2d_bnred_f16", byref(d), ptr(x), ptr(w_kc), ptr(y), ptr(partial), ptr(by), ptr(sc),
+           ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), _st())
+    if L.RECORDER is not None:
+        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+        L.RECORDER.tag_last((conv2d_variant(d), flops))
+
+
+def bn_relu_bwd_apply(y, scale, shift, save_mean, save_invstd, da_full, relu, partial, T, dgamma, dbeta, dy, ws):
+    n, h, w, c = y.shape
+    stage = ws.get(bn_reduce_workspace(T, c))
+    L.call("ocr_bn_relu_bwd_apply_f16", ptr(y), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd),
+           ptr(da_full), c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(partial), c_int(T),
+           ptr(dgamma), ptr(dbeta), ptr(dy), ptr(stage), c_size_t(stage.numel()), _st())
+
+
 def conv2d_wgrad(d, x, dy, dw, ws):
     nbytes = L.call_size("ocr_conv2d_wgrad_workspace", byref(d))
     buf = ws.get(nbytes)
