@@ -8,6 +8,7 @@ W = [1,1,1,1,2,1,2,3,1,1]
 def run(hw,cin,cout,k,dil,iters=5,B=32):
     dev='cuda'
     x=torch.randn(B,hw,hw,cin,device=dev).half(); w=(torch.randn(k*k,cout,cin,device=dev)*0.05).half()
+    if os.environ.get('ZERO'): x.zero_(); w.zero_()
     pad=dil*(k-1)//2
     d=L.ConvDesc(B,hw,hw,cin,hw,hw,cout,k,k,1,dil,pad,pad,0,L.CONV_STATS)
     y=torch.empty(B,hw,hw,cout,dtype=torch.half,device=dev)

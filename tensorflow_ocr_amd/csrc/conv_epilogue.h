@@ -21,47 +21,16 @@ struct BnRed {
 // LDS needed by the epilogue for a BN-wide tile.
 constexpr size_t conv_epilogue_lds(int bn, int nt = 256) { return 256 * (bn * 2 + 16) + nt * 16 * sizeof(float); }
 
-template <int BN, int TCO, int TPX, int WCO, int NT = 256>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* smem, int flags,
-                                              const float* __restrict__ bias,
-                                              half_t* __restrict__ y, float* __restrict__ stats,
-                                              int img, int tyi, int txi, int mt, int co0, int oh,
-                                              int ow, int cout, int wco, int wpx, bool active,
-                                              const BnRed* br = nullptr) {
+// Second half of the epilogue, shared by both accumulator layouts: LDS [256 px][BN] f16 -> HBM rows.
+template <int BN, int NT>
+__device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_t* __restrict__ y,
+                                                    float* __restrict__ stats, int img, int tyi, int txi,
+                                                    int mt, int co0, int oh, int ow, int cout,
+                                                    const BnRed* br) {
   constexpr int OSTR = BN * 2 + 16;
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int r = lane & 31, hh = lane >> 5;
   char* otile = smem;
   float* red = reinterpret_cast<float*>(smem + 256 * OSTR);
-  const bool has_bias = (flags & OCR_CONV_BIAS) != 0;
-  const bool relu = (flags & OCR_CONV_RELU) != 0;
-  if (active) {
-#pragma unroll
-  for (int i = 0; i < TCO; ++i) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = wco * TCO * 32 + i * 32 + q * 8 + hh * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (has_bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + col + e];
-      }
-#pragma unroll
-      for (int t = 0; t < TPX; ++t) {
-        const int px = (wpx * TPX + t) * 32 + r;
-        half4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[i][t][q * 4 + e] + bv[e];
-          if (relu) v = v > 0.f ? v : 0.f;
-          o[e] = (half_t)v;
-        }
-        *reinterpret_cast<half4_t*>(otile + px * OSTR + col * 2) = o;
-      }
-    }
-  }
-  }
   __syncthreads();
   constexpr int NC = BN / 8;    // 16-byte chunks per output row
   constexpr int RG = NT / NC;   // row groups
@@ -123,4 +92,88 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* sme
       stats[((size_t)mt * 2 + (e >> 3)) * cout + co0 + cc2 * 8 + (e & 7)] = tot;
     }
   }
+}
+
+template <int BN, int TCO, int TPX, int WCO, int NT = 256>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* smem, int flags,
+                                              const float* __restrict__ bias,
+                                              half_t* __restrict__ y, float* __restrict__ stats,
+                                              int img, int tyi, int txi, int mt, int co0, int oh,
+                                              int ow, int cout, int wco, int wpx, bool active,
+                                              const BnRed* br = nullptr) {
+  constexpr int OSTR = BN * 2 + 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  char* otile = smem;
+  const bool has_bias = (flags & OCR_CONV_BIAS) != 0;
+  const bool relu = (flags & OCR_CONV_RELU) != 0;
+  if (active) {
+#pragma unroll
+  for (int i = 0; i < TCO; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = wco * TCO * 32 + i * 32 + q * 8 + hh * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (has_bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + col + e];
+      }
+#pragma unroll
+      for (int t = 0; t < TPX; ++t) {
+        const int px = (wpx * TPX + t) * 32 + r;
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][t][q * 4 + e] + bv[e];
+          if (relu) v = v > 0.f ? v : 0.f;
+          o[e] = (half_t)v;
+        }
+        *reinterpret_cast<half4_t*>(otile + px * OSTR + col * 2) = o;
+      }
+    }
+  }
+  }
+  conv_epilogue_store<BN, NT>(smem, flags, y, stats, img, tyi, txi, mt, co0, oh, ow, cout, br);
+}
+
+// Same epilogue for 16x16 accumulator tiles (v_mfma_f32_16x16x32_f16): lane l holds couts
+// 4*(l>>4)..+3 of pixel l&15 of each tile; acc[i][t] covers couts i*16.., pixels t*16.. of the wave.
+template <int BN, int TCO, int TPX, int WCO, int NT = 256>
+__device__ __forceinline__ void conv_epilogue16(f32x4 (&acc)[TCO * 2][TPX * 2], char* smem, int flags,
+                                                const float* __restrict__ bias,
+                                                half_t* __restrict__ y, float* __restrict__ stats,
+                                                int img, int tyi, int txi, int mt, int co0, int oh,
+                                                int ow, int cout, int wco, int wpx, bool active,
+                                                const BnRed* br = nullptr) {
+  constexpr int OSTR = BN * 2 + 16;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, g4 = lane >> 4;
+  char* otile = smem;
+  const bool has_bias = (flags & OCR_CONV_BIAS) != 0;
+  const bool relu = (flags & OCR_CONV_RELU) != 0;
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < TCO * 2; ++i) {
+      const int col = wco * TCO * 32 + i * 16 + g4 * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (has_bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + col + e];
+      }
+#pragma unroll
+      for (int t = 0; t < TPX * 2; ++t) {
+        const int px = wpx * TPX * 32 + t * 16 + r;
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][t][e] + bv[e];
+          if (relu) v = v > 0.f ? v : 0.f;
+          o[e] = (half_t)v;
+        }
+        *reinterpret_cast<half4_t*>(otile + px * OSTR + col * 2) = o;
+      }
+    }
+  }
+  conv_epilogue_store<BN, NT>(smem, flags, y, stats, img, tyi, txi, mt, co0, oh, ow, cout, br);
 }
