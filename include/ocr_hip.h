@@ -71,6 +71,11 @@ int ocr_conv2d_f16(const ocr_conv_desc* d, const void* x, const void* w_kc,
                    const void* bias, void* y, void* stats, void* stream);
 int ocr_conv2d_num_mtiles(const ocr_conv_desc* d);
 
+/* Name of the kernel instantiation ocr_conv2d_f16 launches for `d`:
+ * "conv_igemm_kernel<BN,CK,WCO,M16,TH>" (cout tile, channel chunk, cout waves, 16x16x32 MFMA, tile rows),
+ * as it appears (mangled) in rocprofv3 kernel traces.  Measurement only. */
+int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap);
+
 /* Input-gradient convolution fused with the batch-norm BACKWARD reduction of the layer below:
  * y (= gradient w.r.t. that layer's activation) is written as usual and `partial`
  * [ocr_conv2d_num_mtiles][2][cout] receives (sum dz, sum dz*xhat) per tile, dz = y * [relu(bn(bn_y)) > 0],

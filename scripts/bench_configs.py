@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Measurement of the BASELINE.json configs other than the headline one (which is bench.py's):
+
+  pixellink  configs[2]: PixelLink VGG-16 512x512 batch 32 train step (softmax/OHNM + focal-style link
+             loss, Momentum) followed by the link-CC decode of the same batch
+  resnet     configs[3] per-GPU share: EAST ResNet-v1-50 640x640 batch 64 train step (dice), 1 GPU
+  decode     configs[4]: PixelLink inference 1024x1024 batch 16, then pixel/link softmax + link-CC
+             decode, and locality-aware NMS on synthetic quadrangle lists
+
+Prints one JSON line per config.  Same timing discipline as bench.py (resident inputs, warm-up,
+synchronize on both sides).  Dev/measurement tool: not part of the driver contract."""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+
+
+def timed(fn, warmup, steps):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def train_config(name, forward_loss, opt_factory, batch, size, steps, warmup, extra=None):
+    from tensorflow_ocr_amd import synthetic
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.train import TrainStep
+    dev = torch.device("cuda", 0)
+    g = Graph(dev, loss_scale=1024.0, seed=1)
+    rng = np.random.default_rng(100)
+    data = [torch.from_numpy(a).to(dev) for a in synthetic.make_batch(rng, batch, size)]
+    step = TrainStep(g, forward_loss, opt_factory)
+    loss = None
+    for _ in range(3):
+        loss = step(*data)
+    dt = timed(lambda: step(*data), warmup, steps)
+    out = {"config": name, "batch": batch, "size": size, "ms_per_step": round(dt * 1e3, 3),
+           "images_per_sec": round(batch / dt, 1), "loss": round(float(step(*data).item()), 5),
+           "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    if extra:
+        out.update(extra(g, data))
+    print(json.dumps(out), flush=True)
+    return g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="pixellink,resnet,decode")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--resnet-batch", type=int, default=64)
+    ap.add_argument("--resnet-size", type=int, default=640)
+    args = ap.parse_args()
+    which = args.which.split(",")
+    from tensorflow_ocr_amd.train import AdamOptimizer, MomentumOptimizer
+
+    if "pixellink" in which:
+        from tensorflow_ocr_amd.nets import pixellink
+        from tensorflow_ocr_amd.tool import pixellink_fn
+
+        def fl(g, im, sm, gm, tm):
+            net = pixellink.PixelLinkNet((im - 120.0) / 60.0, graph=g)
+            fl.net = net
+            return net.build_loss(sm[..., 0], gm)
+
+        def decode(g, data):
+            from tensorflow_ocr_amd.graph import Graph
+            g2 = Graph(torch.device("cuda", 0))
+            n = 32
+            rng = np.random.default_rng(7)
+            pix = torch.from_numpy(rng.normal(0, 2, (n, 128, 128, 2)).astype(np.float32)).cuda()
+            lnk = torch.from_numpy(rng.normal(0, 2, (n, 128, 128, 16)).astype(np.float32)).cuda()
+
+            def run():
+                ps = pixellink_fn.pixel_scores(pix, graph=g2)
+                ls = pixellink_fn.link_scores(lnk, graph=g2)
+                pixellink_fn.link_cc_decode(ps[..., 1].contiguous(), ls, 0.6, 0.6, min_size=10, graph=g2)
+            dt = timed(run, 2, 10)
+            return {"decode_ms_per_batch": round(dt * 1e3, 3), "decode_images_per_sec": round(n / dt, 1)}
+        train_config("PixelLink VGG-16 512x512 b32: softmax/OHNM + link loss, Momentum", fl,
+                     lambda gr: MomentumOptimizer(gr), 32, 512, args.steps, args.warmup, extra=decode)
+
+    if "resnet" in which:
+        from tensorflow_ocr_amd.nets import model_vgg_16 as MV
+
+        def fr(g, im, sm, gm, tm):
+            a, b = MV.model(im, is_training=True, graph=g)
+            return MV.loss(sm, a, gm, b, tm, graph=g)
+        train_config("EAST ResNet-v1-50 %d^2 b%d: dice, Adam+EMA (per-GPU share of configs[3])" % (
+            args.resnet_size, args.resnet_batch), fr, lambda gr: AdamOptimizer(gr, learning_rate=1e-4),
+            args.resnet_batch, args.resnet_size, args.steps, args.warmup)
+
+    if "decode" in which:
+        from tensorflow_ocr_amd.graph import Graph
+        from tensorflow_ocr_amd.nets import pixellink
+        from tensorflow_ocr_amd.tool import lanms, pixellink_fn
+        dev = torch.device("cuda", 0)
+        g = Graph(dev)
+        rng = np.random.default_rng(3)
+        n, S = 16, 1024
+        x = torch.from_numpy(rng.uniform(0, 255, (n, S, S, 3)).astype(np.float32)).to(dev)
+        xin = (x - 120.0) / 60.0
+        holder = {}
+
+        def fwd():
+            net = pixellink.PixelLinkNet(xin, graph=g)
+            g.reset_tape()
+            holder["net"] = net
+        fwd()
+        dt_net = timed(fwd, 1, 3)
+        net = holder["net"]
+        rng2 = np.random.default_rng(4)
+        pix = torch.from_numpy(rng2.normal(0, 2, (n, S // 4, S // 4, 2)).astype(np.float32)).to(dev)
+        lnk = torch.from_numpy(rng2.normal(0, 2, (n, S // 4, S // 4, 16)).astype(np.float32)).to(dev)
+        res = {}
+
+        def dec():
+            ps = pixellink_fn.pixel_scores(pix, graph=g)
+            ls = pixellink_fn.link_scores(lnk, graph=g)
+            res["out"] = pixellink_fn.link_cc_decode(ps[..., 1].contiguous(), ls, 0.6, 0.6, min_size=10, graph=g)
+        dt_dec = timed(dec, 2, 10)
+        ncomp = int(res["out"][1].sum().item())
+        # LANMS on synthetic row-major quad lists (1024 candidates per image)
+        K = 1024
+        boxes = np.zeros((n, K, 9), np.float32)
+        for i in range(n):
+            cx = np.sort(rng2.uniform(20, S - 20, K)); cy = rng2.uniform(20, S - 20, K)
+            w = rng2.uniform(20, 60, K); h = rng2.uniform(10, 30, K)
+            boxes[i, :, 0] = cx - w; boxes[i, :, 1] = cy - h; boxes[i, :, 2] = cx + w; boxes[i, :, 3] = cy - h
+            boxes[i, :, 4] = cx + w; boxes[i, :, 5] = cy + h; boxes[i, :, 6] = cx - w; boxes[i, :, 7] = cy + h
+            boxes[i, :, 8] = rng2.uniform(0.5, 1.0, K)
+        bt = torch.from_numpy(boxes).to(dev)
+        ct = torch.full((n,), K, dtype=torch.int32, device=dev)
+        dt_nms = timed(lambda: lanms.lanms_batch(bt, ct, 0.2, graph=g), 2, 10)
+        px = n * (S // 4) ** 2
+        print(json.dumps({"config": "PixelLink inference 1024^2 b16 + decode + LANMS",
+                          "net_forward_ms": round(dt_net * 1e3, 2), "net_images_per_sec": round(n / dt_net, 1),
+                          "decode_ms_per_batch": round(dt_dec * 1e3, 3), "decode_images_per_sec": round(n / dt_dec, 1),
+                          "decode_algorithmic_GBps": round(px * 76 / dt_dec / 1e9, 1), "components": ncomp,
+                          "lanms_ms_per_batch": round(dt_nms * 1e3, 3),
+                          "lanms_boxes_per_sec": round(n * K / dt_nms, 0)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -8,8 +8,8 @@ for name, d in (("FETCH_SIZE", sys.argv[1]), ("WRITE_SIZE", sys.argv[2])):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name and "conv_igemm" in r["Kernel_Name"]:
-            k = re.search(r"conv_igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)", r["Kernel_Name"])
-            acc["conv_igemm_kernel<%s,%s,%s>" % k.groups()].append(float(r["Counter_Value"]))
+            k = re.search(r"conv_igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)", r["Kernel_Name"])
+            acc["conv_igemm_kernel<%s,%s,%s,%s,%s>" % k.groups()].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         out.setdefault(k, {})[name] = {"launches": len(v), "avg_KiB": sum(v) / len(v)}
 res = {}

@@ -22,6 +22,7 @@
 //     stored (f16-rounded) values for training-mode batch norm.
 #include "common.h"
 #include "conv_epilogue.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -425,6 +426,17 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
 extern "C" int ocr_conv2d_num_mtiles(const ocr_conv_desc* d) {
   if (!d) return OCR_ERR_INVALID_ARG;
   return d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
+}
+
+extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap) {
+  ConvP p;
+  TileCfg c;
+  int rc = fill_params(d, &p, &c);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(out && cap > 0);
+  const int wco = c.bn == 256 ? 4 : c.bn == 32 ? 1 : 2;
+  snprintf(out, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d>", c.bn, c.ck, wco, p.m16, c.th);
+  return OCR_OK;
 }
 
 static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const void* bias, void* y,

@@ -18,6 +18,11 @@
 // slabs in fixed order, so the result is bitwise reproducible (no atomics).
 #include "common.h"
 
+namespace ocr_detail {   // conv_wgrad_pw.hip: GEMM-tiled path for 1x1 convolutions
+int wgrad_pw_splits(const ocr_conv_desc* d);
+int wgrad_pw_launch(const ocr_conv_desc* d, const void* x, const void* dy, void* slab, hipStream_t st);
+}
+
 namespace {
 
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -414,6 +419,7 @@ int fill(const ocr_conv_desc* d, WgP* p) {
 
 extern "C" size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d) {
   if (!d) return 0;
+  if (const int s = ocr_detail::wgrad_pw_splits(d)) return (size_t)s * d->cin * d->cout * sizeof(float);
   Wg2P p2;
   int cob = 0;
   if (fill2(d, &p2, &cob) == OCR_OK)
@@ -445,7 +451,10 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
   int splits = 0, rc;
   Wg2P p2;
   int cob = 0;
-  if (fill2(d, &p2, &cob) == OCR_OK) {
+  if ((splits = ocr_detail::wgrad_pw_splits(d)) > 0) {
+    if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
+    rc = ocr_detail::wgrad_pw_launch(d, x, dy, workspace, st);
+  } else if (fill2(d, &p2, &cob) == OCR_OK) {
     splits = p2.splits * (cob == 64 ? 2 : 1);
     if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
     const size_t lds = 2 * ((size_t)p2.HT * p2.WT * X2STR + 128 * (cob * 2 + 64));

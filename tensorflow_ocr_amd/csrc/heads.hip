@@ -413,7 +413,7 @@ __global__ void take_cols_kernel(const float* __restrict__ in, int rows, int C, 
 
 // MFMA route: P % 32 == 0 and cin % 64 == 0 (the 1x1 weight gradient with cout padded to 64);
 // otherwise the VALU strip kernel.
-static bool small_wgrad_mfma(int P, int cin) { return P % 32 == 0 && cin % 64 == 0; }
+static bool small_wgrad_mfma(int P, int cin) { return P % 32 == 0 && cin % 32 == 0; }
 
 static ocr_conv_desc small_wgrad_desc(int P, int cin) {
   ocr_conv_desc d = {1, P / 32, 32, cin, P / 32, 32, 64, 1, 1, 1, 1, 0, 0, 0, 0};

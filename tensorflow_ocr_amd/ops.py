@@ -69,15 +69,19 @@ def conv2d_num_mtiles(d):
 KERNEL_TIMING = None
 
 
+_VARIANTS = {}
+
+
 def conv2d_variant(d):
-    """Which conv_igemm_kernel<BN,CK,WCO> instantiation the library picks (conv_igemm.hip)."""
-    bn = 256 if d.cout % 256 == 0 else 128 if d.cout % 128 == 0 else 64
-    ck = 64 if d.cin % 64 == 0 else 32
-    ht = 7 * d.stride + (d.kh - 1) * d.dilation + 1
-    wt = 31 * d.stride + (d.kw - 1) * d.dilation + 1
-    if ck == 64 and ht * wt * (64 * 2 + 16) + 2 * bn * (64 * 2 + 16) > 160 * 1024:
-        ck = 32
-    return "conv_igemm_kernel<%d,%d,%d>" % (bn, ck, 4 if bn == 256 else 2)
+    """Which conv_igemm_kernel<BN,CK,WCO,M16,TH> instantiation the library launches for `d`."""
+    key = (d.n, d.h, d.w, d.cin, d.cout, d.kh, d.kw, d.stride, d.dilation)
+    v = _VARIANTS.get(key)
+    if v is None:
+        import ctypes
+        buf = ctypes.create_string_buffer(96)
+        L.call_int("ocr_conv2d_variant", byref(d), buf, ctypes.c_size_t(96))
+        v = _VARIANTS[key] = buf.value.decode()
+    return v
 
 
 def conv2d(d, x, w_kc, y, bias=None, stats=None):
