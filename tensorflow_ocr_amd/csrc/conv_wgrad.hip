@@ -206,8 +206,12 @@ struct Wg2P {
   int tiles_x, tiles_y, m_tiles, HT, WT, splits, tiles_per_split, nci, nco;
 };
 
-constexpr int X2STR = CIB * 2 + 64;   // 192 B: row stride = 16 dwords mod 64 -> the 4 k-rows of a
-                                       // transposing read land in 4 disjoint bank quarters
+// v2 uses v_mfma_f32_16x16x32_f16 with the K (pixel) order permuted identically for both operands:
+// register j of lane group g holds pixel column 4g+j (j < 4) or 16+4g+(j-4) of the 32-pixel tile
+// row, so the two 32-lane halves of a transposing read touch 8 consecutive pixels each.  With a
+// pixel stride of 32*odd bytes those are 8 distinct 32-byte bank slots: conflict-free for every
+// tap shift.
+constexpr int X2STR = CIB * 2 + 32;   // 160 B
 
 template <int COB2, int MAXTAPS>
 __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __restrict__ x,
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
   constexpr int NT = 512;
   constexpr int NWCO = COB2 / 32;
   constexpr int KG = 8 / (2 * NWCO);
-  constexpr int DSTR2 = COB2 * 2 + 64;     // bytes per dy pixel in LDS (same bank rule)
+  constexpr int DSTR2 = COB2 * 2 + 32;     // bytes per dy pixel in LDS (32*odd)
   constexpr int DCH = COB2 / 8;            // 16-byte chunks per dy pixel
   constexpr int NDY = 128 * DCH / NT;      // dy loads per thread per tile
   constexpr int XPP = NT / 8;              // halo pixels covered per pass
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
   const int kgrp = wave / (2 * NWCO);
   const int ciw = (wave / NWCO) & 1, cow = wave % NWCO;
   const int li = lane & 15, g = lane >> 4;
-  const int q = li >> 2, pp = li & 3, hh = g >> 1, gc = g & 1;
+  const int q = li >> 2, pp = li & 3;
 
   int bid = blockIdx.x;
   const int cob = bid % p.nco;
@@ -244,16 +248,18 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
   const int ci0 = cib * CIB, co0 = cob * COB2;
   const int ntaps = p.kh * p.kw;
 
-  f32x16 acc[MAXTAPS];
+  f32x4 acc[MAXTAPS][2][2];      // [tap][ci half][co half] 16x16 blocks of the wave's 32x32
 #pragma unroll
   for (int t = 0; t < MAXTAPS; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t][i >> 1][i & 1][e] = 0.f;
 
-  const int a_lane = ((8 * hh + q) * p.stride) * X2STR + (ciw * 32 + 16 * gc + 4 * pp) * 2;
-  const int a_half = 4 * p.stride * X2STR;
-  const int b_lane = (8 * hh + q) * DSTR2 + (cow * 32 + 16 * gc + 4 * pp) * 2;
-  const int b_half = 4 * DSTR2;
+  const int a_lane = ((4 * g + q) * p.stride) * X2STR + (ciw * 32 + 4 * pp) * 2;
+  const int a_half = 16 * p.stride * X2STR;
+  const int b_lane = (4 * g + q) * DSTR2 + (cow * 32 + 4 * pp) * 2;
+  const int b_half = 16 * DSTR2;
 
   // this thread's halo chunks (fixed across tiles): packed (hy << 16 | hx), -1 = none
   int xpos[NXMAX];
@@ -327,16 +333,23 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
     const char* xh = smem + buf * stage_bytes;
     const char* dyt = xh + halo_bytes;
 #pragma unroll 1
-    for (int s = kgrp * (8 / KG); s < (kgrp + 1) * (8 / KG); ++s) {
-      const int ty = s >> 1, tx0 = (s & 1) * 16;
-      half8_t b = tr_pair(dyt + b_lane + (ty * 32 + tx0) * DSTR2, b_half);
-      const char* abase = xh + a_lane + ((ty * p.stride) * p.WT + tx0 * p.stride) * X2STR;
+    for (int ty = kgrp * (T2_H / KG); ty < (kgrp + 1) * (T2_H / KG); ++ty) {   // one 32-pixel row = one k32 step
+      half8_t b[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = tr_pair(dyt + b_lane + ty * 32 * DSTR2 + j * 32, b_half);
+      const char* abase = xh + a_lane + ((ty * p.stride) * p.WT) * X2STR;
 #pragma unroll
       for (int t = 0; t < MAXTAPS; ++t) {
         if (t < ntaps) {
           const int ky = t / p.kw, kx = t - ky * p.kw;
-          half8_t a = tr_pair(abase + ((ky * p.dil) * p.WT + kx * p.dil) * X2STR, a_half);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+          const char* at = abase + ((ky * p.dil) * p.WT + kx * p.dil) * X2STR;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            half8_t a = tr_pair(at + i * 32, a_half);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], acc[t][i][j], 0, 0, 0);
+          }
         }
       }
     }
@@ -344,22 +357,24 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
     __syncthreads();
   }
 
-  const int r = lane & 31, h2 = lane >> 5;
+  // D blocks: lane (li, g) holds rows (ci) 4g..4g+3 of column (co) li
 #pragma unroll
   for (int t = 0; t < MAXTAPS; ++t) {
     if (t < ntaps) {
-      float* dst = slab + (((size_t)(split * KG + kgrp) * ntaps + t) * p.cin + ci0 + ciw * 32) * p.cout +
-                   co0 + cow * 32 + r;
+      float* dst = slab + (((size_t)(split * KG + kgrp) * ntaps + t) * p.cin + ci0 + ciw * 32 + 4 * g) * p.cout +
+                   co0 + cow * 32 + li;
       if (ci0 + ciw * 32 < p.cin && co0 + cow * 32 < p.cout) {   // 32-wide partial blocks
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = (e & 3) + 8 * (e >> 2) + 4 * h2;
-          dst[(size_t)row * p.cout] = acc[t][e];
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(size_t)(i * 16 + e) * p.cout + j * 16] = acc[t][i][j][e];
       }
     }
   }
 }
+
 
 // returns OCR_OK when v2 applies (and fills p / cob), OCR_ERR_UNSUPPORTED otherwise
 int fill2(const ocr_conv_desc* d, Wg2P* p, int* cob) {
@@ -375,7 +390,7 @@ int fill2(const ocr_conv_desc* d, Wg2P* p, int* cob) {
   p->HT = (T2_H - 1) * d->stride + (d->kh - 1) * d->dilation + 1;
   p->WT = (TILE_W - 1) * d->stride + (d->kw - 1) * d->dilation + 1;
   if (p->HT * p->WT > 7 * 32) return OCR_ERR_UNSUPPORTED;
-  const size_t stage = (size_t)p->HT * p->WT * X2STR + 128 * (*cob * 2 + 64);
+  const size_t stage = (size_t)p->HT * p->WT * X2STR + 128 * (*cob * 2 + 32);
   if (2 * stage > 160 * 1024) return OCR_ERR_UNSUPPORTED;
   p->nci = ocr_cdiv(d->cin, CIB);
   p->nco = ocr_cdiv(d->cout, *cob);
@@ -457,7 +472,7 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
   } else if (fill2(d, &p2, &cob) == OCR_OK) {
     splits = p2.splits * (cob == 64 ? 2 : 1);
     if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
-    const size_t lds = 2 * ((size_t)p2.HT * p2.WT * X2STR + 128 * (cob * 2 + 64));
+    const size_t lds = 2 * ((size_t)p2.HT * p2.WT * X2STR + 128 * (cob * 2 + 32));
     const unsigned grid = (unsigned)(p2.splits * p2.nci * p2.nco);
     if (cob == 128)
       rc = ntaps == 1 ? launch_wg(wgrad2_kernel<128, 1>, p2, grid, lds, x, dy, workspace, st, 512)
