@@ -41,3 +41,11 @@ for g, at in gaps[:12]:
     prev = max((e for e in seg if e[1] <= at + 1), key=lambda e: e[1], default=None)
     nxt = min((e for e in seg if e[0] >= at + g - 1), key=lambda e: e[0], default=None)
     print('gap %.1f us after %s before %s' % (g / 1e3, re.sub(r'.*N_1\d+', '', prev[2])[:40] if prev else None, re.sub(r'.*N_1\d+', '', nxt[2])[:40] if nxt else None))
+# per-queue totals by kernel (ms/step)
+byk = collections.defaultdict(float)
+for s, e, n, q in seg:
+    n2 = re.sub(r'_ZN12_GLOBAL__N_1\d+', '', n); n2 = re.sub(r'\(anonymous namespace\)::', '', n2)
+    n2 = re.sub(r'EvNS_.*|\(.*', '', n2)
+    byk[(q, n2[:48])] += (e - s) / 2e6
+for (q, n), v in sorted(byk.items(), key=lambda kv: -kv[1])[:28]:
+    print('q%s %-48s %.3f' % (q, n, v))

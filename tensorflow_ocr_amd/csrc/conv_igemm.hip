@@ -31,6 +31,7 @@ namespace {
 struct ConvP {
   int n, h, w, cin, oh, ow, cout, kh, kw, stride, dil, pt, pl, flip, flags;
   int tiles_x, tiles_y, n_tiles, HT, WT, halo_bytes;
+  int xcd_swizzle;
   int m16;        // 1: v_mfma_f32_16x16x32_f16 tiles, 0: v_mfma_f32_32x32x16_f16
   BnRed br;       // br.y != nullptr: fused BN-backward reduction (see conv_epilogue.h)
 };
@@ -67,7 +68,11 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
   const int wco = wave % WCO;
   const int wpx = wave / WCO;
 
+  // XCD-aware order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (private
+  // L2 each); remap so that each XCD runs a CONTIGUOUS range of logical tiles -- the cout tiles of
+  // one pixel tile and its spatial neighbours then share halo and weights through one L2
   int bid = blockIdx.x;
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
   const int nt = bid % p.n_tiles;
   int mt = bid / p.n_tiles;
   const int txi = mt % p.tiles_x;
@@ -352,7 +357,10 @@ int launch_t(const ConvP& p, const void* x, const void* w, const void* bias, voi
   }
   const int m_tiles = p.n * p.tiles_x * p.tiles_y;
   dim3 grid((unsigned)(m_tiles * p.n_tiles));
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p,
+  static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 2; }();
+  ConvP q = p;
+  q.xcd_swizzle = (swz & 1) && grid.x % 8 == 0;
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, q,
                      static_cast<const half_t*>(x), static_cast<const half_t*>(w),
                      static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats));

@@ -17,6 +17,7 @@
 // Partial blocks go to a [split][tap][ci][co] f32 slab; a second kernel sums the
 // slabs in fixed order, so the result is bitwise reproducible (no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace ocr_detail {   // conv_wgrad_pw.hip: GEMM-tiled path for 1x1 convolutions
 int wgrad_pw_splits(const ocr_conv_desc* d);
@@ -203,7 +204,7 @@ constexpr int T2_H = 4;
 
 struct Wg2P {
   int n, h, w, cin, oh, ow, cout, kh, kw, stride, dil, pt, pl;
-  int tiles_x, tiles_y, m_tiles, HT, WT, splits, tiles_per_split, nci, nco;
+  int tiles_x, tiles_y, m_tiles, HT, WT, splits, tiles_per_split, nci, nco, xcd_swizzle;
 };
 
 // v2 uses v_mfma_f32_16x16x32_f16 with the K (pixel) order permuted identically for both operands:
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
   const int q = li >> 2, pp = li & 3;
 
   int bid = blockIdx.x;
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);   // see conv_igemm.hip
   const int cob = bid % p.nco;
   bid /= p.nco;
   const int cib = bid % p.nci;
@@ -474,6 +476,8 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
     if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
     const size_t lds = 2 * ((size_t)p2.HT * p2.WT * X2STR + 128 * (cob * 2 + 32));
     const unsigned grid = (unsigned)(p2.splits * p2.nci * p2.nco);
+    static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 2; }();
+    p2.xcd_swizzle = (swz & 2) && grid % 8 == 0;
     if (cob == 128)
       rc = ntaps == 1 ? launch_wg(wgrad2_kernel<128, 1>, p2, grid, lds, x, dy, workspace, st, 512)
                       : launch_wg(wgrad2_kernel<128, 9>, p2, grid, lds, x, dy, workspace, st, 512);
