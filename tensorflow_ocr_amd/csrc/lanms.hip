@@ -2,13 +2,13 @@
 //
 // The reference tree has NO NMS; the north star asks for one, so this implements the
 // published algorithm: (1) row-major weighted merge of consecutive quads with IoU > thr,
-// (2) standard score-ordered NMS.  One workgroup per image:
-//   * the merge chain is inherently sequential (each step compares with the running merged quad):
-//     lane 0 walks it;
-//   * the stable score ranking is a parallel counting sort (one thread per quad);
-//   * the suppression matrix — IoU of every sorted pair, convex-quad clipping — is computed by
-//     all 256 lanes into 64-bit row masks;
-//   * the final greedy sweep ORs row masks (lane 0, k/64 words per kept quad).
+// (2) standard score-ordered NMS.  Three launches:
+//   * merge (one workgroup per image): the chain is inherently sequential (each step compares with
+//     the running merged quad), lane 0 walks it; then the stable score ranking as a parallel
+//     counting sort (one thread per quad);
+//   * suppression matrix (grid = images x row blocks, fills the chip): IoU of every sorted pair by
+//     convex-quad clipping, one 64-bit mask word per thread, upper triangle only;
+//   * greedy sweep (one wave per image): ORs the row masks of kept quads, removed bits in registers.
 // Float arithmetic is written without FMA contraction so that the kept INDICES are bit-identical
 // to the plain-C oracle (oracle/lanms_oracle.c).
 #include "common.h"
@@ -71,19 +71,38 @@ __device__ float quad_iou(const float* qa, const float* qb) {
   return uni > 0.f ? inter / uni : 0.f;
 }
 
-__global__ __launch_bounds__(256) void lanms_kernel(const float* __restrict__ boxes,
-                                                    const int* __restrict__ counts, int max_k, float thr,
-                                                    float* __restrict__ merged, int* __restrict__ n_merged,
-                                                    int* __restrict__ keep_idx, int* __restrict__ n_keep,
-                                                    int* __restrict__ order_ws,
-                                                    unsigned long long* __restrict__ mask_ws) {
+// Phase 1 (one workgroup per image): sequential weighted merge (lane 0), then the stable score
+// ranking of the merged quads (all lanes).
+// Early-out: quads whose axis-aligned bounding boxes are disjoint have an empty intersection (the
+// clipper could at most leave a rounding-sized sliver), so `quad_iou(a, b) > thr` is false for any
+// thr >= 1e-3 without running the clipper.  Only that decision is consumed, so the kept indices stay
+// bit-identical to the oracle; below 1e-3 the clipper always runs.
+__device__ bool aabb_disjoint(const float* a, const float* b) {
+  float ax0 = a[0], ax1 = a[0], ay0 = a[1], ay1 = a[1], bx0 = b[0], bx1 = b[0], by0 = b[1], by1 = b[1];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    ax0 = fminf(ax0, a[2 * i]); ax1 = fmaxf(ax1, a[2 * i]);
+    ay0 = fminf(ay0, a[2 * i + 1]); ay1 = fmaxf(ay1, a[2 * i + 1]);
+    bx0 = fminf(bx0, b[2 * i]); bx1 = fmaxf(bx1, b[2 * i]);
+    by0 = fminf(by0, b[2 * i + 1]); by1 = fmaxf(by1, b[2 * i + 1]);
+  }
+  return ax1 < bx0 || bx1 < ax0 || ay1 < by0 || by1 < ay0;
+}
+
+__device__ bool iou_above(const float* a, const float* b, float thr) {
+  if (thr >= 1e-3f && aabb_disjoint(a, b)) return false;
+  return quad_iou(a, b) > thr;
+}
+
+__global__ __launch_bounds__(256) void lanms_merge_kernel(const float* __restrict__ boxes,
+                                                          const int* __restrict__ counts, int max_k, float thr,
+                                                          float* __restrict__ merged, int* __restrict__ n_merged,
+                                                          int* __restrict__ order_ws) {
   __shared__ int s_m;
   const int img = blockIdx.x;
   const float* bx = boxes + (size_t)img * max_k * 9;
   float* mg = merged + (size_t)img * max_k * 9;
   int* order = order_ws + (size_t)img * max_k;
-  const int words = (max_k + 63) / 64;
-  unsigned long long* mask = mask_ws + (size_t)img * max_k * words;
   int k = counts[img];
   if (k > max_k) k = max_k;
 
@@ -93,7 +112,7 @@ __global__ __launch_bounds__(256) void lanms_kernel(const float* __restrict__ bo
     float p[9], q[9];
     for (int i = 0; i < k; ++i) {
       const float* g = bx + 9 * i;
-      if (have && quad_iou(g, p) > thr) {
+      if (have && iou_above(g, p, thr)) {
         const float sg = g[8], sp = p[8], s = sg + sp;
         for (int j = 0; j < 8; ++j) q[j] = (sg * g[j] + sp * p[j]) / s;
         q[8] = s;
@@ -120,41 +139,64 @@ __global__ __launch_bounds__(256) void lanms_kernel(const float* __restrict__ bo
     }
     order[r] = i;
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < m * words; idx += 256) {   // (3) suppression row masks
-    const int a = idx / words, wd = idx % words;
-    unsigned long long bits = 0ull;
+}
+
+// Phase 2 (grid = images x row blocks): the suppression matrix of the score-sorted quads, one
+// 64-bit word (64 IoUs) per thread; only the strict upper triangle is evaluated.
+__global__ __launch_bounds__(256) void lanms_mask_kernel(const float* __restrict__ merged,
+                                                         const int* __restrict__ n_merged, int max_k, float thr,
+                                                         const int* __restrict__ order_ws,
+                                                         unsigned long long* __restrict__ mask_ws) {
+  const int img = blockIdx.y;
+  const int m = n_merged[img];
+  const int words = (max_k + 63) / 64;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= m * words) return;
+  const float* mg = merged + (size_t)img * max_k * 9;
+  const int* order = order_ws + (size_t)img * max_k;
+  unsigned long long* mask = mask_ws + (size_t)img * max_k * words;
+  const int a = idx / words, wd = idx % words;
+  unsigned long long bits = 0ull;
+  if (wd * 64 + 63 > a) {
     const float* qa = mg + 9 * order[a];
     for (int bb = 0; bb < 64; ++bb) {
       const int b = wd * 64 + bb;
-      if (b > a && b < m && quad_iou(qa, mg + 9 * order[b]) > thr) bits |= 1ull << bb;
+      if (b > a && b < m && iou_above(qa, mg + 9 * order[b], thr)) bits |= 1ull << bb;
     }
-    mask[(size_t)a * words + wd] = bits;
   }
-  __syncthreads();
-  if (threadIdx.x < 64) {                       // (4) greedy sweep, one wave: lane w owns word(s) w, w+64, ...
-    // removed bits live in registers of the owning lanes
-    unsigned long long removed[8];
+  mask[(size_t)a * words + wd] = bits;
+}
+
+// Phase 3 (one wave per image): greedy sweep over the row masks; lane w owns mask words w, w+64, ...
+__global__ __launch_bounds__(64) void lanms_sweep_kernel(const int* __restrict__ n_merged, int max_k,
+                                                         const int* __restrict__ order_ws,
+                                                         const unsigned long long* __restrict__ mask_ws,
+                                                         int* __restrict__ keep_idx, int* __restrict__ n_keep) {
+  const int img = blockIdx.x;
+  const int m = n_merged[img];
+  const int words = (max_k + 63) / 64;
+  const int* order = order_ws + (size_t)img * max_k;
+  const unsigned long long* mask = mask_ws + (size_t)img * max_k * words;
+  unsigned long long removed[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) removed[j] = 0ull;
-    int nk = 0;
-    for (int a = 0; a < m; ++a) {
-      const int wd = a >> 6, owner = wd & 63, slot = wd >> 6;
-      unsigned long long rv = 0ull;
+  for (int j = 0; j < 8; ++j) removed[j] = 0ull;
+  int nk = 0;
+  for (int a = 0; a < m; ++a) {
+    const int wd = a >> 6, owner = wd & 63, slot = wd >> 6;
+    unsigned long long rv = 0ull;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) if (j == slot) rv = removed[j];
-      rv = __shfl(rv, owner, 64);
-      if ((rv >> (a & 63)) & 1ull) continue;
-      if (threadIdx.x == 0) keep_idx[(size_t)img * max_k + nk] = order[a];
-      ++nk;
+    for (int j = 0; j < 8; ++j) if (j == slot) rv = removed[j];
+    rv = __shfl(rv, owner, 64);
+    if ((rv >> (a & 63)) & 1ull) continue;
+    if (threadIdx.x == 0) keep_idx[(size_t)img * max_k + nk] = order[a];
+    ++nk;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int w2 = (int)threadIdx.x + 64 * j;
-        if (w2 < words) removed[j] |= mask[(size_t)a * words + w2];
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int w2 = (int)threadIdx.x + 64 * j;
+      if (w2 < words) removed[j] |= mask[(size_t)a * words + w2];
     }
-    if (threadIdx.x == 0) n_keep[img] = nk;
   }
+  if (threadIdx.x == 0) n_keep[img] = nk;
 }
 
 }  // namespace
@@ -175,9 +217,15 @@ extern "C" int ocr_lanms(const void* boxes, const void* counts, int n_images, in
   int* order = reinterpret_cast<int*>(ws);
   size_t off = ((size_t)n_images * max_k * sizeof(int) + 255) / 256 * 256;
   unsigned long long* mask = reinterpret_cast<unsigned long long*>(ws + off);
-  hipLaunchKernelGGL(lanms_kernel, dim3(n_images), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const float*>(boxes), static_cast<const int*>(counts), max_k, iou_thresh,
-                     static_cast<float*>(merged), static_cast<int*>(n_merged), static_cast<int*>(keep_idx),
-                     static_cast<int*>(n_keep), order, mask);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int words = (max_k + 63) / 64;
+  hipLaunchKernelGGL(lanms_merge_kernel, dim3(n_images), dim3(256), 0, st, static_cast<const float*>(boxes),
+                     static_cast<const int*>(counts), max_k, iou_thresh, static_cast<float*>(merged),
+                     static_cast<int*>(n_merged), order);
+  hipLaunchKernelGGL(lanms_mask_kernel, dim3(ocr_cdiv(max_k * words, 256), n_images), dim3(256), 0, st,
+                     static_cast<const float*>(merged), static_cast<const int*>(n_merged), max_k, iou_thresh,
+                     order, mask);
+  hipLaunchKernelGGL(lanms_sweep_kernel, dim3(n_images), dim3(64), 0, st, static_cast<const int*>(n_merged),
+                     max_k, order, mask, static_cast<int*>(keep_idx), static_cast<int*>(n_keep));
   return ocr_launch_status();
 }
