@@ -196,11 +196,13 @@ int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const void* shif
                               void* workspace, size_t ws_bytes, void* stream);
 
 /* slim.max_pool2d k x k / stride SAME as a standalone op (pool5 3x3/1 nets/vgg.py:32; ResNet
- * pool1 3x3/2 nets/resnet_v1.py:194; subsample 1x1/s nets/resnet_utils.py:74), f16 NHWC. */
+ * pool1 3x3/2 nets/resnet_v1.py:194; subsample 1x1/s nets/resnet_utils.py:74), f16 NHWC.
+ * argmax (optional, u8 [n,oh,ow,c]): window position ky*k+kx of the FIRST maximum (TF's gradient
+ * routing); the backward pass takes either it (no re-scan of x) or x itself. */
 int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k, int stride, int pad_top,
-                    int pad_left, int oh, int ow, void* y, void* stream);
-int ocr_maxpool_bwd_f16(const void* x, const void* dy, int n, int h, int w, int c, int k,
-                        int stride, int pad_top, int pad_left, int oh, int ow, void* dx,
+                    int pad_left, int oh, int ow, void* y, void* argmax, void* stream);
+int ocr_maxpool_bwd_f16(const void* x, const void* argmax, const void* dy, int n, int h, int w, int c,
+                        int k, int stride, int pad_top, int pad_left, int oh, int ow, void* dx,
                         int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------- *

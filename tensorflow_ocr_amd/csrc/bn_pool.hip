@@ -514,7 +514,8 @@ struct PoolP {
   int n, h, w, c, oh, ow, k, stride, pt, pl;
 };
 
-__global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, half_t* __restrict__ y) {
+__global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, half_t* __restrict__ y,
+                                   unsigned char* __restrict__ argmax) {
   const int chunks = p.c >> 3;
   const size_t total = (size_t)p.n * p.oh * p.ow * chunks;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -525,6 +526,7 @@ __global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, half_t
     const int oy = (int)(u % p.oh);
     const int img = (int)(u / p.oh);
     float m[8];
+    unsigned long long am = 0xffffffffffffffffull;   // byte e = window position of the FIRST maximum
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
     for (int ky = 0; ky < p.k; ++ky)
@@ -533,18 +535,72 @@ __global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, half_t
         if (iy < 0 || iy >= p.h || ix < 0 || ix >= p.w) continue;
         half8_t v = *reinterpret_cast<const half8_t*>(
             x + (((size_t)img * p.h + iy) * p.w + ix) * p.c + ch * 8);
+        const unsigned long long pos = (unsigned long long)(ky * p.k + kx);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = (float)v[e] > m[e] ? (float)v[e] : m[e];
+        for (int e = 0; e < 8; ++e)
+          if ((float)v[e] > m[e]) {
+            m[e] = (float)v[e];
+            am = (am & ~(0xffull << (8 * e))) | (pos << (8 * e));
+          }
       }
     half8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
     *reinterpret_cast<half8_t*>(y + i * 8) = o;
+    if (argmax) *reinterpret_cast<unsigned long long*>(argmax + i * 8) = am;
   }
 }
 
 // gather form: every input pixel re-derives the arg-max (first maximum in
 // row-major window order) of each window that covers it.
+// same gather, but the arg-max comes from the index tensor the forward pass wrote (one byte per
+// output element): no re-scan of x
+__global__ void maxpool_bwd_idx_kernel(PoolP p, const unsigned char* __restrict__ argmax,
+                                       const half_t* __restrict__ dy, half_t* __restrict__ dx,
+                                       int accumulate) {
+  const int chunks = p.c >> 3;
+  const size_t total = (size_t)p.n * p.h * p.w * chunks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    size_t u = i / chunks;
+    const int ix = (int)(u % p.w);
+    u /= p.w;
+    const int iy = (int)(u % p.h);
+    const int img = (int)(u / p.h);
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    for (int ky = 0; ky < p.k; ++ky) {
+      const int ny = iy + p.pt - ky;
+      if (ny < 0 || ny % p.stride) continue;
+      const int oy = ny / p.stride;
+      if (oy >= p.oh) continue;
+      for (int kx = 0; kx < p.k; ++kx) {
+        const int nx = ix + p.pl - kx;
+        if (nx < 0 || nx % p.stride) continue;
+        const int ox = nx / p.stride;
+        if (ox >= p.ow) continue;
+        const size_t o = (((size_t)img * p.oh + oy) * p.ow + ox) * p.c + ch * 8;
+        const unsigned long long am = *reinterpret_cast<const unsigned long long*>(argmax + o);
+        half8_t d = *reinterpret_cast<const half8_t*>(dy + o);
+        const unsigned pos = (unsigned)(ky * p.k + kx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (((am >> (8 * e)) & 0xffu) == pos) g[e] += (float)d[e];
+      }
+    }
+    if (accumulate) {
+      half8_t old = *reinterpret_cast<const half8_t*>(dx + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] += (float)old[e];
+    }
+    half8_t o8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (half_t)g[e];
+    *reinterpret_cast<half8_t*>(dx + i * 8) = o8;
+  }
+}
+
 __global__ void maxpool_bwd_kernel(PoolP p, const half_t* __restrict__ x,
                                    const half_t* __restrict__ dy, half_t* __restrict__ dx,
                                    int accumulate) {
@@ -575,7 +631,8 @@ __global__ void maxpool_bwd_kernel(PoolP p, const half_t* __restrict__ x,
         float bv[8];
         int bi[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { bv[e] = -INFINITY; bi[e] = -1; }
+        for (int e = 0; e < 8; ++e) { bv[e] = -INFINITY; bi[e] = p.k == 1 ? 0 : -1; }
+        if (p.k > 1)           // (a 1x1 window -- subsample -- has nothing to scan)
         for (int wy = 0; wy < p.k; ++wy)
           for (int wx = 0; wx < p.k; ++wx) {
             const int yy = oy * p.stride + wy - p.pt, xx = ox * p.stride + wx - p.pl;
@@ -738,24 +795,31 @@ extern "C" int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void*
 }
 
 extern "C" int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k, int stride,
-                               int pad_top, int pad_left, int oh, int ow, void* y, void* stream) {
-  OCR_CHECK_ARG(x && y && n > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0);
+                               int pad_top, int pad_left, int oh, int ow, void* y, void* argmax,
+                               void* stream) {
+  OCR_CHECK_ARG(x && y && n > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0 && k * k <= 255);
   OCR_CHECK_SHAPE(c % 8 == 0);
   PoolP p{n, h, w, c, oh, ow, k, stride, pad_top, pad_left};
   const size_t total = (size_t)n * oh * ow * (c / 8);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x),
-                     static_cast<half_t*>(y));
+                     static_cast<half_t*>(y), static_cast<unsigned char*>(argmax));
   return ocr_launch_status();
 }
 
-extern "C" int ocr_maxpool_bwd_f16(const void* x, const void* dy, int n, int h, int w, int c, int k,
-                                   int stride, int pad_top, int pad_left, int oh, int ow, void* dx,
-                                   int accumulate, void* stream) {
-  OCR_CHECK_ARG(x && dy && dx && n > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0);
+extern "C" int ocr_maxpool_bwd_f16(const void* x, const void* argmax, const void* dy, int n, int h, int w,
+                                   int c, int k, int stride, int pad_top, int pad_left, int oh, int ow,
+                                   void* dx, int accumulate, void* stream) {
+  OCR_CHECK_ARG((x || argmax) && dy && dx && n > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0);
   OCR_CHECK_SHAPE(c % 8 == 0);
   PoolP p{n, h, w, c, oh, ow, k, stride, pad_top, pad_left};
   const size_t total = (size_t)n * h * w * (c / 8);
+  if (argmax) {
+    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(stream_grid(total)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p, static_cast<const unsigned char*>(argmax),
+                       static_cast<const half_t*>(dy), static_cast<half_t*>(dx), accumulate);
+    return ocr_launch_status();
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(total)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(dy), static_cast<half_t*>(dx), accumulate);

@@ -196,7 +196,9 @@ def max_pool2d(g, x, k, stride, scope="pool"):
     oh, pt = ops.same_pad(h, k, stride)
     ow, pl = ops.same_pad(w, k, stride)
     y = g.empty((n, oh, ow, c))
-    ops.maxpool(x.data, k, stride, (pt, pl), y)
+    # index of the first maximum per window (TF gradient routing), kept for the backward pass
+    argmax = g.empty((n, oh, ow, c), torch.uint8) if x.requires_grad else None
+    ops.maxpool(x.data, k, stride, (pt, pl), y, argmax)
     out = Act(y, name=scope)
 
     def backward():
@@ -205,7 +207,7 @@ def max_pool2d(g, x, k, stride, scope="pool"):
         acc = x.grad is not None
         if not acc:
             x.grad = g.empty(x.shape)
-        ops.maxpool_bwd(x.data, out.grad, k, stride, (pt, pl), x.grad, acc)
+        ops.maxpool_bwd(x.data, out.grad, k, stride, (pt, pl), x.grad, acc, argmax=argmax, in_shape=x.shape)
         out.grad = None
     g.record(backward)
     return out

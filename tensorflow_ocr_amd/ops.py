@@ -290,19 +290,20 @@ def sc_colsum(x, C, out, ws):
     L.call("ocr_sc_colsum", ptr(x), c_int(P), c_int(C), ptr(out), ptr(buf), _st())
 
 
-def maxpool(x, k, stride, pad, y):
+def maxpool(x, k, stride, pad, y, argmax=None):
     n, h, w, c = x.shape
     _, oh, ow, _ = y.shape
     L.call("ocr_maxpool_f16", ptr(x), c_int(n), c_int(h), c_int(w), c_int(c), c_int(k), c_int(stride),
-           c_int(pad[0]), c_int(pad[1]), c_int(oh), c_int(ow), ptr(y), _st())
+           c_int(pad[0]), c_int(pad[1]), c_int(oh), c_int(ow), ptr(y), ptr(argmax), _st())
 
 
-def maxpool_bwd(x, dy, k, stride, pad, dx, accumulate):
-    n, h, w, c = x.shape
+def maxpool_bwd(x, dy, k, stride, pad, dx, accumulate, argmax=None, in_shape=None):
+    """Either `x` (arg-max re-derived) or the forward pass's `argmax` index tensor."""
+    n, h, w, c = in_shape if in_shape is not None else x.shape
     _, oh, ow, _ = dy.shape
-    L.call("ocr_maxpool_bwd_f16", ptr(x), ptr(dy), c_int(n), c_int(h), c_int(w), c_int(c), c_int(k),
-           c_int(stride), c_int(pad[0]), c_int(pad[1]), c_int(oh), c_int(ow), ptr(dx),
-           c_int(int(accumulate)), _st())
+    L.call("ocr_maxpool_bwd_f16", ptr(None if argmax is not None else x), ptr(argmax), ptr(dy), c_int(n),
+           c_int(h), c_int(w), c_int(c), c_int(k), c_int(stride), c_int(pad[0]), c_int(pad[1]), c_int(oh),
+           c_int(ow), ptr(dx), c_int(int(accumulate)), _st())
 
 
 # ------------------------------------------------------------------------------ heads
