@@ -4,7 +4,7 @@ bytes of a wide (16 B/lane) coalesced read stream -> doubled; WRITE_SIZE is exac
 import csv, glob, json, re, sys, collections
 out = {}
 for name, d in (("FETCH_SIZE", sys.argv[1]), ("WRITE_SIZE", sys.argv[2])):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name and "conv_igemm" in r["Kernel_Name"]:

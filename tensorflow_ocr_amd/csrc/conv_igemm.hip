@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
   // halo has been handed to LDS) and write-late (registers -> LDS at the chunk boundary), so the
   // global latency of chunk cc+1 hides under the kh*kw taps of chunk cc.
   // (8-row tiles narrower than 128 couts keep their registers for occupancy)
-  constexpr int NH = TH > 8 ? 10 : BN >= 128 ? 7 : 1;
+  constexpr int NH = TH > 8 ? 10 : BN >= 128 ? (CK == 32 ? 7 : 6) : 1;
   const int halo_total = halo_px * CPP;
   const bool prefetch = NH > 1 && halo_total <= NH * NT && nchunks > 1;
   u32x4 hreg[NH];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
                        (wpx * TPX) * b_row;
       if constexpr (M16) {
         // pixel fragments in groups of <= 4 so that at most 8 fragments are live beside the accumulators
-        constexpr int TG = AT > 4 ? 4 : AT;
+        constexpr int TG = TH > 8 ? 2 : AT > 4 ? 4 : AT;
 #pragma unroll
         for (int ks = 0; ks < CK / 32; ++ks) {
           half8_t a[AI];
