@@ -4,22 +4,22 @@
 // nets/resnet_v1.py:97-105, nets/model_vgg_16.py:111-131) and, with the
 // transposed/flipped weight pack, its input gradient.
 //
-// Work decomposition (one workgroup = 4 waves = 256 threads):
-//   * output tile  = 8 rows x 32 columns of one image (256 pixels) x BN couts
-//   * the input halo tile for one CK-wide channel chunk is staged ONCE in LDS
-//     ([HT][WT][CK] f16, pixel stride padded by 16 B so ds_read_b128 is
-//     conflict-free) and re-read at shifted addresses by all kh*kw taps: no
-//     im2col is ever materialised and each input byte crosses L2->LDS once per
-//     cout tile;
-//   * per tap a [BN][CK] weight slice is streamed through a 2-deep LDS ring
-//     (global->register loads of tap t+1 fly under the MFMAs of tap t);
-//   * MFMA v_mfma_f32_32x32x16_f16 with A = weights (rows = cout) and
-//     B = activations (cols = pixels), so each lane ends up holding 4
-//     consecutive couts of one pixel per register quad -> 8-byte packed LDS
-//     writes in the epilogue, then 16-byte coalesced row stores to HBM;
-//   * the epilogue optionally adds bias / ReLU, accumulates into an existing
-//     f16 tensor, and emits per-tile per-cout sum and sum of squares of the
-//     stored (f16-rounded) values for training-mode batch norm.
+// Work decomposition (one workgroup = 8 waves = 512 threads, 2 waves per SIMD):
+//   * output tile  = TH rows x 32 columns of one image x BN couts; each wave owns 64 couts x 128
+//     pixels wherever cout allows (256 couts x 8 rows, 128 couts x 16 rows);
+//   * the input halo tile for one CK-wide channel chunk is staged ONCE in LDS ([HT][WT][CK] f16,
+//     pixel stride padded so the 16-byte fragment reads are conflict-free) and re-read at shifted
+//     addresses by all kh*kw taps: no im2col is ever materialised and each input byte crosses
+//     L2->LDS once per cout tile; the next chunk's halo is prefetched into registers;
+//   * per tap a [BN][CK] weight slice is streamed through a 2-deep LDS ring by LDS-DMA
+//     (global_load_lds_dwordx4: the slice of tap t+1 lands under the MFMAs of tap t, no VGPRs);
+//   * MFMA v_mfma_f32_16x16x32_f16 (multi-tap layers) or v_mfma_f32_32x32x16_f16 (1x1) with
+//     A = weights (rows = cout) and B = activations (cols = pixels), so each lane ends up holding 4
+//     consecutive couts of one pixel per register quad -> 8-byte packed LDS writes in the epilogue,
+//     then 16-byte coalesced row stores to HBM;
+//   * the epilogue optionally adds bias / ReLU, accumulates into an existing f16 tensor, and emits
+//     per-tile per-cout sum and sum of squares of the stored (f16-rounded) values for training-mode
+//     batch norm (or, in the input-gradient form, the producing layer's BN-backward sums).
 #include "common.h"
 #include "conv_epilogue.h"
 #include <stdio.h>
@@ -41,6 +41,15 @@ struct ConvP {
 // conflict-free for the lane->(row, k-group) map of the MFMA shape in use.
 constexpr int conv_pstr(int ck, bool m16) { return ck * 2 + (m16 ? 32 : 16); }
 
+// Weight slices go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
+// ds_write).  The DMA image is lane-linear, so the rows are unpadded and the bank-conflict-free
+// layout is an XOR swizzle of the 16-byte chunk index applied on the SOURCE address and again on
+// the fragment read: chunk' = chunk ^ wswz(row).
+constexpr int conv_wrs(int ck) { return ck * 2; }
+__device__ __forceinline__ int wswz(int row, int ck, bool m16) {
+  return ck == 64 ? ((row >> 1) & 7) : m16 ? (((row >> 3) & 1) << 1) : ((row >> 2) & 3);
+}
+
 template <int BN, int CK, int WCO, bool M16, int TH>
 __global__ __launch_bounds__(512) void conv_igemm_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
@@ -55,6 +64,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
   constexpr int KSTEPS = CK / 16;
   constexpr int CPP = CK / 8;  // 16-byte chunks per pixel / per weight row
   constexpr int NWLD = (BN * CPP + NT - 1) / NT;
+  constexpr int WRS = conv_wrs(CK);   // weight row stride in LDS (unpadded, swizzled)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
@@ -101,32 +111,28 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
   // per-lane LDS byte offsets
   // (32x32x16: lane -> row l&31, k-group l>>5;  16x16x32: row l&15, k-group l>>4; 8 k per group)
   const int frow = M16 ? (lane & 15) : r, fkg = M16 ? (lane >> 4) : hh;
-  const int a_lane = (wco * TCO * 32 + frow) * PSTR + fkg * 16;           // weights
+  const int a_lane = (wco * TCO * 32 + frow) * WRS;                       // weights (row part)
+  const int fx = wswz(frow, CK, M16);
+  // byte offset of this lane's 8 k-values of k-step ks inside its weight row
+  auto a_k = [&](int ks) { return (((M16 ? ks * 4 : ks * 2) + fkg) ^ fx) << 4; };
   const int b_lane = (frow * p.stride) * PSTR + fkg * 16;                 // activations
   const int b_half = 16 * p.stride * PSTR;                                // M16: second 16 px of a row
   const int b_row = p.stride * WT * PSTR;                                 // per tile row
 
-  u32x4 wreg[NWLD];
-  auto load_w = [&](int tap, int cc) {
+  auto dma_w = [&](int tap, int cc, int buf) {
     const int tapw = p.flip ? (ntaps - 1 - tap) : tap;
     const half_t* src = w + ((size_t)tapw * p.cout + co0) * p.cin + cc * CK;
 #pragma unroll
     for (int u = 0; u < NWLD; ++u) {
-      int idx = u * NT + tid;
-      int rr = idx / CPP, c = idx % CPP;
-      if (idx < BN * CPP) wreg[u] = *reinterpret_cast<const u32x4*>(src + (size_t)rr * p.cin + c * 8);
+      const int idx = u * NT + tid;
+      const int rr = idx / CPP, c = idx % CPP;
+      if (idx < BN * CPP)     // whole waves: BN * CPP is a multiple of 64
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (size_t)rr * p.cin + ((c ^ wswz(rr, CK, M16)) << 3)),
+            (__attribute__((address_space(3))) void*)(wbuf + buf * (BN * WRS) + (u * NT + (tid & ~63)) * 16),
+            16, 0, 0);
     }
   };
-  auto store_w = [&](int buf) {
-    char* dst = wbuf + buf * (BN * PSTR);
-#pragma unroll
-    for (int u = 0; u < NWLD; ++u) {
-      int idx = u * NT + tid;
-      int rr = idx / CPP, c = idx % CPP;
-      if (idx < BN * CPP) *reinterpret_cast<u32x4*>(dst + rr * PSTR + c * 16) = wreg[u];
-    }
-  };
-
   // halo staging split into issue-early (global -> registers, right after the previous chunk's
   // halo has been handed to LDS) and write-late (registers -> LDS at the chunk boundary), so the
   // global latency of chunk cc+1 hides under the kh*kw taps of chunk cc.
@@ -192,23 +198,19 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
           if (off[u] >= 0) *reinterpret_cast<u32x4*>(halo + off[u]) = v[u];
       }
     }
-    load_w(0, cc);
-    store_w(wb);
-    if (ntaps > 1) load_w(1, cc);
+    dma_w(0, cc, wb);
     if (prefetch && cc + 1 < nchunks) halo_load(cc + 1);
     for (int tap = 0; tap < ntaps; ++tap) {
       // after this barrier: buf[wb] (this tap, and at tap 0 the halo) is visible and
       // buf[wb^1] is free (its readers finished tap-1)
       __syncthreads();
       auto restage = [&]() {
-        if (tap + 1 < ntaps) {
-          store_w(wb ^ 1);
-          if (tap + 2 < ntaps) load_w(tap + 2, cc);
-        }
+        // lands under this tap's MFMAs; the next barrier's vmcnt(0) retires it
+        if (tap + 1 < ntaps) dma_w(tap + 1, cc, wb ^ 1);
       };
       if constexpr (BN == 128 && !M16) restage();
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
-      const char* ab = wbuf + wb * (BN * PSTR) + a_lane;
+      const char* ab = wbuf + wb * (BN * WRS) + a_lane;
       const char* bb = halo + b_lane + ((ky * p.dil) * WT + kx * p.dil) * PSTR +
                        (wpx * TPX) * b_row;
       if constexpr (M16) {
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
           half8_t a[AI];
 #pragma unroll
           for (int i = 0; i < AI; ++i)
-            a[i] = *reinterpret_cast<const half8_t*>(ab + i * 16 * PSTR + ks * 64);
+            a[i] = *reinterpret_cast<const half8_t*>(ab + i * 16 * WRS + a_k(ks));
 #pragma unroll
           for (int t0 = 0; t0 < AT; t0 += TG) {
             half8_t b[TG];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
       // step ks (two named fragment sets; sched_barrier keeps hipcc from sinking the reads)
       half8_t a0[TCO], b0[TPX], a1[TCO], b1[TPX];
 #pragma unroll
-      for (int i = 0; i < TCO; ++i) a0[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * PSTR);
+      for (int i = 0; i < TCO; ++i) a0[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * WRS + a_k(0));
 #pragma unroll
       for (int t = 0; t < TPX; ++t) b0[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row);
 #pragma unroll
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
         if (ks + 1 < KSTEPS) {
 #pragma unroll
           for (int i = 0; i < TCO; ++i)
-            a1[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * PSTR + (ks + 1) * 32);
+            a1[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * WRS + a_k(ks + 1));
 #pragma unroll
           for (int t = 0; t < TPX; ++t)
             b1[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row + (ks + 1) * 32);
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
           if (ks + 2 < KSTEPS) {
 #pragma unroll
             for (int i = 0; i < TCO; ++i)
-              a0[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * PSTR + (ks + 2) * 32);
+              a0[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * WRS + a_k(ks + 2));
 #pragma unroll
             for (int t = 0; t < TPX; ++t)
               b0[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row + (ks + 2) * 32);
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
           half8_t a[TCO], b[TPX];
 #pragma unroll
           for (int i = 0; i < TCO; ++i)
-            a[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * PSTR + ks * 32);
+            a[i] = *reinterpret_cast<const half8_t*>(ab + i * 32 * WRS + a_k(ks));
 #pragma unroll
           for (int t = 0; t < TPX; ++t)
             b[t] = *reinterpret_cast<const half8_t*>(bb + t * b_row + ks * 32);
@@ -341,8 +343,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
 template <int BN, int CK, int WCO, bool M16, int TH>
 int launch_t(const ConvP& p, const void* x, const void* w, const void* bias, void* y,
              void* stats, hipStream_t st) {
-  constexpr int PSTR = conv_pstr(CK, M16);
-  size_t main_bytes = (size_t)p.halo_bytes + 2 * BN * PSTR;
+  size_t main_bytes = (size_t)p.halo_bytes + 2 * BN * conv_wrs(CK);
   size_t epi_bytes = conv_epilogue_lds(BN > 128 ? 128 : BN, 512);
   size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (lds > 160 * 1024) return OCR_ERR_UNSUPPORTED;
@@ -417,7 +418,7 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
     const TileCfg c = cand[i];
     const int HT = (c.th - 1) * d->stride + (d->kh - 1) * d->dilation + 1;
     const size_t pstr = conv_pstr(c.ck, p->m16);
-    if ((size_t)HT * p->WT * pstr + 2 * (size_t)c.bn * pstr > 160 * 1024) continue;   // halo + weight ring
+    if ((size_t)HT * p->WT * pstr + 2 * (size_t)c.bn * conv_wrs(c.ck) > 160 * 1024) continue;   // halo + weight ring
     *cfg = c;
     p->HT = HT;
     p->tiles_y = ocr_cdiv(d->oh, c.th);
