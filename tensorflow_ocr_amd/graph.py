@@ -139,7 +139,13 @@ class Graph:
     """One tower: variable store + tape + scratch.  `loss_scale` multiplies the loss gradient so
     that f16 activation gradients stay in range; the optimiser divides it out."""
 
-    def __init__(self, device="cuda:0", loss_scale=1024.0, seed=1):
+    def __init__(self, device="cuda:0", loss_scale=1024.0, seed=1, precision="f16"):
+        """precision: "f16" = the product path (f16 storage, f32 accumulate, MFMA kernels);
+        "f32" = forward-only VERIFICATION precision (f32 storage and arithmetic, plain kernels;
+        layers_f32.py) used to compare whole-graph outputs with the f32 CPU reference at 1e-3."""
+        if precision not in ("f16", "f32"):
+            raise ValueError("precision must be 'f16' or 'f32'")
+        self.precision = precision
         self.device = torch.device(device)
         self.store = VariableStore(self.device)
         self.tape = []
@@ -213,6 +219,8 @@ class Graph:
         called as soon as a closure has finished a set of parameter gradients — the hook the
         data-parallel all-reduce uses to overlap communication with the rest of backward."""
         from . import _lib
+        if self.precision != "f16":
+            raise NotImplementedError("the f32 verification precision is forward-only")
         for fn, produces in reversed(self.tape):
             fn()
             if on_grads_ready is not None and produces:

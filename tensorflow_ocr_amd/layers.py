@@ -54,6 +54,12 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
     Reference: nets/vgg.py:14-39 under resnet_arg_scope (nets/model_vgg_16.py:144) or the
     PixelLink bias scope (nets/pixellink.py:41-48).
     """
+    if g.precision == "f32":
+        from . import layers_f32
+        return layers_f32.conv2d(g, x, cout, k, scope, stride=stride, rate=rate, normalizer=normalizer,
+                                 relu=relu, pool=pool, keep_full=keep_full, is_training=is_training,
+                                 bn_training=bn_training, first=first, weight_decay=weight_decay,
+                                 initializer=initializer)
     n, h, w, cin_x = x.shape
     cin = 3 if first else cin_x
     bn_training = is_training if bn_training is None else bn_training
@@ -192,6 +198,9 @@ def _conv_backward(g, x, wv, w_dg, d, dy, first):
 
 def max_pool2d(g, x, k, stride, scope="pool"):
     """slim.max_pool2d(padding='SAME') as a standalone op (pool5 3x3/1, ResNet pool1, subsample)."""
+    if g.precision == "f32":
+        from . import layers_f32
+        return layers_f32.max_pool2d(g, x, k, stride, scope)
     n, h, w, c = x.shape
     oh, pt = ops.same_pad(h, k, stride)
     ow, pl = ops.same_pad(w, k, stride)
@@ -217,6 +226,9 @@ def prep_images(g, images, means=(123.68, 116.78, 103.94)):
     """mean_image_subtraction (nets/model.py:18-31) + f16 cast into the [n,h,w,4] layout."""
     if images.shape[-1] != len(means):
         raise ValueError("len(means) must match the number of channels")
+    if g.precision == "f32":
+        from . import layers_f32
+        return layers_f32.prep_images(g, images, means)
     n, h, w, _ = images.shape
     x4 = g.empty((n, h, w, 4))
     ops.prep_images(images, x4, means)
@@ -252,7 +264,11 @@ def head_conv_bn(g, feat, names, couts, is_training=True, relu=True):
         return old
     w_kc32, w_ck32 = g.packed(wv, "small", mk)
     z = g.empty((n, h, w, C), F32)
-    ops.conv1x1_small(feat.data, w_kc32, C, z)
+    if g.precision == "f32":
+        from . import layers_f32
+        layers_f32.head_conv(g, feat, wv, C, z)
+    else:
+        ops.conv1x1_small(feat.data, w_kc32, C, z)
     P = n * h * w
     scale, shift = g.empty((C,), F32), g.empty((C,), F32)
     mean, invstd = g.empty((C,), F32), g.empty((C,), F32)
@@ -301,7 +317,11 @@ def head_conv_bias(g, feat, names, couts, initializer=None):
         return old
     w_kc32, w_ck32 = g.packed(wv, "small", mk)
     z = g.empty((n, h, w, C), F32)
-    ops.conv1x1_small(feat.data, w_kc32, C, z, bias.data)
+    if g.precision == "f32":
+        from . import layers_f32
+        layers_f32.head_conv(g, feat, wv, C, z, bias)
+    else:
+        ops.conv1x1_small(feat.data, w_kc32, C, z, bias.data)
     out = SmallAct(z)
 
     def backward():
