@@ -345,6 +345,7 @@ int ocr_fill_f32(void* x, int64_t n, float value, void* stream);   /* n 4-byte w
  * exists so that end-to-end outputs can be checked against the f32 oracle at the north star's 1e-3.
  * Tensors NHWC f32; conv weights in the TF HWIO master layout [kh][kw][cin][cout] (no packing).
  * ------------------------------------------------------------------------- */
+/* flags: OCR_CONV_BIAS, OCR_CONV_RELU, OCR_CONV_ACCUM_F16 (here: y += conv, f32) */
 int ocr_conv2d_f32(const ocr_conv_desc* d, const void* x, const void* w_hwio, const void* bias, void* y,
                    void* stream);
 int ocr_channel_stats_f32_num_partials(int64_t npix, int c);
@@ -356,6 +357,9 @@ int ocr_maxpool_f32(const void* x, int n, int h, int w, int c, int k, int stride
                     int oh, int ow, void* y, void* stream);
 int ocr_prep_images_f32(const void* images, int64_t npix, float mean_r, float mean_g, float mean_b, void* out,
                         void* stream);
+int ocr_bn_add_relu_f32(const void* y, const void* scale, const void* shift, const void* shortcut,
+                        int64_t npix, int c, void* out, void* stream);
+int ocr_unpool_f32(const void* x, int n, int lh, int lw, int c, void* y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,7 @@ __global__ void conv_f32_kernel(CvP p, const float* __restrict__ x, const float*
     }
     if (p.flags & OCR_CONV_BIAS) acc += bias[co];
     if ((p.flags & OCR_CONV_RELU) && acc < 0.f) acc = 0.f;
+    if (p.flags & OCR_CONV_ACCUM_F16) acc += y[i];     // accumulate into y (concat-free 1x1 convs)
     y[i] = acc;
   }
 }
@@ -133,6 +134,41 @@ __global__ void prep_images_f32_kernel(const float* __restrict__ im, size_t npix
   }
 }
 
+// out = relu(y*scale + shift + shortcut)   (bottleneck tail, nets/resnet_v1.py:104-111)
+__global__ void bn_add_relu_f32_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, const float* __restrict__ sc,
+                                       size_t total, int c, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    const float v = y[i] * scale[ch] + shift[ch] + sc[i];
+    out[i] = v > 0.f ? v : 0.f;
+  }
+}
+
+// tf.image.resize_bilinear x2, TF-1.4 legacy sampling (see unpool_f16_kernel in bn_pool.hip)
+__global__ void unpool_f32_kernel(const float* __restrict__ x, int n, int lh, int lw, int c,
+                                  float* __restrict__ y) {
+  const int H = 2 * lh, W = 2 * lw;
+  const size_t total = (size_t)n * H * W * c;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    size_t u = i / c;
+    const int ox = (int)(u % W);
+    u /= W;
+    const int oy = (int)(u % H);
+    const int img = (int)(u / H);
+    const int y0 = oy >> 1, x0 = ox >> 1;
+    const int y1 = (oy & 1) ? (y0 + 1 < lh ? y0 + 1 : lh - 1) : y0;
+    const int x1 = (ox & 1) ? (x0 + 1 < lw ? x0 + 1 : lw - 1) : x0;
+    const float wy = (oy & 1) ? 0.5f : 0.f, wx = (ox & 1) ? 0.5f : 0.f;
+    const float* b = x + (size_t)img * lh * lw * c + ch;
+    const float v00 = b[((size_t)y0 * lw + x0) * c], v01 = b[((size_t)y0 * lw + x1) * c];
+    const float v10 = b[((size_t)y1 * lw + x0) * c], v11 = b[((size_t)y1 * lw + x1) * c];
+    const float top = v00 + (v01 - v00) * wx, bot = v10 + (v11 - v10) * wx;
+    y[i] = top + (bot - top) * wy;
+  }
+}
+
 unsigned vgrid(size_t work) {
   size_t b = (work + 255) / 256;
   if (b > 65536) b = 65536;
@@ -148,7 +184,7 @@ extern "C" int ocr_conv2d_f32(const ocr_conv_desc* d, const void* x, const void*
   OCR_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0 && d->cin > 0 && d->cout > 0);
   OCR_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dilation > 0);
   OCR_CHECK_ARG(!(d->flags & OCR_CONV_BIAS) || bias);
-  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_STATS | OCR_CONV_ACCUM_F16)) && !d->flip_taps);
+  OCR_CHECK_ARG(!(d->flags & OCR_CONV_STATS) && !d->flip_taps);
   CvP p{d->n, d->h, d->w, d->cin, d->oh, d->ow, d->cout, d->kh, d->kw, d->stride, d->dilation,
         d->pad_top, d->pad_left, d->flags};
   hipLaunchKernelGGL(conv_f32_kernel, dim3(vgrid((size_t)d->n * d->oh * d->ow * d->cout)), dim3(256), 0,
@@ -201,5 +237,23 @@ extern "C" int ocr_prep_images_f32(const void* images, int64_t npix, float mean_
   hipLaunchKernelGGL(prep_images_f32_kernel, dim3(vgrid((size_t)npix)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const float*>(images), (size_t)npix, mean_r,
                      mean_g, mean_b, static_cast<float*>(out));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_add_relu_f32(const void* y, const void* scale, const void* shift, const void* shortcut,
+                                   int64_t npix, int c, void* out, void* stream) {
+  OCR_CHECK_ARG(y && scale && shift && shortcut && out && npix > 0 && c > 0);
+  hipLaunchKernelGGL(bn_add_relu_f32_kernel, dim3(vgrid((size_t)npix * c)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(y),
+                     static_cast<const float*>(scale), static_cast<const float*>(shift),
+                     static_cast<const float*>(shortcut), (size_t)npix * c, c, static_cast<float*>(out));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_unpool_f32(const void* x, int n, int lh, int lw, int c, void* y, void* stream) {
+  OCR_CHECK_ARG(x && y && n > 0 && lh > 0 && lw > 0 && c > 0);
+  hipLaunchKernelGGL(unpool_f32_kernel, dim3(vgrid((size_t)n * lh * lw * 4 * c)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(x), n, lh, lw, c,
+                     static_cast<float*>(y));
   return ocr_launch_status();
 }

@@ -85,3 +85,88 @@ def head_conv(g, feat, wv, C, z, bias=None):
     d = ops.conv_desc((n, h, w, cin), C, 1, 1, 1, 1)
     d.flags = CONV_BIAS if bias is not None else 0
     ops.conv2d_f32(d, feat.data, wv.data, z, bias.data if bias is not None else None)
+
+
+# ------------------------------------------------------------------ ResNet-v1 / EAST merge branch
+class ConvBN:
+    """Raw conv output + the batch-norm affine (what resnet_layers.conv_bn_raw returns)."""
+    __slots__ = ("y", "scale", "shift")
+
+
+def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, weight_decay=True):
+    """conv2d_same (stride-1 SAME conv, then subsample: resnet_utils.py:74-123) + BN statistics."""
+    from .layers import BN_DECAY, BN_EPS
+    n, h, w, cin = x.shape
+    with g.variable_scope(scope):
+        wv = g.get_variable("weights", (k, k, cin, cout), variance_scaling(g.rng), regularized=weight_decay)
+        gamma, beta, mm, mv = _bn_vars(g, cout)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, 1, rate)
+    d.flags = 0
+    y = g.empty((n, d.oh, d.ow, cout), F32)
+    ops.conv2d_f32(d, x.data, wv.data, y)
+    if stride > 1:
+        oh, ow = (d.oh + stride - 1) // stride, (d.ow + stride - 1) // stride
+        ys = g.empty((n, oh, ow, cout), F32)
+        ops.maxpool_f32(y, 1, stride, (0, 0), ys)
+        y = ys
+    c = ConvBN()
+    c.y = y
+    c.scale, c.shift = _bn_affine(g, y, gamma, beta, mm, mv, is_training, BN_EPS, BN_DECAY)
+    return c
+
+
+def _bn_affine(g, y, gamma, beta, mm, mv, is_training, eps, decay):
+    n, oh, ow, cout = y.shape
+    scale, shift = g.empty((cout,), F32), g.empty((cout,), F32)
+    if is_training:
+        mean, invstd = g.empty((cout,), F32), g.empty((cout,), F32)
+        T = ops.channel_stats_f32_num_partials(n * oh * ow, cout)
+        g.workspace()
+        part, stage = g.ws_small.two(T * 2 * cout * 4, ops.bn_reduce_workspace(T, cout))
+        ops.channel_stats_f32(y, cout, part)
+        ops.bn_finalize(part, T, cout, float(n) * oh * ow, gamma.data, beta.data, eps, decay, mm.data, mv.data,
+                        scale, shift, mean, invstd, stage)
+    else:
+        ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, eps, scale, shift)
+    return scale, shift
+
+
+def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_training=True):
+    c = conv_bn_raw(g, x, cout, k, scope, stride=stride, rate=rate, is_training=is_training)
+    a = Act(g.empty(c.y.shape, F32), requires_grad=False, name=scope)
+    ops.bn_relu_f32(c.y, c.scale, c.shift, relu, 0, a.data, None)
+    return a
+
+
+def bn_add_relu(g, c3, shortcut, scope):
+    out = Act(g.empty(c3.y.shape, F32), requires_grad=False, name=scope)
+    ops.bn_add_relu_f32(c3.y, c3.scale, c3.shift, shortcut.data, out.data)
+    return out
+
+
+def unpool(g, x):
+    n, h, w, c = x.shape
+    out = Act(g.empty((n, 2 * h, 2 * w, c), F32), requires_grad=False, name="unpool")
+    ops.unpool_f32(x.data, out.data)
+    return out
+
+
+def concat_conv_bn_relu(g, xa, xb, cout, scope, is_training=True):
+    from .layers import BN_DECAY, BN_EPS
+    from ._lib import CONV_ACCUM_F16
+    n, h, w, ca = xa.shape
+    cb = xb.shape[-1]
+    with g.variable_scope(scope):
+        wv = g.get_variable("weights", (1, 1, ca + cb, cout), variance_scaling(g.rng), regularized=True)
+        gamma, beta, mm, mv = _bn_vars(g, cout)
+    y = g.empty((n, h, w, cout), F32)
+    da = ops.conv_desc((n, h, w, ca), cout, 1, 1)
+    db = ops.conv_desc((n, h, w, cb), cout, 1, 1)
+    da.flags = 0
+    ops.conv2d_f32(da, xa.data, wv.data[0, 0, :ca], y)          # rows [0, ca) of the [ca+cb, cout] matrix
+    db.flags = CONV_ACCUM_F16
+    ops.conv2d_f32(db, xb.data, wv.data[0, 0, ca:], y)
+    scale, shift = _bn_affine(g, y, gamma, beta, mm, mv, is_training, BN_EPS, BN_DECAY)
+    a = Act(g.empty(y.shape, F32), requires_grad=False, name=scope)
+    ops.bn_relu_f32(y, scale, shift, True, 0, a.data, None)
+    return a

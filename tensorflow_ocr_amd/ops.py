@@ -495,3 +495,14 @@ def maxpool_f32(x, k, stride, pad, y):
 def prep_images_f32(images, out, means):
     L.call("ocr_prep_images_f32", ptr(images), c_int64(images.numel() // 3), c_float(means[0]),
            c_float(means[1]), c_float(means[2]), ptr(out), _st())
+
+
+def bn_add_relu_f32(y, scale, shift, shortcut, out):
+    c = y.shape[-1]
+    L.call("ocr_bn_add_relu_f32", ptr(y), ptr(scale), ptr(shift), ptr(shortcut), c_int64(y.numel() // c),
+           c_int(c), ptr(out), _st())
+
+
+def unpool_f32(x, y):
+    n, h, w, c = x.shape
+    L.call("ocr_unpool_f32", ptr(x), c_int(n), c_int(h), c_int(w), c_int(c), ptr(y), _st())

@@ -23,6 +23,10 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
     """slim.conv2d(normalizer_fn=slim.batch_norm) up to (not including) the normalise step.
     x: Act f16 [n,h,w,cin].  Returns ConvBN; `backward_from(dy)` propagates the gradient of the
     conv output into the weights and into x."""
+    if g.precision == "f32":
+        from . import layers_f32
+        return layers_f32.conv_bn_raw(g, x, cout, k, scope, stride=stride, rate=rate, is_training=is_training,
+                                      weight_decay=weight_decay)
     n, h, w, cin = x.shape
     with g.variable_scope(scope):
         wv = g.get_variable("weights", (k, k, cin, cout), variance_scaling(g.rng), regularized=weight_decay)
@@ -87,6 +91,10 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
 
 def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_training=True):
     """conv + batch_norm + (ReLU | identity) -> Act."""
+    if g.precision == "f32":
+        from . import layers_f32
+        return layers_f32.conv_bn_act(g, x, cout, k, scope, stride=stride, rate=rate, relu=relu,
+                                      is_training=is_training)
     c = conv_bn_raw(g, x, cout, k, scope, stride=stride, rate=rate, is_training=is_training)
     a = Act(g.empty(c.y.shape), name=scope)
     ops.bn_relu(c.y, c.scale, c.shift, relu, 0, a.data, None)
@@ -106,6 +114,9 @@ def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_trainin
 
 def root_block(g, x4, scope="conv1", cout=64, is_training=True):
     """conv2d_same(inputs, 64, 7, stride=2) + BN + ReLU (nets/resnet_v1.py:193).  x4: prepared image."""
+    if g.precision == "f32":
+        from . import layers_f32
+        return layers_f32.conv_bn_act(g, x4, cout, 7, scope, stride=2, is_training=is_training)
     n, h, w, _ = x4.shape
     with g.variable_scope(scope):
         wv = g.get_variable("weights", (7, 7, 3, cout), variance_scaling(g.rng), regularized=True)
@@ -161,6 +172,9 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
             r = conv_bn_act(g, x, depth_bottleneck, 1, "conv1", is_training=is_training)
             r = conv_bn_act(g, r, depth_bottleneck, 3, "conv2", stride=stride, is_training=is_training)
             c3 = conv_bn_raw(g, r, depth, 1, "conv3", is_training=is_training)
+    if g.precision == "f32":
+        from . import layers_f32
+        return layers_f32.bn_add_relu(g, c3, shortcut, scope)
     out = Act(g.empty(c3.y.shape), name=scope)
     ops.bn_add_relu(c3.y, c3.scale, c3.shift, shortcut.data, out.data)
 
@@ -186,6 +200,9 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
 # ----------------------------------------------------------------- EAST feature-merging branch
 def unpool(g, x):
     """tf.image.resize_bilinear x2 (legacy sampling) on an f16 feature map (nets/model_vgg_16.py:15-16)."""
+    if g.precision == "f32":
+        from . import layers_f32
+        return layers_f32.unpool(g, x)
     n, h, w, c = x.shape
     out = Act(g.empty((n, 2 * h, 2 * w, c)), name="unpool")
     ops.unpool_f16(x.data, out.data)
@@ -206,6 +223,9 @@ def concat_conv_bn_relu(g, xa, xb, cout, scope, is_training=True):
     """slim.conv2d(tf.concat([xa, xb], axis=-1), cout, 1) + BN + ReLU (nets/model_vgg_16.py:118) without
     materialising the concatenation: conv(xa, W[:ca]) + conv(xb, W[ca:]) through the accumulating
     epilogue; ONE variable `<scope>/weights` [1,1,ca+cb,cout] as in the reference."""
+    if g.precision == "f32":
+        from . import layers_f32
+        return layers_f32.concat_conv_bn_relu(g, xa, xb, cout, scope, is_training=is_training)
     n, h, w, ca = xa.shape
     cb = xb.shape[-1]
     with g.variable_scope(scope):

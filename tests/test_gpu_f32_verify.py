@@ -78,3 +78,35 @@ def test_pixellink_scores_within_1e3(device):
     print("pixel_cls %.3e link_cls %.3e pixel_scores %.3e" % (e1, e2, e3))
     assert max(e1, e2, e3) < TOL
     assert abs(L.item() - float(p2 + ltot)) < 1e-3
+
+
+SMALL = [("block1", [(128, 64, 1), (128, 64, 2)]), ("block2", [(256, 64, 1), (256, 64, 2)]),
+         ("block3", [(256, 128, 1), (256, 128, 2)]), ("block4", [(512, 128, 1)])]
+
+
+@pytest.mark.parametrize("blocks", [SMALL, None])
+def test_model_east_score_geometry_within_1e3(device, blocks):
+    """EAST `model` (nets/model_vgg_16.py:85-136): ResNet-v1-50 (full, and a reduced block list) +
+    feature-merging branch; F_score / geo_map (sigmoid outputs) and the dice loss."""
+    from tensorflow_ocr_amd import checkpoint
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model_vgg_16 as M
+    rng = np.random.default_rng(4)
+    p = O.init_model_east_params(rng, blocks)
+    images, pixel, link, mask = O.synthetic_batch(rng, 2, 64 if blocks is None else 128)
+    g = Graph(device, precision="f32")
+    M.model(images, graph=g, blocks=blocks)
+    g.reset_tape()
+    g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, p))
+    fs, geo = M.model(images, graph=g, blocks=blocks)
+    L = M.loss(pixel, fs, link, geo, mask, graph=g)
+    g.reset_tape()
+    tp = O.to_torch_params(p)
+    with torch.no_grad():
+        ofs, ogeo, _ = O.model_east(torch.from_numpy(images), tp, True, mixed=False, blocks=blocks)
+        oL = O.dice_loss(torch.from_numpy(pixel), ofs, torch.from_numpy(link), ogeo, torch.from_numpy(mask))
+    e1 = np.abs(fs.data.cpu().numpy() - ofs.numpy()).max()
+    e2 = np.abs(geo.data.cpu().numpy() - ogeo.numpy()).max()
+    print("F_score Linf %.3e  geo_map Linf %.3e  loss %.6f vs %.6f" % (e1, e2, L.item(), float(oL)))
+    assert e1 < TOL and e2 < TOL
+    assert abs(L.item() - float(oL)) < 1e-4
