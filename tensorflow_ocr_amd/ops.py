@@ -86,16 +86,19 @@ def conv2d_variant(d):
 
 def conv2d(d, x, w_kc, y, bias=None, stats=None):
     flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+    # tag: (kernel instantiation, FLOP, phase) -- phase "fwd" launches run with nothing beside them,
+    # "dgrad" launches share the GPU with the side-stream weight gradients
+    tag = (conv2d_variant(d), flops, "dgrad" if d.flip_taps else "fwd")
     if KERNEL_TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.call("ocr_conv2d_f16", byref(d), ptr(x), ptr(w_kc), ptr(bias), ptr(y), ptr(stats), _st())
         e1.record()
-        KERNEL_TIMING.append((conv2d_variant(d), flops, e0, e1))
+        KERNEL_TIMING.append(tag + (e0, e1))
     else:
         L.call("ocr_conv2d_f16", byref(d), ptr(x), ptr(w_kc), ptr(bias), ptr(y), ptr(stats), _st())
     if L.RECORDER is not None:
-        L.RECORDER.tag_last((conv2d_variant(d), flops))
+        L.RECORDER.tag_last(tag)
 
 
 def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx):
@@ -105,7 +108,7 @@ def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx):
            ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), _st())
     if L.RECORDER is not None:
         flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
-        L.RECORDER.tag_last((conv2d_variant(d), flops))
+        L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
 
 
 def bn_relu_bwd_apply(y, scale, shift, save_mean, save_invstd, da_full, relu, partial, T, dgamma, dbeta, dy, ws):

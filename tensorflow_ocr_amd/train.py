@@ -127,7 +127,10 @@ class TrainStep:
         self.loss = None
         self.side_stream = None
         self.side_ptr = None
-        self.use_side_stream = True
+        # weight gradients on a second stream: measured neutral-to-negative once the wgrad kernels
+        # reached the conv kernels' efficiency (both saturate the VGPR file, so they time-slice rather
+        # than overlap, and every overlapped launch is stretched); off by default, kept as a switch
+        self.use_side_stream = __import__("os").environ.get("OCR_SIDE_STREAM", "0") == "1"
 
     # -- eager / recording path --------------------------------------------------------------
     def _eager(self, batch, record):
@@ -186,7 +189,7 @@ class TrainStep:
                     e0.record()
                     rc = e[1](*e[2])
                     e1.record()
-                    timing.append((tag[0], tag[1], e0, e1))
+                    timing.append((tag[0], tag[1], tag[2] if len(tag) > 2 else "", e0, e1))
                 else:
                     rc = e[1](*e[2])
                 if rc != 0:
