@@ -436,7 +436,8 @@ int fill(const ocr_conv_desc* d, WgP* p) {
 
 extern "C" size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d) {
   if (!d) return 0;
-  if (const int s = ocr_detail::wgrad_pw_splits(d)) return (size_t)s * d->cin * d->cout * sizeof(float);
+  if (const int s = ocr_detail::wgrad_pw_splits(d))
+    return (size_t)s * d->kh * d->kw * d->cin * d->cout * sizeof(float);
   Wg2P p2;
   int cob = 0;
   if (fill2(d, &p2, &cob) == OCR_OK)

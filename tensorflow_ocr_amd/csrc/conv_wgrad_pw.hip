@@ -1,4 +1,5 @@
-// Weight gradient of 1x1 (pointwise) convolutions on gfx950 MFMA: a K-major x K-major GEMM
+// Weight gradient of 1x1 (pointwise) convolutions -- and, tap by tap, of dilated k x k convolutions
+// (fc6, nets/vgg.py:36) -- on gfx950 MFMA: a K-major x K-major GEMM
 //
 //   dw[ci,co] = sum_{n,oy,ox} x[n, oy*s, ox*s, ci] * dy[n,oy,ox,co]          (M = ci, N = co, K = pixels)
 //
@@ -33,7 +34,7 @@ __device__ __forceinline__ half8_t tr_pair16(const char* base, int second_off) {
 }
 
 struct PwP {
-  int n, h, w, cin, oh, ow, cout, stride, pt, pl;
+  int n, h, w, cin, oh, ow, cout, stride, pt, pl, kh, kw, dil;
   int tiles_x, tiles_y, m_tiles, splits, tiles_per_split, nci, nco;
 };
 
@@ -60,12 +61,19 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(PwP p, const half_t* __re
   const int wci = wave % NWCI, wco = wave / NWCI;
   const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
 
+  // kh*kw > 1 (dilated convs whose halo is too large for the tap-sweeping kernel): every tap is its
+  // own pointwise GEMM on a window of x shifted by the tap offset -- one workgroup per (tap, block)
   int bid = blockIdx.x;
+  const int ntaps = p.kh * p.kw;
+  const int tap = bid % ntaps;
+  bid /= ntaps;
   const int cob = bid % p.nco;
   bid /= p.nco;
   const int cib = bid % p.nci;
   const int split = bid / p.nci;
   const int ci0 = cib * CIB, co0 = cob * COB;
+  const int tky = tap / p.kw, tkx = tap - tky * p.kw;
+  const int pt = p.pt - tky * p.dil, pl = p.pl - tkx * p.dil;
 
   f32x4 acc[AI][AJ];
 #pragma unroll
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(PwP p, const half_t* __re
       const int idx = u * NT + tid;
       const int px = idx / XCH, c = idx % XCH;
       const int oy = tyi * PW_ROWS + (px >> 5), ox = txi * 32 + (px & 31);
-      const int iy = oy * p.stride - p.pt, ix = ox * p.stride - p.pl;
+      const int iy = oy * p.stride - pt, ix = ox * p.stride - pl;
       xr[u] = u32x4{0u, 0u, 0u, 0u};
       if (oy < p.oh && ox < p.ow && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
         xr[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin + c * 8);
@@ -154,7 +162,8 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(PwP p, const half_t* __re
   }
 
   // D block: lane (li, g) holds rows (ci) 4g..4g+3 of column (co) li
-  float* dst = slab + ((size_t)split * p.cin + ci0 + wci * WCI + 4 * g) * p.cout + co0 + wco * WCO + li;
+  float* dst = slab + (((size_t)split * ntaps + tap) * p.cin + ci0 + wci * WCI + 4 * g) * p.cout + co0 +
+               wco * WCO + li;
 #pragma unroll
   for (int i = 0; i < AI; ++i)
 #pragma unroll
@@ -166,18 +175,21 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(PwP p, const half_t* __re
 struct PwCfg { int cib, cob; };
 
 bool pw_plan(const ocr_conv_desc* d, PwP* p, PwCfg* c) {
-  if (d->kh != 1 || d->kw != 1 || d->cin % 64 || d->cout % 64) return false;
+  if (d->cin % 64 || d->cout % 64) return false;
+  // 1x1 convs, and dilated k x k convs (taps far apart: no halo reuse worth a tap-sweeping tile)
+  if (!(d->kh * d->kw == 1 || (d->dilation > 1 && d->kh * d->kw <= 9))) return false;
   c->cib = d->cin % 256 == 0 ? 256 : d->cin % 128 == 0 ? 128 : 64;
   c->cob = d->cout % 256 == 0 ? 256 : d->cout % 128 == 0 ? 128 : 64;
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
   p->stride = d->stride; p->pt = d->pad_top; p->pl = d->pad_left;
+  p->kh = d->kh; p->kw = d->kw; p->dil = d->dilation;
   p->tiles_x = ocr_cdiv(d->ow, 32);
   p->tiles_y = ocr_cdiv(d->oh, PW_ROWS);
   p->m_tiles = d->n * p->tiles_x * p->tiles_y;
   p->nci = d->cin / c->cib;
   p->nco = d->cout / c->cob;
-  const int blocks = p->nci * p->nco;
+  const int blocks = p->nci * p->nco * d->kh * d->kw;
   int want = ocr_cdiv(256, blocks);              // one resident workgroup per CU
   if (want > p->m_tiles) want = p->m_tiles;
   if (want < 1) want = 1;
@@ -197,7 +209,7 @@ int pw_launch(const PwP& p, const void* x, const void* dy, void* slab, hipStream
       return OCR_ERR_HIP;
     configured = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.splits * p.nci * p.nco)), dim3(512), lds, st, p,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.splits * p.nci * p.nco * p.kh * p.kw)), dim3(512), lds, st, p,
                      static_cast<const half_t*>(x), static_cast<const half_t*>(dy), static_cast<float*>(slab));
   return ocr_launch_status();
 }
@@ -206,7 +218,7 @@ int pw_launch(const PwP& p, const void* x, const void* dy, void* slab, hipStream
 
 namespace ocr_detail {
 
-// Number of split-K slabs ([cin][cout] f32 each) the pointwise path writes; 0 = shape not handled.
+// Number of split-K slabs ([taps][cin][cout] f32 each) the pointwise path writes; 0 = shape not handled.
 int wgrad_pw_splits(const ocr_conv_desc* d) {
   PwP p;
   PwCfg c;
