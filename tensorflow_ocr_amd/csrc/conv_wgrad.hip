@@ -176,17 +176,45 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgP p, const half_t* __restr
   }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                   size_t elems4, int splits) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= elems4) return;
+// dw = sum over splits of slab[split], in a FIXED order (bitwise reproducible).  SL lanes share one
+// output (each sums splits sl, sl+SL, ... in order, then a fixed-order LDS tree): small weight tensors
+// with hundreds of splits (conv1_2: 9216 float4 outputs x 512 slabs) would otherwise run on a few
+// dozen workgroups of 512 dependent loads each.
+template <int SL>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                          size_t elems4, int splits) {
+  constexpr int OUTS = 256 / SL;
+  __shared__ f32x4 red[256];
+  const int sl = threadIdx.x / OUTS, o = threadIdx.x % OUTS;
+  const size_t i = (size_t)blockIdx.x * OUTS + o;
   const f32x4* s = reinterpret_cast<const f32x4*>(slab);
-  f32x4 a = s[i];
-  for (int k = 1; k < splits; ++k) {
-    f32x4 b = s[(size_t)k * elems4 + i];
-    a += b;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < elems4)
+    for (int k = sl; k < splits; k += SL) a += s[(size_t)k * elems4 + i];
+  if constexpr (SL > 1) {
+    red[threadIdx.x] = a;
+    __syncthreads();
+#pragma unroll
+    for (int step = SL / 2; step >= 1; step >>= 1) {
+      if (sl < step) red[threadIdx.x] += red[threadIdx.x + step * OUTS];
+      __syncthreads();
+    }
+    a = red[threadIdx.x];
   }
-  reinterpret_cast<f32x4*>(dw)[i] = a;
+  if (sl == 0 && i < elems4) reinterpret_cast<f32x4*>(dw)[i] = a;
+}
+
+static void launch_slab_reduce(const float* slab, float* dw, size_t elems4, int splits, hipStream_t st) {
+  // enough workgroups to fill the chip, but never more split lanes than slabs
+  int sl = 1;
+  while (sl < 64 && sl * 4 <= splits && (elems4 * sl) / 256 < 2048) sl *= 4;
+  const unsigned grid = (unsigned)((elems4 * sl + 255) / 256);
+  switch (sl) {
+    case 1: hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, slab, dw, elems4, splits); break;
+    case 4: hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(grid), dim3(256), 0, st, slab, dw, elems4, splits); break;
+    case 16: hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3(grid), dim3(256), 0, st, slab, dw, elems4, splits); break;
+    default: hipLaunchKernelGGL(slab_reduce_kernel<64>, dim3(grid), dim3(256), 0, st, slab, dw, elems4, splits); break;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -498,7 +526,6 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
   }
   if (rc != OCR_OK) return rc;
   const size_t elems4 = elems / 4;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((elems4 + 255) / 256)), dim3(256), 0, st,
-                     static_cast<const float*>(workspace), static_cast<float*>(dw), elems4, splits);
+  launch_slab_reduce(static_cast<const float*>(workspace), static_cast<float*>(dw), elems4, splits, st);
   return ocr_launch_status();
 }
