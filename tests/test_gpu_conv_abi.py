@@ -30,6 +30,9 @@ SHAPES = [
     (1, 8, 8, 512, 1024, 1, 1),
     (3, 7, 5, 32, 32, 3, 1),         # 32-channel partial blocks
     (1, 17, 19, 96, 160, 3, 1),      # cin/cout not multiples of 64: 32-wide tiles
+    (2, 8, 32, 32, 64, 3, 1),        # 64-cout tile with 32-channel chunks
+    (1, 9, 20, 96, 64, 3, 1),
+    (1, 8, 16, 96, 128, 1, 1),
 ]
 
 
