@@ -32,6 +32,8 @@ struct ConvP {
   int n, h, w, cin, oh, ow, cout, kh, kw, stride, dil, pt, pl, flip, flags;
   int tiles_x, tiles_y, n_tiles, HT, WT, halo_bytes;
   int xcd_swizzle;
+  int pw;         // 1: pointwise GEMM kernel (conv_pw_kernel) on flat 256-pixel tiles
+  long long npix; // n * oh * ow
   int m16;        // 1: v_mfma_f32_16x16x32_f16 tiles, 0: v_mfma_f32_32x32x16_f16
   BnRed br;       // br.y != nullptr: fused BN-backward reduction (see conv_epilogue.h)
 };
@@ -340,6 +342,152 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pointwise (1x1, stride 1) convolutions as a plain GEMM:  y[px][co] = sum_ci x[px][ci] * w[co][ci].
+// (ResNet bottleneck / shortcut / feature-merge convs, fc7, and their input gradients.)
+// The tap-sweeping kernel above degenerates here to one tap per 64-channel chunk: two barriers, a
+// halo hand-off and an exposed weight fetch per 32 MFMAs.  This kernel is the canonical
+// double-buffered GEMM instead: tile = 256 consecutive pixels of the flattened [N*H*W] index x BN
+// couts, K in 64-channel stages; BOTH operands are K-contiguous in HBM, staged by LDS-DMA into
+// unpadded 128-byte rows with the chunk index XOR-swizzled on the source address (weights:
+// (row>>1)&7, pixels: px&7 -- conflict-free for the 16x16x32 fragment reads), stage s+1 landing
+// under the 64 MFMAs per wave of stage s; one barrier per stage.  Pixels past the end read a zero
+// page.  Same epilogue (and batch-norm statistics per 256-pixel tile) as the kernel above.
+__device__ const u32x4 ocr_conv_zero_page[4] = {};
+
+template <int BN, int WCO>
+__global__ __launch_bounds__(512) void conv_pw_kernel(
+    ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
+    const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
+  constexpr int NT = 512;
+  constexpr int WPX = 8 / WCO;
+  constexpr int TCO = BN / WCO / 32;
+  constexpr int TPX = 8 / WPX;
+  constexpr int AI = TCO * 2, AT = TPX * 2;
+  constexpr int RS = 128;                       // bytes per staged row (64 channels)
+  constexpr int ABYTES = BN * RS, BBYTES = 256 * RS, STAGE = ABYTES + BBYTES;
+  constexpr int NA = BN * 8 / NT, NB = 256 * 8 / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wco = wave % WCO, wpx = wave / WCO;
+  const int frow = lane & 15, fkg = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int nt = bid % p.n_tiles;
+  const int mt = bid / p.n_tiles;
+  const int co0 = nt * BN;
+  const long long px0 = (long long)mt * 256;
+  const int nk = p.cin / 64;
+
+  f32x4 acc[AI][AT];
+#pragma unroll
+  for (int i = 0; i < AI; ++i)
+#pragma unroll
+    for (int t = 0; t < AT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][t][e] = 0.f;
+
+  const int a_lane = (wco * TCO * 32 + frow) * RS;
+  const int b_lane = (wpx * TPX * 32 + frow) * RS;
+  const int fxa = (frow >> 1) & 7, fxb = frow & 7;
+
+  const __attribute__((address_space(1))) void* zero =
+      (const __attribute__((address_space(1))) void*)(&ocr_conv_zero_page[0]);
+  auto dma_stage = [&](int kc, int buf) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + ABYTES;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int idx = u * NT + tid;
+      const int rr = idx >> 3, c = idx & 7;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(w + (size_t)(co0 + rr) * p.cin + kc * 64 +
+                                                          ((c ^ ((rr >> 1) & 7)) << 3)),
+          (__attribute__((address_space(3))) void*)(As + (u * NT + (tid & ~63)) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int idx = u * NT + tid;
+      const int pr = idx >> 3, c = idx & 7;
+      const long long gp = px0 + pr;
+      const __attribute__((address_space(1))) void* src =
+          gp < p.npix ? (const __attribute__((address_space(1))) void*)(x + (size_t)gp * p.cin + kc * 64 +
+                                                                        ((c ^ (pr & 7)) << 3))
+                      : zero;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(Bs + (u * NT + (tid & ~63)) * 16),
+                                       16, 0, 0);
+    }
+  };
+
+  dma_stage(0, 0);
+  int buf = 0;
+  for (int kc = 0; kc < nk; ++kc) {
+    // after this barrier: stage kc has landed (its vmcnt(0)), and stage kc-1's readers are done,
+    // so the other buffer may be overwritten
+    __syncthreads();
+    if (kc + 1 < nk) dma_stage(kc + 1, buf ^ 1);
+    const char* ab = smem + buf * STAGE + a_lane;
+    const char* bb = smem + buf * STAGE + ABYTES + b_lane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8_t a[AI];
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        a[i] = *reinterpret_cast<const half8_t*>(ab + i * 16 * RS + (((ks * 4 + fkg) ^ fxa) << 4));
+      constexpr int TG = AT > 4 ? 4 : AT;
+#pragma unroll
+      for (int t0 = 0; t0 < AT; t0 += TG) {
+        half8_t b[TG];
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+          b[t] = *reinterpret_cast<const half8_t*>(bb + (t0 + t) * 16 * RS + (((ks * 4 + fkg) ^ fxb) << 4));
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int t = 0; t < TG; ++t)
+            acc[i][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[t], acc[i][t0 + t], 0, 0, 0);
+      }
+    }
+    buf ^= 1;
+  }
+
+  // epilogue on the flat tile: "row" r of the 8x32 layout = pixels px0 + 32r .. +31
+  constexpr int EBN = BN > 128 ? 128 : BN;
+  constexpr int EWCO = BN > 128 ? 2 : WCO;
+  const int rows = (int)(p.npix / 32);
+#pragma unroll
+  for (int h = 0; h < BN / EBN; ++h) {
+    __syncthreads();
+    const bool active = BN <= 128 || (wco >> 1) == h;
+    conv_epilogue16<EBN, TCO, TPX, EWCO, NT>(acc, smem, p.flags, bias, y, stats, 0, mt, 0, mt, co0 + h * EBN,
+                                             rows, 32, p.cout, BN > 128 ? (wco & 1) : wco, wpx, active,
+                                             p.br.y ? &p.br : nullptr);
+  }
+}
+
+template <int BN, int WCO>
+int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
+              hipStream_t st) {
+  const size_t main_bytes = 2 * ((size_t)BN * 128 + 256 * 128);
+  const size_t epi_bytes = conv_epilogue_lds(BN > 128 ? 128 : BN, 512);
+  const size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  auto kern = conv_pw_kernel<BN, WCO>;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(160 * 1024)) != hipSuccess)
+      return OCR_ERR_HIP;
+    configured = true;
+  }
+  const unsigned m_tiles = (unsigned)((p.npix + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(m_tiles * p.n_tiles), dim3(512), lds, st, p, static_cast<const half_t*>(x),
+                     static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
+                     static_cast<float*>(stats));
+  return ocr_launch_status();
+}
+
 template <int BN, int CK, int WCO, bool M16, int TH>
 int launch_t(const ConvP& p, const void* x, const void* w, const void* bias, void* y,
              void* stats, hipStream_t st) {
@@ -381,6 +529,14 @@ int launch(const ConvP& p, const void* x, const void* w, const void* bias, void*
 // 64-/128-cout layers and amortises each streamed weight slice over more pixels.
 struct TileCfg { int bn, ck, th; };
 
+// 1x1 stride-1 convs whose pixel count is a multiple of 32 go to the pointwise GEMM kernel
+static bool conv_is_pw(const ocr_conv_desc* d) {
+  static const int on = [] { const char* e = getenv("OCR_CONV_PW"); return e ? atoi(e) : 1; }();
+  return on && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 &&
+         d->oh == d->h && d->ow == d->w && d->cin % 64 == 0 && d->cout % 64 == 0 &&
+         ((long long)d->n * d->oh * d->ow) % 32 == 0;
+}
+
 int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
   OCR_CHECK_ARG(d != nullptr);
   OCR_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0);
@@ -412,6 +568,15 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
     if (c64) cand[nc++] = {32, 64, 8};
     cand[nc++] = {32, 32, 8};
   }
+  p->npix = (long long)d->n * d->oh * d->ow;
+  p->pw = conv_is_pw(d);
+  if (p->pw) {
+    *cfg = {d->cout % 256 == 0 ? 256 : d->cout % 128 == 0 ? 128 : 64, 64, 8};
+    p->HT = p->WT = 0; p->tiles_x = p->tiles_y = 0; p->halo_bytes = 0;
+    p->n_tiles = d->cout / cfg->bn;
+    p->br = BnRed{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    return OCR_OK;
+  }
   p->WT = (TILE_W - 1) * d->stride + (d->kw - 1) * d->dilation + 1;
   p->tiles_x = ocr_cdiv(d->ow, TILE_W);
   for (int i = 0; i < nc; ++i) {
@@ -434,6 +599,7 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
 
 extern "C" int ocr_conv2d_num_mtiles(const ocr_conv_desc* d) {
   if (!d) return OCR_ERR_INVALID_ARG;
+  if (conv_is_pw(d)) return (int)(((long long)d->n * d->oh * d->ow + 255) / 256);   // flat 256-pixel tiles
   return d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
 }
 
@@ -443,6 +609,10 @@ extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap)
   int rc = fill_params(d, &p, &c);
   if (rc != OCR_OK) return rc;
   OCR_CHECK_ARG(out && cap > 0);
+  if (p.pw) {
+    snprintf(out, cap, "conv_pw_kernel<%d,%d>", c.bn, c.bn == 256 ? 4 : c.bn == 128 ? 2 : 1);
+    return OCR_OK;
+  }
   const int wco = c.bn == 256 ? 4 : c.bn == 32 ? 1 : 2;
   snprintf(out, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d>", c.bn, c.ck, wco, p.m16, c.th);
   return OCR_OK;
@@ -450,6 +620,11 @@ extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap)
 
 static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const void* bias, void* y,
                     void* stats, hipStream_t st) {
+  if (p.pw) {
+    if (c.bn == 256) return launch_pw<256, 4>(p, x, w_kc, bias, y, stats, st);
+    if (c.bn == 128) return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
+    return launch_pw<64, 1>(p, x, w_kc, bias, y, stats, st);
+  }
   const int key = c.bn * 10000 + c.ck * 100 + c.th;
   switch (key) {
     case 2566408: return launch<256, 64, 4>(p, x, w_kc, bias, y, stats, st);

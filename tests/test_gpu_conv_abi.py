@@ -33,6 +33,9 @@ SHAPES = [
     (2, 8, 32, 32, 64, 3, 1),        # 64-cout tile with 32-channel chunks
     (1, 9, 20, 96, 64, 3, 1),
     (1, 8, 16, 96, 128, 1, 1),
+    (2, 24, 40, 256, 256, 1, 1),     # pointwise GEMM kernel: 7.5 flat tiles, 256-cout tile
+    (1, 16, 32, 64, 64, 1, 1),       # ... 64-cout tile, one K stage
+    (1, 32, 32, 1024, 128, 1, 1),    # ... 128-cout tile, 16 K stages
 ]
 
 
