@@ -22,13 +22,63 @@ __global__ void prep_images_kernel(const float* __restrict__ img, half_t* __rest
 }
 
 // ------------------------------------------------- per-channel partial reduce
-// partial [T][2][C] f32  ->  stage [R][2][C] f64, R = ceil(T/256)
-__global__ void reduce_stage1_kernel(const float* __restrict__ partial, double* __restrict__ stage,
-                                     int T, int C) {
+// partial [T][2][C] f32 -> stage [R][2][C] f64 (R = ceil(T/256)) -> final per-channel sums, in ONE
+// launch: every block reduces its 256 rows, publishes them and takes a ticket; the block that draws
+// the last ticket of its 64-channel group sums the R stage rows IN ROW ORDER (so the result does not
+// depend on which block happens to be last: bitwise reproducible) and runs the finalisation.  No
+// block ever waits for another one (no spinning), the ticket counter resets itself.
+struct BnFin {            // MODE 0: batch-norm forward statistics -> scale/shift (+ moving stats)
+  double count;
+  const float *gamma, *beta;
+  float eps, decay;
+  float *moving_mean, *moving_var, *scale, *shift, *save_mean, *save_invstd;
+};
+struct BnBwdFin {         // MODE 1: batch-norm backward sums -> dbeta, dgamma
+  float *dgamma, *dbeta;
+};
+
+__device__ unsigned ocr_bn_tickets[64 * 32];      // [slot][channel group], zero at load, self-resetting
+
+template <typename FIN>
+__device__ __forceinline__ void bn_fin_apply(const FIN& f, int c, double s, double q);
+
+template <>
+__device__ __forceinline__ void bn_fin_apply<BnFin>(const BnFin& f, int c, double s, double q) {
+  double mean = s / f.count;
+  double var = q / f.count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+  float g = f.gamma ? f.gamma[c] : 1.f;
+  float b = f.beta ? f.beta[c] : 0.f;
+  float sc = g * invstd;
+  f.scale[c] = sc;
+  f.shift[c] = b - (float)mean * sc;
+  if (f.save_mean) f.save_mean[c] = (float)mean;
+  if (f.save_invstd) f.save_invstd[c] = invstd;
+  if (f.moving_mean) {
+    // fused batch norm feeds the unbiased variance to the moving average
+    double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+    f.moving_mean[c] = f.moving_mean[c] * f.decay + (float)mean * (1.f - f.decay);
+    f.moving_var[c] = f.moving_var[c] * f.decay + (float)unbiased * (1.f - f.decay);
+  }
+}
+
+template <>
+__device__ __forceinline__ void bn_fin_apply<BnBwdFin>(const BnBwdFin& f, int c, double s, double q) {
+  f.dbeta[c] = (float)s;
+  f.dgamma[c] = (float)q;
+}
+
+template <typename FIN>
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ partial,
+                                                              double* __restrict__ stage, int T, int C, int slot,
+                                                              FIN fin) {
   __shared__ double red[4][2][64];
+  __shared__ unsigned s_ticket;
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
   const int t0 = blockIdx.x * 256;
+  const int R = gridDim.x;
   double s = 0.0, q = 0.0;
   if (c < C) {
     for (int t = t0 + rl; t < t0 + 256 && t < T; t += 4) {
@@ -42,41 +92,43 @@ __global__ void reduce_stage1_kernel(const float* __restrict__ partial, double* 
   if (rl == 0 && c < C) {
     s = red[0][0][cl] + red[1][0][cl] + red[2][0][cl] + red[3][0][cl];
     q = red[0][1][cl] + red[1][1][cl] + red[2][1][cl] + red[3][1][cl];
-    stage[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
-    stage[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+    if (R > 1) {
+      stage[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
+      stage[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+    }
   }
+  if (R == 1) {                                   // single block per channel group: finalise directly
+    if (rl == 0 && c < C) bn_fin_apply(fin, c, s, q);
+    return;
+  }
+  __threadfence();                                // publish this block's stage rows
+  __syncthreads();
+  unsigned* ticket = &ocr_bn_tickets[slot * 32 + blockIdx.y];
+  if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+  __syncthreads();
+  if (s_ticket != (unsigned)(R - 1)) return;      // not the last block of this channel group
+  __threadfence();
+  if (rl == 0 && c < C) {
+    s = 0.0;
+    q = 0.0;
+    const unsigned long long* st = reinterpret_cast<const unsigned long long*>(stage);
+    for (int r = 0; r < R; ++r) {                 // fixed row order; agent-scope loads (other CUs wrote these)
+      unsigned long long us = __hip_atomic_load(st + ((size_t)r * 2 + 0) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long uq = __hip_atomic_load(st + ((size_t)r * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s += __builtin_bit_cast(double, us);
+      q += __builtin_bit_cast(double, uq);
+    }
+    bn_fin_apply(fin, c, s, q);
+  }
+  if (threadIdx.x == 0) *ticket = 0u;             // ready for the next launch that uses this slot
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stage, int R, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float decay, float* __restrict__ moving_mean,
-                                   float* __restrict__ moving_var, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < R; ++r) {
-    s += stage[((size_t)r * 2 + 0) * C + c];
-    q += stage[((size_t)r * 2 + 1) * C + c];
-  }
-  double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  float g = gamma ? gamma[c] : 1.f;
-  float b = beta ? beta[c] : 0.f;
-  float sc = g * invstd;
-  scale[c] = sc;
-  shift[c] = b - (float)mean * sc;
-  if (save_mean) save_mean[c] = (float)mean;
-  if (save_invstd) save_invstd[c] = invstd;
-  if (moving_mean) {
-    // fused batch norm feeds the unbiased variance to the moving average
-    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    moving_mean[c] = moving_mean[c] * decay + (float)mean * (1.f - decay);
-    moving_var[c] = moving_var[c] * decay + (float)unbiased * (1.f - decay);
-  }
+// launches on one stream are ordered; the rotating slot keeps launches that might overlap on
+// DIFFERENT streams (side-stream experiments) off each other's counters
+static int bn_ticket_slot() {
+  static int next = 0;
+  next = (next + 1) & 63;
+  return next;
 }
 
 __global__ void bn_inference_params_kernel(const float* gamma, const float* beta, const float* mm,
@@ -88,19 +140,6 @@ __global__ void bn_inference_params_kernel(const float* gamma, const float* beta
   float sc = (gamma ? gamma[c] : 1.f) * invstd;
   scale[c] = sc;
   shift[c] = (beta ? beta[c] : 0.f) - mm[c] * sc;
-}
-
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ stage, int R, int C,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < R; ++r) {
-    s += stage[((size_t)r * 2 + 0) * C + c];
-    q += stage[((size_t)r * 2 + 1) * C + c];
-  }
-  dbeta[c] = (float)s;
-  dgamma[c] = (float)q;
 }
 
 // ------------------------------------------------ fused normalise+ReLU(+pool)
@@ -704,14 +743,13 @@ extern "C" int ocr_bn_finalize(const void* partial, int T, int C, double count, 
   if (ws_bytes < ocr_bn_reduce_workspace(T, C)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int R = ocr_cdiv(T, 256);
-  hipLaunchKernelGGL(reduce_stage1_kernel, dim3(R, ocr_cdiv(C, 64)), dim3(256), 0, st,
-                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, C);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ocr_cdiv(C, 64)), dim3(64), 0, st,
-                     static_cast<const double*>(workspace), R, C, count,
-                     static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, decay,
-                     static_cast<float*>(moving_mean), static_cast<float*>(moving_var),
-                     static_cast<float*>(scale), static_cast<float*>(shift),
-                     static_cast<float*>(save_mean), static_cast<float*>(save_invstd));
+  OCR_CHECK_SHAPE(ocr_cdiv(C, 64) <= 32);
+  BnFin fin{count, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, decay,
+            static_cast<float*>(moving_mean), static_cast<float*>(moving_var), static_cast<float*>(scale),
+            static_cast<float*>(shift), static_cast<float*>(save_mean), static_cast<float*>(save_invstd)};
+  hipLaunchKernelGGL(reduce_finalize_kernel<BnFin>, dim3(R, ocr_cdiv(C, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, C, bn_ticket_slot(),
+                     fin);
   return ocr_launch_status();
 }
 
@@ -780,11 +818,10 @@ extern "C" int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void*
                      static_cast<const half_t*>(da_full), static_cast<const half_t*>(da_pool),
                      static_cast<float*>(partial), (half_t*)nullptr);
   const int R = ocr_cdiv(T, 256);
-  hipLaunchKernelGGL(reduce_stage1_kernel, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
-                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ocr_cdiv(c, 64)), dim3(64), 0, st,
-                     static_cast<const double*>(workspace), R, c, static_cast<float*>(dgamma),
-                     static_cast<float*>(dbeta));
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32);
+  hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFin>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(),
+                     BnBwdFin{static_cast<float*>(dgamma), static_cast<float*>(dbeta)});
   hipLaunchKernelGGL(bn_relu_bwd_kernel<1>, dim3(T), dim3(256), 0, st, p, yp,
                      static_cast<const float*>(scale), static_cast<const float*>(shift),
                      static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
@@ -920,11 +957,10 @@ extern "C" int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const
   if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int R = ocr_cdiv(T, 256);
-  hipLaunchKernelGGL(reduce_stage1_kernel, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
-                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ocr_cdiv(c, 64)), dim3(64), 0, st,
-                     static_cast<const double*>(workspace), R, c, static_cast<float*>(dgamma),
-                     static_cast<float*>(dbeta));
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32);
+  hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFin>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(),
+                     BnBwdFin{static_cast<float*>(dgamma), static_cast<float*>(dbeta)});
   BnBwdP p{n, h, w, c, relu, 0, (float)(1.0 / ((double)n * h * w))};
   const int B = bwd_blocks(n, h, w, c, 0);
   hipLaunchKernelGGL(bn_relu_bwd_kernel<1>, dim3(B), dim3(256), 0, st, p, static_cast<const half_t*>(y),
