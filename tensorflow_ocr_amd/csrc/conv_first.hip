@@ -124,6 +124,25 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
   const int a_lane = (8 * hh + q) * PSTRF + (16 * gc + 4 * pp) * 2;
   const int b_lane = (8 * hh + q) * DSTRF + (cow * 32 + 16 * gc + 4 * pp) * 2;
 
+  // the dy tile (32 KB, the stream that bounds this kernel) of tile t+1 is fetched into registers
+  // while tile t's patch rows are built and multiplied
+  u32x4 dreg[8];
+  auto load_dy = [&](int mt) {
+    const int txi = mt % p.tiles_x;
+    const int tmp = mt / p.tiles_x;
+    const int tyi = tmp % p.tiles_y;
+    const int img = tmp / p.tiles_y;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = u * 256 + tid;
+      const int px = idx >> 3, c = idx & 7;
+      const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
+      dreg[u] = u32x4{0u, 0u, 0u, 0u};
+      if (oy < p.h && ox < p.w)
+        dreg[u] = *reinterpret_cast<const u32x4*>(dy + (((size_t)img * p.h + oy) * p.w + ox) * p.cout + co0 + c * 8);
+    }
+  };
+  if ((int)blockIdx.x < p.m_tiles) load_dy(blockIdx.x);
   for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
     const int txi = mt % p.tiles_x;
     const int tmp = mt / p.tiles_x;
@@ -134,13 +153,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int idx = u * 256 + tid;
-      const int px = idx >> 3, c = idx & 7;
-      const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (oy < p.h && ox < p.w)
-        v = *reinterpret_cast<const u32x4*>(dy + (((size_t)img * p.h + oy) * p.w + ox) * p.cout + co0 + c * 8);
-      *reinterpret_cast<u32x4*>(dyt + px * DSTRF + c * 16) = v;
+      *reinterpret_cast<u32x4*>(dyt + (idx >> 3) * DSTRF + (idx & 7) * 16) = dreg[u];
     }
+    if (mt + (int)gridDim.x < p.m_tiles) load_dy(mt + gridDim.x);
     __syncthreads();
     {  // im2col row of this thread's pixel: 27 values, k = (ky*3+kx)*3 + c, zero padded to 32
       const int ty = tid >> 5, tx = tid & 31;
