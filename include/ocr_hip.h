@@ -325,6 +325,23 @@ int ocr_lanms(const void* boxes, const void* counts, int n_images, int max_k, fl
               size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * One oriented box per component: the device side of
+ *   rectangle = cv2.minAreaRect(show_xy); box = np.int0(cv2.boxPoints(rectangle))
+ * (test_pixellink_fast.py:193-202, test_pixellink.py:207-216; cv2 = OpenCV 3.x convexHull +
+ * rotatingCalipers, restated in oracle/cvgeom_oracle.c and matched bit for bit).
+ * labels int32 [n][h][w] with ids 1..ncomp[img] (ocr_link_cc's output).  A component's points are
+ * X = (int)(x*scale_x), Y = (int)(y*scale_y) (scale >= 1, h <= 1024).  Outputs, per
+ * (image, id-1) in [n][max_comps]: hull_n = number of convex-hull vertices (0: id without pixels),
+ * hull_head [4] = the first two hull vertices (x0,y0,x1,y1) in OpenCV's clockwise order,
+ * calipers [6] = (corner x, corner y, edge-1 vector, edge-2 vector) of the minimum-area rectangle
+ * (zeros when hull_n <= 2).  RotatedRect / boxPoints are O(1) per box on the host.
+ * ------------------------------------------------------------------------- */
+size_t ocr_min_area_rects_workspace(int n, int h, int w, int max_comps);
+int ocr_min_area_rects(const void* labels_i32, const void* ncomp_i32, int n, int h, int w, int max_comps,
+                       double scale_x, double scale_y, void* hull_n_i32, void* hull_head_i32,
+                       void* calipers_f32, void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Optimisers over the flat parameter buffer: elements [0, n_regularized) also get
  * the slim.l2_regularizer gradient weight_decay*w.  g is multiplied by
  * inv_loss_scale first.  ema (may be NULL) follows ExponentialMovingAverage.

@@ -446,6 +446,15 @@ def lanms(boxes, counts, iou_thresh, merged, n_merged, keep_idx, n_keep, ws):
            ptr(merged), ptr(n_merged), ptr(keep_idx), ptr(n_keep), ptr(buf), c_size_t(nbytes), _st())
 
 
+def min_area_rects(labels, ncomp, max_comps, scale_x, scale_y, hull_n, hull_head, calipers, ws):
+    n, h, w = labels.shape
+    nbytes = L.call_size("ocr_min_area_rects_workspace", c_int(n), c_int(h), c_int(w), c_int(max_comps))
+    buf = ws.get(nbytes)
+    L.call("ocr_min_area_rects", ptr(labels), ptr(ncomp), c_int(n), c_int(h), c_int(w), c_int(max_comps),
+           c_double(scale_x), c_double(scale_y), ptr(hull_n), ptr(hull_head), ptr(calipers), ptr(buf),
+           c_size_t(nbytes), _st())
+
+
 # -------------------------------------------------------------------------- optimiser
 def adam_step(w, g, m, v, ema, n_reg, lr_t, beta1, beta2, eps, wd, inv_scale, ema_decay):
     L.call("ocr_adam_step", ptr(w), ptr(g), ptr(m), ptr(v), ptr(ema), c_int64(w.numel()),

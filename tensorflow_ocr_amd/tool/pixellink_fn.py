@@ -70,3 +70,82 @@ def link_cc_decode(pixel_score, link_score, pixel_conf_threshold=0.8, link_conf_
     ops.link_cc(ps, lk, stride, off, n, h, w, float(pixel_conf_threshold), float(link_conf_threshold),
                 int(min_size), labels, ncomp, comps, g.workspace())
     return labels, ncomp, comps
+
+
+def _rotated_rect(nh, head, cal):
+    """Tail of cv2.minAreaRect (OpenCV 3.x `minAreaRect`): RotatedRect (cx, cy, w, h, angle°) from the
+    calipers' corner + edge vectors (hull of > 2 points) or from a 1/2-point hull.  float32
+    arithmetic with the double-precision sqrt/atan2 steps of the original; O(1) per box."""
+    import math
+    import numpy as np
+    f = np.float32
+    cx = cy = w = h = ang = f(0)
+    if nh > 2:
+        c = [f(v) for v in cal]
+        cx = c[0] + (c[2] + c[4]) * f(0.5)
+        cy = c[1] + (c[3] + c[5]) * f(0.5)
+        w = f(math.sqrt(float(c[2]) * float(c[2]) + float(c[3]) * float(c[3])))
+        h = f(math.sqrt(float(c[4]) * float(c[4]) + float(c[5]) * float(c[5])))
+        ang = f(math.atan2(float(c[3]), float(c[2])))
+    elif nh == 2:
+        x0, y0, x1, y1 = [f(v) for v in head]
+        cx = (x0 + x1) * f(0.5)
+        cy = (y0 + y1) * f(0.5)
+        dx, dy = float(x1 - x0), float(y1 - y0)
+        w = f(math.sqrt(dx * dx + dy * dy))
+        ang = f(math.atan2(dy, dx))
+    elif nh == 1:
+        cx, cy = f(head[0]), f(head[1])
+    ang = f(float(ang * f(180)) / math.pi)
+    return np.array([cx, cy, w, h, ang], np.float32)
+
+
+def _box_points(rect):
+    """cv2.boxPoints = RotatedRect::points -> float32 [4,2]."""
+    import math
+    import numpy as np
+    f = np.float32
+    cx, cy, w, h, ang = [f(v) for v in rect]
+    a_ = float(ang) * math.pi / 180.
+    b = f(math.cos(a_)) * f(0.5)
+    a = f(math.sin(a_)) * f(0.5)
+    p0x = cx - a * h - b * w
+    p0y = cy + b * h - a * w
+    p1x = cx + a * h - b * w
+    p1y = cy - b * h - a * w
+    two = f(2)
+    return np.array([[p0x, p0y], [p1x, p1y], [two * cx - p0x, two * cy - p0y],
+                     [two * cx - p1x, two * cy - p1y]], np.float32)
+
+
+def min_area_rect_boxes(labels, ncomp, scale_x=4.0, scale_y=4.0, max_comps=4096, graph=None):
+    """`cv2.minAreaRect(show_xy)` + `np.int0(cv2.boxPoints(rectangle))` for every component of a batch
+    of label maps (test_pixellink_fast.py:193-202): show_xy = (int(x*scale_x), int(y*scale_y)).
+    labels int32 [N,h,w], ncomp int32 [N] (link_cc_decode's outputs).  Hull + rotating calipers run
+    on the GPU (ocr_min_area_rects); the RotatedRect / corner formatting is O(1) per box here.
+    Returns per image (rects float32 [k,5] = cx,cy,w,h,angle; boxes int64 [k,4,2])."""
+    import numpy as np
+    g = graph or get_default_graph()
+    if labels.dim() != 3:
+        raise ValueError("labels must be [N,h,w]")
+    n = labels.shape[0]
+    labels = labels.to(device=g.device, dtype=torch.int32).contiguous()
+    ncomp = ncomp.to(device=g.device, dtype=torch.int32).contiguous()
+    hull_n = torch.zeros((n, max_comps), dtype=torch.int32, device=g.device)
+    head = torch.zeros((n, max_comps, 4), dtype=torch.int32, device=g.device)
+    cal = torch.zeros((n, max_comps, 6), dtype=F32, device=g.device)
+    ops.min_area_rects(labels, ncomp, max_comps, float(scale_x), float(scale_y), hull_n, head, cal, g.workspace())
+    k = np.minimum(ncomp.cpu().numpy(), max_comps)
+    kmax = int(k.max()) if n else 0
+    hn = hull_n[:, :kmax].cpu().numpy()
+    hd = head[:, :kmax].cpu().numpy()
+    cl = cal[:, :kmax].cpu().numpy()
+    out = []
+    for b in range(n):
+        rects = np.zeros((int(k[b]), 5), np.float32)
+        boxes = np.zeros((int(k[b]), 4, 2), np.int64)
+        for i in range(int(k[b])):
+            rects[i] = _rotated_rect(int(hn[b, i]), hd[b, i], cl[b, i])
+            boxes[i] = _box_points(rects[i]).astype(np.int64)        # np.int0: truncation
+        out.append((rects, boxes))
+    return out

@@ -4,9 +4,9 @@ per-direction softmax, pixel_detect mask, link-gated connected components at 1/4
 box per component, `res_<name>.txt` lines `x1,y1,x2,y2,x3,y3,x4,y4\\r\\n` (:215-217).
 
 Flag names follow the reference (:12-19).  Differences, all forced by the container:
-images are read with NumPy-decodable formats only (.npy arrays [H,W,3] RGB; no cv2), and the box of
-a component is its axis-aligned bounding rectangle (cv2.minAreaRect is §8f "next"), scaled x4 like
-the reference's `show_xy` mapping."""
+images are read with NumPy-decodable formats only (.npy arrays [H,W,3] RGB; no cv2).  The box of a
+component is `np.int0(cv2.boxPoints(cv2.minAreaRect(show_xy)))` as in the reference (:193-202), with
+hull + rotating calipers on the GPU (tool/pixellink_fn.min_area_rect_boxes)."""
 import argparse
 import os
 import time
@@ -73,17 +73,12 @@ def main():
         labels, ncomp, comps = pixellink_fn.link_cc_decode(pixel_score[..., 1].contiguous(), link_score,
                                                            FLAGS.pixel_conf_threshold, FLAGS.link_conf_threshold,
                                                            min_size=10, graph=g)
-        lab = labels[0].cpu().numpy()
         k = int(ncomp[0].item())
         print('%s: net+decode %.0f ms, %d components, mask pixels %d' % (
             name, (time.time() - t0) * 1e3, k, int(score_res.sum().item())))
-        h4, w4 = lab.shape
-        boxes = []
-        for i in range(1, k + 1):
-            ys, xs = np.nonzero(lab == i)
-            x0, x1 = xs.min() * (W / w4), xs.max() * (W / w4)
-            y0, y1 = ys.min() * (H / h4), ys.max() * (H / h4)
-            boxes.append(np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]]).astype(np.int64))
+        h4, w4 = labels.shape[1:]
+        # rectangle = cv2.minAreaRect(show_xy); box = np.int0(cv2.boxPoints(rectangle))  (:193-202)
+        _, boxes = pixellink_fn.min_area_rect_boxes(labels, ncomp, float(W) / w4, float(H) / h4, graph=g)[0]
         with open(os.path.join(FLAGS.output_dir, 'res_{}.txt'.format(name)), 'w') as f:
             for box in boxes:
                 f.write('{},{},{},{},{},{},{},{}\r\n'.format(box[0, 0], box[0, 1], box[1, 0], box[1, 1],
