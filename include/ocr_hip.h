@@ -342,6 +342,35 @@ int ocr_min_area_rects(const void* labels_i32, const void* ncomp_i32, int n, int
                        void* calipers_f32, void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Ground-truth label maps: datasets/icdar.py:486-539 `generate_rbox` (+ the
+ * generator's [::4,::4] subsample, :632-634) and tool/pixellink_fn.py:53-110 `generate_rbox`, both on
+ * cv2.fillPoly rasters of the text polygons (OpenCV restated in oracle/cvgeom_oracle.c, matched
+ * bit for bit).
+ * polys int32 [n][max_polys][verts][2] (x,y as the reference casts them: .astype(np.int32)), counts
+ * int32 [n], ignore uint8 [n][max_polys] (icdar: `tag or min(poly_h, poly_w) < min_text_size`).
+ * cover uint32 [n][h][w]: bits 0-7 = 1 + smallest index of a polygon whose raster contains the pixel
+ * (0: none), bits 8-15 = 1 + largest such index (= the reference's poly_mask), bit 16 = covered by an
+ * ignored polygon.  max_polys <= 254 (poly_mask is uint8), 3 <= verts <= 8.
+ * ------------------------------------------------------------------------- */
+int ocr_poly_cover(const void* polys_i32, const void* counts_i32, const void* ignore_u8, int n, int max_polys,
+                   int verts, int h, int w, void* cover_u32, void* stream);
+/* icdar labels at every `step`-th pixel: score f32 [n][oh][ow][1], geo f32 [n][oh][ow][8] (channel
+ * order and transposed directions of icdar.py:522-537 / valid_link :83-105, index -1 wraps),
+ * training mask f32 [n][oh][ow][1]; oh = ceil(h/step).  h == w (the reference's border rule). */
+int ocr_icdar_labels(const void* cover_u32, int n, int h, int w, int step, void* score_f32, void* geo_f32,
+                     void* mask_f32, void* stream);
+/* pixellink_fn labels: INTER_NEAREST resize of score / poly_mask to [new_h][new_w], link = neighbour
+ * has the same poly_mask value (true directions), borders 1: score f32 [n][new_h][new_w], link f32
+ * [n][new_h][new_w][8]. */
+int ocr_pixellink_labels(const void* cover_u32, int n, int h, int w, int new_h, int new_w, void* score_f32,
+                         void* link_f32, void* stream);
+
+/* cv2.resize(im, dsize=(dw, dh)) (default INTER_LINEAR, 8-bit fixed-point path) + astype(float32):
+ * datasets/icdar.py:615,630.  src uint8 [H][W][cn] -> dst f32 [dh][dw][cn]. */
+int ocr_resize_linear_u8(const void* src_u8, int H, int W, int cn, void* dst_f32, int dh, int dw,
+                         void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Optimisers over the flat parameter buffer: elements [0, n_regularized) also get
  * the slim.l2_regularizer gradient weight_decay*w.  g is multiplied by
  * inv_loss_scale first.  ema (may be NULL) follows ExponentialMovingAverage.

@@ -57,3 +57,24 @@ def box_points(rect):
     pts = np.zeros((4, 2), np.float32)
     _load().cvgeom_box_points(_p(rect), _p(pts))
     return pts
+
+
+def fill_poly(img, pts, color):
+    """cv2.fillPoly(img uint8 [h,w], [pts int32 [k,2]], color) in place."""
+    assert img.dtype == np.uint8 and img.ndim == 2 and img.flags["C_CONTIGUOUS"]
+    pts = np.ascontiguousarray(pts, np.int32).reshape(-1, 2)
+    _load().cvgeom_fill_poly(_p(img), ctypes.c_int(img.shape[0]), ctypes.c_int(img.shape[1]), _p(pts),
+                             ctypes.c_int(len(pts)), ctypes.c_int(int(color)))
+    return img
+
+
+def resize_linear_u8(src, dh, dw):
+    """cv2.resize(src uint8 [H,W,cn], dsize=(dw, dh)) with the default INTER_LINEAR."""
+    src = np.ascontiguousarray(src, np.uint8)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    H, W, cn = src.shape
+    dst = np.zeros((dh, dw, cn), np.uint8)
+    _load().cvgeom_resize_linear_u8(_p(src), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(cn), _p(dst),
+                                    ctypes.c_int(dh), ctypes.c_int(dw))
+    return dst

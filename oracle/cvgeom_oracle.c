@@ -336,3 +336,287 @@ int cvgeom_min_area_rect(const int* pts_xy, int n, float* rect, float* cal6, int
   free(hull);
   return nh;
 }
+
+/* ------------------------------------------------------------------------------------------ *
+ * cv2.fillPoly(img uint8 [h][w], [pts int32 [count][2]], color), lineType 8, shift 0:
+ * CollectPolyEdges (draws every edge with Line -> clipLine + LineIterator(left_to_right)) and
+ * FillEdgeCollection (sorted edge table, active list, even-odd spans with 16.16 fixed point).
+ * ------------------------------------------------------------------------------------------ */
+#define XY_SHIFT 16
+#define XY_ONE (1 << XY_SHIFT)
+
+static int clip_line(int64_t width, int64_t height, int64_t* px1, int64_t* py1, int64_t* px2, int64_t* py2) {
+  int c1, c2;
+  const int64_t right = width - 1, bottom = height - 1;
+  int64_t x1 = *px1, y1 = *py1, x2 = *px2, y2 = *py2;
+  if (width <= 0 || height <= 0) return 0;
+  c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+  c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+    int64_t a;
+    if (c1 & 12) {
+      a = c1 < 8 ? 0 : bottom;
+      x1 += (int64_t)((double)(a - y1) * (x2 - x1) / (y2 - y1));
+      y1 = a;
+      c1 = (x1 < 0) + (x1 > right) * 2;
+    }
+    if (c2 & 12) {
+      a = c2 < 8 ? 0 : bottom;
+      x2 += (int64_t)((double)(a - y2) * (x2 - x1) / (y2 - y1));
+      y2 = a;
+      c2 = (x2 < 0) + (x2 > right) * 2;
+    }
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+      if (c1) {
+        a = c1 == 1 ? 0 : right;
+        y1 += (int64_t)((double)(a - x1) * (y2 - y1) / (x2 - x1));
+        x1 = a;
+        c1 = 0;
+      }
+      if (c2) {
+        a = c2 == 1 ? 0 : right;
+        y2 += (int64_t)((double)(a - x2) * (y2 - y1) / (x2 - x1));
+        x2 = a;
+        c2 = 0;
+      }
+    }
+  }
+  *px1 = x1; *py1 = y1; *px2 = x2; *py2 = y2;
+  return (c1 | c2) == 0;
+}
+
+/* Line(): 8-connected LineIterator from the left end point to the right one */
+static void draw_line(unsigned char* img, int h, int w, int64_t X1, int64_t Y1, int64_t X2, int64_t Y2,
+                      unsigned char color) {
+  if (!clip_line(w, h, &X1, &Y1, &X2, &Y2)) return;
+  int x1 = (int)X1, y1 = (int)Y1, x2 = (int)X2, y2 = (int)Y2;
+  int dx = x2 - x1, dy = y2 - y1;
+  int xstep = 1, ystep = 1;
+  if (dx < 0) {            /* left_to_right: start from the left end */
+    dx = -dx;
+    dy = -dy;
+    x1 = x2;
+    y1 = y2;
+  }
+  if (dy < 0) { dy = -dy; ystep = -1; }
+  int x = x1, y = y1;
+  const int steep = dy > dx;
+  int major = steep ? dy : dx, minor = steep ? dx : dy;
+  int err = major - (minor + minor);
+  const int plusDelta = major + major, minusDelta = -(minor + minor);
+  const int count = major + 1;
+  for (int i = 0; i < count; ++i) {
+    img[(size_t)y * w + x] = color;
+    const int mask = err < 0 ? -1 : 0;
+    err += minusDelta + (plusDelta & mask);
+    if (steep) { y += ystep; if (mask) x += xstep; }
+    else { x += xstep; if (mask) y += ystep; }
+  }
+}
+
+typedef struct PolyEdge {
+  int y0, y1;
+  int64_t x, dx;
+  struct PolyEdge* next;
+} PolyEdge;
+
+static int cmp_edges(const void* a, const void* b) {
+  const PolyEdge* e1 = (const PolyEdge*)a;
+  const PolyEdge* e2 = (const PolyEdge*)b;
+  if (e1->y0 != e2->y0) return e1->y0 < e2->y0 ? -1 : 1;
+  if (e1->x != e2->x) return e1->x < e2->x ? -1 : 1;
+  if (e1->dx != e2->dx) return e1->dx < e2->dx ? -1 : 1;
+  return 0;
+}
+
+static void hline(unsigned char* row, int x1, int x2, unsigned char color) {
+  for (int x = x1; x <= x2; ++x) row[x] = color;
+}
+
+void cvgeom_fill_poly(unsigned char* img, int h, int w, const int* pts_xy, int count, int color) {
+  if (count <= 0) return;
+  const unsigned char col = (unsigned char)(color < 0 ? 0 : (color > 255 ? 255 : color));
+  PolyEdge* edges = (PolyEdge*)malloc(sizeof(PolyEdge) * (size_t)(count + 1));
+  int total = 0, i;
+  /* CollectPolyEdges, shift 0, offset 0 */
+  int64_t p0x = (int64_t)pts_xy[2 * (count - 1)] << XY_SHIFT, p0y = pts_xy[2 * (count - 1) + 1];
+  for (i = 0; i < count; ++i) {
+    const int64_t p1x = (int64_t)pts_xy[2 * i] << XY_SHIFT, p1y = pts_xy[2 * i + 1];
+    const int64_t t0x = (p0x + (XY_ONE >> 1)) >> XY_SHIFT, t1x = (p1x + (XY_ONE >> 1)) >> XY_SHIFT;
+    draw_line(img, h, w, t0x, p0y, t1x, p1y, col);
+    if (p0y != p1y) {
+      PolyEdge e;
+      if (p0y < p1y) { e.y0 = (int)p0y; e.y1 = (int)p1y; e.x = p0x; }
+      else { e.y0 = (int)p1y; e.y1 = (int)p0y; e.x = p1x; }
+      e.dx = (p1x - p0x) / (p1y - p0y);
+      e.next = 0;
+      edges[total++] = e;
+    }
+    p0x = p1x;
+    p0y = p1y;
+  }
+  /* FillEdgeCollection */
+  if (total >= 2) {
+    int y_max = INT_MIN, y_min = INT_MAX;
+    int64_t x_max = -1, x_min = 0x7FFFFFFFFFFFFFFFLL;
+    for (i = 0; i < total; ++i) {
+      const PolyEdge* e1 = &edges[i];
+      const int64_t x1 = e1->x + (e1->y1 - e1->y0) * e1->dx;
+      if (e1->y0 < y_min) y_min = e1->y0;
+      if (e1->y1 > y_max) y_max = e1->y1;
+      if (e1->x < x_min) x_min = e1->x;
+      if (e1->x > x_max) x_max = e1->x;
+      if (x1 < x_min) x_min = x1;
+      if (x1 > x_max) x_max = x1;
+    }
+    if (!(y_max < 0 || y_min >= h || x_max < 0 || x_min >= ((int64_t)w << XY_SHIFT))) {
+      qsort(edges, (size_t)total, sizeof(PolyEdge), cmp_edges);
+      PolyEdge tmp;
+      tmp.y0 = INT_MAX;
+      tmp.next = 0;
+      edges[total] = tmp;
+      edges[total].y0 = INT_MAX;
+      i = 0;
+      PolyEdge* e = &edges[i];
+      if (y_max > h) y_max = h;
+      for (int y = e->y0; y < y_max; ++y) {
+        PolyEdge *last, *prelast, *keep_prelast;
+        int sort_flag = 0, draw = 0;
+        const int clipline = y < 0;
+        prelast = &tmp;
+        last = tmp.next;
+        while (last || e->y0 == y) {
+          if (last && last->y1 == y) {
+            prelast->next = last->next;
+            last = last->next;
+            continue;
+          }
+          keep_prelast = prelast;
+          if (last && (e->y0 > y || last->x < e->x)) {
+            prelast = last;
+            last = last->next;
+          } else if (i < total) {
+            prelast->next = e;
+            e->next = last;
+            prelast = e;
+            e = &edges[++i];
+          } else
+            break;
+          if (draw) {
+            if (!clipline) {
+              int x1, x2;
+              if (keep_prelast->x > prelast->x) {
+                x1 = (int)((prelast->x + XY_ONE - 1) >> XY_SHIFT);
+                x2 = (int)(keep_prelast->x >> XY_SHIFT);
+              } else {
+                x1 = (int)((keep_prelast->x + XY_ONE - 1) >> XY_SHIFT);
+                x2 = (int)(prelast->x >> XY_SHIFT);
+              }
+              if (x1 < w && x2 >= 0) {
+                if (x1 < 0) x1 = 0;
+                if (x2 >= w) x2 = w - 1;
+                hline(img + (size_t)y * w, x1, x2, col);
+              }
+            }
+            keep_prelast->x += keep_prelast->dx;
+            prelast->x += prelast->dx;
+          }
+          draw ^= 1;
+        }
+        /* bubble-sort the active list by x */
+        keep_prelast = 0;
+        do {
+          prelast = &tmp;
+          last = tmp.next;
+          while (last != keep_prelast && last->next != 0) {
+            PolyEdge* te = last->next;
+            if (last->x > te->x) {
+              prelast->next = te;
+              last->next = te->next;
+              te->next = last;
+              prelast = te;
+              sort_flag = 1;
+            } else {
+              prelast = last;
+              last = te;
+            }
+          }
+          keep_prelast = prelast;
+        } while (sort_flag && keep_prelast != tmp.next && keep_prelast != &tmp);
+      }
+    }
+  }
+  free(edges);
+}
+
+/* ------------------------------------------------------------------------------------------ *
+ * cv2.resize(src uint8 [H][W][cn], dsize=(dw, dh)), default INTER_LINEAR (datasets/icdar.py:615):
+ * resizeGeneric_ with HResizeLinear<uchar,int,short,2048> / VResizeLinear<uchar,int,short> —
+ * 11-bit fixed-point coefficients (cvRound of float weights), half-pixel centres, horizontal pass
+ * into int, vertical pass ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2.  An exact 2x2 downscale
+ * is rerouted to INTER_AREA by resize() itself ((a+b+c+d+2)>>2).
+ * ------------------------------------------------------------------------------------------ */
+static int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+static short sat_short_round(float v) {
+  long r = lrintf(v);           /* cvRound: round half to even */
+  if (r < -32768) r = -32768;
+  if (r > 32767) r = 32767;
+  return (short)r;
+}
+
+void cvgeom_resize_linear_u8(const unsigned char* src, int H, int W, int cn, unsigned char* dst, int dh, int dw) {
+  const double inv_scale_x = (double)dw / W, inv_scale_y = (double)dh / H;
+  const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+  const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+  const int is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+  if (is_area_fast && iscale_x == 2 && iscale_y == 2) {
+    for (int y = 0; y < dh; ++y)
+      for (int x = 0; x < dw; ++x)
+        for (int k = 0; k < cn; ++k) {
+          const unsigned char* s0 = src + ((size_t)(2 * y) * W + 2 * x) * cn + k;
+          const unsigned char* s1 = s0 + (size_t)W * cn;
+          dst[((size_t)y * dw + x) * cn + k] = (unsigned char)((s0[0] + s0[cn] + s1[0] + s1[cn] + 2) >> 2);
+        }
+    return;
+  }
+  int* xofs = (int*)malloc(sizeof(int) * (size_t)dw);
+  short* ialpha = (short*)malloc(sizeof(short) * 2 * (size_t)dw);
+  for (int dx = 0; dx < dw; ++dx) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= W - 1) { fx = 0; sx = W - 1; }
+    xofs[dx] = sx;
+    ialpha[2 * dx] = sat_short_round((1.f - fx) * 2048);
+    ialpha[2 * dx + 1] = sat_short_round(fx * 2048);
+  }
+  int* hbuf0 = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+  int* hbuf1 = (int*)malloc(sizeof(int) * (size_t)dw * cn);
+  for (int dy = 0; dy < dh; ++dy) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = cv_floor(fy);
+    fy -= sy;
+    const short b0 = sat_short_round((1.f - fy) * 2048), b1 = sat_short_round(fy * 2048);
+    int r0 = sy, r1 = sy + 1;
+    if (r0 < 0) r0 = 0;
+    if (r0 > H - 1) r0 = H - 1;
+    if (r1 < 0) r1 = 0;
+    if (r1 > H - 1) r1 = H - 1;
+    for (int pass = 0; pass < 2; ++pass) {
+      const unsigned char* S = src + (size_t)(pass ? r1 : r0) * W * cn;
+      int* D = pass ? hbuf1 : hbuf0;
+      for (int dx = 0; dx < dw; ++dx) {
+        const int sx = xofs[dx];
+        const int sx1 = sx + 1 < W ? sx + 1 : sx;      /* dx >= xmax: D = S[sx] * ONE (alpha1 is 0) */
+        for (int k = 0; k < cn; ++k)
+          D[dx * cn + k] = S[sx * cn + k] * ialpha[2 * dx] + S[sx1 * cn + k] * ialpha[2 * dx + 1];
+      }
+    }
+    for (int x = 0; x < dw * cn; ++x) {
+      const int v = (((b0 * (hbuf0[x] >> 4)) >> 16) + ((b1 * (hbuf1[x] >> 4)) >> 16) + 2) >> 2;
+      dst[(size_t)dy * dw * cn + x] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  }
+  free(hbuf0); free(hbuf1); free(ialpha); free(xofs);
+}

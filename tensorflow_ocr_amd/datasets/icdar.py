@@ -1,0 +1,216 @@
+"""Mirror of the reference's datasets/icdar.py on the training path: ICDAR
+annotation parsing and validation on the host (tiny), label maps and image preparation on the GPU.
+
+Same function names and argument order as the reference where it has them:
+  load_annoataion           icdar.py:43-66   gt_<name>.txt CSV -> (polys float32 [k,4,2], tags bool [k])
+  polygon_area              icdar.py:69-81
+  check_and_validate_polys  icdar.py:108-135
+  generate_rbox             icdar.py:486-539 (one image, full resolution, NumPy results)
+  generator / get_batch     icdar.py:542-668 (resize to input_size, BGR->RGB float, labels at 1/4)
+plus the batched device entry point the feeder uses:
+  generate_rbox_batch       all images of a batch in two launches; device tensors at 1/4 resolution
+
+The reference rasterises with cv2.fillPoly and resizes with cv2.resize; here both run as HIP kernels
+(ocr_poly_cover / ocr_icdar_labels / ocr_resize_linear_u8) matched bit for bit against the OpenCV
+restatement in oracle/cvgeom_oracle.c.  There is no CPU fallback.
+"""
+import csv
+import glob
+import os
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..graph import F32, get_default_graph
+
+MIN_TEXT_SIZE = 10          # FLAGS.min_text_size (icdar.py:24)
+MAX_POLYS = 254             # poly_mask is a uint8 image in the reference
+
+
+def get_images(training_data_path):
+    """icdar.py:36-41 (plus .npy arrays for containers without an image decoder)."""
+    files = []
+    for ext in ['jpg', 'png', 'jpeg', 'JPG', 'npy']:
+        files.extend(glob.glob(os.path.join(training_data_path, '*.{}'.format(ext))))
+    return files
+
+
+def load_annoataion(p):
+    """icdar.py:43-66: x1,y1,...,x4,y4,label per line; label '*' or '###' = ignored text."""
+    text_polys, text_tags = [], []
+    if not os.path.exists(p):
+        return np.array(text_polys, dtype=np.float32)
+    with open(p, 'r', encoding='utf-8-sig') as f:
+        for line in csv.reader(f):
+            if not line:
+                continue
+            label = line[-1]
+            line = [i.strip('\ufeff').strip('\xef\xbb\xbf') for i in line]
+            x1, y1, x2, y2, x3, y3, x4, y4 = list(map(float, line[:8]))
+            text_polys.append([[x1, y1], [x2, y2], [x3, y3], [x4, y4]])
+            text_tags.append(label == '*' or label == '###')
+    return np.array(text_polys, dtype=np.float32), np.array(text_tags, dtype=bool)
+
+
+def polygon_area(poly):
+    """icdar.py:69-81 (shoelace, sign = orientation)."""
+    edge = [(poly[1][0] - poly[0][0]) * (poly[1][1] + poly[0][1]),
+            (poly[2][0] - poly[1][0]) * (poly[2][1] + poly[1][1]),
+            (poly[3][0] - poly[2][0]) * (poly[3][1] + poly[2][1]),
+            (poly[0][0] - poly[3][0]) * (poly[0][1] + poly[3][1])]
+    return np.sum(edge) / 2.
+
+
+def check_and_validate_polys(polys, tags, size):
+    """icdar.py:108-135: clip to the image, drop |area| < 1, flip clockwise-wrong polygons."""
+    (h, w) = size
+    if polys.shape[0] == 0:
+        return polys
+    polys[:, :, 0] = np.clip(polys[:, :, 0], 0, w - 1)
+    polys[:, :, 1] = np.clip(polys[:, :, 1], 0, h - 1)
+    validated_polys, validated_tags = [], []
+    for poly, tag in zip(polys, tags):
+        p_area = polygon_area(poly)
+        if abs(p_area) < 1:
+            continue
+        if p_area > 0:
+            poly = poly[(0, 3, 2, 1), :]
+        validated_polys.append(poly)
+        validated_tags.append(tag)
+    return np.array(validated_polys), np.array(validated_tags)
+
+
+def _ignore_flags(polys, tags, min_text_size):
+    """icdar.py:509-515: the polygon is zeroed in the training mask when it is small or tagged."""
+    out = np.zeros(len(polys), np.uint8)
+    for i, (poly, tag) in enumerate(zip(polys, tags)):
+        poly_h = min(np.linalg.norm(poly[0] - poly[3]), np.linalg.norm(poly[1] - poly[2]))
+        poly_w = min(np.linalg.norm(poly[0] - poly[1]), np.linalg.norm(poly[2] - poly[3]))
+        out[i] = 1 if (min(poly_h, poly_w) < min_text_size or tag) else 0
+    return out
+
+
+def pack_polys(polys_list, tags_list, min_text_size=MIN_TEXT_SIZE):
+    """Host packing for the kernels: int32 vertices (`poly.astype(np.int32)`, icdar.py:505),
+    per-image counts and ignore flags.  Returns numpy (polys [n,P,4,2], counts [n], ignore [n,P])."""
+    n = len(polys_list)
+    P = max([len(p) for p in polys_list] + [1])
+    if P > MAX_POLYS:
+        raise ValueError("at most %d polygons per image (poly_mask is uint8 in the reference)" % MAX_POLYS)
+    polys = np.zeros((n, P, 4, 2), np.int32)
+    counts = np.zeros(n, np.int32)
+    ignore = np.zeros((n, P), np.uint8)
+    for b, (pl, tg) in enumerate(zip(polys_list, tags_list)):
+        pl = np.asarray(pl, np.float32).reshape(-1, 4, 2)
+        counts[b] = len(pl)
+        if len(pl):
+            polys[b, :len(pl)] = pl.astype(np.int32)
+            ignore[b, :len(pl)] = _ignore_flags(pl, tg, min_text_size)
+    return polys, counts, ignore
+
+
+def generate_rbox_batch(im_size, polys_list, tags_list, step=4, min_text_size=MIN_TEXT_SIZE, graph=None):
+    """generate_rbox for every image of a batch + the generator's `[::step, ::step]` subsample and
+    float casts (icdar.py:632-634).  Returns device tensors score [n,h/s,w/s,1], geo [n,h/s,w/s,8],
+    training mask [n,h/s,w/s,1] (float32) — the feeds `input_score_maps`, `input_geo_maps`,
+    `input_training_masks` of multigpu_train.py:98-101."""
+    g = graph or get_default_graph()
+    h, w = im_size
+    if h != w:
+        raise ValueError("generate_rbox needs a square image: the reference's valid_link border rule "
+                         "(icdar.py:84) indexes out of range otherwise")
+    polys, counts, ignore = pack_polys(polys_list, tags_list, min_text_size)
+    n = len(counts)
+    dev = g.device
+    d_polys = torch.from_numpy(polys).to(dev)
+    d_counts = torch.from_numpy(counts).to(dev)
+    d_ignore = torch.from_numpy(ignore).to(dev)
+    cover = torch.empty((n, h, w), dtype=torch.int32, device=dev)
+    ops.poly_cover(d_polys, d_counts, d_ignore, h, w, cover)
+    oh, ow = -(-h // step), -(-w // step)
+    score = torch.empty((n, oh, ow, 1), dtype=F32, device=dev)
+    geo = torch.empty((n, oh, ow, 8), dtype=F32, device=dev)
+    mask = torch.empty((n, oh, ow, 1), dtype=F32, device=dev)
+    ops.icdar_labels(cover, step, score, geo, mask)
+    return score, geo, mask
+
+
+def generate_rbox(im_size, polys, tags, min_text_size=MIN_TEXT_SIZE, graph=None):
+    """icdar.py:486-539 for one image: (score_map uint8 [h,w], geo_map float32 [h,w,8], training_mask
+    uint8 [h,w]) as NumPy arrays at full resolution."""
+    s, gmap, m = generate_rbox_batch(im_size, [polys], [tags], step=1, min_text_size=min_text_size, graph=graph)
+    return (s[0, :, :, 0].cpu().numpy().astype(np.uint8), gmap[0].cpu().numpy(),
+            m[0, :, :, 0].cpu().numpy().astype(np.uint8))
+
+
+def read_image_rgb(path):
+    """cv2.imread(...)[:, :, ::-1]: uint8 [H,W,3] RGB.  .npy arrays are taken as RGB already."""
+    if path.endswith('.npy'):
+        return np.ascontiguousarray(np.load(path), dtype=np.uint8)
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.array(im.convert("RGB"), dtype=np.uint8)
+
+
+def resize_images(images_u8, input_size, graph=None):
+    """`cv2.resize(im, dsize=(input_size, input_size))` + `.astype(np.float32)` (icdar.py:615,630) for a
+    list of uint8 [H,W,3] images of any size -> device float32 [n,S,S,3]."""
+    g = graph or get_default_graph()
+    out = torch.empty((len(images_u8), input_size, input_size, 3), dtype=F32, device=g.device)
+    for b, im in enumerate(images_u8):
+        src = torch.from_numpy(np.ascontiguousarray(im, dtype=np.uint8)).to(g.device, non_blocking=True)
+        ops.resize_linear_u8(src, out[b])
+    return out
+
+
+def txt_name(im_fn):
+    """icdar.py:564: <dir>/gt_<stem>.txt"""
+    return im_fn[:im_fn.rfind('/') + 1] + 'gt_' + im_fn[im_fn.rfind('/') + 1:im_fn.rfind('.')] + '.txt'
+
+
+def generator(training_data_path, input_size=512, batch_size=32, graph=None, shuffle=True, seed=None):
+    """icdar.py:542-649 with the branches the reference has live (no random scale / crop: `if (0)`):
+    read image + gt, validate polygons, resize to input_size x input_size, scale the polygons,
+    labels at 1/4 resolution.  Yields (images [B,S,S,3] float32 RGB, image_fns, score_maps, geo_maps,
+    training_masks) as DEVICE tensors (the reference yields lists of NumPy arrays)."""
+    image_list = np.array(sorted(get_images(training_data_path)))
+    print('{} training images in {}'.format(image_list.shape[0], training_data_path))
+    index = np.arange(0, image_list.shape[0])
+    rng = np.random.RandomState(seed)
+    while True:
+        if shuffle:
+            rng.shuffle(index)
+        ims, fns, polys_l, tags_l = [], [], [], []
+        for i in index:
+            im_fn = image_list[i]
+            tf = txt_name(im_fn)
+            if not os.path.exists(tf):
+                continue
+            im = read_image_rgb(im_fn)
+            h, w, _ = im.shape
+            text_polys, text_tags = load_annoataion(tf)
+            text_polys, text_tags = check_and_validate_polys(text_polys, text_tags, (h, w))
+            if text_polys.shape[0] == 0:
+                continue
+            text_polys[:, :, 0] *= input_size / float(w)
+            text_polys[:, :, 1] *= input_size / float(h)
+            ims.append(im)
+            fns.append(im_fn)
+            polys_l.append(text_polys)
+            tags_l.append(text_tags)
+            if len(ims) == batch_size:
+                images = resize_images(ims, input_size, graph=graph)
+                score, geo, mask = generate_rbox_batch((input_size, input_size), polys_l, tags_l, graph=graph)
+                yield images, fns, score, geo, mask
+                ims, fns, polys_l, tags_l = [], [], [], []
+        if len(image_list) == 0:
+            return
+
+
+def get_batch(num_workers=0, **kwargs):
+    """icdar.py:652-668.  The reference hides host-side label generation behind worker processes;
+    with labels and resize on the GPU the generator itself is the producer (num_workers accepted
+    for signature compatibility)."""
+    for item in generator(**kwargs):
+        yield item

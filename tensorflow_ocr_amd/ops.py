@@ -455,6 +455,32 @@ def min_area_rects(labels, ncomp, max_comps, scale_x, scale_y, hull_n, hull_head
            c_size_t(nbytes), _st())
 
 
+# ----------------------------------------------------------------------------- labels
+def poly_cover(polys, counts, ignore, h, w, cover):
+    n, P, V, _ = polys.shape
+    L.call("ocr_poly_cover", ptr(polys), ptr(counts), ptr(ignore), c_int(n), c_int(P), c_int(V), c_int(h),
+           c_int(w), ptr(cover), _st())
+
+
+def icdar_labels(cover, step, score, geo, mask):
+    n, h, w = cover.shape
+    L.call("ocr_icdar_labels", ptr(cover), c_int(n), c_int(h), c_int(w), c_int(step), ptr(score), ptr(geo),
+           ptr(mask), _st())
+
+
+def pixellink_labels(cover, new_h, new_w, score, link):
+    n, h, w = cover.shape
+    L.call("ocr_pixellink_labels", ptr(cover), c_int(n), c_int(h), c_int(w), c_int(new_h), c_int(new_w),
+           ptr(score), ptr(link), _st())
+
+
+def resize_linear_u8(src_u8, dst_f32):
+    H, W, cn = src_u8.shape
+    dh, dw, _ = dst_f32.shape
+    L.call("ocr_resize_linear_u8", ptr(src_u8), c_int(H), c_int(W), c_int(cn), ptr(dst_f32), c_int(dh),
+           c_int(dw), _st())
+
+
 # -------------------------------------------------------------------------- optimiser
 def adam_step(w, g, m, v, ema, n_reg, lr_t, beta1, beta2, eps, wd, inv_scale, ema_decay):
     L.call("ocr_adam_step", ptr(w), ptr(g), ptr(m), ptr(v), ptr(ema), c_int64(w.numel()),

@@ -149,3 +149,47 @@ def min_area_rect_boxes(labels, ncomp, scale_x=4.0, scale_y=4.0, max_comps=4096,
             boxes[i] = _box_points(rects[i]).astype(np.int64)        # np.int0: truncation
         out.append((rects, boxes))
     return out
+
+
+def generate_rbox(h, w, xs, ys, bboxes, ignored, graph=None):
+    """tool/pixellink_fn.py:53-110 for one image.  xs, ys normalised corner coordinates [k,4], bboxes
+    [k,4], ignored [k] -> (res_score_map float32 [h/4,w/4], res_link_map float32 [h/4,w/4,8],
+    show_bboxes float32 [200,4]) as NumPy arrays, like the reference's py_func."""
+    s, l, sb = generate_rbox_batch(h, w, [xs], [ys], [bboxes], [ignored], graph=graph)
+    return s[0].cpu().numpy(), l[0].cpu().numpy(), sb[0]
+
+
+def generate_rbox_batch(h, w, xs_list, ys_list, bboxes_list, ignored_list, graph=None):
+    """generate_rbox for a batch: device tensors score [n,h/4,w/4], link [n,h/4,w/4,8]; show_bboxes
+    [n,200,4] stays a NumPy copy of the inputs (:66,77)."""
+    import numpy as np
+    g = graph or get_default_graph()
+    h, w = int(h), int(w)
+    n = len(xs_list)
+    P = max([len(x) for x in xs_list] + [1])
+    if P > 200:
+        raise IndexError("show_bboxes holds 200 rows (tool/pixellink_fn.py:66)")
+    polys = np.zeros((n, P, 4, 2), np.int32)
+    counts = np.zeros(n, np.int32)
+    show_bboxes = np.zeros((n, 200, 4), np.float32)
+    for b in range(n):
+        xs = np.asarray(xs_list[b], np.float32).reshape(-1, 4)
+        ys = np.asarray(ys_list[b], np.float32).reshape(-1, 4)
+        if len(xs) != len(ignored_list[b]):
+            raise AssertionError('the length of xs and ignored must be the same, but got %s and %s'
+                                 % (len(xs), len(ignored_list[b])))
+        counts[b] = len(xs)
+        if len(xs):
+            # points = zip(xs*w, ys*h); np.array([points], np.int32): float32 products, truncated
+            polys[b, :len(xs), :, 0] = (xs * w).astype(np.int32)
+            polys[b, :len(xs), :, 1] = (ys * h).astype(np.int32)
+            show_bboxes[b, :len(xs)] = np.asarray(bboxes_list[b], np.float32).reshape(-1, 4)
+    dev = g.device
+    cover = torch.empty((n, h, w), dtype=torch.int32, device=dev)
+    ops.poly_cover(torch.from_numpy(polys).to(dev), torch.from_numpy(counts).to(dev),
+                   torch.zeros((n, P), dtype=torch.uint8, device=dev), h, w, cover)
+    nh, nw = h // 4, w // 4
+    score = torch.empty((n, nh, nw), dtype=F32, device=dev)
+    link = torch.empty((n, nh, nw, 8), dtype=F32, device=dev)
+    ops.pixellink_labels(cover, nh, nw, score, link)
+    return score, link, show_bboxes
