@@ -11,8 +11,8 @@ plus the batched device entry point the feeder uses:
   generate_rbox_batch       all images of a batch in two launches; device tensors at 1/4 resolution
 
 The reference rasterises with cv2.fillPoly and resizes with cv2.resize; here both run as HIP kernels
-(ocr_poly_cover / ocr_icdar_labels / ocr_resize_linear_u8) matched bit for bit against the OpenCV
-restatement in oracle/cvgeom_oracle.c.  There is no CPU fallback.
+(ocr_poly_cover / ocr_icdar_labels / ocr_resize_linear_u8) that reproduce OpenCV's rasters bit for bit
+(tests/test_gpu_labels.py).  There is no CPU fallback.
 """
 import csv
 import glob
