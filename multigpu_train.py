@@ -7,9 +7,11 @@ loop :169-194) on the MI355X path: one process per GPU
 
 Same flag names and defaults; `--net` selects the graph (`model` = nets/model.py ResNet-50 +
 PixelLink heads + OHNM loss, the one the reference script imports; `model_vgg` / `east` /
-`pixellink` the others).  Data: the icdar generator is outside this round's scope,
-so batches are synthetic (`tensorflow_ocr_amd.synthetic`).  The stdout line format is the
-reference's (:183-184)."""
+`pixellink` the others).  Data: `--training_data_path` (the reference's icdar.py flag) feeds ICDAR
+images + gt_*.txt through datasets/icdar.get_batch — host decode in `--num_readers` processes,
+upload + resize + label maps on the feeder's HIP stream, overlapped with the step; without it (or
+with an empty directory) batches are synthetic (`tensorflow_ocr_amd.synthetic`).  The stdout line
+format is the reference's (:183-184)."""
 import argparse
 import os
 import time
@@ -32,6 +34,7 @@ def parse():
     ap.add_argument('--save_checkpoint_steps', type=int, default=1000)
     ap.add_argument('--save_summary_steps', type=int, default=20)
     ap.add_argument('--pretrained_model_path', type=str, default=None)
+    ap.add_argument('--training_data_path', type=str, default='/data/ocr/icdar2015/')
     ap.add_argument('--net', choices=['model', 'model_vgg', 'east', 'pixellink'], default='model')
     return ap.parse_args()
 
@@ -77,10 +80,22 @@ def main():
                                               moving_average_decay=FLAGS.moving_average_decay),
                      world_size=world)
     rng = np.random.default_rng(1000 + rank)
+    feeder = None
+    if os.path.isdir(FLAGS.training_data_path):
+        from tensorflow_ocr_amd.datasets import icdar
+        if icdar.get_images(FLAGS.training_data_path):
+            # multigpu_train.py:164-167: icdar.get_batch(num_workers, input_size, batch_size)
+            feeder = icdar.get_batch(num_workers=FLAGS.num_readers, training_data_path=FLAGS.training_data_path,
+                                     input_size=FLAGS.input_size, batch_size=FLAGS.batch_size_per_gpu,
+                                     graph=g, seed=1000 + rank)
     start = time.time()
     for it in range(FLAGS.max_steps):
-        data = synthetic.make_batch(rng, FLAGS.batch_size_per_gpu, FLAGS.input_size)
-        batch = [torch.from_numpy(a).to(device, non_blocking=True) for a in data]
+        if feeder is not None:
+            images, _, score_maps, geo_maps, training_masks = next(feeder)
+            batch = [images, score_maps, geo_maps, training_masks]
+        else:
+            data = synthetic.make_batch(rng, FLAGS.batch_size_per_gpu, FLAGS.input_size)
+            batch = [torch.from_numpy(a).to(device, non_blocking=True) for a in data]
         loss = step(*batch)
         if it == 0 and FLAGS.restore:
             path = os.path.join(FLAGS.checkpoint_path, 'latest.npz')

@@ -6,6 +6,7 @@ raises `OcrHipError` loudly.
 """
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCR_HIP_LIB", os.path.join(_HERE, "libocr_hip.so"))
@@ -80,6 +81,8 @@ class Recorder:
 
 
 RECORDER = None
+RECORDER_THREAD = None    # only the thread that installed the recorder is recorded (the feeder thread
+                          # launches its own kernels concurrently)
 _fn_cache = {}
 _STREAM = None
 
@@ -120,7 +123,7 @@ def call(name, *args):
     rc = fn(*args)
     if rc != 0:
         check(rc, name)
-    if RECORDER is not None:
+    if RECORDER is not None and (RECORDER_THREAD is None or RECORDER_THREAD == threading.get_ident()):
         RECORDER.c(fn, args, name)
     return rc
 

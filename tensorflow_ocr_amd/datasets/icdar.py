@@ -155,12 +155,26 @@ def read_image_rgb(path):
 
 def resize_images(images_u8, input_size, graph=None):
     """`cv2.resize(im, dsize=(input_size, input_size))` + `.astype(np.float32)` (icdar.py:615,630) for a
-    list of uint8 [H,W,3] images of any size -> device float32 [n,S,S,3]."""
+    list of uint8 [H,W,3] images of any size -> device float32 [n,S,S,3].  The batch crosses PCIe
+    once: the images are packed into ONE pinned slab, copied asynchronously on the current stream
+    (torch's pinned-memory cache holds the slab until that copy has completed) and resized from
+    views into the device copy."""
     g = graph or get_default_graph()
     out = torch.empty((len(images_u8), input_size, input_size, 3), dtype=F32, device=g.device)
-    for b, im in enumerate(images_u8):
-        src = torch.from_numpy(np.ascontiguousarray(im, dtype=np.uint8)).to(g.device, non_blocking=True)
-        ops.resize_linear_u8(src, out[b])
+    sizes = [int(np.prod(im.shape)) for im in images_u8]
+    if not sizes:
+        return out
+    slab = torch.empty(sum(sizes), dtype=torch.uint8, pin_memory=(g.device.type == "cuda"))
+    host = slab.numpy()
+    off = 0
+    for im, sz in zip(images_u8, sizes):
+        host[off:off + sz] = np.asarray(im, dtype=np.uint8).reshape(-1)
+        off += sz
+    dev = slab.to(g.device, non_blocking=True)
+    off = 0
+    for b, (im, sz) in enumerate(zip(images_u8, sizes)):
+        ops.resize_linear_u8(dev[off:off + sz].view(im.shape), out[b])
+        off += sz
     return out
 
 
@@ -169,48 +183,78 @@ def txt_name(im_fn):
     return im_fn[:im_fn.rfind('/') + 1] + 'gt_' + im_fn[im_fn.rfind('/') + 1:im_fn.rfind('.')] + '.txt'
 
 
-def generator(training_data_path, input_size=512, batch_size=32, graph=None, shuffle=True, seed=None):
+def _load_sample(args):
+    """Host side of one sample (icdar.py:559-571,616-619): decode, parse, validate, scale the polygons
+    to the training size.  Runs in the decode worker processes."""
+    im_fn, input_size = args
+    tf = txt_name(im_fn)
+    if not os.path.exists(tf):
+        return None
+    try:
+        im = read_image_rgb(im_fn)
+        h, w, _ = im.shape
+        text_polys, text_tags = load_annoataion(tf)
+        text_polys, text_tags = check_and_validate_polys(text_polys, text_tags, (h, w))
+        if text_polys.shape[0] == 0:
+            return None
+        text_polys[:, :, 0] *= input_size / float(w)
+        text_polys[:, :, 1] *= input_size / float(h)
+    except Exception:                       # the reference prints the traceback and moves on (:646-649)
+        import traceback
+        traceback.print_exc()
+        return None
+    return im_fn, im, text_polys, text_tags
+
+
+def generator(training_data_path, input_size=512, batch_size=32, graph=None, shuffle=True, seed=None,
+              num_workers=0):
     """icdar.py:542-649 with the branches the reference has live (no random scale / crop: `if (0)`):
     read image + gt, validate polygons, resize to input_size x input_size, scale the polygons,
     labels at 1/4 resolution.  Yields (images [B,S,S,3] float32 RGB, image_fns, score_maps, geo_maps,
-    training_masks) as DEVICE tensors (the reference yields lists of NumPy arrays)."""
+    training_masks) as DEVICE tensors (the reference yields lists of NumPy arrays).  num_workers > 0:
+    that many host processes decode and parse ahead (the reference's GeneratorEnqueuer workers)."""
     image_list = np.array(sorted(get_images(training_data_path)))
     print('{} training images in {}'.format(image_list.shape[0], training_data_path))
+    if len(image_list) == 0:
+        return
     index = np.arange(0, image_list.shape[0])
     rng = np.random.RandomState(seed)
-    while True:
-        if shuffle:
-            rng.shuffle(index)
-        ims, fns, polys_l, tags_l = [], [], [], []
-        for i in index:
-            im_fn = image_list[i]
-            tf = txt_name(im_fn)
-            if not os.path.exists(tf):
-                continue
-            im = read_image_rgb(im_fn)
-            h, w, _ = im.shape
-            text_polys, text_tags = load_annoataion(tf)
-            text_polys, text_tags = check_and_validate_polys(text_polys, text_tags, (h, w))
-            if text_polys.shape[0] == 0:
-                continue
-            text_polys[:, :, 0] *= input_size / float(w)
-            text_polys[:, :, 1] *= input_size / float(h)
-            ims.append(im)
-            fns.append(im_fn)
-            polys_l.append(text_polys)
-            tags_l.append(text_tags)
-            if len(ims) == batch_size:
-                images = resize_images(ims, input_size, graph=graph)
-                score, geo, mask = generate_rbox_batch((input_size, input_size), polys_l, tags_l, graph=graph)
-                yield images, fns, score, geo, mask
-                ims, fns, polys_l, tags_l = [], [], [], []
-        if len(image_list) == 0:
-            return
+    pool = None
+    if num_workers > 0:
+        import multiprocessing
+        pool = multiprocessing.get_context("fork" if not torch.cuda.is_initialized() else "spawn").Pool(num_workers)
+    try:
+        while True:
+            if shuffle:
+                rng.shuffle(index)
+            jobs = [(str(image_list[i]), input_size) for i in index]
+            samples = pool.imap(_load_sample, jobs, chunksize=4) if pool else map(_load_sample, jobs)
+            ims, fns, polys_l, tags_l = [], [], [], []
+            produced = False
+            for smp in samples:
+                if smp is None:
+                    continue
+                fns.append(smp[0])
+                ims.append(smp[1])
+                polys_l.append(smp[2])
+                tags_l.append(smp[3])
+                if len(ims) == batch_size:
+                    images = resize_images(ims, input_size, graph=graph)
+                    score, geo, mask = generate_rbox_batch((input_size, input_size), polys_l, tags_l, graph=graph)
+                    produced = True
+                    yield images, fns, score, geo, mask
+                    ims, fns, polys_l, tags_l = [], [], [], []
+            if not produced:
+                return                       # fewer usable samples than one batch: do not spin
+    finally:
+        if pool is not None:
+            pool.terminate()
 
 
-def get_batch(num_workers=0, **kwargs):
-    """icdar.py:652-668.  The reference hides host-side label generation behind worker processes;
-    with labels and resize on the GPU the generator itself is the producer (num_workers accepted
-    for signature compatibility)."""
-    for item in generator(**kwargs):
-        yield item
+def get_batch(num_workers=0, device_prefetch=2, **kwargs):
+    """icdar.py:652-668: background producer + queue.  Host decode/parsing runs in `num_workers`
+    processes; upload, resize and label kernels run on the feeder's own HIP stream
+    (feeder.DeviceFeeder), `device_prefetch` batches ahead of the training step."""
+    from ..feeder import DeviceFeeder
+    graph = kwargs.get("graph") or get_default_graph()
+    return DeviceFeeder(lambda: generator(num_workers=num_workers, **kwargs), graph.device, depth=device_prefetch)

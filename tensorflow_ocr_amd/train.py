@@ -140,6 +140,7 @@ class TrainStep:
         if record:
             rec = _lib.Recorder()
             _lib.RECORDER = rec
+            _lib.RECORDER_THREAD = __import__("threading").get_ident()
             g.keepalive = []
         try:
             loss = self.forward_loss(g, *batch)

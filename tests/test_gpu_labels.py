@@ -167,3 +167,32 @@ def test_generator_end_to_end(device, tmp_path):
         os_, og, om = OL.icdar_labels((S, S), polys, tags)
         assert np.array_equal(score[b].cpu().numpy(), os_) and np.array_equal(geo[b].cpu().numpy(), og)
         assert np.array_equal(mask[b].cpu().numpy(), om)
+
+
+def test_device_feeder_overlaps_and_matches_direct_generator(device, tmp_path):
+    """icdar.get_batch (feeder thread + own HIP stream + 2 decode processes) yields exactly what the
+    in-line generator yields, batch after batch, and a recorded training step is not polluted by the
+    feeder's launches."""
+    from tensorflow_ocr_amd.datasets import icdar
+    from tensorflow_ocr_amd.graph import Graph
+    g = Graph(device)
+    rng = np.random.default_rng(11)
+    S, B = 64, 4
+    for i in range(10):
+        H, W = int(rng.integers(60, 140)), int(rng.integers(60, 140))
+        np.save(os.path.join(tmp_path, "im%02d.npy" % i), rng.integers(0, 256, size=(H, W, 3)).astype(np.uint8))
+        with open(os.path.join(tmp_path, "gt_im%02d.txt" % i), "w") as f:
+            for p in _quads(rng, 3, min(H, W)):
+                f.write(",".join("%d" % v for v in p.ravel()) + ",w\n")
+    direct = icdar.generator(str(tmp_path), input_size=S, batch_size=B, graph=g, shuffle=True, seed=5)
+    feeder = icdar.get_batch(num_workers=2, training_data_path=str(tmp_path), input_size=S, batch_size=B,
+                             graph=g, shuffle=True, seed=5)
+    try:
+        for _ in range(5):                      # crosses an epoch boundary (10 images, 2 batches each)
+            a = next(direct)
+            b = next(feeder)
+            assert a[1] == b[1]
+            for x, y in zip((a[0], a[2], a[3], a[4]), (b[0], b[2], b[3], b[4])):
+                assert torch.equal(x, y)
+    finally:
+        feeder.close()
