@@ -34,6 +34,10 @@ enum {
 
 int ocr_abi_version(void);
 const char* ocr_status_string(int status);
+/* "f16" (libocr_hip.so: IEEE half storage, f16 MFMA) or "bf16" (libocr_hip_bf16.so: the same sources
+ * built with bfloat16 storage and bf16 MFMA — BASELINE.json configs[3] "ResNet-v1-50 ... bf16").  The
+ * `_f16` suffix of the entry points below names the 16-bit storage slot in both libraries. */
+const char* ocr_storage_dtype(void);
 
 /* ------------------------------------------------------------------------- *
  * Convolution (slim.conv2d: nets/vgg.py:14-39, nets/resnet_v1.py:97-105,193,

@@ -14,16 +14,20 @@ tests/test_oracle.py.
 Two arithmetic modes:
   * fp32 (default): every tensor f32 — the reference's arithmetic.
   * mixed=True: emulates the device pipeline's storage precision — conv inputs/outputs,
-    activations and activation gradients are rounded to IEEE f16 at exactly the points where the
-    HIP path stores f16 tensors (reductions, BN statistics and parameters stay f32/f64).
+    activations and activation gradients are rounded to the 16-bit storage type (IEEE f16, or
+    bfloat16 when the environment says OCR_STORAGE=bf16, the libocr_hip_bf16.so build) at exactly
+    the points where the HIP path stores 16-bit tensors (reductions, BN statistics and parameters
+    stay f32/f64).
 """
 import math
+import os
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 torch.set_grad_enabled(True)
+STORAGE = torch.bfloat16 if os.environ.get("OCR_STORAGE", "f16") == "bf16" else torch.float16
 
 
 # ----------------------------------------------------------------------------- rounding
@@ -31,7 +35,7 @@ class _Q(torch.autograd.Function):
     """forward: round to f16 storage; backward: straight through."""
     @staticmethod
     def forward(ctx, x):
-        return x.half().float()
+        return x.to(STORAGE).float()
 
     @staticmethod
     def backward(ctx, g):
@@ -46,7 +50,7 @@ class _QG(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g.half().float()
+        return g.to(STORAGE).float()
 
 
 def q(x, mixed):

@@ -7,6 +7,10 @@
   decode     configs[4]: PixelLink inference 1024x1024 batch 16, then pixel/link softmax + link-CC
              decode, and locality-aware NMS on synthetic quadrangle lists
 
+  pipeline   SURVEY 8f-1/2/4: label maps for 32 x 512^2 (16 quads each), cv2.resize of 32 720x1280
+             images to 512^2, oriented boxes of the decode's components; with the CPU restatement timed
+             beside them (baseline only)
+
 Prints one JSON line per config.  Same timing discipline as bench.py (resident inputs, warm-up,
 synchronize on both sides).  Dev/measurement tool: not part of the driver contract."""
 import argparse
@@ -149,6 +153,121 @@ def main():
                           "decode_algorithmic_GBps": round(px * 76 / dt_dec / 1e9, 1), "components": ncomp,
                           "lanms_ms_per_batch": round(dt_nms * 1e3, 3),
                           "lanms_boxes_per_sec": round(n * K / dt_nms, 0)}), flush=True)
+
+
+    if "pipeline" in which:
+        pipeline_config()
+
+
+def dev_ms(fn, warmup=2, steps=10):
+    """Device time of fn() from HIP events on the current stream."""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def pipeline_config():
+    from tensorflow_ocr_amd import ops
+    from tensorflow_ocr_amd.datasets import icdar
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.tool import pixellink_fn
+    dev = torch.device("cuda", 0)
+    g = Graph(dev)
+    rng = np.random.default_rng(9)
+    n, S, K = 32, 512, 16
+
+    def quads(k, size):
+        out = []
+        for _ in range(k):
+            c = rng.uniform(20, size - 20, 2)
+            w, h = rng.uniform(30, size / 3), rng.uniform(10, size / 10)
+            th = rng.uniform(-0.5, 0.5)
+            R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+            out.append(np.clip((np.array([[-w, -h], [w, -h], [w, h], [-w, h]]) / 2) @ R.T + c, 0, size - 1))
+        return np.array(out, np.float32)
+    polys_l = [quads(K, S) for _ in range(n)]
+    tags_l = [rng.uniform(size=K) < 0.2 for _ in range(n)]
+    # --- label maps
+    polys, counts, ignore = icdar.pack_polys(polys_l, tags_l)
+    d_p, d_c, d_i = [torch.from_numpy(a).to(dev) for a in (polys, counts, ignore)]
+    cover = torch.empty((n, S, S), dtype=torch.int32, device=dev)
+    score = torch.empty((n, S // 4, S // 4, 1), device=dev)
+    geo = torch.empty((n, S // 4, S // 4, 8), device=dev)
+    mask = torch.empty((n, S // 4, S // 4, 1), device=dev)
+    ms_cover = dev_ms(lambda: ops.poly_cover(d_p, d_c, d_i, S, S, cover))
+    ms_lab = dev_ms(lambda: ops.icdar_labels(cover, 4, score, geo, mask))
+    t_e2e = timed(lambda: icdar.generate_rbox_batch((S, S), polys_l, tags_l, graph=g), 2, 10)
+    lab_bytes = n * (S * S * 4 + (S // 4) ** 2 * (9 * 4 + 40))       # cover write + 9 neighbour reads + 10 f32 out
+    # --- resize 720x1280 -> 512x512
+    ims = [rng.integers(0, 256, size=(720, 1280, 3)).astype(np.uint8) for _ in range(n)]
+    src = torch.from_numpy(ims[0]).to(dev)
+    dst = torch.empty((S, S, 3), device=dev)
+    ms_resize = dev_ms(lambda: ops.resize_linear_u8(src, dst)) * n
+    t_resize_e2e = timed(lambda: icdar.resize_images(ims, S, graph=g), 1, 5)
+    # --- oriented boxes of decoded components (16 x 256^2 maps with rotated text-like blobs)
+    nb, hq = 16, 256
+    lab = np.zeros((nb, hq, hq), np.int32)
+    ncomp = np.zeros(nb, np.int32)
+    ys, xs = np.mgrid[0:hq, 0:hq]
+    for b in range(nb):
+        k = 0
+        for _ in range(24):
+            cy, cx = rng.uniform(10, hq - 10, 2)
+            a, bb, th = rng.uniform(8, 40), rng.uniform(2, 7), rng.uniform(-0.6, 0.6)
+            u = (xs - cx) * np.cos(th) + (ys - cy) * np.sin(th)
+            v = -(xs - cx) * np.sin(th) + (ys - cy) * np.cos(th)
+            m = (np.abs(u) <= a) & (np.abs(v) <= bb) & (lab[b] == 0)
+            if m.sum() > 10:
+                k += 1
+                lab[b][m] = k
+        ncomp[b] = k
+    d_lab, d_nc = torch.from_numpy(lab).to(dev), torch.from_numpy(ncomp).to(dev)
+    hn = torch.zeros((nb, 64), dtype=torch.int32, device=dev)
+    hd = torch.zeros((nb, 64, 4), dtype=torch.int32, device=dev)
+    cal = torch.zeros((nb, 64, 6), device=dev)
+    ms_mar = dev_ms(lambda: ops.min_area_rects(d_lab, d_nc, 64, 4.0, 4.0, hn, hd, cal, g.workspace()))
+    t_boxes_e2e = timed(lambda: pixellink_fn.min_area_rect_boxes(d_lab, d_nc, 4.0, 4.0, max_comps=64, graph=g), 1, 5)
+    # --- CPU restatement beside it (bounded samples; baseline only)
+    from oracle import cvgeom as C
+    from oracle import labels as OL
+    t0 = time.perf_counter()
+    OL.icdar_labels((S, S), polys_l[0], tags_l[0])
+    cpu_lab = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    C.resize_linear_u8(ims[0], S, S)
+    cpu_resize = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for i in range(1, ncomp[0] + 1):
+        xy = np.argwhere(lab[0] == i)
+        show = xy.copy()
+        show[:, 0] = xy[:, 1] * 4.0
+        show[:, 1] = xy[:, 0] * 4.0
+        C.box_points(C.min_area_rect(show)[0])
+    cpu_boxes = time.perf_counter() - t0
+    print(json.dumps({
+        "config": "input pipeline + boxes (SURVEY 8f): 32 x 512^2 labels (16 quads), 32 x 720x1280 -> 512^2 resize, 16 x 256^2 boxes",
+        "labels_cover_ms": round(ms_cover, 4), "labels_maps_ms": round(ms_lab, 4),
+        "labels_GBps": round(lab_bytes / ((ms_cover + ms_lab) * 1e-3) / 1e9, 1),
+        "labels_images_per_sec_kernels": round(n / ((ms_cover + ms_lab) * 1e-3), 0),
+        "labels_e2e_ms_incl_host_pack": round(t_e2e * 1e3, 3),
+        "resize_ms_per_32": round(ms_resize, 4),
+        "resize_GBps": round(n * (720 * 1280 * 3 + S * S * 12) / (ms_resize * 1e-3) / 1e9, 1),
+        "resize_e2e_ms_incl_pcie": round(t_resize_e2e * 1e3, 3),
+        "resize_e2e_pcie_GBps": round(n * 720 * 1280 * 3 / t_resize_e2e / 1e9, 1),
+        "boxes_kernels_ms": round(ms_mar, 4), "boxes_components": int(ncomp.sum()),
+        "boxes_e2e_ms_incl_host_format": round(t_boxes_e2e * 1e3, 3),
+        "cpu_baseline": {"kind": "port", "cores": 1,
+                         "labels_images_per_sec": round(1 / cpu_lab, 2), "resize_images_per_sec": round(1 / cpu_resize, 1),
+                         "boxes_components_per_sec": round(int(ncomp[0]) / cpu_boxes, 0),
+                         "sample": "one 512^2 image of labels (python loops over the C fillPoly), one 720x1280 resize (C), one 256^2 map of boxes (C)"}}),
+        flush=True)
 
 
 if __name__ == "__main__":

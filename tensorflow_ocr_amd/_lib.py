@@ -9,7 +9,12 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("OCR_HIP_LIB", os.path.join(_HERE, "libocr_hip.so"))
+# 16-bit storage type of activations / packed weights, process wide: "f16" (default) or "bf16"
+# (OCR_STORAGE=bf16 selects libocr_hip_bf16.so, the same sources built with bfloat16 storage + bf16 MFMA)
+STORAGE = os.environ.get("OCR_STORAGE", "f16")
+if STORAGE not in ("f16", "bf16"):
+    raise ValueError("OCR_STORAGE must be f16 or bf16, got %r" % STORAGE)
+LIB_PATH = os.environ.get("OCR_HIP_LIB", os.path.join(_HERE, "libocr_hip.so" if STORAGE == "f16" else "libocr_hip_bf16.so"))
 
 
 class OcrHipError(RuntimeError):
@@ -50,6 +55,9 @@ def load():
     lib.ocr_status_string.restype = ctypes.c_char_p
     lib.ocr_status_string.argtypes = [ctypes.c_int]
     lib.ocr_abi_version.restype = ctypes.c_int
+    lib.ocr_storage_dtype.restype = ctypes.c_char_p
+    if lib.ocr_storage_dtype().decode() != STORAGE:
+        raise OcrHipError("%s stores %s but OCR_STORAGE=%s" % (LIB_PATH, lib.ocr_storage_dtype().decode(), STORAGE))
     _lib = lib
     return lib
 

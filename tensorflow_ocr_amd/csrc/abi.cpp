@@ -1,7 +1,9 @@
 // ABI bookkeeping for libocr_hip.so (include/ocr_hip.h).
-#include "../../include/ocr_hip.h"
+#include "common.h"
 
 extern "C" int ocr_abi_version(void) { return OCR_ABI_VERSION; }
+
+extern "C" const char* ocr_storage_dtype(void) { return OCR_STORAGE_NAME; }
 
 extern "C" const char* ocr_status_string(int status) {
   switch (status) {

@@ -4,10 +4,27 @@
 #include <stdint.h>
 #include "../../include/ocr_hip.h"
 
+// 16-bit storage type of activations / packed weights / activation gradients.  The library is built
+// twice from the same sources: libocr_hip.so (IEEE half, the default product path) and
+// libocr_hip_bf16.so (-DOCR_BF16: bfloat16 storage + bf16 MFMA, BASELINE config "ResNet-50 bf16").
+// Entry points keep their `_f16` names in both: the suffix names the 16-bit storage slot.
+#ifdef OCR_BF16
+typedef __bf16 half_t;
+typedef __bf16 half2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 half4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 half8_t __attribute__((ext_vector_type(8)));
+#define OCR_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define OCR_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define OCR_STORAGE_NAME "bf16"
+#else
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+#define OCR_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define OCR_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define OCR_STORAGE_NAME "f16"
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

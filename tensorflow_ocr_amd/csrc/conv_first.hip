@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstP p, const half_t*
       half8_t b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ky][i], b, acc[i][t], 0, 0, 0);
+        acc[i][t] = OCR_MFMA_32x32x16(a[ky][i], b, acc[i][t], 0, 0, 0);
     }
   }
   __syncthreads();
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
       const int k0 = (kw * 8 + s) * 16;     // this wave's 16-pixel k-step
       half8_t a = tr_pair_f(patch + a_lane + k0 * PSTRF, 4 * PSTRF);
       half8_t b = tr_pair_f(dyt + b_lane + k0 * DSTRF, 4 * DSTRF);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+      acc = OCR_MFMA_32x32x16(a, b, acc, 0, 0, 0);
     }
   }
   // partial[blk][kw][27][cout]: the two K halves are separate partial rows

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
             for (int i = 0; i < AI; ++i)
 #pragma unroll
               for (int t = 0; t < TG; ++t)
-                acc[i][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[t], acc[i][t0 + t], 0, 0, 0);
+                acc[i][t0 + t] = OCR_MFMA_16x16x32(a[i], b[t], acc[i][t0 + t], 0, 0, 0);
             if constexpr (BN == 256) __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
         for (int i = 0; i < TCO; ++i)
 #pragma unroll
           for (int t = 0; t < TPX; ++t)
-            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[i], b0[t], acc[i][t], 0, 0, 0);
+            acc[i][t] = OCR_MFMA_32x32x16(a0[i], b0[t], acc[i][t], 0, 0, 0);
         if (ks + 1 < KSTEPS) {
           if (ks + 2 < KSTEPS) {
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
           for (int i = 0; i < TCO; ++i)
 #pragma unroll
             for (int t = 0; t < TPX; ++t)
-              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b1[t], acc[i][t], 0, 0, 0);
+              acc[i][t] = OCR_MFMA_32x32x16(a1[i], b1[t], acc[i][t], 0, 0, 0);
         }
       }
       } else if constexpr (!M16) {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
           for (int i = 0; i < TCO; ++i)
 #pragma unroll
             for (int t = 0; t < TPX; ++t)
-              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[t], acc[i][t], 0, 0, 0);
+              acc[i][t] = OCR_MFMA_32x32x16(a[i], b[t], acc[i][t], 0, 0, 0);
         }
       }
       wb ^= 1;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
         for (int i = 0; i < AI; ++i)
 #pragma unroll
           for (int t = 0; t < TG; ++t)
-            acc[i][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[t], acc[i][t0 + t], 0, 0, 0);
+            acc[i][t0 + t] = OCR_MFMA_16x16x32(a[i], b[t], acc[i][t0 + t], 0, 0, 0);
       }
     }
     buf ^= 1;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemP p, const half_t* _
         half8_t b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b, acc[i][t], 0, 0, 0);
+          acc[i][t] = OCR_MFMA_32x32x16(a[i], b, acc[i][t], 0, 0, 0);
       }
     }
   }
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemP p, const hal
         const int k0 = (kw * 8 + s) * 16;
         half8_t a = tr_pair_s(patch + a_lane + k0 * PSTRS, 4 * PSTRS);
         half8_t b = tr_pair_s(dyt + b_lane + k0 * DSTRS, 4 * DSTRS);
-        acc[ky] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ky], 0, 0, 0);
+        acc[ky] = OCR_MFMA_32x32x16(a, b, acc[ky], 0, 0, 0);
       }
     }
   }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgP p, const half_t* __restr
         if (t < ntaps) {
           const int ky = t / p.kw, kx = t - ky * p.kw;
           half8_t a = tr_pair(abase + ((ky * p.dil) * p.WT + kx * p.dil) * XSTR, a_half);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t], 0, 0, 0);
+          acc[t] = OCR_MFMA_32x32x16(a, b, acc[t], 0, 0, 0);
         }
       }
     }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
             half8_t a = tr_pair(at + i * 32, a_half);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], acc[t][i][j], 0, 0, 0);
+              acc[t][i][j] = OCR_MFMA_16x16x32(a, b[j], acc[t][i][j], 0, 0, 0);
           }
         }
       }

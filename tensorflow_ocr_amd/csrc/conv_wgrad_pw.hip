@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(PwP p, const half_t* __re
       for (int i = 0; i < AI; ++i)
 #pragma unroll
         for (int j = 0; j < AJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = OCR_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();

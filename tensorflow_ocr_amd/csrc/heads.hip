@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const half_t* __rest
   for (int k = 0; k < cin; k += 16) {
     half8_t a = *reinterpret_cast<const half8_t*>(wp + k);
     half8_t b = ok ? *reinterpret_cast<const half8_t*>(xp + k) : zero;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    acc = OCR_MFMA_32x32x16(a, b, acc, 0, 0, 0);
   }
   if (ok) {
 #pragma unroll
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_dgrad_kernel(const float* _
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       half8_t a = *reinterpret_cast<const half8_t*>(w_ck + (size_t)(ct * 32 + r) * 32 + ks * 16 + 8 * hh);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks], acc, 0, 0, 0);
+      acc = OCR_MFMA_32x32x16(a, b[ks], acc, 0, 0, 0);
     }
     if (ok) {
 #pragma unroll

@@ -11,9 +11,11 @@ import math
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import ops
 
-F16, F32 = torch.float16, torch.float32
+# F16 = the library's 16-bit storage dtype (IEEE half, or bfloat16 under OCR_STORAGE=bf16)
+F16, F32 = (torch.bfloat16 if L.STORAGE == "bf16" else torch.float16), torch.float32
 
 
 class Variable:

@@ -13,7 +13,7 @@ import torch
 from . import _lib as L
 from ._lib import ConvDesc, CONV_ACCUM_F16, CONV_BIAS, CONV_RELU, CONV_STATS, ptr
 
-F16, F32 = torch.float16, torch.float32
+F16, F32 = (torch.bfloat16 if L.STORAGE == "bf16" else torch.float16), torch.float32
 
 
 def _st():

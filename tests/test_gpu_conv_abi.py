@@ -6,7 +6,9 @@ convolution (torch CPU f32 on the same f16-rounded operands).
 
 Tolerance: operands are exact f16 values, products accumulate in f32 on both sides; the forward /
 dgrad outputs are rounded to f16 once (<= 2^-11 relative = 4.9e-4 of the tensor's max here 1e-3),
-weight gradients stay f32 (measured 1e-7..5e-7, bar 5e-6: accumulation order only)."""
+weight gradients stay f32 (measured 1e-7..5e-7, bar 5e-6: accumulation order only).  Under
+OCR_STORAGE=bf16 (libocr_hip_bf16.so, run by tests/test_gpu_bf16.py) the operands are exact bf16
+values and the single output rounding is 2^-8: bar 8e-3."""
 import ctypes
 
 import numpy as np
@@ -40,7 +42,8 @@ SHAPES = [
 
 
 def _h(x):
-    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+    """round to the library's 16-bit storage type"""
+    return torch.from_numpy(np.asarray(x, np.float32)).to(O.STORAGE).float().numpy()
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,k,dil", SHAPES)
@@ -57,20 +60,20 @@ def test_conv_fwd_dgrad_wgrad(device, n, h, w, cin, cout, k, dil):
     yo = O.conv2d(xt, wtt, 1, dil)
     yo.backward(torch.from_numpy(dy))
     # device
-    xd = torch.from_numpy(x).half().to(device)
-    dyd = torch.from_numpy(dy).half().to(device)
+    xd = torch.from_numpy(x).to(O.STORAGE).to(device)
+    dyd = torch.from_numpy(dy).to(O.STORAGE).to(device)
     wm = torch.from_numpy(wt).to(device)                      # HWIO f32 master
-    w_kc = torch.empty((k * k, cout, cin), dtype=torch.float16, device=device)
-    w_ck = torch.empty((k * k, cin, cout), dtype=torch.float16, device=device)
+    w_kc = torch.empty((k * k, cout, cin), dtype=O.STORAGE, device=device)
+    w_ck = torch.empty((k * k, cin, cout), dtype=O.STORAGE, device=device)
     ops.pack_weights(wm, w_kc, w_ck)
     d = ops.conv_desc((n, h, w, cin), cout, k, k, 1, dil)
     d.flags = 0
-    y = torch.empty((n, h, w, cout), dtype=torch.float16, device=device)
+    y = torch.empty((n, h, w, cout), dtype=O.STORAGE, device=device)
     ops.conv2d(d, xd, w_kc, y)
     pt = dil * (k - 1) - d.pad_top
     pl = dil * (k - 1) - d.pad_left
     dg = ops.ConvDesc(n, h, w, cout, h, w, cin, k, k, 1, dil, pt, pl, 1, 0)
-    dx = torch.empty((n, h, w, cin), dtype=torch.float16, device=device)
+    dx = torch.empty((n, h, w, cin), dtype=O.STORAGE, device=device)
     ops.conv2d(dg, dyd, w_ck, dx)
     dw = torch.zeros((k, k, cin, cout), dtype=torch.float32, device=device)
     ws = Workspace(device, 256 << 20)
@@ -84,4 +87,5 @@ def test_conv_fwd_dgrad_wgrad(device, n, h, w, cin, cout, k, dil):
     e_dx = rel(dx.float().cpu().numpy(), xt.grad.numpy())
     e_dw = rel(dw.cpu().numpy(), wtt.grad.numpy())
     print("%s variant %s: y %.2e dx %.2e dw %.2e" % ((n, h, w, cin, cout, k, dil), ops.conv2d_variant(d), e_y, e_dx, e_dw))
-    assert e_y < 1e-3 and e_dx < 1e-3 and e_dw < 5e-6
+    tol = 8e-3 if O.STORAGE == torch.bfloat16 else 1e-3
+    assert e_y < tol and e_dx < tol and e_dw < 5e-6

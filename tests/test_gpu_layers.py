@@ -206,3 +206,16 @@ def test_heads_and_dice(device):
         r = _rel(acts[k].grad.float().cpu().numpy() / 64.0, ft[k].grad.numpy())
         print("dfeat %-10s %.3e" % (k, r))
         assert r < 1e-2
+
+
+def test_storage_dtype_matches_library(device):
+    """The loaded library, the host's tensor dtype and the oracle's rounding agree on the 16-bit
+    storage type (f16 by default; bf16 in the child run of tests/test_gpu_bf16.py)."""
+    import os
+    from tensorflow_ocr_amd import _lib
+    from tensorflow_ocr_amd.graph import F16
+    want = os.environ.get("OCR_STORAGE", "f16")
+    lib = _lib.load()
+    assert lib.ocr_storage_dtype().decode() == want == _lib.STORAGE
+    assert F16 == O.STORAGE == (torch.bfloat16 if want == "bf16" else torch.float16)
+    assert os.path.basename(_lib.LIB_PATH) == ("libocr_hip_bf16.so" if want == "bf16" else "libocr_hip.so")

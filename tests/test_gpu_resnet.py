@@ -170,11 +170,19 @@ def test_model_east_merge_branch_dice(device):
     (oL * S).backward()
     d = np.abs(fs.data.cpu().numpy() - ofs.detach().numpy())
     print("loss %.5f vs %.5f; F_score Linf %.3e mean %.3e" % (L.item(), float(oL), d.max(), d.mean()))
-    assert abs(L.item() - float(oL)) < 5e-3 and d.mean() < 5e-3
+    tol = 8.0 if O.STORAGE == torch.bfloat16 else 1.0          # bf16 storage rounds 8x coarser than f16
+    assert abs(L.item() - float(oL)) < 5e-3 * tol and d.mean() < 5e-3 * tol
 
     def cos(a, b):
         a, b = a.ravel().astype(np.float64), b.ravel().astype(np.float64)
         return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
     cs = sorted((cos(grads[k], (tp[k].grad / S).numpy()), k) for k in grads if grads[k].size >= 64)
     print("lowest gradient cosines", cs[:3])
-    assert cs[0][0] > 0.9
+    # per-tensor gradient direction.  The bars sit at the network's intrinsic sensitivity to storage
+    # rounding: the oracle itself, f32 vs 16-bit-storage mode on this same graph, moves to cosine
+    # 0.94 (f16) / 0.72 (bf16) on its worst tensor and 0.96 / 0.75 on its worst >=4096-element tensor;
+    # device vs oracle in the SAME storage mode measures 0.93+ (f16) / 0.87, 0.90 (bf16).
+    bf = O.STORAGE == torch.bfloat16
+    assert cs[0][0] > (0.8 if bf else 0.9)
+    big = [c for c, k in cs if grads[k].size >= 4096]
+    assert min(big) > (0.85 if bf else 0.9)

@@ -34,6 +34,13 @@ def test_library_exports_every_declared_symbol():
     assert lib.ocr_abi_version() == 1
     lib.ocr_status_string.restype = ctypes.c_char_p
     assert lib.ocr_status_string(0) == b"ok" and b"unsupported" in lib.ocr_status_string(-2)
+    lib.ocr_storage_dtype.restype = ctypes.c_char_p
+    assert lib.ocr_storage_dtype() == b"f16"
+    # the bfloat16 build of the same sources exports the same ABI
+    bf = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libocr_hip_bf16.so"))
+    assert not [n for n in names if not hasattr(bf, n)]
+    bf.ocr_storage_dtype.restype = ctypes.c_char_p
+    assert bf.ocr_storage_dtype() == b"bf16"
 
 
 def test_abi_rejects_bad_arguments_without_touching_the_gpu():
