@@ -1,6 +1,6 @@
 import csv,glob,re,sys
 d=sys.argv[1]; steps=float(sys.argv[2]) if len(sys.argv)>2 else 4
-f=glob.glob(d+'/*/*kernel_stats.csv')[0]
+f=(glob.glob(d+'/*/*kernel_stats.csv')+glob.glob(d+'/*kernel_stats.csv'))[0]
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 print('total GPU ms/step %.2f'%(tot/steps/1e6))

@@ -69,6 +69,8 @@ __device__ __forceinline__ void bn_fin_apply<BnBwdFin>(const BnBwdFin& f, int c,
   f.dgamma[c] = (float)q;
 }
 
+constexpr int kRedRows = 64;     // partial rows per block: many small blocks, short dependent chains
+
 template <typename FIN>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ partial,
                                                               double* __restrict__ stage, int T, int C, int slot,
@@ -77,13 +79,25 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
   __shared__ unsigned s_ticket;
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
-  const int t0 = blockIdx.x * 256;
+  const int t0 = blockIdx.x * kRedRows;
   const int R = gridDim.x;
   double s = 0.0, q = 0.0;
   if (c < C) {
-    for (int t = t0 + rl; t < t0 + 256 && t < T; t += 4) {
-      s += (double)partial[((size_t)t * 2 + 0) * C + c];
-      q += (double)partial[((size_t)t * 2 + 1) * C + c];
+    // 16 rows per lane, loads issued four rows at a time (independent), summed in row order
+    for (int t = t0 + rl; t < t0 + kRedRows && t < T; t += 16) {
+      float a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int tt = t + 4 * k;
+        const bool ok = tt < t0 + kRedRows && tt < T;
+        a[k] = ok ? partial[((size_t)tt * 2 + 0) * C + c] : 0.f;
+        b[k] = ok ? partial[((size_t)tt * 2 + 1) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s += (double)a[k];
+        q += (double)b[k];
+      }
     }
   }
   red[rl][0][cl] = s;
@@ -108,16 +122,25 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
   __syncthreads();
   if (s_ticket != (unsigned)(R - 1)) return;      // not the last block of this channel group
   __threadfence();
-  if (rl == 0 && c < C) {
-    s = 0.0;
-    q = 0.0;
+  // the last arriver sums the R stage rows: row lane rl takes rows rl, rl+4, ... in order, the four
+  // lane sums are combined in lane order -> the result does not depend on which block is last
+  s = 0.0;
+  q = 0.0;
+  if (c < C) {
     const unsigned long long* st = reinterpret_cast<const unsigned long long*>(stage);
-    for (int r = 0; r < R; ++r) {                 // fixed row order; agent-scope loads (other CUs wrote these)
+    for (int r = rl; r < R; r += 4) {             // agent-scope loads (other CUs wrote these)
       unsigned long long us = __hip_atomic_load(st + ((size_t)r * 2 + 0) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       unsigned long long uq = __hip_atomic_load(st + ((size_t)r * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s += __builtin_bit_cast(double, us);
       q += __builtin_bit_cast(double, uq);
     }
+  }
+  red[rl][0][cl] = s;                             // (every reader of the first use passed the barriers above)
+  red[rl][1][cl] = q;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    s = red[0][0][cl] + red[1][0][cl] + red[2][0][cl] + red[3][0][cl];
+    q = red[0][1][cl] + red[1][1][cl] + red[2][1][cl] + red[3][1][cl];
     bn_fin_apply(fin, c, s, q);
   }
   if (threadIdx.x == 0) *ticket = 0u;             // ready for the next launch that uses this slot
@@ -731,7 +754,7 @@ extern "C" int ocr_prep_images_f16(const void* images_f32, int64_t npix, float m
 }
 
 extern "C" size_t ocr_bn_reduce_workspace(int T, int C) {
-  return (size_t)ocr_cdiv(T, 256) * 2 * C * sizeof(double);
+  return (size_t)ocr_cdiv(T, kRedRows) * 2 * C * sizeof(double);
 }
 
 extern "C" int ocr_bn_finalize(const void* partial, int T, int C, double count, const void* gamma,
@@ -742,7 +765,7 @@ extern "C" int ocr_bn_finalize(const void* partial, int T, int C, double count, 
   OCR_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
   if (ws_bytes < ocr_bn_reduce_workspace(T, C)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int R = ocr_cdiv(T, 256);
+  const int R = ocr_cdiv(T, kRedRows);
   OCR_CHECK_SHAPE(ocr_cdiv(C, 64) <= 32);
   BnFin fin{count, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, decay,
             static_cast<float*>(moving_mean), static_cast<float*>(moving_var), static_cast<float*>(scale),
@@ -817,7 +840,7 @@ extern "C" int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void*
                      (const float*)nullptr, (const float*)nullptr,
                      static_cast<const half_t*>(da_full), static_cast<const half_t*>(da_pool),
                      static_cast<float*>(partial), (half_t*)nullptr);
-  const int R = ocr_cdiv(T, 256);
+  const int R = ocr_cdiv(T, kRedRows);
   OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32);
   hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFin>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
                      static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(),
@@ -956,7 +979,7 @@ extern "C" int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const
   OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
   if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int R = ocr_cdiv(T, 256);
+  const int R = ocr_cdiv(T, kRedRows);
   OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32);
   hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFin>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
                      static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(),

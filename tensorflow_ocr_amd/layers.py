@@ -185,6 +185,7 @@ def _conv_backward(g, x, wv, w_dg, d, dy, first):
         x.grad = g.empty(x.shape)
     else:
         flags |= CONV_ACCUM_F16
+        x.bn_partial = None     # an earlier consumer's fused BN-backward sums no longer cover the full gradient
     dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1,
                       flags)
     if x.bn_ctx is not None and not flags and FUSE_BN_REDUCE:

@@ -10,7 +10,7 @@ sub-sampling is the 1x1/s max-pool kernel; only 3 of ResNet-50's 53 convolutions
 """
 from . import ops
 from .graph import Act, F32, constant, variance_scaling
-from .layers import BN_DECAY, BN_EPS, _bn_vars, _packs
+from .layers import BN_DECAY, BN_EPS, FUSE_BN_REDUCE, _bn_vars, _packs
 from ._lib import CONV_ACCUM_F16, CONV_STATS
 
 
@@ -83,8 +83,17 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             x.grad = g.empty(x.shape)
         else:
             flags |= CONV_ACCUM_F16
+            x.bn_partial = None     # an earlier consumer's fused BN-backward sums no longer cover the full gradient
         dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, flags)
-        ops.conv2d(dg, dy, w_dg, x.grad, None, None)
+        if x.bn_ctx is not None and not flags and FUSE_BN_REDUCE:
+            # sole consumer of a conv+BN(+ReLU) output: this input-gradient kernel also emits that
+            # layer's BN-backward sums, so its backward skips the reduction pass (layers.py does the same)
+            Tm = ops.conv2d_num_mtiles(dg)
+            partial = g.empty((Tm, 2, d.cin), F32)
+            ops.conv2d_bnred(dg, dy, w_dg, x.grad, partial, x.bn_ctx)
+            x.bn_partial = (partial, Tm)
+        else:
+            ops.conv2d(dg, dy, w_dg, x.grad, None, None)
     c.backward_from = backward_from
     return c
 
@@ -99,13 +108,21 @@ def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_trainin
     a = Act(g.empty(c.y.shape), name=scope)
     ops.bn_relu(c.y, c.scale, c.shift, relu, 0, a.data, None)
     ws = g.workspace()
+    if is_training:
+        a.bn_ctx = (c.y, c.scale, c.shift, c.mean, c.invstd, relu)
 
     def backward():
         if a.grad is None:
             return
         dy = g.empty(c.y.shape)
-        ops.bn_relu_bwd(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, None, relu, 0, c.gamma.grad,
-                        c.beta.grad, dy, ws)
+        if a.bn_partial is not None:
+            part_f, T_f = a.bn_partial
+            ops.bn_relu_bwd_apply(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, relu, part_f, T_f,
+                                  c.gamma.grad, c.beta.grad, dy, ws)
+            a.bn_partial = None
+        else:
+            ops.bn_relu_bwd(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, None, relu, 0, c.gamma.grad,
+                            c.beta.grad, dy, ws)
         c.backward_from(dy)
         a.grad = None
     g.record(backward, (c.wv, c.gamma, c.beta))
