@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (functional check only)")
     args = ap.parse_args()
 
-    from tensorflow_ocr_amd import dist, ops, synthetic
+    from tensorflow_ocr_amd import _lib, dist, ops, synthetic
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.nets import model_vgg_16 as M
     from tensorflow_ocr_amd.train import AdamOptimizer, TrainStep
@@ -153,9 +153,9 @@ def main():
             "metric": "images/sec training, 512x512 ICDAR, VGG-16 EAST, batch 32, 1/2/4/8 GPU",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": _lib.STORAGE, "data": "synthetic",
             "config": {"workload": "VGG-16 model_vgg + dice loss train step, %dx%d, batch %d per GPU, "
-                                   "f16 storage / f32 accumulate, Adam+EMA" % (args.size, args.size, args.batch),
+                                   "%s storage / f32 accumulate, Adam+EMA" % (args.size, args.size, args.batch, _lib.STORAGE),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "loss_scale": args.loss_scale},
             "loss": round(loss_val, 5),

@@ -42,7 +42,9 @@ __global__ void mar_yext_kernel(MarP p, const int* __restrict__ labels, int* __r
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int L = labels[i];
     if (L < 1 || L > p.max_comps) continue;
-    const int img = (int)(i / hw), y = (int)((i % hw) / p.w);
+    const int img = (int)(i / hw), local = (int)(i % hw);
+    const int y = local / p.w, x = local - y * p.w;
+    if (x > 0 && labels[i - 1] == L) continue;        // one atomic pair per horizontal run, not per pixel
     int* e = yext + ((size_t)img * (p.max_comps + 1) + L) * 2;
     atomicMin(e, y);
     atomicMax(e + 1, y);
@@ -92,11 +94,13 @@ __global__ void mar_rows_kernel(MarP p, const int* __restrict__ labels, const in
     if (L < 1 || L > p.max_comps) continue;
     const int img = (int)(i / hw), local = (int)(i % hw);
     const int y = local / p.w, x = local - y * p.w;
+    const bool run_start = x == 0 || labels[i - 1] != L, run_end = x == p.w - 1 || labels[i + 1] != L;
+    if (!run_start && !run_end) continue;             // only the ends of a horizontal run can be row extremes
     const size_t c = (size_t)img * (p.max_comps + 1) + L;
     const int r = rowoff[c] + y - yext[2 * c];
     int* e = rows + ((size_t)img * hw + r) * 2;
-    atomicMin(e, x);
-    atomicMax(e + 1, x);
+    if (run_start) atomicMin(e, x);
+    if (run_end) atomicMax(e + 1, x);
   }
 }
 
