@@ -369,6 +369,13 @@ int ocr_icdar_labels(const void* cover_u32, int n, int h, int w, int step, void*
 int ocr_pixellink_labels(const void* cover_u32, int n, int h, int w, int new_h, int new_w, void* score_f32,
                          void* link_f32, void* stream);
 
+/* Evaluation (tool/bboxes.py:246-283 np_bboxes_jaccard, called from bboxes_matching :171-240): pixel
+ * counts of the filled rasters (cv2.drawContours thickness=-1 = the fillPoly raster) of every
+ * detection x ground-truth pair inside a mask_h x mask_w image: inter = |A and B|, union = |A or B|,
+ * int32 [nd][ng].  dets int32 [nd][verts][2], gts int32 [ng][verts][2]; 3 <= verts <= 8. */
+int ocr_quad_iou(const void* dets_i32, int nd, const void* gts_i32, int ng, int verts, int mask_h, int mask_w,
+                 void* inter_i32, void* union_i32, void* stream);
+
 /* cv2.resize(im, dsize=(dw, dh)) (default INTER_LINEAR, 8-bit fixed-point path) + astype(float32):
  * datasets/icdar.py:615,630.  src uint8 [H][W][cn] -> dst f32 [dh][dw][cn]. */
 int ocr_resize_linear_u8(const void* src_u8, int H, int W, int cn, void* dst_f32, int dh, int dw,

@@ -25,8 +25,7 @@
 //   * interior: the edges active on row y (y0 <= y < y1) cross it at x_e = x_top + (y - y0) * dx,
 //     dx = ((x1 - x0) << 16) / (y1 - y0) truncated; OpenCV fills [ceil(xs[2k]), floor(xs[2k+1])] of
 //     the sorted crossings, which is  (some x_e == X)  or  (#{x_e < X} is odd).
-#include <limits.h>
-#include "common.h"
+#include "raster.h"
 
 namespace {
 
@@ -38,50 +37,8 @@ struct CoverP {
   int n, P, V, h, w;
 };
 
-struct Seg {      // clipped outline segment, start = left end
-  int x1, y1, major, minor, flags;     // flags: 1 ok, 2 steep, 4 y decreasing
-};
-struct FillEdge {
-  int y0, y1;
-  long long x, dx;
-};
-
-__device__ __forceinline__ bool clip_line(long long width, long long height, long long& x1, long long& y1,
-                                          long long& x2, long long& y2) {
-  const long long right = width - 1, bottom = height - 1;
-  int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
-  int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
-  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
-    long long a;
-    if (c1 & 12) {
-      a = c1 < 8 ? 0 : bottom;
-      x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
-      y1 = a;
-      c1 = (x1 < 0) + (x1 > right) * 2;
-    }
-    if (c2 & 12) {
-      a = c2 < 8 ? 0 : bottom;
-      x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
-      y2 = a;
-      c2 = (x2 < 0) + (x2 > right) * 2;
-    }
-    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
-      if (c1) {
-        a = c1 == 1 ? 0 : right;
-        y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
-        x1 = a;
-        c1 = 0;
-      }
-      if (c2) {
-        a = c2 == 1 ? 0 : right;
-        y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
-        x2 = a;
-        c2 = 0;
-      }
-    }
-  }
-  return (c1 | c2) == 0;
-}
+using raster::FillEdge;
+using raster::Seg;
 
 // grid (tiles_x, tiles_y, n), 256 threads = one 64 x 4 pixel tile
 __global__ __launch_bounds__(256) void poly_cover_kernel(CoverP p, const int* __restrict__ polys,
@@ -99,7 +56,6 @@ __global__ __launch_bounds__(256) void poly_cover_kernel(CoverP p, const int* __
   const int x = tx0 + (threadIdx.x & 63), y = ty0 + (threadIdx.x >> 6);
   int count = counts[img];
   if (count > p.P) count = p.P;
-  const long long X = (long long)x << 16;
   unsigned mn = 0, mx = 0, ign = 0;
   for (int base = 0; base < count; base += kChunk) {
     __syncthreads();       // previous chunk fully consumed
@@ -108,30 +64,11 @@ __global__ __launch_bounds__(256) void poly_cover_kernel(CoverP p, const int* __
       const int pl = threadIdx.x >> 3, e = threadIdx.x & 7;
       const int pi = base + pl;
       Seg sg{0, 0, 0, 0, 0};
-      FillEdge fe{0, 0, 0, 0};     // y0 == y1: never active
+      FillEdge fe{0, 0, 0, 0};
       if (pi < count && e < p.V) {
         const int* v = polys + (((size_t)img * p.P + pi) * p.V) * 2;
         const int e0 = e == 0 ? p.V - 1 : e - 1;
-        const long long ax = v[2 * e0], ay = v[2 * e0 + 1], bx = v[2 * e], by = v[2 * e + 1];
-        long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
-        if (clip_line(p.w, p.h, x1, y1, x2, y2)) {
-          int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
-          int sx1 = (int)x1, sy1 = (int)y1;
-          if (dx < 0) { dx = -dx; dy = -dy; sx1 = (int)x2; sy1 = (int)y2; }
-          int fl = 1;
-          if (dy < 0) { dy = -dy; fl |= 4; }
-          if (dy > dx) { fl |= 2; sg.major = dy; sg.minor = dx; }
-          else { sg.major = dx; sg.minor = dy; }
-          sg.x1 = sx1;
-          sg.y1 = sy1;
-          sg.flags = fl;
-        }
-        if (ay != by) {
-          const long long fax = ax << 16, fbx = bx << 16;
-          if (ay < by) { fe.y0 = (int)ay; fe.y1 = (int)by; fe.x = fax; }
-          else { fe.y0 = (int)by; fe.y1 = (int)ay; fe.x = fbx; }
-          fe.dx = (fbx - fax) / (by - ay);
-        }
+        raster::setup_edge(v[2 * e0], v[2 * e0 + 1], v[2 * e], v[2 * e + 1], p.w, p.h, sg, fe);
       }
       s_seg[threadIdx.x] = sg;
       s_edge[threadIdx.x] = fe;
@@ -147,21 +84,7 @@ __global__ __launch_bounds__(256) void poly_cover_kernel(CoverP p, const int* __
           bx0 = min(bx0, v[2 * k]); bx1 = max(bx1, v[2 * k]);
           by0 = min(by0, v[2 * k + 1]); by1 = max(by1, v[2 * k + 1]);
         }
-        // FillEdgeCollection's early outs
-        int total = 0, y_min = INT_MAX, y_max = INT_MIN;
-        long long x_min = LLONG_MAX, x_max = -1;
-        for (int k = 0; k < p.V; ++k) {
-          const FillEdge fe = s_edge[threadIdx.x * kMaxV + k];
-          if (fe.y0 == fe.y1) continue;
-          ++total;
-          const long long xe = fe.x + (long long)(fe.y1 - fe.y0) * fe.dx;
-          y_min = min(y_min, fe.y0);
-          y_max = max(y_max, fe.y1);
-          x_min = min(x_min, min(fe.x, xe));
-          x_max = max(x_max, max(fe.x, xe));
-        }
-        s_fill[threadIdx.x] = total >= 2 && !(y_max < 0 || y_min >= p.h || x_max < 0 ||
-                                              x_min >= ((long long)p.w << 16));
+        s_fill[threadIdx.x] = raster::fill_enabled(&s_edge[threadIdx.x * kMaxV], p.V, p.w, p.h) ? 1 : 0;
         s_ign[threadIdx.x] = ignore[(size_t)img * p.P + pi] ? 1 : 0;
         // tile culling on the vertex bounding box (+1 px slack; the exact test follows per pixel)
         hit = !(bx1 + 1 < tx0 || bx0 - 1 > tx0 + kTileW - 1 || by1 + 1 < ty0 || by0 - 1 > ty0 + kTileH - 1);
@@ -174,36 +97,7 @@ __global__ __launch_bounds__(256) void poly_cover_kernel(CoverP p, const int* __
     const int nhit = s_nhit;
     for (int q = 0; q < nhit; ++q) {
       const int pl = s_hit[q];
-      bool in = false;
-      bool eq = false;
-      int below = 0;
-      const bool fill = s_fill[pl] != 0;
-      for (int e = 0; e < p.V; ++e) {
-        const Seg sg = s_seg[pl * kMaxV + e];
-        if (sg.flags & 1) {
-          const int ys = (sg.flags & 4) ? -1 : 1;
-          if (sg.flags & 2) {           // steep: major axis y
-            const int j = (y - sg.y1) * ys;
-            if (j >= 0 && j <= sg.major) {
-              const int m = (int)((2ll * sg.minor * j + sg.major - 1) / (2ll * sg.major));
-              in |= x == sg.x1 + m;
-            }
-          } else {
-            const int j = x - sg.x1;
-            if (j >= 0 && j <= sg.major) {
-              const int m = sg.major > 0 ? (int)((2ll * sg.minor * j + sg.major - 1) / (2ll * sg.major)) : 0;
-              in |= y == sg.y1 + ys * m;
-            }
-          }
-        }
-        const FillEdge fe = s_edge[pl * kMaxV + e];
-        if (fill && fe.y0 <= y && y < fe.y1) {
-          const long long xe = fe.x + (long long)(y - fe.y0) * fe.dx;
-          below += xe < X;
-          eq |= xe == X;
-        }
-      }
-      in |= eq || (below & 1);
+      const bool in = raster::covers(&s_seg[pl * kMaxV], &s_edge[pl * kMaxV], p.V, s_fill[pl] != 0, x, y);
       if (in) {
         const unsigned id = (unsigned)(base + pl + 1);
         if (mn == 0) mn = id;

@@ -481,6 +481,13 @@ def resize_linear_u8(src_u8, dst_f32):
            c_int(dw), _st())
 
 
+def quad_iou(dets, gts, mask_h, mask_w, inter, uni):
+    nd, V, _ = dets.shape
+    ng = gts.shape[0]
+    L.call("ocr_quad_iou", ptr(dets), c_int(nd), ptr(gts), c_int(ng), c_int(V), c_int(mask_h), c_int(mask_w),
+           ptr(inter), ptr(uni), _st())
+
+
 # -------------------------------------------------------------------------- optimiser
 def adam_step(w, g, m, v, ema, n_reg, lr_t, beta1, beta2, eps, wd, inv_scale, ema_decay):
     L.call("ocr_adam_step", ptr(w), ptr(g), ptr(m), ptr(v), ptr(ema), c_int64(w.numel()),
