@@ -38,6 +38,10 @@ const char* ocr_status_string(int status);
  * built with bfloat16 storage and bf16 MFMA — BASELINE.json configs[3] "ResNet-v1-50 ... bf16").  The
  * `_f16` suffix of the entry points below names the 16-bit storage slot in both libraries. */
 const char* ocr_storage_dtype(void);
+/* HOST routine (no GPU): CRC-32C of n bytes continuing from `seed` (0 to start) — the per-tensor /
+ * per-block checksum of TensorFlow checkpoint bundles (saver.save / saver.restore,
+ * multigpu_train.py:188-189, test.py:146-150; tensorflow_ocr_amd/tf_bundle.py). */
+uint32_t ocr_crc32c(const void* data, size_t n, uint32_t seed);
 
 /* ------------------------------------------------------------------------- *
  * Convolution (slim.conv2d: nets/vgg.py:14-39, nets/resnet_v1.py:97-105,193,

@@ -97,10 +97,14 @@ def main():
             data = synthetic.make_batch(rng, FLAGS.batch_size_per_gpu, FLAGS.input_size)
             batch = [torch.from_numpy(a).to(device, non_blocking=True) for a in data]
         loss = step(*batch)
-        if it == 0 and FLAGS.restore:
-            path = os.path.join(FLAGS.checkpoint_path, 'latest.npz')
-            if os.path.exists(path):
-                g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, dict(np.load(path))), strict=False)
+        if it == 0:
+            # variables exist after the first step: restore (:145-148) or load the pretrained backbone (:149-151)
+            src = FLAGS.checkpoint_path if FLAGS.restore else FLAGS.pretrained_model_path
+            if src and (os.path.isdir(src) and os.path.exists(os.path.join(src, 'checkpoint')) or os.path.exists(src + '.index')):
+                sd, _ = checkpoint.load_tf_checkpoint(src)
+                g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
+                if rank == 0:
+                    print('continue training from previous checkpoint' if FLAGS.restore else 'loaded ' + src)
         if it % 10 == 0:
             ml = loss.item()
             if np.isnan(ml):
@@ -114,10 +118,10 @@ def main():
                 print('Step {:06d}, model loss {:.4f}, total loss {:.4f}, {:.2f} seconds/step, {:.2f} examples/second'.format(
                     it, ml, tl, avg_time_per_step, avg_examples_per_second), flush=True)
         if rank == 0 and it % FLAGS.save_checkpoint_steps == 0 and it > 0:
-            sd = checkpoint.internal_to_tf(g.store.state_dict())
-            np.savez(os.path.join(FLAGS.checkpoint_path, 'model.ckpt-%d.npz' % it), **sd)
-            np.savez(os.path.join(FLAGS.checkpoint_path, 'latest.npz'), **sd)
-
+            # saver.save(sess, FLAGS.checkpoint_path + 'model.ckpt', global_step=global_step) (:188-189):
+            # a TensorFlow V2 bundle with the reference's variable names + the EMA shadows
+            checkpoint.save_tf_checkpoint(FLAGS.checkpoint_path, it, checkpoint.internal_to_tf(g.store.state_dict()),
+                                          checkpoint.internal_to_tf(step.opt.shadow_state_dict()) if step.opt.ema is not None else None)
 
 if __name__ == '__main__':
     main()

@@ -5,6 +5,8 @@ joins the reference scopes with '+', e.g. `feature_fusion/Conv+Conv_5/weights` [
 `feature_fusion/Conv/weights` [1,1,cin,2] and `feature_fusion/Conv_5/weights` [1,1,cin,16] side by
 side.  These helpers split / join along the last axis so state dicts use the reference names.
 """
+import os
+
 import numpy as np
 
 
@@ -69,3 +71,47 @@ def tf_to_internal(internal_names, tf_sd):
         if pieces is not None:
             out[name] = np.concatenate(pieces, axis=-1)
     return out
+
+
+# ----------------------------------------------------------------------------- TF checkpoint files
+EMA_SUFFIX = "/ExponentialMovingAverage"
+
+
+def save_tf_checkpoint(checkpoint_dir, global_step, tf_state_dict, ema_state_dict=None, basename="model.ckpt"):
+    """`saver.save(sess, checkpoint_path + 'model.ckpt', global_step=global_step)`
+    (multigpu_train.py:188-189): writes `<dir>/model.ckpt-<step>.{index,data-00000-of-00001}` as a
+    TensorFlow V2 bundle with the reference's variable names, the EMA shadows under
+    `<name>/ExponentialMovingAverage` (what `variable_averages.variables_to_restore()` asks for,
+    test.py:149-150), `global_step`, and updates the directory's `checkpoint` file."""
+    from . import tf_bundle
+    tensors = {k: np.asarray(v) for k, v in tf_state_dict.items()}
+    for k, v in (ema_state_dict or {}).items():
+        tensors[k + EMA_SUFFIX] = np.asarray(v)
+    tensors["global_step"] = np.asarray(int(global_step), np.int64)
+    prefix = os.path.join(checkpoint_dir, "%s-%d" % (basename, int(global_step)))
+    tf_bundle.write_bundle(prefix, tensors)
+    tf_bundle.update_checkpoint_state(checkpoint_dir, prefix)
+    return prefix
+
+
+def load_tf_checkpoint(path, use_moving_averages=False):
+    """`tf.train.get_checkpoint_state(dir)` + `saver.restore` (test.py:146-150), or a checkpoint
+    prefix directly (`slim.assign_from_checkpoint_fn(pretrained_model_path, ...)`,
+    multigpu_train.py:149-151).  Returns ({reference variable name: array}, global_step or None);
+    with use_moving_averages the EMA shadows replace the raw variables where they exist."""
+    from . import tf_bundle
+    prefix = path
+    if os.path.isdir(path):
+        prefix = tf_bundle.get_checkpoint_state(path)
+        if prefix is None:
+            raise FileNotFoundError("no `checkpoint` state file in %s" % path)
+    if prefix.endswith(".index"):
+        prefix = prefix[:-len(".index")]
+    raw = tf_bundle.read_bundle(prefix)
+    step = int(raw.pop("global_step")) if "global_step" in raw else None
+    sd = {k: v for k, v in raw.items() if not k.endswith(EMA_SUFFIX)}
+    if use_moving_averages:
+        for k, v in raw.items():
+            if k.endswith(EMA_SUFFIX):
+                sd[k[:-len(EMA_SUFFIX)]] = v
+    return sd, step

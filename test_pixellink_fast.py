@@ -62,7 +62,11 @@ def main():
         net = pixellink.PixelLinkNet(x, graph=g)
         g.reset_tape()
         if FLAGS.checkpoint_path and not loaded:
-            g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, dict(np.load(FLAGS.checkpoint_path))), strict=False)
+            if FLAGS.checkpoint_path.endswith('.npz'):
+                sd = dict(np.load(FLAGS.checkpoint_path))
+            else:       # a TF checkpoint directory / prefix; EMA shadows restored like test.py:149-150
+                sd, _ = checkpoint.load_tf_checkpoint(FLAGS.checkpoint_path, use_moving_averages=True)
+            g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
             loaded = True
             net = pixellink.PixelLinkNet(x, graph=g)
             g.reset_tape()

@@ -43,11 +43,25 @@ def test_multigpu_train_on_icdar_directory(device, tmp_path, capsys):
     d = _dataset(tmp_path)
     out = _run("multigpu_train", ["--gpu_list", "0", "--batch_size_per_gpu", "2", "--input_size", "128",
                                   "--max_steps", "11", "--net", "model_vgg", "--num_readers", "2",
-                                  "--training_data_path", d, "--checkpoint_path", os.path.join(d, "ckpt")], capsys)
+                                  "--training_data_path", d, "--checkpoint_path", os.path.join(d, "ckpt"),
+                                  "--save_checkpoint_steps", "5"], capsys)
     lines = [l for l in out.splitlines() if l.startswith("Step ")]
     assert len(lines) == 2 and lines[0].startswith("Step 000000, model loss ") and "examples/second" in lines[1]
     losses = [float(l.split("model loss ")[1].split(",")[0]) for l in lines]
     assert all(np.isfinite(losses))
+    # saver.save every --save_checkpoint_steps: TF V2 bundles with the reference's names + EMA shadows
+    from tensorflow_ocr_amd import checkpoint, tf_bundle
+    ck = os.path.join(d, "ckpt")
+    assert tf_bundle.get_checkpoint_state(ck).endswith("model.ckpt-10")
+    sd, step = checkpoint.load_tf_checkpoint(ck)
+    assert step == 10 and sd["conv1/conv1_1/weights"].shape == (3, 3, 3, 64)
+    assert "conv5/conv5_3/BatchNorm/moving_variance" in sd
+    keys = [k.decode() for k, _ in tf_bundle.read_table(tf_bundle.get_checkpoint_state(ck) + ".index")]
+    assert "conv1/conv1_1/weights/ExponentialMovingAverage" in keys and "global_step" in keys
+    out = _run("multigpu_train", ["--gpu_list", "0", "--batch_size_per_gpu", "2", "--input_size", "128",
+                                  "--max_steps", "1", "--net", "model_vgg", "--num_readers", "0", "--restore",
+                                  "--training_data_path", os.path.join(d, "none"), "--checkpoint_path", ck], capsys)
+    assert "continue training from previous checkpoint" in out
 
 
 def test_train_pixellink_on_icdar_directory(device, tmp_path, capsys):

@@ -148,8 +148,7 @@ def main():
             if np.isnan(v):
                 break
         if FLAGS.train_dir and rank == 0 and it > 0 and it % 1000 == 0:
-            np.savez(os.path.join(FLAGS.train_dir, 'model.ckpt-%d.npz' % it),
-                     **checkpoint.internal_to_tf(g.store.state_dict()))
+            checkpoint.save_tf_checkpoint(FLAGS.train_dir, it, checkpoint.internal_to_tf(g.store.state_dict()))
     if feeder is not None:
         feeder.close()
 
