@@ -343,6 +343,231 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// 64-channel multi-tap layers at large spatial size (conv1_2 forward / input gradient: cin = 64,
+// cout = 64, 8 x 32 pixel tiles).  There the tap-sweeping kernel above is bound by its per-tile
+// latency chain, not by MFMA, LDS or HBM throughput: one channel chunk means nothing to prefetch
+// under, every 16 MFMAs per wave sit between two barriers + a weight DMA, and the block-wide staged
+// epilogue costs as much as the main loop (measured: main loop alone 0.35 ms, epilogue alone 0.54 ms
+// of 1.15 ms for conv1_2).  This variant is PERSISTENT and WEIGHT-STATIONARY:
+//   * a workgroup stages all kh*kw weight slices of its cout tile in LDS once (73 KB for 3x3x64x64)
+//     and then walks pixel tiles;
+//   * per tile the halo of the NEXT tile is already in flight in registers while the kh*kw*2 k-steps
+//     of MFMAs run without a single barrier;
+//   * wave w owns tile row w (32 pixels) x all 64 couts, so its output rows are whole 128-byte
+//     lines: the epilogue is WAVE-PRIVATE (4 KB of LDS per wave, XOR-swizzled, no block barrier):
+//     a wave that is done computing transposes and drains its row with 16-byte coalesced stores
+//     while slower waves still compute;
+//   * batch-norm partials (of the STORED 16-bit values; with `br` the producing layer's BN-backward
+//     sums): per lane over its 4 pixels, butterfly over the 8 pixel groups of the wave, then the 8
+//     waves through LDS in wave order (deterministic).
+// Same weight/halo fragment layout and MFMA shape as conv_igemm_kernel<64,64,2,true,8>.
+template <int BN>
+__global__ __launch_bounds__(512) void conv_c64_persist_kernel(
+    ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
+    const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats, int halo_area) {
+  constexpr int NT = 512, CK = 64, TH = 8;
+  constexpr int PSTR = conv_pstr(CK, true);
+  constexpr int CPP = CK / 8;
+  constexpr int WRS = conv_wrs(CK);
+  constexpr int AI = 4, AT = 2;                      // 64 couts x 32 pixels per wave
+  constexpr int NH = 6;                              // halo prefetch registers (16 B each) per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + halo_area;                     // [ntaps][BN][CK] f16, rows XOR-swizzled
+  char* stage_all = wbuf + p.kh * p.kw * (BN * WRS); // [8 waves][32 px][128 B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* stage = stage_all + wave * (32 * 128);
+  const int ntaps = p.kh * p.kw;
+  const int WT = p.WT;
+  const int halo_total = p.HT * WT * CPP;            // <= NH * NT (checked by the launcher)
+  const int nt = blockIdx.x % p.n_tiles;
+  const int co0 = nt * BN;
+  const int m_first = blockIdx.x / p.n_tiles, m_step = gridDim.x / p.n_tiles;
+  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
+  const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
+  const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
+  const BnRed* br = p.br.y ? &p.br : nullptr;
+
+  // all weight slices of this cout tile -> LDS, once (BN * CPP = 512 chunks per slice: one per thread)
+  for (int tap = 0; tap < ntaps; ++tap) {
+    const int tapw = p.flip ? (ntaps - 1 - tap) : tap;
+    const half_t* src = w + ((size_t)tapw * p.cout + co0) * p.cin;
+    const int rr = tid / CPP, c = tid % CPP;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + (size_t)rr * p.cin + ((c ^ wswz(rr, CK, true)) << 3)),
+        (__attribute__((address_space(3))) void*)(wbuf + tap * (BN * WRS) + (tid & ~63) * 16), 16, 0, 0);
+  }
+
+  const int frow = lane & 15, fkg = lane >> 4;
+  const int a_lane = frow * WRS;
+  const int fx = wswz(frow, CK, true);
+  const int b_lane = (frow * p.stride) * PSTR + fkg * 16;
+  const int b_half = 16 * p.stride * PSTR;
+  const int b_row = p.stride * WT * PSTR;
+
+  u32x4 hreg[NH];
+  auto halo_load = [&](int mt) {
+    const int txi = mt % p.tiles_x;
+    const int tmp = mt / p.tiles_x;
+    const int tyi = tmp % p.tiles_y, img = tmp / p.tiles_y;
+    const int iy0 = tyi * TH * p.stride - p.pt, ix0 = txi * TILE_W * p.stride - p.pl;
+    const half_t* xb = x + (size_t)img * p.h * p.w * p.cin;
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int idx = u * NT + tid;
+      hreg[u] = u32x4{0u, 0u, 0u, 0u};
+      if (idx < halo_total) {
+        const int hp = idx / CPP, c = idx % CPP;
+        const int hy = hp / WT, hx = hp - hy * WT;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+          hreg[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin + c * 8);
+      }
+    }
+  };
+
+  if (m_first < m_tiles) halo_load(m_first);
+  for (int mt = m_first; mt < m_tiles; mt += m_step) {
+    const int txi = mt % p.tiles_x;
+    const int tmp = mt / p.tiles_x;
+    const int tyi = tmp % p.tiles_y, img = tmp / p.tiles_y;
+    __syncthreads();                                 // every wave has finished the previous tile (halo + partials free)
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int idx = u * NT + tid;
+      if (idx < halo_total) *reinterpret_cast<u32x4*>(halo + (idx / CPP) * PSTR + (idx % CPP) * 16) = hreg[u];
+    }
+    __syncthreads();                                 // halo (and, the first time, the weights) visible
+    if (mt + m_step < m_tiles) halo_load(mt + m_step);   // in flight under this tile's MFMAs
+
+    f32x4 acc[AI][AT];
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int t = 0; t < AT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][t][e] = 0.f;
+    for (int tap = 0; tap < ntaps; ++tap) {
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      const char* ab = wbuf + tap * (BN * WRS) + a_lane;
+      const char* bb = halo + b_lane + ((ky * p.dil) * WT + kx * p.dil) * PSTR + wave * b_row;
+#pragma unroll
+      for (int ks = 0; ks < CK / 32; ++ks) {
+        half8_t a[AI], b[AT];
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+          a[i] = *reinterpret_cast<const half8_t*>(ab + i * 16 * WRS + (((ks * 4 + fkg) ^ fx) << 4));
+#pragma unroll
+        for (int t = 0; t < AT; ++t) b[t] = *reinterpret_cast<const half8_t*>(bb + t * b_half + ks * 64);
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int t = 0; t < AT; ++t) acc[i][t] = OCR_MFMA_16x16x32(a[i], b[t], acc[i][t], 0, 0, 0);
+      }
+    }
+
+    // ---- wave-private epilogue: accumulator quads -> this wave's [32 px][64 co] staging rows
+    // (16-byte chunk index XOR-swizzled by the pixel) -> whole 128-byte output rows
+    {
+      const int r = lane & 15, g4 = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + i * 16 + g4 * 4 + e];
+        }
+#pragma unroll
+        for (int t = 0; t < AT; ++t) {
+          const int px = t * 16 + r;
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][t][e] + bv[e];
+            if (relu) v = v > 0.f ? v : 0.f;
+            o[e] = (half_t)v;
+          }
+          *reinterpret_cast<half4_t*>(stage + px * 128 + (((i * 2 + (g4 >> 1)) ^ (px & 7)) << 4) + (g4 & 1) * 8) = o;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const int c = lane & 7, pg = lane >> 3;          // 16-byte chunk of the row, pixel group
+      const int oy = tyi * TILE_H + wave;
+      float s[8], q2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int px = k * 8 + pg;
+        const int ox = txi * TILE_W + px;
+        if (oy < p.oh && ox < p.ow) {
+          half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
+          const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8;
+          if (accum) {
+            const half8_t old = *reinterpret_cast<const half8_t*>(y + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+          }
+          *reinterpret_cast<half8_t*>(y + off) = v;
+          if (do_stats) {
+            if (br != nullptr) {
+              const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int cc = co0 + c * 8 + e;
+                const float yf = (float)yv[e];
+                const float z = (float)(half_t)(yf * br->scale[cc] + br->shift[cc]);
+                const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
+                s[e] += dz;
+                q2[e] += dz * ((yf - br->mean[cc]) * br->invstd[cc]);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s[e] += f;
+                q2[e] += f * f;
+              }
+            }
+          }
+        }
+      }
+      if (do_stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) {
+            s[e] += __shfl_xor(s[e], o, 64);
+            q2[e] += __shfl_xor(q2[e], o, 64);
+          }
+        }
+        // (in-order LDS: this wave's row reads above are complete before these writes land)
+        float* part = reinterpret_cast<float*>(stage);          // [2][64] of this wave
+        if (pg == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            part[c * 8 + e] = s[e];
+            part[64 + c * 8 + e] = q2[e];
+          }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+          float tot = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < 8; ++wv) tot += reinterpret_cast<const float*>(stage_all + wv * (32 * 128))[tid];
+          stats[((size_t)mt * 2 + (tid >> 6)) * p.cout + co0 + (tid & 63)] = tot;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pointwise (1x1, stride 1) convolutions as a plain GEMM:  y[px][co] = sum_ci x[px][ci] * w[co][ci].
 // (ResNet bottleneck / shortcut / feature-merge convs, fc7, and their input gradients.)
 // The tap-sweeping kernel above degenerates here to one tap per 64-channel chunk: two barriers, a
@@ -516,6 +741,40 @@ int launch_t(const ConvP& p, const void* x, const void* w, const void* bias, voi
   return ocr_launch_status();
 }
 
+// persistent weight-stationary variant: cin == 64, 64-cout tiles, 16x16x32 MFMA, 8-row tiles
+static bool conv_c64_ok(const ConvP& p) {
+  static const int on = [] { const char* e = getenv("OCR_CONV_PERSIST"); return e ? atoi(e) : 1; }();
+  const int ntaps = p.kh * p.kw;
+  return on && p.m16 && p.cin == 64 && ntaps > 1 && ntaps <= 9 && p.HT * p.WT * 8 <= 6 * 512 &&
+         p.n * p.tiles_x * p.tiles_y >= 128;        // enough pixel tiles to amortise the weight staging
+}
+
+static int launch_c64(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
+                      hipStream_t st) {
+  const size_t area = ((size_t)p.halo_bytes + 15) & ~(size_t)15;
+  const size_t lds = area + (size_t)p.kh * p.kw * 64 * conv_wrs(64) + 8 * 32 * 128;   // halo + weights + wave staging
+  if (lds > 160 * 1024) return OCR_ERR_UNSUPPORTED;
+  auto kern = conv_c64_persist_kernel<64>;
+  static int cus = 0;
+  if (!cus) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(160 * 1024)) != hipSuccess)
+      return OCR_ERR_HIP;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OCR_ERR_HIP;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
+  int per = cus / p.n_tiles;                          // workgroups per cout tile: one workgroup per CU
+  if (per < 1) per = 1;
+  if (per > m_tiles) per = m_tiles;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per * p.n_tiles)), dim3(512), lds, st, p, static_cast<const half_t*>(x),
+                     static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
+                     static_cast<float*>(stats), (int)area);
+  return ocr_launch_status();
+}
+
 template <int BN, int CK, int WCO, int TH = 8>
 int launch(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
            hipStream_t st) {
@@ -614,6 +873,10 @@ extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap)
     return OCR_OK;
   }
   const int wco = c.bn == 256 ? 4 : c.bn == 32 ? 1 : 2;
+  if (c.bn == 64 && c.ck == 64 && c.th == 8 && conv_c64_ok(p)) {
+    snprintf(out, cap, "conv_c64_persist_kernel<64>");
+    return OCR_OK;
+  }
   snprintf(out, cap, "conv_igemm_kernel<%d,%d,%d,%d,%d>", c.bn, c.ck, wco, p.m16, c.th);
   return OCR_OK;
 }
@@ -633,7 +896,9 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     case 1283216: return launch<128, 32, 2, 16>(p, x, w_kc, bias, y, stats, st);
     case 1286408: return launch<128, 64, 2>(p, x, w_kc, bias, y, stats, st);
     case 1283208: return launch<128, 32, 2>(p, x, w_kc, bias, y, stats, st);
-    case 646408: return launch<64, 64, 2>(p, x, w_kc, bias, y, stats, st);
+    case 646408:
+      if (conv_c64_ok(p)) return launch_c64(p, x, w_kc, bias, y, stats, st);
+      return launch<64, 64, 2>(p, x, w_kc, bias, y, stats, st);
     case 643208: return launch<64, 32, 2>(p, x, w_kc, bias, y, stats, st);
     case 326408: return launch<32, 64, 1>(p, x, w_kc, bias, y, stats, st);
     case 323208: return launch<32, 32, 1>(p, x, w_kc, bias, y, stats, st);

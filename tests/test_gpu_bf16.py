@@ -22,4 +22,6 @@ def test_bf16_build_conv_sweep_and_east_step(device):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
-    assert "19 passed" in r.stdout, tail
+    import re
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 19 and "failed" not in r.stdout, tail

@@ -38,6 +38,9 @@ SHAPES = [
     (2, 24, 40, 256, 256, 1, 1),     # pointwise GEMM kernel: 7.5 flat tiles, 256-cout tile
     (1, 16, 32, 64, 64, 1, 1),       # ... 64-cout tile, one K stage
     (1, 32, 32, 1024, 128, 1, 1),    # ... 128-cout tile, 16 K stages
+    (2, 100, 130, 64, 64, 3, 1),     # persistent weight-stationary 64-channel kernel: 130 ragged pixel tiles
+    (1, 128, 256, 64, 128, 3, 1),    # ... two cout tiles, workgroups split between them
+    (9, 64, 64, 64, 64, 3, 1),       # ... more images than tiles per image
 ]
 
 
@@ -89,3 +92,49 @@ def test_conv_fwd_dgrad_wgrad(device, n, h, w, cin, cout, k, dil):
     print("%s variant %s: y %.2e dx %.2e dw %.2e" % ((n, h, w, cin, cout, k, dil), ops.conv2d_variant(d), e_y, e_dx, e_dw))
     tol = 8e-3 if O.STORAGE == torch.bfloat16 else 1e-3
     assert e_y < tol and e_dx < tol and e_dw < 5e-6
+
+
+def test_persistent_c64_kernel_is_selected_and_emits_stats(device):
+    """The 64-channel large-map layers (conv1_2 class) run the persistent weight-stationary kernel;
+    its per-tile batch-norm partials (sum, sum of squares of the STORED 16-bit values) add up to the
+    tensor's own sums, and the fused BN-backward variant's partials to (sum dz, sum dz*xhat)."""
+    from tensorflow_ocr_amd import ops
+    n, h, w, c = 2, 100, 130, 64
+    rng = np.random.default_rng(5)
+    x = _h(rng.standard_normal((n, h, w, c)))
+    wt = _h(rng.standard_normal((3, 3, c, c)) * np.sqrt(2.0 / (9 * c)))
+    xd = torch.from_numpy(x).to(O.STORAGE).to(device)
+    wm = torch.from_numpy(wt).to(device)
+    w_kc = torch.empty((9, c, c), dtype=O.STORAGE, device=device)
+    w_ck = torch.empty((9, c, c), dtype=O.STORAGE, device=device)
+    ops.pack_weights(wm, w_kc, w_ck)
+    d = ops.conv_desc((n, h, w, c), c, 3, 3, 1, 1)
+    assert ops.conv2d_variant(d) == "conv_c64_persist_kernel<64>"
+    d.flags = ops.CONV_STATS
+    T = ops.conv2d_num_mtiles(d)
+    y = torch.empty((n, h, w, c), dtype=O.STORAGE, device=device)
+    part = torch.zeros((T, 2, c), dtype=torch.float32, device=device)
+    ops.conv2d(d, xd, w_kc, y, None, part)
+    yf = y.float().cpu().numpy().astype(np.float64)
+    got = part.cpu().numpy().astype(np.float64).sum(0)
+    assert np.allclose(got[0], yf.sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+    assert np.allclose(got[1], (yf * yf).sum((0, 1, 2)), rtol=1e-4)
+    # fused BN-backward reduction: dz = out * [relu(bn(by)) > 0], xhat = (by - mean) * invstd
+    by = _h(rng.standard_normal((n, h, w, c)))
+    scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    shift = rng.normal(0, 0.3, c).astype(np.float32)
+    mean = rng.normal(0, 0.2, c).astype(np.float32)
+    invstd = rng.uniform(0.7, 1.3, c).astype(np.float32)
+    d2 = ops.conv_desc((n, h, w, c), c, 3, 3, 1, 1)
+    d2.flags = 0
+    y2 = torch.empty_like(y)
+    part2 = torch.zeros((T, 2, c), dtype=torch.float32, device=device)
+    ctx = tuple(torch.from_numpy(a).to(device) for a in (scale, shift, mean, invstd))
+    ops.conv2d_bnred(d2, xd, w_kc, y2, part2, (torch.from_numpy(by).to(O.STORAGE).to(device),) + ctx + (True,))
+    assert torch.equal(y2, y)
+    z = torch.from_numpy(by * scale + shift).to(O.STORAGE).float().numpy()
+    dz = yf * (z > 0)
+    xh = (by.astype(np.float64) - mean) * invstd
+    got2 = part2.cpu().numpy().astype(np.float64).sum(0)
+    assert np.allclose(got2[0], dz.sum((0, 1, 2)), rtol=1e-3, atol=5e-2)
+    assert np.allclose(got2[1], (dz * xh).sum((0, 1, 2)), rtol=1e-3, atol=5e-2)
