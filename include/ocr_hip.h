@@ -350,6 +350,30 @@ int ocr_min_area_rects(const void* labels_i32, const void* ncomp_i32, int n, int
                        void* calipers_f32, void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * EAST-script decode (test.py:45-74,182-201): the `pixel_detect` twin, the regions cv2.findContours
+ * (RETR_TREE) traces, and one oriented box per contour.
+ * ------------------------------------------------------------------------- */
+/* mask = score > score_thresh (score f32 [h][w]); first_second int32 [2][8] (pre-filled with INT_MAX)
+ * receives, per link channel c, the raster indices of the first and the second pixel with
+ * link16[.., 2c+1] < link_thresh — the only two `argwhere` rows test.py:70-72 uses. */
+int ocr_east_pixel_detect(const void* score_f32, const void* link16_f32, int h, int w, float score_thresh,
+                          float link_thresh, void* mask_u8, void* first_second_i32, void* stream);
+int ocr_zero_pixels_u8(void* mask_u8, const void* idx_i32, int count, void* stream);
+/* Connected components of the pixels with (mask != 0) == (value != 0), connectivity 4 or 8; outputs as
+ * ocr_link_cc (dense ids in ascending order of the smallest pixel index).  Workspace:
+ * ocr_link_cc_workspace(n, h, w). */
+int ocr_mask_cc(const void* mask_u8, int value, int connectivity, int n, int h, int w, void* labels_i32,
+                void* ncomp_i32, void* comps_i32, int max_comps, void* workspace, size_t ws_bytes, void* stream);
+/* Inner contours: zlabels = 4-connected components of the 0-pixels (ocr_mask_cc value 0).  A region
+ * touching the image edge is background; any other is a hole whose contour is the set of 1-pixels
+ * with a 4-neighbour in it.  Per region id: hull_n (0 for background regions), hull_head, calipers as
+ * ocr_min_area_rects. */
+size_t ocr_hole_border_rects_workspace(int n, int h, int w, int max_regions);
+int ocr_hole_border_rects(const void* mask_u8, const void* zlabels_i32, const void* nregions_i32, int n, int h,
+                          int w, int max_regions, double scale_x, double scale_y, void* hull_n_i32,
+                          void* hull_head_i32, void* calipers_f32, void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Ground-truth label maps: datasets/icdar.py:486-539 `generate_rbox` (+ the
  * generator's [::4,::4] subsample, :632-634) and tool/pixellink_fn.py:53-110 `generate_rbox`, both on
  * cv2.fillPoly rasters of the text polygons (OpenCV restated in oracle/cvgeom_oracle.c, matched

@@ -28,6 +28,7 @@ constexpr int kMaxRows = 1024;     // rows of one component staged in LDS (56 KB
 struct MarP {
   int n, h, w, max_comps;
   double sx, sy;
+  int rows_per_img;      // row-table entries per image (h*w for components, 3*h*w for hole borders)
 };
 
 __global__ void mar_init_kernel(int* __restrict__ yext, size_t n_ext, int* __restrict__ rows, size_t n_rows) {
@@ -98,9 +99,61 @@ __global__ void mar_rows_kernel(MarP p, const int* __restrict__ labels, const in
     if (!run_start && !run_end) continue;             // only the ends of a horizontal run can be row extremes
     const size_t c = (size_t)img * (p.max_comps + 1) + L;
     const int r = rowoff[c] + y - yext[2 * c];
-    int* e = rows + ((size_t)img * hw + r) * 2;
+    int* e = rows + ((size_t)img * p.rows_per_img + r) * 2;
     if (run_start) atomicMin(e, x);
     if (run_end) atomicMax(e + 1, x);
+  }
+}
+
+// ---- hole borders (cv2.findContours RETR_TREE inner contours, test.py:182) -------------------
+// zlabels: 4-connected components of the 0-pixels.  A 0-region that touches the image edge is
+// background (OpenCV pads the image with zeros), every other one is a hole whose border is the set
+// of 1-pixels with a 4-neighbour inside it (Suzuki's border points for 8-connected foreground).
+__global__ void mar_edge_kernel(MarP p, const int* __restrict__ zlabels, unsigned char* __restrict__ edge) {
+  const int per = 2 * (p.h + p.w);
+  const size_t total = (size_t)p.n * per;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int img = (int)(i / per), k = (int)(i % per);
+    int x, y;
+    if (k < p.w) { x = k; y = 0; }
+    else if (k < 2 * p.w) { x = k - p.w; y = p.h - 1; }
+    else if (k < 2 * p.w + p.h) { x = 0; y = k - 2 * p.w; }
+    else { x = p.w - 1; y = k - 2 * p.w - p.h; }
+    const int L = zlabels[((size_t)img * p.h + y) * p.w + x];
+    if (L >= 1 && L <= p.max_comps) edge[(size_t)img * (p.max_comps + 1) + L] = 1;
+  }
+}
+
+template <int PASS>   // 0: y extents, 1: row extremes
+__global__ void mar_border_kernel(MarP p, const unsigned char* __restrict__ mask, const int* __restrict__ zlabels,
+                                  const unsigned char* __restrict__ edge, int* __restrict__ yext,
+                                  const int* __restrict__ rowoff, int* __restrict__ rows) {
+  const size_t hw = (size_t)p.h * p.w, total = (size_t)p.n * hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    if (!mask[i]) continue;
+    const int img = (int)(i / hw), local = (int)(i % hw);
+    const int y = local / p.w, x = local - y * p.w;
+    const int* zl = zlabels + (size_t)img * hw;
+    int nb[4] = {x > 0 ? zl[local - 1] : 0, x + 1 < p.w ? zl[local + 1] : 0, y > 0 ? zl[local - p.w] : 0,
+                 y + 1 < p.h ? zl[local + p.w] : 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int L = nb[k];
+      if (L < 1 || L > p.max_comps) continue;
+      bool dup = false;
+      for (int j = 0; j < k; ++j) dup |= nb[j] == L;
+      if (dup) continue;
+      const size_t c = (size_t)img * (p.max_comps + 1) + L;
+      if (edge[c]) continue;
+      if (PASS == 0) {
+        atomicMin(yext + 2 * c, y);
+        atomicMax(yext + 2 * c + 1, y);
+      } else {
+        int* e = rows + ((size_t)img * p.rows_per_img + rowoff[c] + y - yext[2 * c]) * 2;
+        atomicMin(e, x);
+        atomicMax(e + 1, x);
+      }
+    }
   }
 }
 
@@ -130,7 +183,7 @@ __global__ __launch_bounds__(64) void mar_hull_calipers_kernel(
     if (lane == 0) hull_n[o] = 0;
     return;
   }
-  const int* rw = rows + ((size_t)img * p.h * p.w + rowoff[c]) * 2;
+  const int* rw = rows + ((size_t)img * p.rows_per_img + rowoff[c]) * 2;
   // scaled candidates of every row (rows are distinct Y because sy >= 1)
   for (int r = lane; r < R; r += 64) {
     const int xl = rw[2 * r], xr = rw[2 * r + 1];
@@ -319,7 +372,7 @@ extern "C" int ocr_min_area_rects(const void* labels_i32, const void* ncomp_i32,
   OCR_CHECK_SHAPE((double)w * scale_x < 16777216.0 && (double)h * scale_y < 16777216.0);   // exact in f32
   if (ws_bytes < ocr_min_area_rects_workspace(n, h, w, max_comps)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  MarP p{n, h, w, max_comps, scale_x, scale_y};
+  MarP p{n, h, w, max_comps, scale_x, scale_y, h * w};
   int* yext = static_cast<int*>(workspace);
   const size_t n_ext = (size_t)n * (max_comps + 1) * 2;
   int* rowoff = yext + n_ext;
@@ -336,5 +389,44 @@ extern "C" int ocr_min_area_rects(const void* labels_i32, const void* ncomp_i32,
                      static_cast<const int*>(ncomp_i32), yext, rowoff, rows,
                      static_cast<int*>(hull_n_i32), static_cast<int*>(hull_head_i32),
                      static_cast<float*>(calipers_f32));
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_hole_border_rects_workspace(int n, int h, int w, int max_regions) {
+  // (ymin,ymax), rowoff per region; rows [n][3*h*w][2] (a hole of e rows has a border of e + 2 rows
+  // and at least e pixels); edge flags
+  return ((size_t)n * (max_regions + 1) * 3 + (size_t)n * h * w * 3 * 2) * sizeof(int) +
+         (((size_t)n * (max_regions + 1) + 15) & ~(size_t)15);
+}
+
+extern "C" int ocr_hole_border_rects(const void* mask_u8, const void* zlabels_i32, const void* nregions_i32, int n,
+                                     int h, int w, int max_regions, double scale_x, double scale_y,
+                                     void* hull_n_i32, void* hull_head_i32, void* calipers_f32, void* workspace,
+                                     size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(mask_u8 && zlabels_i32 && nregions_i32 && hull_n_i32 && hull_head_i32 && calipers_f32 && workspace);
+  OCR_CHECK_ARG(n > 0 && h > 0 && w > 0 && max_regions > 0);
+  OCR_CHECK_SHAPE(scale_x >= 1.0 && scale_y >= 1.0 && h <= kMaxRows && max_regions <= 65535 && n <= 65535);
+  OCR_CHECK_SHAPE((double)w * scale_x < 16777216.0 && (double)h * scale_y < 16777216.0);
+  if (ws_bytes < ocr_hole_border_rects_workspace(n, h, w, max_regions)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MarP p{n, h, w, max_regions, scale_x, scale_y, 3 * h * w};
+  int* yext = static_cast<int*>(workspace);
+  const size_t n_ext = (size_t)n * (max_regions + 1) * 2;
+  int* rowoff = yext + n_ext;
+  int* rows = rowoff + (size_t)n * (max_regions + 1);
+  const size_t n_rows = (size_t)n * p.rows_per_img * 2;
+  unsigned char* edge = reinterpret_cast<unsigned char*>(rows + n_rows);
+  const size_t total = (size_t)n * h * w;
+  const unsigned char* mask = static_cast<const unsigned char*>(mask_u8);
+  const int* zl = static_cast<const int*>(zlabels_i32);
+  if (hipMemsetAsync(edge, 0, (size_t)n * (max_regions + 1), st) != hipSuccess) return OCR_ERR_HIP;
+  hipLaunchKernelGGL(mar_init_kernel, dim3(bgrid(n_rows)), dim3(256), 0, st, yext, n_ext, rows, n_rows);
+  hipLaunchKernelGGL(mar_edge_kernel, dim3(bgrid((size_t)n * 2 * (h + w))), dim3(256), 0, st, p, zl, edge);
+  hipLaunchKernelGGL(mar_border_kernel<0>, dim3(bgrid(total)), dim3(256), 0, st, p, mask, zl, edge, yext, rowoff, rows);
+  hipLaunchKernelGGL(mar_scan_kernel, dim3(n), dim3(1024), 0, st, p, yext, rowoff);
+  hipLaunchKernelGGL(mar_border_kernel<1>, dim3(bgrid(total)), dim3(256), 0, st, p, mask, zl, edge, yext, rowoff, rows);
+  hipLaunchKernelGGL(mar_hull_calipers_kernel, dim3(max_regions, n), dim3(64), 0, st, p,
+                     static_cast<const int*>(nregions_i32), yext, rowoff, rows, static_cast<int*>(hull_n_i32),
+                     static_cast<int*>(hull_head_i32), static_cast<float*>(calipers_f32));
   return ocr_launch_status();
 }

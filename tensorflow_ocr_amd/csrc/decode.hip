@@ -183,6 +183,65 @@ __global__ __launch_bounds__(1024) void cc_label_kernel(CcP p, const int* __rest
   }
 }
 
+// ---- plain connected components of a binary mask (test.py:182: cv2.findContours' regions) -------
+// value-pixels of `mask` joined with 4- or 8-connectivity, same union-find and dense numbering as
+// above (ids ascend with each component's smallest pixel index).
+__global__ void cc_init_mask_kernel(CcP p, const unsigned char* __restrict__ mask, int value,
+                                    int* __restrict__ parent, int* __restrict__ size) {
+  const size_t total = (size_t)p.n * p.h * p.w;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int local = (int)(i % ((size_t)p.h * p.w));
+    parent[i] = (mask[i] != 0) == (value != 0) ? local : -1;
+    size[i] = 0;
+  }
+}
+
+__global__ void cc_union_mask_kernel(CcP p, int conn8, int* __restrict__ parent) {
+  const size_t hw = (size_t)p.h * p.w, total = (size_t)p.n * hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int img = (int)(i / hw), local = (int)(i % hw);
+    const int y = local / p.w, x = local - y * p.w;
+    int* par = parent + (size_t)img * hw;
+    if (par[local] < 0) continue;
+    // right, down (4-connectivity) + down-left, down-right (8): every undirected edge once
+    if (x + 1 < p.w && par[local + 1] >= 0) uf_unite(par, local, local + 1);
+    if (y + 1 < p.h) {
+      if (par[local + p.w] >= 0) uf_unite(par, local, local + p.w);
+      if (conn8) {
+        if (x > 0 && par[local + p.w - 1] >= 0) uf_unite(par, local, local + p.w - 1);
+        if (x + 1 < p.w && par[local + p.w + 1] >= 0) uf_unite(par, local, local + p.w + 1);
+      }
+    }
+  }
+}
+
+// test.py:45-74 `pixel_detect` (the EAST-script twin of tool/pixellink_fn.pixel_detect):
+//   res = score > t_s;  for each of the 8 link channels: link_text = argwhere(link[..., 2i+1] < t_l);
+//   res[link_text[0], link_text[1]] = 0
+// i.e. only the FIRST TWO below-threshold pixels (raster order) of each channel are looked at, and
+// they are used as (row list, column list).  The kernels find those two indices per channel; the
+// O(16) index arithmetic and the IndexError cases stay on the host, as in the reference.
+__global__ void east_mask_first_kernel(const float* __restrict__ score, const float* __restrict__ link16, int hw,
+                                       float ts, float tl, unsigned char* __restrict__ mask, int* __restrict__ first) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+    mask[i] = score[i] > ts ? 1 : 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (link16[(size_t)i * 16 + 2 * c + 1] < tl) atomicMin(first + c, i);
+  }
+}
+__global__ void east_second_kernel(const float* __restrict__ link16, int hw, float tl, const int* __restrict__ first,
+                                   int* __restrict__ second) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (i > first[c] && link16[(size_t)i * 16 + 2 * c + 1] < tl) atomicMin(second + c, i);
+  }
+}
+__global__ void zero_pixels_kernel(unsigned char* __restrict__ mask, const int* __restrict__ idx, int count) {
+  if ((int)threadIdx.x < count) mask[idx[threadIdx.x]] = 0;
+}
+
 unsigned dgrid(size_t items) {
   size_t b = (items + 255) / 256;
   if (b > 4096) b = 4096;
@@ -247,5 +306,49 @@ extern "C" int ocr_link_cc(const void* pixel_score, const void* link_score, int 
   hipLaunchKernelGGL(cc_label_kernel, dim3(n), dim3(1024), 0, st, p, root, size, ids,
                      static_cast<int*>(labels_i32), static_cast<int*>(ncomp_i32),
                      static_cast<int*>(comps_i32), max_comps);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_mask_cc(const void* mask_u8, int value, int connectivity, int n, int h, int w, void* labels_i32,
+                           void* ncomp_i32, void* comps_i32, int max_comps, void* workspace, size_t ws_bytes,
+                           void* stream) {
+  OCR_CHECK_ARG(mask_u8 && labels_i32 && ncomp_i32 && comps_i32 && workspace);
+  OCR_CHECK_ARG(n > 0 && h > 0 && w > 0 && max_comps > 0 && (connectivity == 4 || connectivity == 8));
+  if (ws_bytes < ocr_link_cc_workspace(n, h, w)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t total = (size_t)n * h * w;
+  int* parent = static_cast<int*>(workspace);
+  int* size = parent + total;
+  int* root = size + total;
+  int* ids = root + total;
+  CcP p{n, h, w, 0, 0.f, 0.f, 1, 0};
+  hipLaunchKernelGGL(cc_init_mask_kernel, dim3(dgrid(total)), dim3(256), 0, st, p,
+                     static_cast<const unsigned char*>(mask_u8), value, parent, size);
+  hipLaunchKernelGGL(cc_union_mask_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, connectivity == 8 ? 1 : 0, parent);
+  hipLaunchKernelGGL(cc_root_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, parent, root, size);
+  hipLaunchKernelGGL(cc_label_kernel, dim3(n), dim3(1024), 0, st, p, root, size, ids, static_cast<int*>(labels_i32),
+                     static_cast<int*>(ncomp_i32), static_cast<int*>(comps_i32), max_comps);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_east_pixel_detect(const void* score_f32, const void* link16_f32, int h, int w, float score_thresh,
+                                     float link_thresh, void* mask_u8, void* first_second_i32, void* stream) {
+  OCR_CHECK_ARG(score_f32 && link16_f32 && mask_u8 && first_second_i32 && h > 0 && w > 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int* fs = static_cast<int*>(first_second_i32);      // [2][8], pre-filled with INT_MAX by the caller
+  const int hw = h * w;
+  hipLaunchKernelGGL(east_mask_first_kernel, dim3(dgrid((size_t)hw)), dim3(256), 0, st,
+                     static_cast<const float*>(score_f32), static_cast<const float*>(link16_f32), hw, score_thresh,
+                     link_thresh, static_cast<unsigned char*>(mask_u8), fs);
+  hipLaunchKernelGGL(east_second_kernel, dim3(dgrid((size_t)hw)), dim3(256), 0, st,
+                     static_cast<const float*>(link16_f32), hw, link_thresh, fs, fs + 8);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_zero_pixels_u8(void* mask_u8, const void* idx_i32, int count, void* stream) {
+  OCR_CHECK_ARG(mask_u8 && idx_i32 && count >= 0 && count <= 256);
+  if (count == 0) return OCR_OK;
+  hipLaunchKernelGGL(zero_pixels_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<unsigned char*>(mask_u8), static_cast<const int*>(idx_i32), count);
   return ocr_launch_status();
 }

@@ -455,6 +455,32 @@ def min_area_rects(labels, ncomp, max_comps, scale_x, scale_y, hull_n, hull_head
            c_size_t(nbytes), _st())
 
 
+def mask_cc(mask, value, connectivity, labels, ncomp, comps, ws):
+    n, h, w = mask.shape
+    nbytes = L.call_size("ocr_link_cc_workspace", c_int(n), c_int(h), c_int(w))
+    buf = ws.get(nbytes)
+    L.call("ocr_mask_cc", ptr(mask), c_int(value), c_int(connectivity), c_int(n), c_int(h), c_int(w), ptr(labels),
+           ptr(ncomp), ptr(comps), c_int(comps.shape[1]), ptr(buf), c_size_t(nbytes), _st())
+
+
+def hole_border_rects(mask, zlabels, nregions, max_regions, scale_x, scale_y, hull_n, hull_head, calipers, ws):
+    n, h, w = mask.shape
+    nbytes = L.call_size("ocr_hole_border_rects_workspace", c_int(n), c_int(h), c_int(w), c_int(max_regions))
+    buf = ws.get(nbytes)
+    L.call("ocr_hole_border_rects", ptr(mask), ptr(zlabels), ptr(nregions), c_int(n), c_int(h), c_int(w),
+           c_int(max_regions), c_double(scale_x), c_double(scale_y), ptr(hull_n), ptr(hull_head), ptr(calipers),
+           ptr(buf), c_size_t(nbytes), _st())
+
+
+def east_pixel_detect(score, link16, h, w, score_thresh, link_thresh, mask, first_second):
+    L.call("ocr_east_pixel_detect", ptr(score), ptr(link16), c_int(h), c_int(w), c_float(score_thresh),
+           c_float(link_thresh), ptr(mask), ptr(first_second), _st())
+
+
+def zero_pixels(mask, idx):
+    L.call("ocr_zero_pixels_u8", ptr(mask), ptr(idx), c_int(idx.numel()), _st())
+
+
 # ----------------------------------------------------------------------------- labels
 def poly_cover(polys, counts, ignore, h, w, cover):
     n, P, V, _ = polys.shape

@@ -193,3 +193,83 @@ def generate_rbox_batch(h, w, xs_list, ys_list, bboxes_list, ignored_list, graph
     link = torch.empty((n, nh, nw, 8), dtype=F32, device=dev)
     ops.pixellink_labels(cover, nh, nw, score, link)
     return score, link, show_bboxes
+
+
+def east_pixel_detect(score_map, geo_map, score_map_thresh=0.8, link_thresh=0.8, graph=None):
+    """test.py:45-74, the EAST script's own `pixel_detect` — NOT the same function as
+    tool/pixellink_fn.pixel_detect above: after `res = score > t`, each of the 8 link channels only
+    contributes `res[link_text[0], link_text[1]] = 0` with link_text = np.argwhere(channel < t_l), i.e.
+    the first two below-threshold pixels (y0,x0), (y1,x1) in raster order zero res[y0,y1] and
+    res[x0,x1].  Reproduced as written, including numpy's IndexError when a channel has fewer than
+    two such pixels or an index falls outside the map.  score_map [1,h,w,1] or [h,w]; geo_map
+    [1,h,w,16] or [h,w,16] (softmaxed link pairs).  Returns uint8 [h,w] on the device."""
+    import numpy as np
+    g = graph or get_default_graph()
+    s = _dev(g, score_map)
+    lk = _dev(g, geo_map)
+    if s.dim() == 4:
+        s = s[0, :, :, 0].contiguous()
+        lk = lk[0].contiguous()
+    h, w = s.shape
+    mask = torch.empty((h, w), dtype=torch.uint8, device=g.device)
+    fs = torch.full((2, 8), 2 ** 31 - 1, dtype=torch.int32, device=g.device)
+    ops.east_pixel_detect(s, lk, h, w, float(score_map_thresh), float(link_thresh), mask, fs)
+    first, second = fs.cpu().numpy()
+    idx = []
+    for i in range(8):
+        if second[i] == 2 ** 31 - 1:
+            n_found = 0 if first[i] == 2 ** 31 - 1 else 1
+            raise IndexError("index %d is out of bounds for axis 0 with size %d" % (n_found, n_found))
+        (y0, x0), (y1, x1) = divmod(int(first[i]), w), divmod(int(second[i]), w)
+        for row, col in ((y0, y1), (x0, x1)):            # res[[y0, x0], [y1, x1]] = 0
+            if row >= h or col >= w:
+                raise IndexError("index %d is out of bounds" % (row if row >= h else col))
+            idx.append(row * w + col)
+    ops.zero_pixels(mask, torch.tensor(idx, dtype=torch.int32, device=g.device))
+    return mask
+
+
+def find_contour_boxes(mask, scale_x=1.0, scale_y=1.0, max_regions=4096, graph=None):
+    """One `cv2.minAreaRect` / `np.int0(cv2.boxPoints(.))` per contour of
+    `cv2.findContours(mask, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)` (test.py:182-190): the outer
+    border of every 8-connected component of 1-pixels, and the border of every hole (a 4-connected
+    0-region that does not reach the image edge; its contour = the 1-pixels with a 4-neighbour in it).
+    A contour's rectangle depends only on the convex hull of its points, so regions are labelled
+    (ocr_mask_cc) and hulled (ocr_min_area_rects / ocr_hole_border_rects) on the GPU without tracing
+    borders.  mask uint8 [h,w].  Returns (rects float32 [k,5], boxes int64 [k,4,2]); outer contours
+    first (components in raster order of their first pixel), then holes — OpenCV's list order differs,
+    the set of boxes does not."""
+    import numpy as np
+    g = graph or get_default_graph()
+    m = mask if isinstance(mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8))
+    m = (m.to(g.device) != 0).to(torch.uint8).contiguous()[None]
+    _, h, w = m.shape
+    out_r, out_b = [], []
+    for value, conn in ((1, 8), (0, 4)):
+        labels = torch.empty((1, h, w), dtype=torch.int32, device=g.device)
+        ncomp = torch.empty((1,), dtype=torch.int32, device=g.device)
+        comps = torch.zeros((1, max_regions, 2), dtype=torch.int32, device=g.device)
+        ops.mask_cc(m, value, conn, labels, ncomp, comps, g.workspace())
+        k = int(ncomp[0].item())
+        if k > max_regions:
+            raise ValueError("more than %d regions" % max_regions)
+        if k == 0:
+            continue
+        hull_n = torch.zeros((1, max_regions), dtype=torch.int32, device=g.device)
+        head = torch.zeros((1, max_regions, 4), dtype=torch.int32, device=g.device)
+        cal = torch.zeros((1, max_regions, 6), dtype=F32, device=g.device)
+        if value == 1:
+            ops.min_area_rects(labels, ncomp, max_regions, float(scale_x), float(scale_y), hull_n, head, cal, g.workspace())
+        else:
+            ops.hole_border_rects(m, labels, ncomp, max_regions, float(scale_x), float(scale_y), hull_n, head, cal,
+                                  g.workspace())
+        hn, hd, cl = hull_n[0, :k].cpu().numpy(), head[0, :k].cpu().numpy(), cal[0, :k].cpu().numpy()
+        for i in range(k):
+            if hn[i] == 0:                       # a 0-region that reaches the edge: background, no contour
+                continue
+            r = _rotated_rect(int(hn[i]), hd[i], cl[i])
+            out_r.append(r)
+            out_b.append(_box_points(r).astype(np.int64))
+    if not out_r:
+        return np.zeros((0, 5), np.float32), np.zeros((0, 4, 2), np.int64)
+    return np.stack(out_r), np.stack(out_b)

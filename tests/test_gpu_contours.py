@@ -1,0 +1,85 @@
+"""GPU: the EAST script's decode (test.py:45-74,182-201): `pixel_detect` twin, findContours regions
+(components + holes) and one oriented box per contour, against the definitional CPU restatement
+(oracle/contours.py) — masks bit-exact, box SETS bit-exact (OpenCV's list order is not reproduced)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import contours as OC
+
+pytestmark = pytest.mark.gpu
+
+
+def _mask(rng, h, w, blobs=10, holes=True):
+    ys, xs = np.mgrid[0:h, 0:w]
+    m = np.zeros((h, w), bool)
+    for _ in range(blobs):
+        cy, cx = rng.uniform(0, h), rng.uniform(0, w)
+        a, b, th = rng.uniform(3, w / 5), rng.uniform(2, h / 6), rng.uniform(-1, 1)
+        u = (xs - cx) * np.cos(th) + (ys - cy) * np.sin(th)
+        v = -(xs - cx) * np.sin(th) + (ys - cy) * np.cos(th)
+        blob = (np.abs(u) <= a) & (np.abs(v) <= b)
+        if holes and rng.uniform() < 0.7:
+            blob &= ~(((u / (a * 0.5)) ** 2 + (v / (b * 0.5)) ** 2) <= 1)      # ring: one hole (maybe open at the edge)
+        m |= blob
+    m ^= rng.uniform(size=(h, w)) < 0.01                                       # salt & pepper: tiny holes / dots
+    return m.astype(np.uint8)
+
+
+def _keyset(boxes):
+    return sorted(tuple(np.asarray(b).ravel().tolist()) for b in boxes)
+
+
+@pytest.mark.parametrize("h,w,seed", [(40, 56, 0), (96, 128, 1), (128, 128, 2), (64, 200, 3)])
+def test_contour_boxes_match_definition(device, h, w, seed):
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.tool import pixellink_fn as P
+    g = Graph(device)
+    rng = np.random.default_rng(seed)
+    m = _mask(rng, h, w)
+    if seed == 0:
+        m[:] = 0
+        m[5:20, 5:30] = 1
+        m[8:12, 8:12] = 0                 # one hole
+        m[9:11, 9:11] = 1                 # an island inside the hole
+        m[25:35, 0:10] = 1
+        m[28:32, 0:4] = 0                 # a notch open to the image edge: NOT a hole
+        m[38, 50] = 1                     # a single pixel
+    rects, boxes = P.find_contour_boxes(m, graph=g)
+    orects, oboxes = OC.contour_boxes(m)
+    assert len(boxes) == len(oboxes)
+    assert _keyset(boxes) == _keyset(oboxes)
+    assert sorted(r.tobytes() for r in rects) == sorted(r.tobytes() for r in orects)
+    if seed == 0:
+        kinds = [k for k, _ in OC.contour_point_sets(m)]
+        assert kinds.count("outer") == 4 and kinds.count("hole") == 1
+
+
+def test_empty_and_full_masks(device):
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.tool import pixellink_fn as P
+    g = Graph(device)
+    r, b = P.find_contour_boxes(np.zeros((16, 16), np.uint8), graph=g)
+    assert r.shape == (0, 5) and b.shape == (0, 4, 2)
+    r, b = P.find_contour_boxes(np.ones((16, 24), np.uint8), graph=g)
+    assert len(b) == 1 and _keyset(b) == _keyset(OC.contour_boxes(np.ones((16, 24), np.uint8))[1])
+
+
+def test_east_pixel_detect_twin(device):
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.tool import pixellink_fn as P
+    g = Graph(device)
+    rng = np.random.default_rng(4)
+    h, w = 48, 48
+    score = rng.uniform(size=(1, h, w, 1)).astype(np.float32)
+    geo = rng.uniform(0.7, 1.0, size=(1, h, w, 16)).astype(np.float32)
+    got = P.east_pixel_detect(score, geo, 0.8, 0.8, graph=g).cpu().numpy()
+    want = OC.east_pixel_detect(score, geo, 0.8, 0.8)
+    assert got.dtype == np.uint8 and np.array_equal(got, want)
+    assert got.sum() > 100 and (got != (score[0, :, :, 0] > 0.8)).sum() <= 16
+    # a channel with fewer than two pixels below the threshold: numpy raises IndexError, so do we
+    geo[..., 5] = 0.95
+    with pytest.raises(IndexError):
+        OC.east_pixel_detect(score, geo, 0.8, 0.8)
+    with pytest.raises(IndexError):
+        P.east_pixel_detect(score, geo, 0.8, 0.8, graph=g)

@@ -74,3 +74,66 @@ def test_train_pixellink_on_icdar_directory(device, tmp_path, capsys):
     assert len(lines) == 2
     assert "lr 0.001000" in lines[0] and "lr 0.000100" in lines[1]          # 0.01 * 0.1, then * 0.01
     assert all(np.isfinite(float(l.split("loss = ")[1].split(" ")[0])) for l in lines)
+
+
+def test_east_test_script_end_to_end(device, tmp_path, capsys):
+    """test.py counterpart: network -> softmaxes -> pixel_detect twin -> contour boxes -> res files;
+    the mask-to-lines tail is compared with the CPU restatement on a synthetic mask."""
+    import re
+    from oracle import contours as OC
+    sys.path.insert(0, ROOT)
+    east = importlib.import_module("test")
+    assert east.__file__.startswith(ROOT)
+    rng = np.random.default_rng(2)
+    os.makedirs(os.path.join(tmp_path, "in"))
+    for i, (H, W) in enumerate([(200, 260), (160, 160)]):
+        np.save(os.path.join(tmp_path, "in", "photo_%d.npy" % i), rng.integers(0, 256, size=(H, W, 3)).astype(np.uint8))
+    out_dir = os.path.join(tmp_path, "res")
+    # a checkpoint whose link head is zero (softmax 0.5 < 0.8 everywhere): with random weights some link
+    # channel may have no pixel below the threshold and test.py:70-72 — reproduced faithfully — raises
+    from tensorflow_ocr_amd import checkpoint
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model
+    g0 = Graph(device, seed=3)
+    model.model(np.zeros((1, 64, 64, 3), np.float32), is_training=False, graph=g0)
+    sd = checkpoint.internal_to_tf(g0.store.state_dict())
+    assert sd["feature_fusion/Conv_9/weights"].shape == (1, 1, 16, 16) or sd["feature_fusion/Conv_9/weights"].shape[-1] == 16
+    sd["feature_fusion/Conv_9/weights"] = np.zeros_like(sd["feature_fusion/Conv_9/weights"])
+    sd["feature_fusion/Conv_9/biases"] = np.zeros_like(sd["feature_fusion/Conv_9/biases"])
+    # random weights under inference-mode BN (moving stats 0 / 1) overflow f16 through 50 layers: switch
+    # the trunk off (gamma = 0) and let the pixel head's bias say "text" everywhere (softmax 0.95)
+    for k in sd:
+        if k.endswith("BatchNorm/gamma"):
+            sd[k] = np.zeros_like(sd[k])
+    sd["feature_fusion/Conv_8/biases"] = np.array([0.0, 3.0], np.float32)
+    ck = os.path.join(tmp_path, "ckpt")
+    checkpoint.save_tf_checkpoint(ck, 7, sd, {k: v for k, v in sd.items() if "moving_" not in k})
+    out = _run("test", ["--test_data_path", os.path.join(tmp_path, "in"), "--output_dir", out_dir,
+                        "--checkpoint_path", ck], capsys)
+    assert "Find 2 images" in out and out.count("net time:") == 2 and "Restore from" in out
+    for i in range(2):
+        txt = open(os.path.join(out_dir, "res_photo_%d.txt" % i), newline="").read()
+        lines = txt.split("\r\n")[:-1]
+        assert len(lines) == 1                      # one component: the whole (resized) image at 1/4 resolution
+        for line in lines:
+            assert re.fullmatch(r"-?\d+(,-?\d+){7}", line), line
+    # resize rule of test.py:92-121 and the mask -> boxes -> ordered lines tail
+    g = Graph(device)
+    im = rng.integers(0, 256, size=(200, 260, 3)).astype(np.uint8)
+    t, (rh, rw) = east.resize_image(im, graph=g)
+    assert tuple(t.shape) == (160, 224, 3) and (rh, rw) == (160 / 200.0, 224 / 260.0)
+    m = np.zeros((40, 56), np.uint8)
+    m[4:12, 6:30] = 1
+    m[6:9, 10:14] = 0
+    ys, xs = np.mgrid[0:40, 0:56]
+    m[(np.abs((xs - 35) * 0.8 + (ys - 28) * 0.6) <= 12) & (np.abs(-(xs - 35) * 0.6 + (ys - 28) * 0.8) <= 3)] = 1
+    got = [east.order_points(b) for b in east.boxes_from_mask(m, rh, rw, graph=g)]
+    want = []
+    for b in OC.contour_boxes(m)[1]:
+        b = b.copy()
+        b[:, 0] = b[:, 0] * 4
+        b[:, 1] = b[:, 1] * 4
+        b[:, 0] = b[:, 0] / rw
+        b[:, 1] = b[:, 1] / rh
+        want.append(OC.order_points(b))
+    assert len(got) == 3 and sorted(x.ravel().tolist() for x in got) == sorted(x.ravel().tolist() for x in want)
