@@ -27,25 +27,25 @@ TRAIN_GFLOP_PER_IMG = 516.5       # BASELINE.md §2, VGG-16 + PixelLink heads at
 
 
 def cpu_baseline(size, threads):
-    """The oracle's (CPU restatement, f32) full train step on a bounded sample: batch 1."""
+    """The oracle's (CPU restatement, f32) full train step on a bounded sample: ONE image of the
+    benchmark's size (1/32 of a step's batch), forward + loss + backward, best of 3 after a warm-up."""
     from oracle import ocr_oracle as O
     threads = min(threads, 64)            # batch-1 convs stop scaling long before 256 threads
     torch.set_num_threads(threads)
     rng = np.random.default_rng(0)
     p = O.init_model_vgg_params(rng)
-    size = size // 2                       # bounded sample: a quarter-image crop
     images, pixel, link, mask = O.synthetic_batch(rng, 1, size)
     times = []
-    for it in range(2):
+    for it in range(4):
         t0 = time.time()
         tp = O.to_torch_params(p)
         px, lk, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=False)
         L = O.dice_loss(torch.from_numpy(pixel), px, torch.from_numpy(link), lk, torch.from_numpy(mask))
         L.backward()
         times.append(time.time() - t0)
-    return {"value": round(0.25 / min(times), 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "one %dx%d crop (= 1/4 of a 512x512 image's work), forward+loss+backward, best of 2, "
-                      "torch-CPU f32 oracle; value scaled to full images" % (size, size)}
+    return {"value": round(1.0 / min(times[1:]), 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "one %dx%d image (1/32 of the step's batch), forward+loss+backward, best of 3 after a warm-up, "
+                      "torch-CPU f32 oracle (%.1f s of CPU work in all)" % (size, size, sum(times))}
 
 
 def main():
