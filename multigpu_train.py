@@ -100,7 +100,8 @@ def main():
         if it == 0:
             # variables exist after the first step: restore (:145-148) or load the pretrained backbone (:149-151)
             src = FLAGS.checkpoint_path if FLAGS.restore else FLAGS.pretrained_model_path
-            if src and (os.path.isdir(src) and os.path.exists(os.path.join(src, 'checkpoint')) or os.path.exists(src + '.index')):
+            if src and (os.path.isdir(src) and os.path.exists(os.path.join(src, 'checkpoint')) or os.path.exists(src + '.index')
+                        or os.path.isfile(src)):
                 sd, _ = checkpoint.load_tf_checkpoint(src)
                 g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
                 if rank == 0:

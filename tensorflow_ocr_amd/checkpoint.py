@@ -107,7 +107,10 @@ def load_tf_checkpoint(path, use_moving_averages=False):
             raise FileNotFoundError("no `checkpoint` state file in %s" % path)
     if prefix.endswith(".index"):
         prefix = prefix[:-len(".index")]
-    raw = tf_bundle.read_bundle(prefix)
+    if tf_bundle.is_v1_checkpoint(prefix):                # slim model-zoo files (resnet_v1_50.ckpt, train.sh:3)
+        raw = tf_bundle.read_v1_checkpoint(prefix)
+    else:
+        raw = tf_bundle.read_bundle(prefix)
     step = int(raw.pop("global_step")) if "global_step" in raw else None
     sd = {k: v for k, v in raw.items() if not k.endswith(EMA_SUFFIX)}
     if use_moving_averages:

@@ -417,3 +417,109 @@ def get_checkpoint_state(checkpoint_dir):
             rel = line.split(":", 1)[1].strip().strip('"')
             return rel if os.path.isabs(rel) else os.path.join(checkpoint_dir, rel)
     return None
+
+
+# ------------------------------------------------------------------------------- V1 checkpoints
+# The slim model-zoo files the reference starts from (`--pretrained_model_path
+# /data/resnet_v1_50.ckpt`, train.sh:3, multigpu_train.py:149-151) are "V1" checkpoints: ONE table file
+# (tensorflow/core/util/tensor_slice_writer.cc, saved_tensor_slice.proto), usually with
+# snappy-compressed blocks.  Key "" holds SavedTensorSlices{meta: SavedTensorSliceMeta{tensor:
+# SavedSliceMeta{name=1, shape=2, type=3, slice=4}}}; every other entry holds
+# SavedTensorSlices{data: SavedSlice{name=1, slice=2, data=3: TensorProto}} with the values in the
+# TensorProto's typed repeated field (float_val=5 packed, double_val=6, int_val=7, int64_val=10,
+# half_val=13) or in tensor_content=4.  Only whole-tensor slices are supported (no partitioned
+# variables), which is what single-device savers write.
+_V1_FIELD = {DT_FLOAT: (5, "<f4"), DT_DOUBLE: (6, "<f8"), DT_INT32: (7, None), DT_INT64: (10, None), DT_HALF: (13, None)}
+
+
+def _packed_varints(buf):
+    out, pos = [], 0
+    while pos < len(buf):
+        v, pos = _get_varint(buf, pos)
+        out.append(v - (1 << 64) if v >= (1 << 63) else v)
+    return out
+
+
+def _decode_tensor_proto(buf, dtype, count):
+    fld, fmt = _V1_FIELD[dtype]
+    content, chunks = None, []
+    for fn, wt, v in _pb_fields(buf):
+        if fn == 4:
+            content = bytes(v)
+        elif fn == fld:
+            if wt == 2 and fmt:                           # packed fixed-width
+                chunks.append(np.frombuffer(bytes(v), dtype=fmt))
+            elif wt == 2:                                 # packed varints
+                chunks.append(np.array(_packed_varints(v), dtype=np.int64))
+            elif wt == 0:
+                chunks.append(np.array([v - (1 << 64) if v >= (1 << 63) else v], dtype=np.int64))
+            else:                                         # unpacked fixed32 / fixed64
+                chunks.append(np.frombuffer(bytes(v), dtype=fmt))
+    np_dt = _NP_OF[dtype]
+    if content is not None and len(content):
+        return np.frombuffer(content, dtype=np_dt).copy()
+    if not chunks:
+        return np.zeros(count, np_dt)
+    a = np.concatenate(chunks)
+    if dtype == DT_HALF:                                  # half_val carries the 16 raw bits in an int32
+        a = a.astype(np.uint16).view(np.float16)
+    a = a.astype(np_dt)
+    if a.size == 1 and count > 1:                         # TensorProto's "all elements equal" compression
+        a = np.repeat(a, count)
+    return a
+
+
+def read_v1_checkpoint(path):
+    """{variable name: numpy array} of a V1 (single-file) TensorFlow checkpoint."""
+    entries = read_table(path)
+    if not entries or entries[0][0] != b"":
+        raise ValueError("%s has no SavedTensorSliceMeta entry" % path)
+    meta = {}
+    for fn, _, v in _pb_fields(entries[0][1]):
+        if fn != 1:
+            continue
+        for f2, _, v2 in _pb_fields(v):                   # SavedTensorSliceMeta.tensor
+            if f2 != 1:
+                continue
+            name, shape, dtype, nslices = None, (), DT_FLOAT, 0
+            for f3, _, v3 in _pb_fields(v2):              # SavedSliceMeta
+                if f3 == 1:
+                    name = bytes(v3).decode()
+                elif f3 == 2:
+                    shape = _decode_shape(v3)
+                elif f3 == 3:
+                    dtype = v3
+                elif f3 == 4:
+                    nslices += 1
+            if nslices > 1:
+                raise ValueError("%s: partitioned variables are not supported" % name)
+            meta[name] = (shape, dtype)
+    out = {}
+    for _, val in entries[1:]:
+        for fn, _, v in _pb_fields(val):
+            if fn != 2:
+                continue
+            name, data = None, b""
+            for f2, _, v2 in _pb_fields(v):               # SavedSlice
+                if f2 == 1:
+                    name = bytes(v2).decode()
+                elif f2 == 3:
+                    data = v2
+            shape, dtype = meta[name]
+            if dtype not in _V1_FIELD:
+                raise TypeError("%s: unsupported checkpoint dtype %d" % (name, dtype))
+            count = int(np.prod(shape)) if shape else 1
+            out[name] = _decode_tensor_proto(data, dtype, count).reshape(shape)
+    return out
+
+
+def is_v1_checkpoint(path):
+    """A single table file (V2 checkpoints are a prefix with .index / .data-* files)."""
+    if not os.path.isfile(path) or os.path.exists(path + ".index"):
+        return False
+    with open(path, "rb") as f:
+        f.seek(0, 2)
+        if f.tell() < 48:
+            return False
+        f.seek(-8, 2)
+        return struct.unpack("<Q", f.read(8))[0] == TABLE_MAGIC

@@ -99,3 +99,80 @@ def test_checkpoint_round_trip_with_ema_and_state_file(tmp_path):
     open(data, "wb").write(raw)
     with pytest.raises(ValueError):
         C.load_tf_checkpoint(prefix)
+
+
+def _v1_file(path, tensors, compress):
+    """A V1 checkpoint written field by field (saved_tensor_slice.proto), optionally with snappy blocks
+    (literal-only streams: valid snappy, no compressor needed)."""
+    def tensor_proto(a):
+        a = np.asarray(a)
+        if a.dtype == np.float32:
+            return B._pb_bytes(5, a.astype("<f4").tobytes())                       # float_val, packed
+        if a.dtype == np.int64:
+            return B._pb_bytes(10, b"".join(B._put_varint(int(v)) for v in a.ravel()))   # int64_val, packed
+        if a.dtype == np.int32:
+            return b"".join(B._pb_varint(7, int(v)) for v in a.ravel())            # int_val, unpacked
+        raise TypeError(a.dtype)
+    metas, items = b"", []
+    for name in sorted(tensors):
+        a = np.asarray(tensors[name])
+        full = b"".join(B._pb_bytes(1, b"") for _ in a.shape)                       # TensorSliceProto: full extents
+        sm = B._pb_bytes(1, name.encode()) + B._pb_bytes(2, B._encode_shape(a.shape)) + \
+            B._pb_varint(3, B._DT_OF[a.dtype]) + B._pb_bytes(4, full)
+        metas += B._pb_bytes(1, sm)
+        sl = B._pb_bytes(1, name.encode()) + B._pb_bytes(2, full) + B._pb_bytes(3, tensor_proto(a))
+        items.append((b"\x00" + name.encode() + b"\x00\x01", B._pb_bytes(2, sl)))   # stand-in for the ordered-code key
+    items = [(b"", B._pb_bytes(1, metas))] + sorted(items)
+    B.write_table(path, items)
+    if compress:                                   # rewrite every block as a snappy literal stream
+        raw = open(path, "rb").read()
+        import struct as st
+        footer = raw[-48:]
+        _, pos = B._get_varint(footer, 0)
+        _, pos = B._get_varint(footer, pos)
+        ioff, pos = B._get_varint(footer, pos)
+        isize, pos = B._get_varint(footer, pos)
+        out = bytearray()
+        index = B._BlockBuilder()
+
+        def emit(block, ctype):
+            off = len(out)
+            out.extend(block)
+            out.append(ctype)
+            out.extend(st.pack("<I", B.mask_crc(B.crc32c(bytes(block) + bytes([ctype])))))
+            return off, len(block)
+
+        def snappy_literal(b):
+            o = bytearray(B._put_varint(len(b)))
+            for i in range(0, len(b), 60):
+                chunk = b[i:i + 60]
+                o.append((len(chunk) - 1) << 2)
+                o.extend(chunk)
+            return bytes(o)
+        for key, handle in B._block_entries(B._read_block(raw, ioff, isize)):
+            boff, p2 = B._get_varint(handle, 0)
+            bsize, _ = B._get_varint(handle, p2)
+            off, size = emit(snappy_literal(B._read_block(raw, boff, bsize)), 1)
+            index.add(key, B._put_varint(off) + B._put_varint(size))
+        moff, msize = emit(B._BlockBuilder().finish(), 0)
+        ioff2, isize2 = emit(index.finish(), 0)
+        f = B._put_varint(moff) + B._put_varint(msize) + B._put_varint(ioff2) + B._put_varint(isize2)
+        out.extend(f + b"\x00" * (40 - len(f)) + st.pack("<Q", B.TABLE_MAGIC))
+        open(path, "wb").write(out)
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_v1_model_zoo_checkpoint_reader(tmp_path, compress):
+    rng = np.random.default_rng(2)
+    sd = {"resnet_v1_50/conv1/weights": rng.standard_normal((7, 7, 3, 64)).astype(np.float32),
+          "resnet_v1_50/block1/unit_1/bottleneck_v1/conv1/BatchNorm/gamma": np.ones(64, np.float32),
+          "global_step": np.asarray(12345, np.int64), "counts": np.arange(6, dtype=np.int32).reshape(2, 3)}
+    path = str(tmp_path / "resnet_v1_50.ckpt")
+    _v1_file(path, sd, compress)
+    assert B.is_v1_checkpoint(path)
+    out = B.read_v1_checkpoint(path)
+    assert set(out) == set(sd)
+    for k in sd:
+        assert out[k].dtype == np.asarray(sd[k]).dtype and np.array_equal(out[k], sd[k])
+    got, step = C.load_tf_checkpoint(path)                 # the --pretrained_model_path route
+    assert step == 12345 and np.array_equal(got["resnet_v1_50/conv1/weights"], sd["resnet_v1_50/conv1/weights"])
