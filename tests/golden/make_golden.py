@@ -1,4 +1,5 @@
-"""Generates the golden fixtures in this directory FROM THE ORACLE (oracle/ocr_oracle.py).
+"""Generates the golden fixtures in this directory FROM THE ORACLE (oracle/ocr_oracle.py and the
+OpenCV / pipeline restatements beside it).
 
 The reference itself cannot run (Python 2 / TF 1.4 / cv2 absent) and ships no
 vectors, so these pin the oracle against accidental change and give the GPU tests fixed
@@ -61,7 +62,45 @@ def primitives():
                         dice=np.float32(dl))
 
 
+def cv_geometry():
+    """Pins of the OpenCV / pipeline restatements (oracle/cvgeom_oracle.c, labels.py, evalboxes.py,
+    contours.py): fixed inputs and the outputs they produce today."""
+    from oracle import contours as OC
+    from oracle import cvgeom as C
+    from oracle import evalboxes as OE
+    from oracle import labels as OL
+    rng = np.random.default_rng(21)
+    out = {}
+    pts = rng.integers(0, 200, size=(40, 2)).astype(np.int32)
+    rect, cal, hull = C.min_area_rect(pts)
+    out.update(mar_pts=pts, mar_rect=rect, mar_cal=cal, mar_hull=hull, mar_box=C.box_points(rect))
+    quad = np.array([[5, 3], [58, 9], [49, 40], [2, 30]], np.int32)
+    out.update(fill_quad=quad, fill_img=C.fill_poly(np.zeros((48, 64), np.uint8), quad, 1))
+    src = rng.integers(0, 256, size=(37, 53, 3)).astype(np.uint8)
+    out.update(rs_src=src, rs_64=C.resize_linear_u8(src, 64, 64), rs_half=C.resize_linear_u8(src[:36, :52], 18, 26))
+    polys = np.array([[[10, 8], [50, 12], [48, 30], [8, 26]], [[30, 20], [60, 22], [58, 44], [28, 40]],
+                      [[2, 50], [12, 50], [12, 56], [2, 56]]], np.float32)
+    tags = np.array([False, True, False])
+    s4, g4, m4 = OL.icdar_labels((64, 64), polys, tags)
+    out.update(lab_polys=polys, lab_tags=tags, lab_score=s4, lab_geo=g4, lab_mask=m4)
+    ps, pl, _ = OL.pixellink_generate_rbox(64, 64, polys[:, :, 0] / 64, polys[:, :, 1] / 64,
+                                           np.zeros((3, 4), np.float32), np.zeros(3, np.int32))
+    out.update(pl_score=ps, pl_link=pl)
+    det = np.array([[10, 8, 50, 12, 48, 30, 8, 26], [31, 21, 59, 23, 57, 43, 29, 39], [70, 70, 90, 70, 90, 80, 70, 80]])
+    n, tp, fp = OE.bboxes_matching(det, polys[:, :, 0].astype(int), polys[:, :, 1].astype(int), np.array([0, 0, 1]))
+    out.update(ev_det=det, ev_n=np.int32(n), ev_tp=tp, ev_fp=fp,
+               ev_iou=np.stack([OE.np_bboxes_jaccard(d, polys[:, :, 0].astype(int), polys[:, :, 1].astype(int)) for d in det]))
+    mask = np.zeros((24, 32), np.uint8)
+    mask[3:15, 4:20] = 1
+    mask[6:10, 8:12] = 0
+    mask[18:22, 25:31] = 1
+    rects, boxes = OC.contour_boxes(mask)
+    out.update(ct_mask=mask, ct_rects=np.stack(rects), ct_boxes=np.stack(boxes))
+    np.savez_compressed(os.path.join(HERE, "cv_geometry.npz"), **out)
+
+
 if __name__ == "__main__":
     model_vgg_small()
     primitives()
+    cv_geometry()
     print("golden fixtures written to", HERE)

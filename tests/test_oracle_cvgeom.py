@@ -218,3 +218,32 @@ def test_icdar_host_parsing_and_validation(tmp_path):
     assert pk.shape == (2, 3, 4, 2) and cnt.tolist() == [3, 0] and ign[0].tolist() == [0, 1, 0]
     with pytest.raises(ValueError):
         icdar.pack_polys([np.zeros((255, 4, 2), np.float32)], [np.zeros(255, bool)])
+
+
+def test_golden_cv_geometry_fixture():
+    """The restatements still produce the committed vectors (tests/golden/cv_geometry.npz, written by
+    tests/golden/make_golden.py from these same functions: a pin against accidental change)."""
+    import os
+    from oracle import contours as OC
+    from oracle import evalboxes as OE
+    from oracle import labels as OL
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cv_geometry.npz"))
+    rect, cal, hull = C.min_area_rect(g["mar_pts"])
+    assert rect.tobytes() == g["mar_rect"].tobytes() and cal.tobytes() == g["mar_cal"].tobytes()
+    assert np.array_equal(hull, g["mar_hull"]) and C.box_points(rect).tobytes() == g["mar_box"].tobytes()
+    assert np.array_equal(C.fill_poly(np.zeros((48, 64), np.uint8), g["fill_quad"], 1), g["fill_img"])
+    assert np.array_equal(C.resize_linear_u8(g["rs_src"], 64, 64), g["rs_64"])
+    assert np.array_equal(C.resize_linear_u8(g["rs_src"][:36, :52], 18, 26), g["rs_half"])
+    s4, g4, m4 = OL.icdar_labels((64, 64), g["lab_polys"], g["lab_tags"])
+    assert np.array_equal(s4, g["lab_score"]) and np.array_equal(g4, g["lab_geo"]) and np.array_equal(m4, g["lab_mask"])
+    polys = g["lab_polys"]
+    ps, pl, _ = OL.pixellink_generate_rbox(64, 64, polys[:, :, 0] / 64, polys[:, :, 1] / 64,
+                                           np.zeros((3, 4), np.float32), np.zeros(3, np.int32))
+    assert np.array_equal(ps, g["pl_score"]) and np.array_equal(pl, g["pl_link"])
+    gx, gy = polys[:, :, 0].astype(int), polys[:, :, 1].astype(int)
+    n, tp, fp = OE.bboxes_matching(g["ev_det"], gx, gy, np.array([0, 0, 1]))
+    assert n == int(g["ev_n"]) and np.array_equal(tp, g["ev_tp"]) and np.array_equal(fp, g["ev_fp"])
+    assert np.array_equal(np.stack([OE.np_bboxes_jaccard(d, gx, gy) for d in g["ev_det"]]), g["ev_iou"])
+    rects, boxes = OC.contour_boxes(g["ct_mask"])
+    assert np.array_equal(np.stack(rects), g["ct_rects"]) and np.array_equal(np.stack(boxes), g["ct_boxes"])
+    assert len(boxes) == 3 and g["ev_tp"].tolist() == [True, True, False] and g["ev_fp"].tolist() == [False, False, True]
