@@ -89,6 +89,15 @@ def main():
                                      input_size=FLAGS.input_size, batch_size=FLAGS.batch_size_per_gpu,
                                      graph=g, seed=1000 + rank)
     start = time.time()
+    try:
+        _train_loop(FLAGS, g, step, feeder, rng, rank, world, device, start)
+    finally:
+        if feeder is not None:
+            feeder.close()
+
+
+def _train_loop(FLAGS, g, step, feeder, rng, rank, world, device, start):
+    from tensorflow_ocr_amd import checkpoint, synthetic
     for it in range(FLAGS.max_steps):
         if feeder is not None:
             images, _, score_maps, geo_maps, training_masks = next(feeder)

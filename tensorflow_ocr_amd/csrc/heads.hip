@@ -308,6 +308,34 @@ __global__ void sc_pointwise_dgrad_kernel(const float* __restrict__ dout, int ld
   }
 }
 
+// Fast paths of the two kernels above for the shapes the PixelLink predication convs have
+// (16 -> 16 link, 2 -> 2 pixel; square so one template serves forward and input gradient): one
+// thread per PIXEL — the input row is read once into registers, the C x C weights sit in LDS, and a
+// thread writes its C outputs as contiguous floats.  Same summation order per output as the generic
+// kernels (ascending input channel).
+template <int C, bool TRANSPOSE>
+__global__ __launch_bounds__(256) void sc_pointwise_square_kernel(const float* __restrict__ in, int ldi, int io,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, int P,
+                                                                  float* __restrict__ out, int ldo, int oo) {
+  __shared__ float ws[C * C];
+  // forward: out[co] = b[co] + sum_ci in[ci] * w[ci][co];  dgrad (TRANSPOSE): out[ci] = sum_co in[co] * w[ci][co]
+  for (int i = threadIdx.x; i < C * C; i += 256) ws[i] = TRANSPOSE ? w[(i % C) * C + i / C] : w[i];   // ws[k][j]: in k -> out j
+  __syncthreads();
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)P; p += (size_t)gridDim.x * 256) {
+    float v[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) v[k] = in[p * ldi + io + k];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      float a = (!TRANSPOSE && bias) ? bias[j] : 0.f;
+#pragma unroll
+      for (int k = 0; k < C; ++k) a += v[k] * ws[k * C + j];
+      out[p * ldo + oo + j] = a;
+    }
+  }
+}
+
 // partial[blk][ci*cout+co] (weights) and partial[blk][cin*cout+co] (bias) over the block's strip
 // of pixels; the strip is staged through LDS 64 pixels at a time, one thread per output pair.
 __global__ __launch_bounds__(256) void sc_pointwise_wgrad_kernel(
@@ -343,6 +371,81 @@ __global__ __launch_bounds__(256) void sc_pointwise_wgrad_kernel(
     const int j = threadIdx.x + k * 256;
     if (j < pairs) partial[(size_t)blockIdx.x * pairs + j] = acc[k];
   }
+}
+
+// 16 -> 16 fast path of sc_pointwise_wgrad_kernel: the block's 256 threads are 16 pair blocks (4 ci x 4
+// co, 16 accumulators in registers) x 16 pixel lanes; a pixel lane walks every 16th pixel of the
+// strip reading its 4 + 4 values straight from global memory (no LDS in the loop: the generic kernel
+// pays two LDS reads per FMA).  The 16 lane sums are combined in lane order: deterministic.
+__global__ __launch_bounds__(256) void sc_pointwise_wgrad16_kernel(
+    const float* __restrict__ x, int ldx, int xo, const float* __restrict__ dout, int ldo, int oo, int P,
+    int strip, float* __restrict__ partial) {
+  __shared__ float red[16][16 * 16 + 16];
+  const int pb = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int cib = pb >> 2, cob = pb & 3;
+  const int p0 = blockIdx.x * strip;
+  int p1 = p0 + strip;
+  if (p1 > P) p1 = P;
+  float acc[4][4], bacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bacc[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  }
+  for (int q = p0 + pl; q < p1; q += 16) {
+    float xv[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xv[i] = x[(size_t)q * ldx + xo + cib * 4 + i];
+      dv[i] = dout[(size_t)q * ldo + oo + cob * 4 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bacc[i] += dv[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += xv[i] * dv[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[pl][(cib * 4 + i) * 16 + cob * 4 + j] = acc[i][j];
+    if (cib == 0) red[pl][256 + cob * 4 + i] = bacc[i];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 16 * 16 + 16; j += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][j];
+    partial[(size_t)blockIdx.x * (16 * 16 + 16) + j] = t;
+  }
+}
+
+// 2 -> 2 fast path (the pixel predication conv): every thread walks pixels and keeps all 2x2 + 2 sums;
+// wave butterfly, then the four waves in order.
+__global__ __launch_bounds__(256) void sc_pointwise_wgrad2_kernel(
+    const float* __restrict__ x, int ldx, int xo, const float* __restrict__ dout, int ldo, int oo, int P,
+    int strip, float* __restrict__ partial) {
+  __shared__ float red[4][6];
+  const int p0 = blockIdx.x * strip;
+  int p1 = p0 + strip;
+  if (p1 > P) p1 = P;
+  float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // w00 w01 w10 w11 b0 b1
+  for (int q = p0 + (int)threadIdx.x; q < p1; q += 256) {
+    const float x0 = x[(size_t)q * ldx + xo], x1 = x[(size_t)q * ldx + xo + 1];
+    const float d0 = dout[(size_t)q * ldo + oo], d1 = dout[(size_t)q * ldo + oo + 1];
+    a[0] += x0 * d0; a[1] += x0 * d1; a[2] += x1 * d0; a[3] += x1 * d1; a[4] += d0; a[5] += d1;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    a[j] = wave_sum(a[j]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = a[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6)
+    partial[(size_t)blockIdx.x * 6 + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 unsigned sgrid(size_t items) {
@@ -546,6 +649,19 @@ extern "C" int ocr_sc_pointwise_fwd(const void* x, int ldx, int xo, int cin, con
                                     const void* bias, int P, void* out, int ldo, int oo, int cout,
                                     void* stream) {
   OCR_CHECK_ARG(x && w && out && P > 0 && cin > 0 && cout > 0);
+  if (cin == cout && (cin == 16 || cin == 2)) {
+    const dim3 grid(sgrid((size_t)P));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (cin == 16)
+      hipLaunchKernelGGL((sc_pointwise_square_kernel<16, false>), grid, dim3(256), 0, st, static_cast<const float*>(x),
+                         ldx, xo, static_cast<const float*>(w), static_cast<const float*>(bias), P,
+                         static_cast<float*>(out), ldo, oo);
+    else
+      hipLaunchKernelGGL((sc_pointwise_square_kernel<2, false>), grid, dim3(256), 0, st, static_cast<const float*>(x),
+                         ldx, xo, static_cast<const float*>(w), static_cast<const float*>(bias), P,
+                         static_cast<float*>(out), ldo, oo);
+    return ocr_launch_status();
+  }
   hipLaunchKernelGGL(sc_pointwise_fwd_kernel, dim3(sgrid((size_t)P * cout)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const float*>(x), ldx, xo, cin,
                      static_cast<const float*>(w), static_cast<const float*>(bias), P,
@@ -556,6 +672,19 @@ extern "C" int ocr_sc_pointwise_fwd(const void* x, int ldx, int xo, int cin, con
 extern "C" int ocr_sc_pointwise_dgrad(const void* dout, int ldo, int oo, int cout, const void* w,
                                       int P, void* dx, int ldx, int xo, int cin, void* stream) {
   OCR_CHECK_ARG(dout && w && dx && P > 0 && cin > 0 && cout > 0);
+  if (cin == cout && (cin == 16 || cin == 2)) {
+    const dim3 grid(sgrid((size_t)P));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (cin == 16)
+      hipLaunchKernelGGL((sc_pointwise_square_kernel<16, true>), grid, dim3(256), 0, st,
+                         static_cast<const float*>(dout), ldo, oo, static_cast<const float*>(w),
+                         (const float*)nullptr, P, static_cast<float*>(dx), ldx, xo);
+    else
+      hipLaunchKernelGGL((sc_pointwise_square_kernel<2, true>), grid, dim3(256), 0, st,
+                         static_cast<const float*>(dout), ldo, oo, static_cast<const float*>(w),
+                         (const float*)nullptr, P, static_cast<float*>(dx), ldx, xo);
+    return ocr_launch_status();
+  }
   hipLaunchKernelGGL(sc_pointwise_dgrad_kernel, dim3(sgrid((size_t)P * cin)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const float*>(dout), ldo, oo,
                      cout, static_cast<const float*>(w), P, static_cast<float*>(dx), ldx, xo, cin);
@@ -578,9 +707,16 @@ extern "C" int ocr_sc_pointwise_wgrad(const void* x, int ldx, int xo, int cin, c
   float* ws = static_cast<float*>(workspace);
   float* tot = ws + (size_t)B * pairs;
   OCR_CHECK_SHAPE(cin <= 32 && cout <= 32 && pairs <= 512);
-  hipLaunchKernelGGL(sc_pointwise_wgrad_kernel, dim3(B), dim3(256), 0, st,
-                     static_cast<const float*>(x), ldx, xo, cin, static_cast<const float*>(dout),
-                     ldo, oo, cout, P, ocr_cdiv(P, B), ws);
+  if (cin == 16 && cout == 16)
+    hipLaunchKernelGGL(sc_pointwise_wgrad16_kernel, dim3(B), dim3(256), 0, st, static_cast<const float*>(x), ldx,
+                       xo, static_cast<const float*>(dout), ldo, oo, P, ocr_cdiv(P, B), ws);
+  else if (cin == 2 && cout == 2)
+    hipLaunchKernelGGL(sc_pointwise_wgrad2_kernel, dim3(B), dim3(256), 0, st, static_cast<const float*>(x), ldx,
+                       xo, static_cast<const float*>(dout), ldo, oo, P, ocr_cdiv(P, B), ws);
+  else
+    hipLaunchKernelGGL(sc_pointwise_wgrad_kernel, dim3(B), dim3(256), 0, st,
+                       static_cast<const float*>(x), ldx, xo, cin, static_cast<const float*>(dout),
+                       ldo, oo, cout, P, ocr_cdiv(P, B), ws);
   hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(pairs)), dim3(256), 0, st, ws, tot,
                      pairs, B, 1.f);
   if (hipMemcpyAsync(dw, tot, (size_t)cin * cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)

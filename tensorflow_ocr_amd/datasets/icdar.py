@@ -185,7 +185,7 @@ def txt_name(im_fn):
 
 def _load_sample(args):
     """Host side of one sample (icdar.py:559-571,616-619): decode, parse, validate, scale the polygons
-    to the training size.  Runs in the decode worker processes."""
+    to the training size.  Runs in the decode workers."""
     im_fn, input_size = args
     tf = txt_name(im_fn)
     if not os.path.exists(tf):
@@ -212,7 +212,7 @@ def generator(training_data_path, input_size=512, batch_size=32, graph=None, shu
     read image + gt, validate polygons, resize to input_size x input_size, scale the polygons,
     labels at 1/4 resolution.  Yields (images [B,S,S,3] float32 RGB, image_fns, score_maps, geo_maps,
     training_masks) as DEVICE tensors (the reference yields lists of NumPy arrays).  num_workers > 0:
-    that many host processes decode and parse ahead (the reference's GeneratorEnqueuer workers)."""
+    that many host threads decode and parse ahead (the reference's GeneratorEnqueuer workers)."""
     image_list = np.array(sorted(get_images(training_data_path)))
     print('{} training images in {}'.format(image_list.shape[0], training_data_path))
     if len(image_list) == 0:
@@ -221,8 +221,10 @@ def generator(training_data_path, input_size=512, batch_size=32, graph=None, shu
     rng = np.random.RandomState(seed)
     pool = None
     if num_workers > 0:
-        import multiprocessing
-        pool = multiprocessing.get_context("fork" if not torch.cuda.is_initialized() else "spawn").Pool(num_workers)
+        # decode workers are THREADS: image decoding (PIL / np.load) runs in C with the GIL released, and
+        # a thread pool has none of the fork-after-HIP-init / spawn-teardown hazards of worker processes
+        from multiprocessing.pool import ThreadPool
+        pool = ThreadPool(num_workers)
     try:
         while True:
             if shuffle:
@@ -249,11 +251,12 @@ def generator(training_data_path, input_size=512, batch_size=32, graph=None, shu
     finally:
         if pool is not None:
             pool.terminate()
+            pool.join()
 
 
 def get_batch(num_workers=0, device_prefetch=2, **kwargs):
     """icdar.py:652-668: background producer + queue.  Host decode/parsing runs in `num_workers`
-    processes; upload, resize and label kernels run on the feeder's own HIP stream
+    threads; upload, resize and label kernels run on the feeder's own HIP stream
     (feeder.DeviceFeeder), `device_prefetch` batches ahead of the training step."""
     from ..feeder import DeviceFeeder
     graph = kwargs.get("graph") or get_default_graph()

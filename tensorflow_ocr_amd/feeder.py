@@ -40,13 +40,18 @@ class DeviceFeeder:
                 import contextlib
                 ctx = contextlib.nullcontext()
             with ctx:
-                for batch in make_iterator():
-                    ev = None
-                    if self.stream is not None:
-                        ev = torch.cuda.Event()
-                        ev.record(self.stream)
-                    if not self._put((batch, ev)):
-                        return
+                it = make_iterator()
+                try:
+                    for batch in it:
+                        ev = None
+                        if self.stream is not None:
+                            ev = torch.cuda.Event()
+                            ev.record(self.stream)
+                        if not self._put((batch, ev)):
+                            return
+                finally:
+                    if hasattr(it, "close"):
+                        it.close()           # runs the generator's own clean-up (worker pool) in THIS thread, now
         except BaseException as e:          # surfaced to the consumer
             self.err = e
         finally:
@@ -78,4 +83,10 @@ class DeviceFeeder:
                 self.q.get_nowait()
             except queue.Empty:
                 break
-        self.thread.join(timeout=5)
+        self.thread.join(timeout=10)
+
+    def __del__(self):
+        try:
+            self.stop.set()
+        except Exception:
+            pass

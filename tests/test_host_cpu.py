@@ -145,14 +145,28 @@ print("rank", rank, "ok")
 def test_gradient_allreduce_world2_gloo(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_WORKER % ROOT)
-    procs = []
-    port = 29500 + os.getpid() % 2000
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    import socket
+
+    def launch():
+        with socket.socket() as sk:                  # a port nobody holds right now
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        ps = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            ps.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                       stderr=subprocess.STDOUT))
+        try:
+            return ps, [p.communicate(timeout=120)[0].decode() for p in ps]
+        except subprocess.TimeoutExpired:
+            for p in ps:
+                p.kill()
+            return ps, None
+    procs, outs = launch()
+    if outs is None:
+        procs, outs = launch()                       # one more try on a fresh port
+    assert outs is not None, "two-rank rendezvous timed out twice"
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
