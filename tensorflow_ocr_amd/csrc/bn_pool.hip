@@ -128,11 +128,20 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
   q = 0.0;
   if (c < C) {
     const unsigned long long* st = reinterpret_cast<const unsigned long long*>(stage);
-    for (int r = rl; r < R; r += 4) {             // agent-scope loads (other CUs wrote these)
-      unsigned long long us = __hip_atomic_load(st + ((size_t)r * 2 + 0) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long uq = __hip_atomic_load(st + ((size_t)r * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s += __builtin_bit_cast(double, us);
-      q += __builtin_bit_cast(double, uq);
+    // agent-scope loads (other CUs wrote these), eight rows in flight per lane, summed in row order
+    for (int r0 = rl; r0 < R; r0 += 32) {
+      unsigned long long us[8], uq[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = r0 + 4 * k;
+        us[k] = r < R ? __hip_atomic_load(st + ((size_t)r * 2 + 0) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        uq[k] = r < R ? __hip_atomic_load(st + ((size_t)r * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s += __builtin_bit_cast(double, us[k]);     // (+0.0 for the rows past the end)
+        q += __builtin_bit_cast(double, uq[k]);
+      }
     }
   }
   red[rl][0][cl] = s;                             // (every reader of the first use passed the barriers above)
