@@ -37,7 +37,11 @@ struct BnBwdFin {         // MODE 1: batch-norm backward sums -> dbeta, dgamma
   float *dgamma, *dbeta;
 };
 
-__device__ unsigned ocr_bn_tickets[64 * 32];      // [slot][channel group], zero at load, self-resetting
+// Arrival counters, zero at load, self-resetting.  Two levels: blocks take a ticket of their group of 32
+// row blocks, the last of a group takes a ticket of the channel group — R same-address atomics in a
+// row cost ~0.1 us each (63 us for the 512 row blocks of conv1_2), 32 + R/32 do not.
+constexpr int kTicketGroup = 32, kTicketGroups = 128;            // R <= 4096 row blocks
+__device__ unsigned ocr_bn_tickets[16 * 32 * (1 + kTicketGroups)];   // [slot][channel group][0: level 2 | 1 + g: level 1]
 
 template <typename FIN>
 __device__ __forceinline__ void bn_fin_apply(const FIN& f, int c, double s, double q);
@@ -69,97 +73,133 @@ __device__ __forceinline__ void bn_fin_apply<BnBwdFin>(const BnBwdFin& f, int c,
   f.dgamma[c] = (float)q;
 }
 
-constexpr int kRedRows = 64;     // partial rows per block: many small blocks, short dependent chains
+// Partial rows per block: small blocks cost ~0.1 us each in dispatch alone (measured: launch time ~
+// 12 us + 0.1 us x blocks), long blocks serialise their loads; aim at <= 128 row blocks per channel group.
+static inline int red_rows(int T) {
+  int rows = ((T + 127) / 128 + 31) / 32 * 32;
+  if (rows < 64) rows = 64;
+  if (rows > 2048) rows = 2048;
+  return rows;
+}
 
 template <typename FIN>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ partial,
                                                               double* __restrict__ stage, int T, int C, int slot,
-                                                              FIN fin) {
-  __shared__ double red[4][2][64];
+                                                              int rows, FIN fin) {
+  // a block = one 64-channel group x `rows` partial rows; thread = 4 channels (one 16-byte load per
+  // row and sum) x one of 16 row lanes
+  __shared__ double red[16][2][64];
   __shared__ unsigned s_ticket;
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
-  const int t0 = blockIdx.x * kRedRows;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c4 = blockIdx.y * 64 + cl * 4;        // first of this thread's 4 channels
+  const int t0 = blockIdx.x * rows;
   const int R = gridDim.x;
-  double s = 0.0, q = 0.0;
-  if (c < C) {
-    // 16 rows per lane, loads issued four rows at a time (independent), summed in row order
-    for (int t = t0 + rl; t < t0 + kRedRows && t < T; t += 16) {
-      float a[4], b[4];
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+  const bool live = c4 < C;
+  const bool vec = (C & 3) == 0;
+  if (live) {
+    const int t1 = min(t0 + rows, T);
+    for (int t = t0 + rl; t < t1; t += 64) {      // rows rl, rl+16, ...: four rows (8 loads) in flight, added in row order
+      f32x4 a[4], b[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int tt = t + 4 * k;
-        const bool ok = tt < t0 + kRedRows && tt < T;
-        a[k] = ok ? partial[((size_t)tt * 2 + 0) * C + c] : 0.f;
-        b[k] = ok ? partial[((size_t)tt * 2 + 1) * C + c] : 0.f;
+        const int tt = t + 16 * k;
+        const bool ok = tt < t1;
+        a[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        b[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const float* pa = partial + ((size_t)tt * 2 + 0) * C + c4;
+          const float* pb = partial + ((size_t)tt * 2 + 1) * C + c4;
+          if (vec) {
+            a[k] = *reinterpret_cast<const f32x4*>(pa);
+            b[k] = *reinterpret_cast<const f32x4*>(pb);
+          } else {                                 // C not a multiple of 4 (the 18-channel heads): scalar, bounded
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c4 + e < C) { a[k][e] = pa[e]; b[k][e] = pb[e]; }
+          }
+        }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        s += (double)a[k];
-        q += (double)b[k];
-      }
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[e] += (double)a[k][e];
+          q[e] += (double)b[k][e];
+        }
     }
   }
-  red[rl][0][cl] = s;
-  red[rl][1][cl] = q;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[rl][0][cl * 4 + e] = s[e];
+    red[rl][1][cl * 4 + e] = q[e];
+  }
   __syncthreads();
-  if (rl == 0 && c < C) {
-    s = red[0][0][cl] + red[1][0][cl] + red[2][0][cl] + red[3][0][cl];
-    q = red[0][1][cl] + red[1][1][cl] + red[2][1][cl] + red[3][1][cl];
-    if (R > 1) {
-      stage[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
-      stage[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
-    }
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int which = threadIdx.x >> 6;             // threads 0..63: sums, 64..127: second sums
+  double tot = 0.0;
+  if (which < 2) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += red[k][which][threadIdx.x & 63];
+    if (R > 1 && c < C) stage[((size_t)blockIdx.x * 2 + which) * C + c] = tot;
   }
   if (R == 1) {                                   // single block per channel group: finalise directly
-    if (rl == 0 && c < C) bn_fin_apply(fin, c, s, q);
+    if (which == 1) red[0][1][threadIdx.x & 63] = tot;
+    __syncthreads();
+    if (which == 0 && c < C) bn_fin_apply(fin, c, tot, red[0][1][threadIdx.x & 63]);
     return;
   }
   __threadfence();                                // publish this block's stage rows
   __syncthreads();
-  unsigned* ticket = &ocr_bn_tickets[slot * 32 + blockIdx.y];
-  if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
-  __syncthreads();
-  if (s_ticket != (unsigned)(R - 1)) return;      // not the last block of this channel group
-  __threadfence();
-  // the last arriver sums the R stage rows: row lane rl takes rows rl, rl+4, ... in order, the four
-  // lane sums are combined in lane order -> the result does not depend on which block is last
-  s = 0.0;
-  q = 0.0;
-  if (c < C) {
-    const unsigned long long* st = reinterpret_cast<const unsigned long long*>(stage);
-    // agent-scope loads (other CUs wrote these), eight rows in flight per lane, summed in row order
-    for (int r0 = rl; r0 < R; r0 += 32) {
-      unsigned long long us[8], uq[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int r = r0 + 4 * k;
-        us[k] = r < R ? __hip_atomic_load(st + ((size_t)r * 2 + 0) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        uq[k] = r < R ? __hip_atomic_load(st + ((size_t)r * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        s += __builtin_bit_cast(double, us[k]);     // (+0.0 for the rows past the end)
-        q += __builtin_bit_cast(double, uq[k]);
+  if (threadIdx.x == 0) {
+    unsigned* tk = &ocr_bn_tickets[(size_t)(slot * 32 + blockIdx.y) * (1 + kTicketGroups)];
+    const int g = blockIdx.x / kTicketGroup, ng = (R + kTicketGroup - 1) / kTicketGroup;
+    const int gsize = min(kTicketGroup, R - g * kTicketGroup);
+    unsigned last = 0u;
+    if (atomicAdd(tk + 1 + g, 1u) == (unsigned)(gsize - 1)) {     // last of its group: everyone else of the group is done
+      tk[1 + g] = 0u;                                             // ready for the next launch that uses this slot
+      __threadfence();
+      if (atomicAdd(tk, 1u) == (unsigned)(ng - 1)) {
+        tk[0] = 0u;
+        last = 1u;
       }
     }
+    s_ticket = last;
   }
-  red[rl][0][cl] = s;                             // (every reader of the first use passed the barriers above)
-  red[rl][1][cl] = q;
   __syncthreads();
-  if (rl == 0 && c < C) {
-    s = red[0][0][cl] + red[1][0][cl] + red[2][0][cl] + red[3][0][cl];
-    q = red[0][1][cl] + red[1][1][cl] + red[2][1][cl] + red[3][1][cl];
-    bn_fin_apply(fin, c, s, q);
+  if (!s_ticket) return;                          // not the last block of this channel group
+  __threadfence();
+  // the last arriver sums the R stage rows: thread = (sum kind, channel) x one of two row lanes... keep
+  // it simple and wide: 128 (kind, channel) columns x 2 row lanes, eight rows in flight, fixed order
+  {
+    const int col = threadIdx.x & 127, lane2 = threadIdx.x >> 7;      // col: kind = col >> 6, channel = col & 63
+    const int cc = blockIdx.y * 64 + (col & 63);
+    double acc = 0.0;
+    if (cc < C) {
+      const unsigned long long* st = reinterpret_cast<const unsigned long long*>(stage);
+      for (int r0 = lane2; r0 < R; r0 += 16) {   // agent-scope loads (other CUs wrote these)
+        unsigned long long u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = r0 + 2 * k;
+          u[k] = r < R ? __hip_atomic_load(st + ((size_t)r * 2 + (col >> 6)) * C + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += __builtin_bit_cast(double, u[k]);
+      }
+    }
+    red[lane2][col >> 6][col & 63] = acc;         // (every reader of the first use passed the barriers above)
   }
-  if (threadIdx.x == 0) *ticket = 0u;             // ready for the next launch that uses this slot
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C)
+    bn_fin_apply(fin, c, red[0][0][threadIdx.x] + red[1][0][threadIdx.x], red[0][1][threadIdx.x] + red[1][1][threadIdx.x]);
 }
 
 // launches on one stream are ordered; the rotating slot keeps launches that might overlap on
 // DIFFERENT streams (side-stream experiments) off each other's counters
 static int bn_ticket_slot() {
   static int next = 0;
-  next = (next + 1) & 63;
+  next = (next + 1) & 15;
   return next;
 }
 
@@ -763,7 +803,7 @@ extern "C" int ocr_prep_images_f16(const void* images_f32, int64_t npix, float m
 }
 
 extern "C" size_t ocr_bn_reduce_workspace(int T, int C) {
-  return (size_t)ocr_cdiv(T, kRedRows) * 2 * C * sizeof(double);
+  return (size_t)ocr_cdiv(T, red_rows(T)) * 2 * C * sizeof(double);
 }
 
 extern "C" int ocr_bn_finalize(const void* partial, int T, int C, double count, const void* gamma,
@@ -774,14 +814,14 @@ extern "C" int ocr_bn_finalize(const void* partial, int T, int C, double count, 
   OCR_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
   if (ws_bytes < ocr_bn_reduce_workspace(T, C)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int R = ocr_cdiv(T, kRedRows);
-  OCR_CHECK_SHAPE(ocr_cdiv(C, 64) <= 32);
+  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
+  OCR_CHECK_SHAPE(ocr_cdiv(C, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
   BnFin fin{count, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, decay,
             static_cast<float*>(moving_mean), static_cast<float*>(moving_var), static_cast<float*>(scale),
             static_cast<float*>(shift), static_cast<float*>(save_mean), static_cast<float*>(save_invstd)};
   hipLaunchKernelGGL(reduce_finalize_kernel<BnFin>, dim3(R, ocr_cdiv(C, 64)), dim3(256), 0, st,
                      static_cast<const float*>(partial), static_cast<double*>(workspace), T, C, bn_ticket_slot(),
-                     fin);
+                     rows, fin);
   return ocr_launch_status();
 }
 
@@ -849,11 +889,11 @@ extern "C" int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void*
                      (const float*)nullptr, (const float*)nullptr,
                      static_cast<const half_t*>(da_full), static_cast<const half_t*>(da_pool),
                      static_cast<float*>(partial), (half_t*)nullptr);
-  const int R = ocr_cdiv(T, kRedRows);
-  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32);
+  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
   hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFin>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
                      static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(),
-                     BnBwdFin{static_cast<float*>(dgamma), static_cast<float*>(dbeta)});
+                     rows, BnBwdFin{static_cast<float*>(dgamma), static_cast<float*>(dbeta)});
   hipLaunchKernelGGL(bn_relu_bwd_kernel<1>, dim3(T), dim3(256), 0, st, p, yp,
                      static_cast<const float*>(scale), static_cast<const float*>(shift),
                      static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
@@ -988,11 +1028,11 @@ extern "C" int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const
   OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
   if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int R = ocr_cdiv(T, kRedRows);
-  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32);
+  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
   hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFin>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
                      static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(),
-                     BnBwdFin{static_cast<float*>(dgamma), static_cast<float*>(dbeta)});
+                     rows, BnBwdFin{static_cast<float*>(dgamma), static_cast<float*>(dbeta)});
   BnBwdP p{n, h, w, c, relu, 0, (float)(1.0 / ((double)n * h * w))};
   const int B = bwd_blocks(n, h, w, c, 0);
   hipLaunchKernelGGL(bn_relu_bwd_kernel<1>, dim3(B), dim3(256), 0, st, p, static_cast<const half_t*>(y),
