@@ -189,8 +189,19 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   const size_t i = (size_t)blockIdx.x * OUTS + o;
   const f32x4* s = reinterpret_cast<const f32x4*>(slab);
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  if (i < elems4)
-    for (int k = sl; k < splits; k += SL) a += s[(size_t)k * elems4 + i];
+  if (i < elems4) {
+    // four slabs in flight per lane, added in slab order
+    for (int k0 = sl; k0 < splits; k0 += 4 * SL) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * SL;
+        v[u] = k < splits ? s[(size_t)k * elems4 + i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a += v[u];
+    }
+  }
   if constexpr (SL > 1) {
     red[threadIdx.x] = a;
     __syncthreads();
