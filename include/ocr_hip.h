@@ -202,6 +202,18 @@ int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const void* shif
                               const void* save_invstd, const void* da_full, int n, int h, int w, int c,
                               int relu, const void* partial, int T, void* dgamma, void* dbeta, void* dy,
                               void* workspace, size_t ws_bytes, void* stream);
+/* Pooled conv+BN+ReLU layers whose only consumer is the 2x2/2 max-pool (conv1_2, conv2_2 of
+ * nets/vgg.py:18,22): the forward also stores the first-max position (0..3 = dy*2+dx, one byte per
+ * pooled element, [n][oh][ow][c]); the backward routes da_pool through it (tf.nn.max_pool's gradient
+ * goes to the first maximum) without recomputing the candidates' activations.  Same results as
+ * ocr_bn_relu_f16(pool=2) / ocr_bn_relu_bwd_f16(pool=2, da_full=NULL). */
+int ocr_bn_relu_pool_idx_f16(const void* y, const void* scale, const void* shift, int n, int h, int w, int c,
+                             int relu, void* a_full, void* a_pool, void* argmax_u8, void* stream);
+int ocr_bn_relu_pool_bwd_idx_f16(const void* y, const void* scale, const void* save_mean, const void* save_invstd,
+                                 const void* a_pool, const void* argmax_u8, const void* da_pool, int n, int h,
+                                 int w, int c, int relu, void* dgamma, void* dbeta, void* dy, void* partial,
+                                 void* workspace, size_t ws_bytes, void* stream);
+
 
 /* slim.max_pool2d k x k / stride SAME as a standalone op (pool5 3x3/1 nets/vgg.py:32; ResNet
  * pool1 3x3/2 nets/resnet_v1.py:194; subsample 1x1/s nets/resnet_utils.py:74), f16 NHWC.

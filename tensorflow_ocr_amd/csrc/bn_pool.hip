@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int n, int h,
                                                       int w, int c, half_t* __restrict__ a_full,
-                                                      half_t* __restrict__ a_pool) {
+                                                      half_t* __restrict__ a_pool,
+                                                      unsigned char* __restrict__ argmax = nullptr) {
   const int chunks = c >> 3;
   const int oh = POOL ? (h + 1) / 2 : h, ow = POOL ? (w + 1) / 2 : w;
   const size_t units = (size_t)n * oh * ow;
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
       const int oy = (int)(t % oh);
       const int img = (int)(t / oh);
       float m[8];
+      unsigned long long am = 0ull;                 // first-max candidate (dy*2+dx) of each channel, one byte each
 #pragma unroll
       for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
 #pragma unroll
@@ -276,7 +278,10 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
             for (int e = 0; e < 8; ++e) {
               o[e] = (half_t)f[e];
               float fr = (float)o[e];
-              m[e] = fr > m[e] ? fr : m[e];
+              if (fr > m[e]) {
+                m[e] = fr;
+                am = (am & ~(0xffull << (8 * e))) | ((unsigned long long)(dy * 2 + dx) << (8 * e));
+              }
             }
             if (a_full) *reinterpret_cast<half8_t*>(a_full + off) = o;
           }
@@ -285,6 +290,7 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
       *reinterpret_cast<half8_t*>(a_pool + u * c + ch * 8) = o;
+      if (argmax) *reinterpret_cast<unsigned long long*>(argmax + u * c + ch * 8) = am;
     }
   }
 }
@@ -407,6 +413,99 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
         }
         if (MODE == 1) *reinterpret_cast<half8_t*>(dy + offs[k]) = o;
       }
+    }
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(ul * chunks + ch) * 16 + e] = s_dz[e];
+      red[(ul * chunks + ch) * 16 + 8 + e] = s_dzx[e];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * c; j += 256) {
+      const int which = j / c, cc = j % c;
+      const int ch2 = cc >> 3, e = (cc & 7) + which * 8;
+      float tot = 0.f;
+      for (int l = 0; l < lanes; ++l) tot += red[(l * chunks + ch2) * 16 + e];
+      partial[((size_t)blockIdx.x * 2 + which) * c + cc] = tot;
+    }
+  }
+}
+
+// Pooled layers whose only consumer is the pool (conv1_2, conv2_2): with the forward's first-max
+// index and the pooled activation at hand the backward needs no recomputation of the four candidate
+// activations — the routed gradient is da_pool where a_pool > 0 (ReLU) at the stored position and 0
+// elsewhere.  Same unit -> thread map, same summation order and the same numbers as the pooled branch
+// of bn_relu_bwd_kernel (which spends ~25 VALU operations per full-resolution element re-deriving the
+// argmax and was VALU-bound: 2.8 / 3.6 TB/s); this one is HBM-bound.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_pool_bwd_idx_kernel(
+    BnBwdP p, const half_t* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dgamma,
+    const float* __restrict__ dbeta, const half_t* __restrict__ a_pool, const unsigned char* __restrict__ argmax,
+    const half_t* __restrict__ da_pool, float* __restrict__ partial, half_t* __restrict__ dy) {
+  __shared__ float red[256 * 16];
+  const int c = p.c, chunks = c >> 3;
+  const int lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  const int oh = (p.h + 1) / 2, ow = (p.w + 1) / 2;
+  const size_t units = (size_t)p.n * oh * ow;
+  float sc[8], mu[8], is[8], k_dz[8], k_dzx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int cc = ch * 8 + e;
+    sc[e] = scale[cc];
+    mu[e] = mean[cc];
+    is[e] = invstd[cc];
+    if (MODE == 1) {
+      k_dz[e] = dbeta[cc] * p.inv_count;
+      k_dzx[e] = dgamma[cc] * p.inv_count;
+    }
+  }
+  float s_dz[8], s_dzx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s_dz[e] = 0.f; s_dzx[e] = 0.f; }
+  for (size_t u = (size_t)blockIdx.x * lanes + ul; u < units; u += (size_t)gridDim.x * lanes) {
+    const int ox = (int)(u % ow);
+    const size_t t = u / ow;
+    const int oy = (int)(t % oh);
+    const int img = (int)(t / oh);
+    const half8_t gp = *reinterpret_cast<const half8_t*>(da_pool + u * c + ch * 8);
+    const half8_t ap = *reinterpret_cast<const half8_t*>(a_pool + u * c + ch * 8);
+    const unsigned long long am = *reinterpret_cast<const unsigned long long*>(argmax + u * c + ch * 8);
+    half8_t v[4];
+    bool valid[4];
+    size_t offs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int iy = oy * 2 + (k >> 1), ix = ox * 2 + (k & 1);
+      valid[k] = iy < p.h && ix < p.w;
+      offs[k] = (((size_t)img * p.h + (valid[k] ? iy : 0)) * p.w + (valid[k] ? ix : 0)) * c + ch * 8;
+      if (valid[k]) v[k] = *reinterpret_cast<const half8_t*>(y + offs[k]);
+    }
+    float g[8];
+    int arg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      arg[e] = (int)((am >> (8 * e)) & 3ull);
+      g[e] = (!p.relu || (float)ap[e] > 0.f) ? (float)gp[e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!valid[k]) continue;
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dz = arg[e] == k ? g[e] : 0.f;
+        const float xh = ((float)v[k][e] - mu[e]) * is[e];
+        if (MODE == 0) {
+          s_dz[e] += dz;
+          s_dzx[e] += dz * xh;
+        } else {
+          o[e] = (half_t)(sc[e] * (dz - k_dz[e] - xh * k_dzx[e]));
+        }
+      }
+      if (MODE == 1) *reinterpret_cast<half8_t*>(dy + offs[k]) = o;
     }
   }
   if (MODE == 0) {
@@ -1041,5 +1140,56 @@ extern "C" int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const
                      static_cast<const float*>(dgamma), static_cast<const float*>(dbeta),
                      static_cast<const half_t*>(da_full), (const half_t*)nullptr, (float*)nullptr,
                      static_cast<half_t*>(dy));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_relu_pool_idx_f16(const void* y, const void* scale, const void* shift, int n, int h, int w,
+                                        int c, int relu, void* a_full, void* a_pool, void* argmax_u8,
+                                        void* stream) {
+  OCR_CHECK_ARG(y && scale && shift && a_pool && argmax_u8 && n > 0 && h > 0 && w > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0);
+  const int oh = (h + 1) / 2, ow = (w + 1) / 2;
+  const size_t total = (size_t)n * oh * ow * (c / 8);
+  dim3 grid(stream_grid(total));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const half_t* yp = static_cast<const half_t*>(y);
+  const float* sc = static_cast<const float*>(scale);
+  const float* sh = static_cast<const float*>(shift);
+  half_t* af = static_cast<half_t*>(a_full);
+  half_t* ap = static_cast<half_t*>(a_pool);
+  unsigned char* am = static_cast<unsigned char*>(argmax_u8);
+  if (relu) hipLaunchKernelGGL((bn_relu_kernel<true, 2>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap, am);
+  else hipLaunchKernelGGL((bn_relu_kernel<false, 2>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap, am);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_relu_pool_bwd_idx_f16(const void* y, const void* scale, const void* save_mean,
+                                            const void* save_invstd, const void* a_pool, const void* argmax_u8,
+                                            const void* da_pool, int n, int h, int w, int c, int relu,
+                                            void* dgamma, void* dbeta, void* dy, void* partial, void* workspace,
+                                            size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(y && scale && save_mean && save_invstd && a_pool && argmax_u8 && da_pool && dgamma && dbeta && dy);
+  OCR_CHECK_ARG(partial && workspace && n > 0 && h > 0 && w > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int T = bwd_blocks(n, h, w, c, 2);
+  if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
+  BnBwdP p{n, h, w, c, relu, 2, (float)(1.0 / ((double)n * h * w))};
+  const half_t* yp = static_cast<const half_t*>(y);
+  hipLaunchKernelGGL(bn_pool_bwd_idx_kernel<0>, dim3(T), dim3(256), 0, st, p, yp, static_cast<const float*>(scale),
+                     static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                     (const float*)nullptr, (const float*)nullptr, static_cast<const half_t*>(a_pool),
+                     static_cast<const unsigned char*>(argmax_u8), static_cast<const half_t*>(da_pool),
+                     static_cast<float*>(partial), (half_t*)nullptr);
+  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
+  hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFin>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(),
+                     rows, BnBwdFin{static_cast<float*>(dgamma), static_cast<float*>(dbeta)});
+  hipLaunchKernelGGL(bn_pool_bwd_idx_kernel<1>, dim3(T), dim3(256), 0, st, p, yp, static_cast<const float*>(scale),
+                     static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                     static_cast<const float*>(dgamma), static_cast<const float*>(dbeta),
+                     static_cast<const half_t*>(a_pool), static_cast<const unsigned char*>(argmax_u8),
+                     static_cast<const half_t*>(da_pool), (float*)nullptr, static_cast<half_t*>(dy));
   return ocr_launch_status();
 }

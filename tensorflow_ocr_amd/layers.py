@@ -100,11 +100,17 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         else:
             ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
         full = pooled = None
+        argmax = None
         if pool:
             pooled = g.empty((n, (oh + 1) // 2, (ow + 1) // 2, cout))
             if keep_full:
                 full = g.empty((n, oh, ow, cout))
-            ops.bn_relu(y, scale, shift, relu, 2, full, pooled)
+                ops.bn_relu(y, scale, shift, relu, 2, full, pooled)
+            else:
+                # the pool is the only consumer: keep the first-max position so that the backward routes
+                # the pooled gradient without re-deriving the four candidates' activations
+                argmax = g.empty(pooled.shape, torch.uint8)
+                ops.bn_relu_pool_idx(y, scale, shift, relu, None, pooled, argmax)
         else:
             full = g.empty((n, oh, ow, cout))
             ops.bn_relu(y, scale, shift, relu, 0, full, None)
@@ -132,6 +138,9 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 ops.bn_relu_bwd_apply(y, scale, shift, mean, invstd, da_full, relu, part_f, T_f,
                                       gamma.grad, beta.grad, dy, ws)
                 a_full.bn_partial = None
+            elif pool and argmax is not None and da_full is None:
+                ops.bn_relu_pool_bwd_idx(y, scale, mean, invstd, a_pool.data, argmax, da_pool, relu,
+                                         gamma.grad, beta.grad, dy, ws)
             else:
                 ops.bn_relu_bwd(y, scale, shift, mean, invstd, da_full, da_pool, relu, 2 if pool else 0,
                                 gamma.grad, beta.grad, dy, ws)

@@ -219,6 +219,22 @@ def bn_relu(y, scale, shift, relu, pool, a_full=None, a_pool=None):
            c_int(int(relu)), c_int(pool), ptr(a_full), ptr(a_pool), _st())
 
 
+def bn_relu_pool_idx(y, scale, shift, relu, a_full, a_pool, argmax):
+    """bn+ReLU+2x2 max-pool that also stores the first-max position (uint8 [n,oh,ow,c])."""
+    n, h, w, c = y.shape
+    L.call("ocr_bn_relu_pool_idx_f16", ptr(y), ptr(scale), ptr(shift), c_int(n), c_int(h), c_int(w), c_int(c),
+           c_int(int(relu)), ptr(a_full), ptr(a_pool), ptr(argmax), _st())
+
+
+def bn_relu_pool_bwd_idx(y, scale, save_mean, save_invstd, a_pool, argmax, da_pool, relu, dgamma, dbeta, dy, ws):
+    n, h, w, c = y.shape
+    T = bn_bwd_num_partials(y.shape, 2)
+    part, stage = ws.two(T * 2 * c * 4, bn_reduce_workspace(T, c))
+    L.call("ocr_bn_relu_pool_bwd_idx_f16", ptr(y), ptr(scale), ptr(save_mean), ptr(save_invstd), ptr(a_pool),
+           ptr(argmax), ptr(da_pool), c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(dgamma),
+           ptr(dbeta), ptr(dy), ptr(part), ptr(stage), c_size_t(stage.numel()), _st())
+
+
 def bn_bwd_num_partials(shape, pool):
     n, h, w, c = shape
     return L.call_int("ocr_bn_bwd_num_partials", c_int(n), c_int(h), c_int(w), c_int(c), c_int(pool))

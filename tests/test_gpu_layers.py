@@ -219,3 +219,42 @@ def test_storage_dtype_matches_library(device):
     assert lib.ocr_storage_dtype().decode() == want == _lib.STORAGE
     assert F16 == O.STORAGE == (torch.bfloat16 if want == "bf16" else torch.float16)
     assert os.path.basename(_lib.LIB_PATH) == ("libocr_hip_bf16.so" if want == "bf16" else "libocr_hip.so")
+
+
+@pytest.mark.parametrize("n,h,w,c,relu", [(2, 16, 24, 64, True), (1, 15, 9, 128, True), (3, 8, 8, 32, False)])
+def test_pooled_bn_backward_with_stored_argmax_equals_recomputing_path(device, n, h, w, c, relu):
+    """ocr_bn_relu_pool_idx_f16 / ocr_bn_relu_pool_bwd_idx_f16 (first-max position stored by the forward)
+    give bit-identical activations, BN gradients and dy to the recomputing path (pool=2, da_full=NULL),
+    including odd sizes whose edge windows are partial."""
+    from tensorflow_ocr_amd import ops
+    from tensorflow_ocr_amd.graph import F16
+    rng = np.random.default_rng(c + h)
+    y = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(F16).to(device)
+    y[0, :2, :2, :8] = 0.5                               # ties: the FIRST maximum must win
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).to(device)
+    shift = torch.from_numpy(rng.normal(0, 0.3, c).astype(np.float32)).to(device)
+    mean = torch.from_numpy(rng.normal(0, 0.2, c).astype(np.float32)).to(device)
+    invstd = torch.from_numpy(rng.uniform(0.7, 1.3, c).astype(np.float32)).to(device)
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    da = torch.from_numpy(rng.standard_normal((n, oh, ow, c)).astype(np.float32)).to(F16).to(device)
+    ws = ops.Workspace(device, 8 << 20)
+    p1 = torch.empty((n, oh, ow, c), dtype=F16, device=device)
+    p2 = torch.empty_like(p1)
+    am = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=device)
+    ops.bn_relu(y, scale, shift, relu, 2, None, p1)
+    ops.bn_relu_pool_idx(y, scale, shift, relu, None, p2, am)
+    assert torch.equal(p1, p2) and int(am.max()) <= 3 and int(am[0, 0, 0, :8].max()) == 0
+    outs = []
+    for which in (0, 1):
+        dg = torch.zeros(c, device=device)
+        db = torch.zeros(c, device=device)
+        dy = torch.empty_like(y)
+        if which == 0:
+            ops.bn_relu_bwd(y, scale, shift, mean, invstd, None, da, relu, 2, dg, db, dy, ws)
+        else:
+            ops.bn_relu_pool_bwd_idx(y, scale, mean, invstd, p2, am, da, relu, dg, db, dy, ws)
+        torch.cuda.synchronize()
+        outs.append((dg.clone(), db.clone(), dy.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert float(outs[0][0].abs().sum()) > 0
