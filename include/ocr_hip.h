@@ -203,8 +203,8 @@ int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const void* shif
                               int relu, const void* partial, int T, void* dgamma, void* dbeta, void* dy,
                               void* workspace, size_t ws_bytes, void* stream);
 /* Pooled conv+BN+ReLU layers whose only consumer is the 2x2/2 max-pool (conv1_2, conv2_2 of
- * nets/vgg.py:18,22): the forward also stores the first-max position (0..3 = dy*2+dx, one byte per
- * pooled element, [n][oh][ow][c]); the backward routes da_pool through it (tf.nn.max_pool's gradient
+ * nets/vgg.py:18,22): the forward also stores, one byte per pooled element [n][oh][ow][c], the first-max
+ * position (bits 0-1 = dy*2+dx) and whether the pooled activation is positive (bit 2); the backward routes da_pool through it (tf.nn.max_pool's gradient
  * goes to the first maximum) without recomputing the candidates' activations.  Same results as
  * ocr_bn_relu_f16(pool=2) / ocr_bn_relu_bwd_f16(pool=2, da_full=NULL). */
 int ocr_bn_relu_pool_idx_f16(const void* y, const void* scale, const void* shift, int n, int h, int w, int c,

@@ -290,7 +290,14 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
       *reinterpret_cast<half8_t*>(a_pool + u * c + ch * 8) = o;
-      if (argmax) *reinterpret_cast<unsigned long long*>(argmax + u * c + ch * 8) = am;
+      if (argmax) {
+        // bit 2 of each byte: the pooled activation is positive (the backward's ReLU mask, so that it
+        // need not read a_pool)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (m[e] > 0.f) am |= 4ull << (8 * e);
+        *reinterpret_cast<unsigned long long*>(argmax + u * c + ch * 8) = am;
+      }
     }
   }
 }
@@ -434,7 +441,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
 
 // Pooled layers whose only consumer is the pool (conv1_2, conv2_2): with the forward's first-max
 // index and the pooled activation at hand the backward needs no recomputation of the four candidate
-// activations — the routed gradient is da_pool where a_pool > 0 (ReLU) at the stored position and 0
+// activations — the routed gradient is da_pool where the pooled activation was positive (ReLU; bit 2 of
+// the stored byte) at the stored position (bits 0-1) and 0
 // elsewhere.  Same unit -> thread map, same summation order and the same numbers as the pooled branch
 // of bn_relu_bwd_kernel (which spends ~25 VALU operations per full-resolution element re-deriving the
 // argmax and was VALU-bound: 2.8 / 3.6 TB/s); this one is HBM-bound.
@@ -471,7 +479,6 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_idx_kernel(
     const int oy = (int)(t % oh);
     const int img = (int)(t / oh);
     const half8_t gp = *reinterpret_cast<const half8_t*>(da_pool + u * c + ch * 8);
-    const half8_t ap = *reinterpret_cast<const half8_t*>(a_pool + u * c + ch * 8);
     const unsigned long long am = *reinterpret_cast<const unsigned long long*>(argmax + u * c + ch * 8);
     half8_t v[4];
     bool valid[4];
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_idx_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       arg[e] = (int)((am >> (8 * e)) & 3ull);
-      g[e] = (!p.relu || (float)ap[e] > 0.f) ? (float)gp[e] : 0.f;
+      g[e] = (!p.relu || ((am >> (8 * e)) & 4ull)) ? (float)gp[e] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1168,7 +1175,7 @@ extern "C" int ocr_bn_relu_pool_bwd_idx_f16(const void* y, const void* scale, co
                                             const void* da_pool, int n, int h, int w, int c, int relu,
                                             void* dgamma, void* dbeta, void* dy, void* partial, void* workspace,
                                             size_t ws_bytes, void* stream) {
-  OCR_CHECK_ARG(y && scale && save_mean && save_invstd && a_pool && argmax_u8 && da_pool && dgamma && dbeta && dy);
+  OCR_CHECK_ARG(y && scale && save_mean && save_invstd && argmax_u8 && da_pool && dgamma && dbeta && dy);   // a_pool: unused (its sign travels in argmax)
   OCR_CHECK_ARG(partial && workspace && n > 0 && h > 0 && w > 0);
   OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
