@@ -787,14 +787,17 @@ __global__ void maxpool_bwd_idx_kernel(PoolP p, const unsigned char* __restrict_
     float g[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = 0.f;
-    for (int ky = 0; ky < p.k; ++ky) {
+    // windows covering (iy, ix): ky = (iy + pt) mod stride, + stride, ... (one division per axis, not
+    // a divisibility test per tap); visited in ascending (ky, kx) like the scan they replace
+    const int ky0 = (iy + p.pt) % p.stride, kx0 = (ix + p.pl) % p.stride;
+    for (int ky = ky0; ky < p.k; ky += p.stride) {
       const int ny = iy + p.pt - ky;
-      if (ny < 0 || ny % p.stride) continue;
+      if (ny < 0) break;
       const int oy = ny / p.stride;
       if (oy >= p.oh) continue;
-      for (int kx = 0; kx < p.k; ++kx) {
+      for (int kx = kx0; kx < p.k; kx += p.stride) {
         const int nx = ix + p.pl - kx;
-        if (nx < 0 || nx % p.stride) continue;
+        if (nx < 0) break;
         const int ox = nx / p.stride;
         if (ox >= p.ow) continue;
         const size_t o = (((size_t)img * p.oh + oy) * p.ow + ox) * p.c + ch * 8;
@@ -834,14 +837,15 @@ __global__ void maxpool_bwd_kernel(PoolP p, const half_t* __restrict__ x,
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = 0.f;
     const half_t* xb = x + (size_t)img * p.h * p.w * p.c + ch * 8;
-    for (int ky = 0; ky < p.k; ++ky) {
+    const int ky0 = (iy + p.pt) % p.stride, kx0 = (ix + p.pl) % p.stride;      // (as in the index variant above)
+    for (int ky = ky0; ky < p.k; ky += p.stride) {
       const int ny = iy + p.pt - ky;
-      if (ny < 0 || ny % p.stride) continue;
+      if (ny < 0) break;
       const int oy = ny / p.stride;
       if (oy >= p.oh) continue;
-      for (int kx = 0; kx < p.k; ++kx) {
+      for (int kx = kx0; kx < p.k; kx += p.stride) {
         const int nx = ix + p.pl - kx;
-        if (nx < 0 || nx % p.stride) continue;
+        if (nx < 0) break;
         const int ox = nx / p.stride;
         if (ox >= p.ow) continue;
         // window (oy,ox): find first max
