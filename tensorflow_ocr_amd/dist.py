@@ -38,7 +38,8 @@ def plan_buckets(var_ranges, total, bucket_elems):
     """var_ranges: [(start, stop)] of each variable in the flat buffer, in creation order.
     Returns [(start, stop)] bucket ranges (contiguous, covering [0,total)) with boundaries on
     variable boundaries, filled from the END of the buffer backwards — gradients complete in
-    reverse creation order, so the last bucket is ready first."""
+    reverse creation order, so the last bucket is ready first; the first bucket (ready last, never
+    overlapped) is kept to a quarter of the bucket size."""
     if not var_ranges:
         return [(0, total)]
     bounds = sorted(set([0, total] + [s for s, _ in var_ranges]))
@@ -50,7 +51,21 @@ def plan_buckets(var_ranges, total, bucket_elems):
             j -= 1
         buckets.append((bounds[j], bounds[idx]))
         idx = j
-    return buckets[::-1]
+    buckets = buckets[::-1]
+    # the FIRST bucket holds the earliest layers, whose gradients complete last: its all-reduce cannot
+    # hide under any backward work, so keep it small (<= a quarter bucket) by splitting off its tail
+    s0, e0 = buckets[0]
+    if e0 - s0 > bucket_elems // 4:
+        inner = [b for b in bounds if s0 < b < e0]
+        cut = None
+        for b in inner:
+            if b - s0 <= bucket_elems // 4:
+                cut = b
+        if cut is None and inner:
+            cut = inner[0]
+        if cut is not None:
+            buckets = [(s0, cut), (cut, e0)] + buckets[1:]
+    return buckets
 
 
 class GradientAllReduce:
