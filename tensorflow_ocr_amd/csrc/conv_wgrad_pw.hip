@@ -190,7 +190,9 @@ bool pw_plan(const ocr_conv_desc* d, PwP* p, PwCfg* c) {
   p->nci = d->cin / c->cib;
   p->nco = d->cout / c->cob;
   const int blocks = p->nci * p->nco * d->kh * d->kw;
-  int want = ocr_cdiv(256, blocks);              // one resident workgroup per CU
+  // one resident workgroup per CU, and never a few workgroups over a full round of 256 (fc6: 72 blocks x
+  // 4 splits = 288 took two rounds; x 3 = 216 takes one)
+  int want = blocks <= 256 ? 256 / blocks : 1;
   if (want > p->m_tiles) want = p->m_tiles;
   if (want < 1) want = 1;
   p->tiles_per_split = ocr_cdiv(p->m_tiles, want);
