@@ -7,6 +7,9 @@
   decode     configs[4]: PixelLink inference 1024x1024 batch 16, then pixel/link softmax + link-CC
              decode, and locality-aware NMS on synthetic quadrangle lists
 
+  east_fwd   configs[0]: the test.py path on ONE 512x512 image — model.model (ResNet-v1-50 + PixelLink heads,
+             is_training=False), softmaxes, pixel_detect twin, contour boxes — with the CPU restatement's
+             forward timed beside it (the reference runs this config on TF-CPU)
   pipeline   SURVEY 8f-1/2/4: label maps for 32 x 512^2 (16 quads each), cv2.resize of 32 720x1280
              images to 512^2, oriented boxes of the decode's components; with the CPU restatement timed
              beside them (baseline only)
@@ -157,6 +160,61 @@ def main():
 
     if "pipeline" in which:
         pipeline_config()
+    if "east_fwd" in which:
+        east_fwd_config()
+
+
+def east_fwd_config():
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model
+    from tensorflow_ocr_amd.tool import pixellink_fn
+    dev = torch.device("cuda", 0)
+    g = Graph(dev, seed=1)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.uniform(0, 255, (1, 512, 512, 3)).astype(np.float32)).to(dev)
+    holder = {}
+
+    def net():
+        a, b = model.model(x, is_training=False, graph=g)
+        g.reset_tape()
+        holder["o"] = (a, b)
+    net()
+    dt_net = timed(net, 2, 10)
+    # decode on a synthetic, well-behaved score map (random-init weights give degenerate maps)
+    sc = torch.from_numpy((rng.uniform(size=(1, 128, 128, 1)) < 0.12).astype(np.float32)).to(dev)
+    ys, xs = np.mgrid[0:128, 0:128]
+    blob = np.zeros((128, 128), np.float32)
+    for _ in range(12):
+        cy, cx = rng.uniform(8, 120, 2)
+        blob[(np.abs(xs - cx) < rng.uniform(4, 20)) & (np.abs(ys - cy) < rng.uniform(2, 6))] = 1
+    sc = torch.from_numpy(blob[None, :, :, None]).to(dev)
+    geo = torch.from_numpy(rng.uniform(0.5, 1.0, (1, 128, 128, 16)).astype(np.float32)).to(dev)
+
+    def dec():
+        m = pixellink_fn.east_pixel_detect(sc, geo, 0.8, 0.8, graph=g)
+        holder["b"] = pixellink_fn.find_contour_boxes(m, graph=g)
+    dec()
+    dt_dec = timed(dec, 1, 5)
+    # CPU restatement of the same forward (f32, torch-CPU): the reference's own configuration for this config
+    import os
+    from oracle import ocr_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    p = O.init_model_resnet_params(np.random.default_rng(1)) if hasattr(O, "init_model_resnet_params") else None
+    cpu = None
+    if p is not None:
+        tp = O.to_torch_params(p)
+        xi = x.cpu()
+        with torch.no_grad():
+            O.model_resnet(xi, tp, False)
+            t0 = time.perf_counter()
+            O.model_resnet(xi, tp, False)
+            cpu = time.perf_counter() - t0
+    print(json.dumps({"config": "test.py path, one 512x512 image: model.model inference + EAST-script decode (configs[0])",
+                      "net_forward_ms": round(dt_net * 1e3, 3), "images_per_sec": round(1 / dt_net, 1),
+                      "decode_ms": round(dt_dec * 1e3, 3), "boxes": int(len(holder["b"][1])),
+                      "cpu_baseline": None if cpu is None else {"kind": "port", "cores": torch.get_num_threads(),
+                                                                  "forward_ms": round(cpu * 1e3, 1),
+                                                                  "images_per_sec": round(1 / cpu, 2)}}), flush=True)
 
 
 def dev_ms(fn, warmup=2, steps=10):
