@@ -94,10 +94,88 @@ __device__ bool iou_above(const float* a, const float* b, float thr) {
   return quad_iou(a, b) > thr;
 }
 
+// Wave-cooperative quad IoU for the merge chain (all 64 lanes of one wave call it with UNIFORM
+// arguments; the result is uniform).  The chain is sequential in the quads, so the parallelism has to
+// come from inside one IoU: lane i owns vertex i of the polygon being clipped (a quad clipped by four
+// half-planes has at most 8 vertices), every Sutherland-Hodgman stage is one step for all vertices —
+// neighbour by shuffle, inside tests and the intersection per lane, output slots by an 8-lane prefix
+// sum, compaction through 16 points of wave-private LDS.  Every lane performs exactly the scalar
+// clipper's arithmetic for its vertex and the areas are summed in vertex order, so the value equals
+// quad_iou()'s bit for bit.
+__device__ float quad_iou_wave(const float* qa, const float* qb, float* scratch, int lane) {
+  pt a[4], b[4];
+  load_ccw(qa, a);                               // uniform: computed redundantly by every lane
+  load_ccw(qb, b);
+  const float area_a = fabsf(signed_area(a, 4)), area_b = fabsf(signed_area(b, 4));
+  pt cur;
+  cur.x = lane < 4 ? a[lane & 3].x : 0.f;
+  cur.y = lane < 4 ? a[lane & 3].y : 0.f;
+  int n = 4;
+  pt* nxt = reinterpret_cast<pt*>(scratch);      // [16]
+  for (int ce = 0; ce < 4 && n > 0; ++ce) {
+    const pt c1 = b[ce], c2 = b[(ce + 1) & 3];
+    const int nb = (lane + 1 == n) ? 0 : lane + 1;
+    pt e;
+    e.x = __shfl(cur.x, nb, 64);
+    e.y = __shfl(cur.y, nb, 64);
+    int cnt = 0;
+    pt o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
+    if (lane < n) {
+      const pt s = cur;
+      const bool sin = cross3(c1, c2, s) >= 0.f, ein = cross3(c1, c2, e) >= 0.f;
+      if (sin && ein) { o0 = e; cnt = 1; }
+      else if (sin && !ein) { o0 = intersect(s, e, c1, c2); cnt = 1; }
+      else if (!sin && ein) { o0 = intersect(s, e, c1, c2); o1 = e; cnt = 2; }
+    }
+    int pos = cnt;                                // inclusive prefix sum over lanes 0..7
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      const int t = __shfl_up(pos, o, 64);
+      if (lane >= o) pos += t;
+    }
+    const int m = __shfl(pos, 7, 64);
+    pos -= cnt;
+    if (cnt >= 1) nxt[pos] = o0;
+    if (cnt == 2) nxt[pos + 1] = o1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    n = m;
+    if (lane < n) cur = nxt[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  float inter = 0.f;
+  if (n >= 3) {
+    // shoelace terms per lane, summed in vertex order like signed_area()
+    const int nb = (lane + 1 == n) ? 0 : lane + 1;
+    const float vx = __shfl(cur.x, nb, 64), vy = __shfl(cur.y, nb, 64);
+    float* terms = scratch + 32;
+    if (lane < n) terms[lane] = cur.x * vy - vx * cur.y;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += terms[i];
+    inter = fabsf(acc * 0.5f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  const float uni = area_a + area_b - inter;
+  return uni > 0.f ? inter / uni : 0.f;
+}
+
+// STAGE: the image's quads are first copied into LDS by the whole workgroup (and the merged list is
+// built there): the chain's per-step cost was one global-memory round trip (~1.4 us) for the next
+// quad, not the clipping arithmetic.
+template <bool STAGE>
 __global__ __launch_bounds__(256) void lanms_merge_kernel(const float* __restrict__ boxes,
                                                           const int* __restrict__ counts, int max_k, float thr,
                                                           float* __restrict__ merged, int* __restrict__ n_merged,
                                                           int* __restrict__ order_ws) {
+  extern __shared__ float s_q[];                 // STAGE: [k][9] input quads, then [k][9] merged quads
   __shared__ int s_m;
   const int img = blockIdx.x;
   const float* bx = boxes + (size_t)img * max_k * 9;
@@ -105,36 +183,62 @@ __global__ __launch_bounds__(256) void lanms_merge_kernel(const float* __restric
   int* order = order_ws + (size_t)img * max_k;
   int k = counts[img];
   if (k > max_k) k = max_k;
+  const float* src = bx;
+  float* dst = mg;
+  if (STAGE) {
+    for (int i = threadIdx.x; i < k * 9; i += 256) s_q[i] = bx[i];
+    __syncthreads();
+    src = s_q;
+    dst = s_q + (size_t)k * 9;
+  }
 
-  if (threadIdx.x == 0) {                       // (1) sequential weighted merge
+  __shared__ float s_scratch[48];
+  if (threadIdx.x < 64) {                       // (1) sequential weighted merge: wave 0, cooperatively per IoU
+    const int lane = threadIdx.x;
     int m = 0;
     bool have = false;
-    float p[9], q[9];
+    float p[9], q[9];                           // the running merged quad, replicated in every lane
     for (int i = 0; i < k; ++i) {
-      const float* g = bx + 9 * i;
-      if (have && iou_above(g, p, thr)) {
-        const float sg = g[8], sp = p[8], s = sg + sp;
-        for (int j = 0; j < 8; ++j) q[j] = (sg * g[j] + sp * p[j]) / s;
-        q[8] = s;
+      const float* g = src + 9 * i;
+      bool mergeable = false;
+      if (have && !(thr >= 1e-3f && aabb_disjoint(g, p))) mergeable = quad_iou_wave(g, p, s_scratch, lane) > thr;
+      if (mergeable) {
+        const float sg = g[8], sp = p[8], sc = sg + sp;
+        for (int j = 0; j < 8; ++j) q[j] = (sg * g[j] + sp * p[j]) / sc;
+        q[8] = sc;
         for (int j = 0; j < 9; ++j) p[j] = q[j];
       } else {
-        if (have) { for (int j = 0; j < 9; ++j) mg[9 * m + j] = p[j]; ++m; }
+        if (have) {
+#pragma unroll
+          for (int j = 0; j < 9; ++j)
+            if (lane == j) dst[9 * m + j] = p[j];
+          ++m;
+        }
         for (int j = 0; j < 9; ++j) p[j] = g[j];
         have = true;
       }
     }
-    if (have) { for (int j = 0; j < 9; ++j) mg[9 * m + j] = p[j]; ++m; }
-    s_m = m;
-    n_merged[img] = m;
+    if (have) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+        if (lane == j) dst[9 * m + j] = p[j];
+      ++m;
+    }
+    if (lane == 0) {
+      s_m = m;
+      n_merged[img] = m;
+    }
     __threadfence_block();
   }
   __syncthreads();
   const int m = s_m;
+  if (STAGE)
+    for (int i = threadIdx.x; i < m * 9; i += 256) mg[i] = dst[i];
   for (int i = threadIdx.x; i < m; i += 256) {  // (2) stable rank by descending score
-    const float si = mg[9 * i + 8];
+    const float si = dst[9 * i + 8];
     int r = 0;
     for (int j = 0; j < m; ++j) {
-      const float sj = mg[9 * j + 8];
+      const float sj = dst[9 * j + 8];
       if (sj > si || (sj == si && j < i)) ++r;
     }
     order[r] = i;
@@ -219,9 +323,24 @@ extern "C" int ocr_lanms(const void* boxes, const void* counts, int n_images, in
   unsigned long long* mask = reinterpret_cast<unsigned long long*>(ws + off);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int words = (max_k + 63) / 64;
-  hipLaunchKernelGGL(lanms_merge_kernel, dim3(n_images), dim3(256), 0, st, static_cast<const float*>(boxes),
-                     static_cast<const int*>(counts), max_k, iou_thresh, static_cast<float*>(merged),
-                     static_cast<int*>(n_merged), order);
+  const size_t stage_bytes = (size_t)max_k * 9 * sizeof(float) * 2;
+  if (stage_bytes <= 144 * 1024) {
+    auto kern = lanms_merge_kernel<true>;
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              144 * 1024) != hipSuccess)      // + the kernel's few static bytes <= 160 KB
+        return OCR_ERR_HIP;
+      configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_images), dim3(256), stage_bytes, st, static_cast<const float*>(boxes),
+                       static_cast<const int*>(counts), max_k, iou_thresh, static_cast<float*>(merged),
+                       static_cast<int*>(n_merged), order);
+  } else {
+    hipLaunchKernelGGL(lanms_merge_kernel<false>, dim3(n_images), dim3(256), 0, st, static_cast<const float*>(boxes),
+                       static_cast<const int*>(counts), max_k, iou_thresh, static_cast<float*>(merged),
+                       static_cast<int*>(n_merged), order);
+  }
   hipLaunchKernelGGL(lanms_mask_kernel, dim3(ocr_cdiv(max_k * words, 256), n_images), dim3(256), 0, st,
                      static_cast<const float*>(merged), static_cast<const int*>(n_merged), max_k, iou_thresh,
                      order, mask);
