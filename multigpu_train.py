@@ -55,7 +55,7 @@ def build_forward_loss(net):
             return model_vgg_16.loss(sm, a, gm, b, tm, graph=g)
     else:
         def f(g, im, sm, gm, tm):
-            n = pixellink.PixelLinkNet((im - 120.0) / 60.0, graph=g)
+            n = pixellink.PixelLinkNet(im, graph=g)        # input normalised by _train_loop, before the step
             return n.build_loss(sm[..., 0], gm)
     return f
 
@@ -105,6 +105,8 @@ def _train_loop(FLAGS, g, step, feeder, rng, rank, world, device, start):
         else:
             data = synthetic.make_batch(rng, FLAGS.batch_size_per_gpu, FLAGS.input_size)
             batch = [torch.from_numpy(a).to(device, non_blocking=True) for a in data]
+        if FLAGS.net == 'pixellink':
+            batch[0] = (batch[0] - 120.0) / 60.0           # PixelLinkNet takes preprocessed input
         loss = step(*batch)
         if it == 0:
             # variables exist after the first step: restore (:145-148) or load the pretrained backbone (:149-151)

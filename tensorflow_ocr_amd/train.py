@@ -99,6 +99,36 @@ class MomentumOptimizer:
         self.global_step += 1
 
 
+_VIEW_OPS = frozenset((
+    "empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided", "view", "_unsafe_view", "reshape",
+    "_reshape_alias", "slice", "select", "permute", "transpose", "t", "as_strided", "detach", "alias", "unsqueeze",
+    "squeeze", "expand", "narrow", "unbind", "split", "split_with_sizes", "unfold", "view_as_real", "lift_fresh",
+    "is_pinned", "_has_compatible_shallow_copy_type", "size", "stride", "sym_size", "sym_stride", "numel", "dim"))
+
+
+def _record_audit():
+    """Dispatch mode for the RECORDED step: the plan holds C-ABI calls only, so a torch operator that
+    launches device work inside `forward_loss` (arithmetic on an input, a dtype cast, a `zeros`) would
+    run once, at record time, and every replayed step would read its stale result.  Collects the names
+    of such operators so `TrainStep` can refuse the recording; views and allocations are fine."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class Audit(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.offenders = []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            name = func.overloadpacket.__name__ if hasattr(func, "overloadpacket") else str(func)
+            if name not in _VIEW_OPS:
+                flat = list(args) + list((kwargs or {}).values()) + (list(out) if isinstance(out, (tuple, list)) else [out])
+                if any(isinstance(t, torch.Tensor) and t.is_cuda for t in flat):
+                    self.offenders.append(name)
+            return out
+    return Audit()
+
+
 class TrainStep:
     """One data-parallel training step of `multigpu_train.py`'s hot loop (:118-142,171-174) for
     this process's tower: forward -> loss -> backward (gradient buckets all-reduced while the rest
@@ -109,7 +139,12 @@ class TrainStep:
     flat list of C-ABI calls (`_lib.Recorder`) and every later step REPLAYS that list: the Python
     graph/tape logic, ~700 ctypes marshalling round trips and all per-step allocations disappear
     from the hot loop (the host was the bottleneck at ~40 ms/step).  New input data is copied into
-    the recorded input buffers; `replay=False` keeps every step eager."""
+    the recorded input buffers; `replay=False` keeps every step eager.
+
+    Everything between the batch tensors and the loss must therefore be C-ABI calls: input
+    preprocessing written with torch operators belongs in the input pipeline, before the step (where
+    the reference has it too — its queues deliver preprocessed images).  The recording runs under an
+    audit that raises if a torch operator touched device memory inside `forward_loss`."""
 
     def __init__(self, graph, forward_loss, optimizer_factory, world_size=1, bucket_bytes=32 << 20,
                  replay=True):
@@ -142,8 +177,14 @@ class TrainStep:
             _lib.RECORDER = rec
             _lib.RECORDER_THREAD = __import__("threading").get_ident()
             g.keepalive = []
+        audit = _record_audit() if record else __import__("contextlib").nullcontext()
         try:
-            loss = self.forward_loss(g, *batch)
+            with audit:
+                loss = self.forward_loss(g, *batch)
+            if record and audit.offenders:
+                raise RuntimeError(
+                    "torch operators inside the recorded step would not be replayed: %s — move them "
+                    "before the step (input pipeline) or use replay=False" % sorted(set(audit.offenders)))
             if self.opt is None:
                 from .dist import GradientAllReduce
                 self.opt = self.optimizer_factory(g)           # materialises the flat buffers

@@ -73,7 +73,7 @@ def test_train_pixellink_on_icdar_directory(device, tmp_path, capsys):
     lines = [l for l in out.splitlines() if l.startswith("global step")]
     assert len(lines) == 2
     assert "lr 0.001000" in lines[0] and "lr 0.000100" in lines[1]          # 0.01 * 0.1, then * 0.01
-    assert all(np.isfinite(float(l.split("loss = ")[1].split(" ")[0])) for l in lines)
+    assert all(np.isfinite(float(l.split("loss = ")[1].split(" ")[0])) for l in lines), lines
 
 
 def test_east_test_script_end_to_end(device, tmp_path, capsys):

@@ -56,10 +56,18 @@ def test_model_vgg_forward_backward(device, size, n):
     print("loss device %.6f oracle(mixed) %.6f oracle(f32) %.6f" % (dL, oL, fL))
     print("pixel_cls Linf vs mixed %.3e vs f32 %.3e" % (np.abs(dpx - opx).max(), np.abs(dpx - fpx).max()))
     print("link_cls  Linf vs mixed %.3e vs f32 %.3e" % (np.abs(dlk - olk).max(), np.abs(dlk - flk).max()))
-    assert np.abs(dpx - opx).max() < 1e-1 * max(1.0, np.abs(opx).max())
-    assert np.abs(dlk - olk).max() < 1e-1 * max(1.0, np.abs(olk).max())
-    assert np.abs(dpx - opx).mean() < 1e-2
-    assert abs(dL - oL) < 5e-3 and abs(dL - fL) < 2e-2
+    # f16 storage: the bars documented in DESIGN.md section 4.  bfloat16 storage (OCR_STORAGE=bf16) rounds 8x
+    # coarser at each of the ~30 storage points; there the device must stay closer to the oracle in the
+    # SAME storage mode than that oracle is to its own f32 mode (the net's intrinsic sensitivity).
+    bf = O.STORAGE == torch.bfloat16
+    if bf:
+        assert np.abs(dpx - opx).max() < np.abs(opx - fpx).max() and np.abs(dlk - olk).max() < np.abs(olk - flk).max()
+        assert np.abs(dpx - opx).mean() < 8e-2 and abs(dL - oL) < 4e-2
+    else:
+        assert np.abs(dpx - opx).max() < 1e-1 * max(1.0, np.abs(opx).max())
+        assert np.abs(dlk - olk).max() < 1e-1 * max(1.0, np.abs(olk).max())
+        assert np.abs(dpx - opx).mean() < 1e-2
+        assert abs(dL - oL) < 5e-3 and abs(dL - fL) < 2e-2
 
     def cos(a, b):
         a, b = a.ravel().astype(np.float64), b.ravel().astype(np.float64)
@@ -75,5 +83,5 @@ def test_model_vgg_forward_backward(device, size, n):
     da = np.concatenate([dgr[k].ravel() for k in sorted(ogr)])
     oa = np.concatenate([ogr[k].ravel() for k in sorted(ogr)])
     print("global gradient cosine vs mixed oracle %.4f" % cos(da, oa))
-    assert worst > 0.9
-    assert cos(da, oa) > 0.95
+    assert worst > (0.6 if bf else 0.9)
+    assert cos(da, oa) > (0.8 if bf else 0.95)

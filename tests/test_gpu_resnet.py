@@ -8,10 +8,12 @@ import torch
 from oracle import ocr_oracle as O
 
 pytestmark = pytest.mark.gpu
+# bars are stated for f16 storage; bfloat16 (OCR_STORAGE=bf16) rounds 8x coarser at every storage point
+TOL = 8.0 if O.STORAGE == torch.bfloat16 else 1.0
 
 
 def _h(x):
-    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+    return torch.from_numpy(np.asarray(x, np.float32)).to(O.STORAGE).float().numpy()      # round to the 16-bit storage type
 
 
 def _rel(a, b):
@@ -41,16 +43,16 @@ def test_root_block(device):
     g.store.load_state_dict(p)
     a = resnet_layers.root_block(g, x4)
     assert a.shape == (n, oh, ow, 64)
-    a.grad = torch.from_numpy(gout).half().to(device)
+    a.grad = torch.from_numpy(gout).to(O.STORAGE).to(device)
     g.backward()
     torch.cuda.synchronize()
     tp = O.to_torch_params(p)
     xm = O.q(O.mean_image_subtraction(torch.from_numpy(img)), True)
     o = O.q(O._conv_bn(xm, tp, "conv1", 2, True, True, True, {}), True)
     (o * torch.from_numpy(gout)).sum().backward()
-    assert np.abs(a.data.float().cpu().numpy() - o.detach().numpy()).max() < 4e-3
-    assert _rel(g.store.vars["conv1/weights"].grad.cpu().numpy(), tp["conv1/weights"].grad.numpy()) < 1e-2
-    assert _rel(g.store.vars["conv1/BatchNorm/gamma"].grad.cpu().numpy(), tp["conv1/BatchNorm/gamma"].grad.numpy()) < 5e-3
+    assert np.abs(a.data.float().cpu().numpy() - o.detach().numpy()).max() < 4e-3 * TOL
+    assert _rel(g.store.vars["conv1/weights"].grad.cpu().numpy(), tp["conv1/weights"].grad.numpy()) < 1e-2 * TOL
+    assert _rel(g.store.vars["conv1/BatchNorm/gamma"].grad.cpu().numpy(), tp["conv1/BatchNorm/gamma"].grad.numpy()) < 5e-3 * TOL
 
 
 @pytest.mark.parametrize("cin,depth,db,stride,hw", [
@@ -77,12 +79,12 @@ def test_bottleneck(device, cin, depth, db, stride, hw):
     oh = -(-hw // stride)
     gout = _h(rng.standard_normal((n, oh, oh, depth)) * 0.1)
     g = Graph(device, loss_scale=1.0)
-    xa = Act(torch.from_numpy(x).half().to(device))
+    xa = Act(torch.from_numpy(x).to(O.STORAGE).to(device))
     resnet_layers.bottleneck(g, xa, depth, db, stride, "u")
     g.reset_tape()
     g.store.load_state_dict(p)
     out = resnet_layers.bottleneck(g, xa, depth, db, stride, "u")
-    out.grad = torch.from_numpy(gout).half().to(device)
+    out.grad = torch.from_numpy(gout).to(O.STORAGE).to(device)
     g.backward()
     torch.cuda.synchronize()
     tp = O.to_torch_params(p)
@@ -90,14 +92,14 @@ def test_bottleneck(device, cin, depth, db, stride, hw):
     o = O.bottleneck(xt, tp, u, depth, stride, True, True, {})
     (o * torch.from_numpy(gout)).sum().backward()
     assert out.shape == tuple(o.shape)
-    assert np.abs(out.data.float().cpu().numpy() - o.detach().numpy()).max() < 1e-2
+    assert np.abs(out.data.float().cpu().numpy() - o.detach().numpy()).max() < 1e-2 * TOL
     # three BN'd convs deep with a few hundred samples per channel: relative L2 (max-norm of a
     # single weight tensor is dominated by one or two cancellation-heavy entries)
-    assert _rel2(xa.grad.float().cpu().numpy(), xt.grad.numpy()) < 3e-2
+    assert _rel2(xa.grad.float().cpu().numpy(), xt.grad.numpy()) < 3e-2 * TOL
     for k in p:
         if k.endswith("weights") or k.endswith("gamma") or k.endswith("beta"):
             r = _rel2(g.store.vars[k].grad.cpu().numpy(), tp[k].grad.numpy())
-            assert r < 3e-2, (k, r)
+            assert r < 3e-2 * TOL, (k, r)
 
 
 SMALL = [("block1", [(128, 64, 1), (128, 64, 2)]), ("block2", [(256, 64, 1), (256, 64, 2)]),
@@ -133,15 +135,15 @@ def test_model_resnet_pixellink_heads_ohnm(device):
     dpx = px.data.cpu().numpy()
     print("loss %.5f vs %.5f; pixel_4 Linf %.3e mean %.3e" % (L.item(), float(oL), np.abs(dpx - opx.detach().numpy()).max(),
                                                           np.abs(dpx - opx.detach().numpy()).mean()))
-    assert abs(L.item() - float(oL)) < 2e-2 * max(1.0, abs(float(oL)))
-    assert np.abs(dpx - opx.detach().numpy()).mean() < 2e-2
+    assert abs(L.item() - float(oL)) < 2e-2 * TOL * max(1.0, abs(float(oL)))
+    assert np.abs(dpx - opx.detach().numpy()).mean() < 2e-2 * TOL
 
     def cos(a, b):
         a, b = a.ravel().astype(np.float64), b.ravel().astype(np.float64)
         return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
     cs = sorted((cos(grads[k], (tp[k].grad / S).numpy()), k) for k in grads if grads[k].size >= 64)
     print("lowest gradient cosines", cs[:3])
-    assert cs[0][0] > 0.9
+    assert cs[0][0] > (0.8 if TOL > 1 else 0.9)
 
 
 def test_model_east_merge_branch_dice(device):

@@ -44,6 +44,59 @@ def test_replay_equals_eager_bitwise(device):
     assert se(*nb).item() == sr(*nb).item()
 
 
+def _make_pixellink(device, replay, normalise_inside=False):
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import pixellink
+    from tensorflow_ocr_amd.train import MomentumOptimizer, TrainStep
+    g = Graph(device, seed=4)
+
+    def fl(gr, im, px, lk):
+        net = pixellink.PixelLinkNet((im - 120.0) / 60.0 if normalise_inside else im, graph=gr)
+        return net.build_loss(px, lk)
+    return g, TrainStep(g, fl, lambda gr: MomentumOptimizer(gr, base_lr=1e-3), replay=replay)
+
+
+def _pixellink_batch(device, seed):
+    from tensorflow_ocr_amd import synthetic
+    im, px, lk, _ = synthetic.make_batch(np.random.default_rng(seed), 2, 64)
+    return [torch.from_numpy(a).to(device) for a in (im, np.ascontiguousarray(px[..., 0]), lk)]
+
+
+def test_pixellink_replay_equals_eager_on_a_fresh_batch_every_step(device):
+    """Every step gets new data (as the feeder delivers it) and nothing synchronises in between:
+    the replayed plan must consume the new batch, not anything left over from the recorded step."""
+    ge, se = _make_pixellink(device, False)
+    gr, sr = _make_pixellink(device, True)
+    le, lr = [], []
+    for i in range(8):
+        b = _pixellink_batch(device, 20 + i)
+        b[0] = (b[0] - 120.0) / 60.0
+        le.append(se(*b).data.clone())
+        lr.append(sr(*[t.clone() for t in b]).data.clone())
+        del b
+        torch.empty(1 << 20, device=device).fill_(float("nan"))       # recycle freed blocks with poison
+    assert sr.plan is not None and se.plan is None
+    le = [v[0].item() for v in le]
+    lr = [v[0].item() for v in lr]
+    assert le == lr, (le, lr)
+    assert all(np.isfinite(le))
+    assert torch.equal(ge.store.flat, gr.store.flat)
+
+
+def test_recording_refuses_torch_operators_inside_the_step(device):
+    """A torch operator on device data inside forward_loss runs once, at record time; replay would
+    read its stale output.  The recording step must raise instead of producing such a plan."""
+    g, step = _make_pixellink(device, True, normalise_inside=True)
+    b = _pixellink_batch(device, 1)
+    step(*b)
+    step(*b)                                    # eager steps are fine
+    with pytest.raises(RuntimeError, match="would not be replayed"):
+        step(*b)
+    g2, eager = _make_pixellink(device, False, normalise_inside=True)
+    for _ in range(4):
+        eager(*b)                               # replay=False keeps torch operators legal
+
+
 def test_adam_ema_update_matches_oracle(device):
     g, batch, step = _make(device, False)
     step(*batch)                       # creates variables + optimiser, first update

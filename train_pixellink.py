@@ -55,6 +55,12 @@ def staircase_lr(step, base, breakpoints, decays):
     return base * 1.0
 
 
+def preprocess(images):
+    """The input normalisation of the reference's pipeline (train_pixellink.py:150-154 hands the queue
+    `ssd_vgg_preprocessing` output); done where the reference does it — before the step."""
+    return (images - 120.0) / 60.0
+
+
 def dataset_batches(FLAGS, g, batch, rank):
     """ICDAR directory -> (images [B,H,W,3] f32, pixel labels [B,H/4,W/4], link labels [B,H/4,W/4,8])."""
     from tensorflow_ocr_amd.datasets import icdar
@@ -87,7 +93,7 @@ def dataset_batches(FLAGS, g, batch, rank):
                 else:
                     raise SystemExit('square train size only (resize_images)')
                 score, link, _ = pixellink_fn.generate_rbox_batch(H, W, xs_l, ys_l, bb_l, ig_l, graph=g)
-                yield images, score, link
+                yield preprocess(images), score, link
                 ims, xs_l, ys_l, bb_l, ig_l = [], [], [], [], []
 
 
@@ -112,7 +118,7 @@ def main():
     g = Graph(device, seed=1)
 
     def forward_loss(gr, im, pixel_labels, link_labels):
-        net = pixellink.PixelLinkNet((im - 120.0) / 60.0, graph=gr)
+        net = pixellink.PixelLinkNet(im, graph=gr)                       # preprocessed input
         return net.build_loss(pixel_labels, link_labels)                 # 2*pixel + link (two LOSSES, :263)
 
     def make_opt(gr):
@@ -137,6 +143,7 @@ def main():
         else:
             im, px, lk, _ = synthetic.make_batch(rng, batch_size_per_gpu, FLAGS.train_image_height)
             images, pixel, link = [torch.from_numpy(a).to(device, non_blocking=True) for a in (im, px[..., 0], lk)]
+            images = preprocess(images)
         loss = step(images, pixel, link)
         if it % FLAGS.log_every_n_steps == 0:
             v = loss.item()
