@@ -421,6 +421,12 @@ int ocr_quad_iou(const void* dets_i32, int nd, const void* gts_i32, int ng, int 
 int ocr_resize_linear_u8(const void* src_u8, int H, int W, int cn, void* dst_f32, int dh, int dw,
                          void* stream);
 
+/* cv2.resize(plane, (dw, dh), interpolation=cv2.INTER_CUBIC) on float32 score maps, the up-sampling
+ * of the full-resolution decode (test_pixellink.py:97-98 `b_score * 255` then resize = pre_scale 255;
+ * :108-109 resize then `* 255` = post_scale 255).  src f32 [planes][h][w] -> dst f32 [planes][dh][dw]. */
+int ocr_resize_cubic_f32(const void* src_f32, int planes, int h, int w, void* dst_f32, int dh, int dw,
+                         float pre_scale, float post_scale, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Optimisers over the flat parameter buffer: elements [0, n_regularized) also get
  * the slim.l2_regularizer gradient weight_decay*w.  g is multiplied by

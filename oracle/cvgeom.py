@@ -68,6 +68,16 @@ def fill_poly(img, pts, color):
     return img
 
 
+def resize_cubic_f32(src, dh, dw):
+    """cv2.resize(src float32 [h,w], (dw, dh), interpolation=cv2.INTER_CUBIC)."""
+    src = np.ascontiguousarray(src, np.float32)
+    h, w = src.shape
+    dst = np.zeros((dh, dw), np.float32)
+    _load().cvgeom_resize_cubic_f32(_p(src), ctypes.c_int(h), ctypes.c_int(w), _p(dst), ctypes.c_int(dh),
+                                    ctypes.c_int(dw))
+    return dst
+
+
 def resize_linear_u8(src, dh, dw):
     """cv2.resize(src uint8 [H,W,cn], dsize=(dw, dh)) with the default INTER_LINEAR."""
     src = np.ascontiguousarray(src, np.uint8)

@@ -620,3 +620,67 @@ void cvgeom_resize_linear_u8(const unsigned char* src, int H, int W, int cn, uns
   }
   free(hbuf0); free(hbuf1); free(ialpha); free(xofs);
 }
+
+
+/* cv2.resize(float32 plane, INTER_CUBIC): OpenCV imgproc resize.cpp — interpolateCubic (A = -0.75),
+ * the xofs/alpha tables of cv::resize (fx at the half-pixel centre, scale = 1/(dsize/ssize)),
+ * HResizeCubic (border taps walked back into the row), VResizeCubic over rows clipped to the image.
+ * src [h][w] float -> dst [dh][dw] float.  test_pixellink.py:97-98,108-109. */
+static void interpolate_cubic(float x, float* coeffs) {
+  const float A = -0.75f;
+  coeffs[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  coeffs[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  coeffs[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  coeffs[3] = 1.f - coeffs[0] - coeffs[1] - coeffs[2];
+}
+
+void cvgeom_resize_cubic_f32(const float* src, int h, int w, float* dst, int dh, int dw) {
+  const double scale_x = 1. / ((double)dw / w), scale_y = 1. / ((double)dh / h);
+  int* xofs = (int*)malloc(sizeof(int) * (size_t)dw);
+  float* alpha = (float*)malloc(sizeof(float) * 4 * (size_t)dw);
+  int xmin = 0, xmax = dw;
+  for (int dx = 0; dx < dw; ++dx) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 1) xmin = dx + 1;
+    if (sx + 2 >= w && dx < xmax) xmax = dx;
+    xofs[dx] = sx;
+    interpolate_cubic(fx, alpha + 4 * dx);
+  }
+  float* rows = (float*)malloc(sizeof(float) * 4 * (size_t)dw);
+  for (int dy = 0; dy < dh; ++dy) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = cv_floor(fy);
+    fy -= sy;
+    float beta[4];
+    interpolate_cubic(fy, beta);
+    for (int k = 0; k < 4; ++k) {
+      int r = sy - 1 + k;
+      if (r < 0) r = 0;
+      if (r > h - 1) r = h - 1;
+      const float* S = src + (size_t)r * w;
+      float* D = rows + (size_t)k * dw;
+      for (int dx = 0; dx < dw; ++dx) {
+        const float* a = alpha + 4 * dx;
+        const int sx = xofs[dx] - 1;
+        if (dx >= xmin && dx < xmax) {
+          D[dx] = S[sx] * a[0] + S[sx + 1] * a[1] + S[sx + 2] * a[2] + S[sx + 3] * a[3];
+        } else {
+          float v = 0;
+          for (int j = 0; j < 4; ++j) {
+            int sxj = sx + j;
+            while (sxj < 0) sxj += 1;
+            while (sxj >= w) sxj -= 1;
+            v += S[sxj] * a[j];
+          }
+          D[dx] = v;
+        }
+      }
+    }
+    for (int x = 0; x < dw; ++x)
+      dst[(size_t)dy * dw + x] = rows[x] * beta[0] + rows[dw + x] * beta[1] + rows[2 * dw + x] * beta[2] +
+                                 rows[3 * dw + x] * beta[3];
+  }
+  free(rows); free(alpha); free(xofs);
+}

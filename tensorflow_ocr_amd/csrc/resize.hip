@@ -58,7 +58,74 @@ __global__ void resize_linear_u8_kernel(ResizeP p, const unsigned char* __restri
   }
 }
 
+// cv2.resize(float32 plane, dsize, interpolation=cv2.INTER_CUBIC) — the score-map up-sampling of the
+// full-resolution decode (test_pixellink.py:97-98,108-109).  OpenCV's float path: 4 taps per axis,
+// Keys' kernel with A = -0.75 evaluated in float at the half-pixel-centre source coordinate
+// (interpolateCubic), tap columns / rows clamped to the image, the horizontal sums
+// S0*a0 + S1*a1 + S2*a2 + S3*a3 formed first (left to right, no contraction) and the vertical
+// combination of the four row sums second.  `pre` multiplies the source samples (b_score * 255 before
+// the resize), `post` the result (pixel_score * 255 after it).
+struct CubicP {
+  int planes, h, w, dh, dw;
+  float pre, post;
+  double scale_x, scale_y;
+};
+
+__device__ __forceinline__ void cubic_coeffs(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+__global__ void resize_cubic_f32_kernel(CubicP p, const float* __restrict__ src, float* __restrict__ dst) {
+  const size_t per = (size_t)p.dh * p.dw, total = per * p.planes;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int pl = (int)(i / per);
+    const int dy = (int)((i % per) / p.dw), dx = (int)(i % p.dw);
+    float fx = (float)((dx + 0.5) * p.scale_x - 0.5);
+    const int sx = (int)floorf(fx);
+    fx -= sx;
+    float fy = (float)((dy + 0.5) * p.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    float a[4], b[4];
+    cubic_coeffs(fx, a);
+    cubic_coeffs(fy, b);
+    int xs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xs[j] = min(max(sx - 1 + j, 0), p.w - 1);
+    const float* S = src + (size_t)pl * p.h * p.w;
+    float rows[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* R = S + (size_t)min(max(sy - 1 + k, 0), p.h - 1) * p.w;
+      rows[k] = (R[xs[0]] * p.pre) * a[0] + (R[xs[1]] * p.pre) * a[1] + (R[xs[2]] * p.pre) * a[2] +
+                (R[xs[3]] * p.pre) * a[3];
+    }
+    dst[i] = (rows[0] * b[0] + rows[1] * b[1] + rows[2] * b[2] + rows[3] * b[3]) * p.post;
+  }
+}
+
 }  // namespace
+
+extern "C" int ocr_resize_cubic_f32(const void* src_f32, int planes, int h, int w, void* dst_f32, int dh, int dw,
+                                    float pre_scale, float post_scale, void* stream) {
+  OCR_CHECK_ARG(src_f32 && dst_f32 && planes > 0 && h > 0 && w > 0 && dh > 0 && dw > 0);
+  CubicP p;
+  p.planes = planes; p.h = h; p.w = w; p.dh = dh; p.dw = dw;
+  p.pre = pre_scale; p.post = post_scale;
+  p.scale_x = 1. / ((double)dw / w);
+  p.scale_y = 1. / ((double)dh / h);
+  const size_t total = (size_t)planes * dh * dw;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(resize_cubic_f32_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, static_cast<const float*>(src_f32),
+                     static_cast<float*>(dst_f32));
+  return ocr_launch_status();
+}
 
 extern "C" int ocr_resize_linear_u8(const void* src_u8, int H, int W, int cn, void* dst_f32, int dh, int dw,
                                     void* stream) {

@@ -523,6 +523,15 @@ def resize_linear_u8(src_u8, dst_f32):
            c_int(dw), _st())
 
 
+def resize_cubic_f32(src_f32, dst_f32, pre_scale=1.0, post_scale=1.0):
+    """src f32 [planes,h,w] -> dst f32 [planes,dh,dw] (cv2.resize INTER_CUBIC per plane)."""
+    planes, h, w = src_f32.shape
+    p2, dh, dw = dst_f32.shape
+    assert planes == p2 and src_f32.dtype == torch.float32 and dst_f32.dtype == torch.float32
+    L.call("ocr_resize_cubic_f32", ptr(src_f32), c_int(planes), c_int(h), c_int(w), ptr(dst_f32), c_int(dh),
+           c_int(dw), c_float(pre_scale), c_float(post_scale), _st())
+
+
 def quad_iou(dets, gts, mask_h, mask_w, inter, uni):
     nd, V, _ = dets.shape
     ng = gts.shape[0]

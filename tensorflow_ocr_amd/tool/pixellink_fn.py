@@ -72,6 +72,38 @@ def link_cc_decode(pixel_score, link_score, pixel_conf_threshold=0.8, link_conf_
     return labels, ncomp, comps
 
 
+def resize_scores_cubic(pixel_score, link_score, out_h=720, out_w=1280, graph=None):
+    """test_pixellink.py:95-109: the eight link maps are `b_score[0,:,:,1] * 255` up-sampled with
+    cv2.resize(..., (1280, 720), INTER_CUBIC); the pixel map is up-sampled first and multiplied by 255
+    after.  pixel_score [N,h,w]; link_score [8,N,h,w,2] or [8,N,h,w].  Returns f32 [9,N,out_h,out_w]
+    (plane 0 = pixel, 1..8 = links), one launch per scaling order."""
+    g = graph or get_default_graph()
+    ps = _dev(g, pixel_score)
+    lk = _dev(g, link_score)
+    if lk.dim() == 5:
+        lk = lk[..., 1]
+    n, h, w = ps.shape
+    src = torch.empty((9, n, h, w), dtype=F32, device=g.device)
+    src[0].copy_(ps)
+    src[1:].copy_(lk)
+    up = torch.empty((9, n, out_h, out_w), dtype=F32, device=g.device)
+    ops.resize_cubic_f32(src[0], up[0], 1.0, 255.0)
+    ops.resize_cubic_f32(src[1:].reshape(8 * n, h, w), up[1:].reshape(8 * n, out_h, out_w), 255.0, 1.0)
+    return up
+
+
+def full_resolution_decode(pixel_score, link_score, out_h=720, out_w=1280, min_size=200, max_comps=4096,
+                           graph=None):
+    """test_pixellink.py:95-184: cubic up-sampling of the nine score maps to out_w x out_h, then the
+    same link-gated grouping as the 1/4-resolution script with the constants of :111,:119
+    (`pixel_score > int(255 * 0.8)`, `link > 255 * 0.9`) and `len(index_list) > 200`.
+    Returns (labels int32 [N,out_h,out_w], ncomp int32 [N], comps int32 [N,max_comps,2])."""
+    g = graph or get_default_graph()
+    up = resize_scores_cubic(pixel_score, link_score, out_h, out_w, graph=g)
+    return link_cc_decode(up[0], up[1:], float(int(255 * 0.8)), 255 * 0.9, min_size=min_size,
+                          max_comps=max_comps, graph=g)
+
+
 def _rotated_rect(nh, head, cal):
     """Tail of cv2.minAreaRect (OpenCV 3.x `minAreaRect`): RotatedRect (cx, cy, w, h, angle°) from the
     calipers' corner + edge vectors (hull of > 2 points) or from a 1/2-point hull.  float32
