@@ -371,6 +371,14 @@ int ocr_min_area_rects(const void* labels_i32, const void* ncomp_i32, int n, int
 int ocr_east_pixel_detect(const void* score_f32, const void* link16_f32, int h, int w, float score_thresh,
                           float link_thresh, void* mask_u8, void* first_second_i32, void* stream);
 int ocr_zero_pixels_u8(void* mask_u8, const void* idx_i32, int count, void* stream);
+/* Parent links of cv2.findContours(mask, RETR_TREE, ...) (test.py:182), from the two ocr_mask_cc
+ * labellings of one mask (labels/comps: 8-connected components of the 1-pixels; zlabels/zcomps:
+ * 4-connected regions of the 0-pixels): parent_c[i] = 0-region left of component i's first pixel,
+ * parent_z[j] = component left of region j's first pixel; 0 = column 0 (the frame).  The host derives
+ * OpenCV's list order from them (newest sibling first, pre-order). */
+int ocr_contour_parents(const void* labels_i32, const void* zlabels_i32, const void* comps_i32, int ncomp,
+                        const void* zcomps_i32, int nregions, int h, int w, void* parent_c_i32,
+                        void* parent_z_i32, void* stream);
 /* Connected components of the pixels with (mask != 0) == (value != 0), connectivity 4 or 8; outputs as
  * ocr_link_cc (dense ids in ascending order of the smallest pixel index).  Workspace:
  * ocr_link_cc_workspace(n, h, w). */

@@ -345,6 +345,38 @@ extern "C" int ocr_east_pixel_detect(const void* score_f32, const void* link16_f
   return ocr_launch_status();
 }
 
+namespace {
+// The region to the LEFT of each region's first pixel: for a component that is the 0-region its outer
+// contour lies in, for a 0-region the component whose pixels carry the hole contour — the parent
+// links of cv2.findContours(RETR_TREE) (0 = the first pixel is in column 0: the frame).
+__global__ void contour_parents_kernel(const int* __restrict__ labels, const int* __restrict__ zlabels,
+                                       const int* __restrict__ comps, int k1, const int* __restrict__ zcomps,
+                                       int k0, int w, int* __restrict__ parent_c, int* __restrict__ parent_z) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < k1) {
+    const int first = comps[2 * i];
+    parent_c[i] = first % w ? zlabels[first - 1] : 0;
+  } else if (i < k1 + k0) {
+    const int first = zcomps[2 * (i - k1)];
+    parent_z[i - k1] = first % w ? labels[first - 1] : 0;
+  }
+}
+}  // namespace
+
+extern "C" int ocr_contour_parents(const void* labels_i32, const void* zlabels_i32, const void* comps_i32,
+                                   int ncomp, const void* zcomps_i32, int nregions, int h, int w,
+                                   void* parent_c_i32, void* parent_z_i32, void* stream) {
+  OCR_CHECK_ARG(labels_i32 && zlabels_i32 && comps_i32 && zcomps_i32 && parent_c_i32 && parent_z_i32);
+  OCR_CHECK_ARG(ncomp >= 0 && nregions >= 0 && h > 0 && w > 0);
+  if (ncomp + nregions == 0) return OCR_OK;
+  hipLaunchKernelGGL(contour_parents_kernel, dim3((ncomp + nregions + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const int*>(labels_i32),
+                     static_cast<const int*>(zlabels_i32), static_cast<const int*>(comps_i32), ncomp,
+                     static_cast<const int*>(zcomps_i32), nregions, w, static_cast<int*>(parent_c_i32),
+                     static_cast<int*>(parent_z_i32));
+  return ocr_launch_status();
+}
+
 extern "C" int ocr_zero_pixels_u8(void* mask_u8, const void* idx_i32, int count, void* stream) {
   OCR_CHECK_ARG(mask_u8 && idx_i32 && count >= 0 && count <= 256);
   if (count == 0) return OCR_OK;

@@ -493,6 +493,12 @@ def east_pixel_detect(score, link16, h, w, score_thresh, link_thresh, mask, firs
            c_float(link_thresh), ptr(mask), ptr(first_second), _st())
 
 
+def contour_parents(labels, zlabels, comps, ncomp, zcomps, nregions, parent_c, parent_z):
+    h, w = labels.shape[-2:]
+    L.call("ocr_contour_parents", ptr(labels), ptr(zlabels), ptr(comps), c_int(ncomp), ptr(zcomps), c_int(nregions),
+           c_int(h), c_int(w), ptr(parent_c), ptr(parent_z), _st())
+
+
 def zero_pixels(mask, idx):
     L.call("ocr_zero_pixels_u8", ptr(mask), ptr(idx), c_int(idx.numel()), _st())
 

@@ -262,21 +262,25 @@ def east_pixel_detect(score_map, geo_map, score_map_thresh=0.8, link_thresh=0.8,
 
 
 def find_contour_boxes(mask, scale_x=1.0, scale_y=1.0, max_regions=4096, graph=None):
-    """One `cv2.minAreaRect` / `np.int0(cv2.boxPoints(.))` per contour of
-    `cv2.findContours(mask, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)` (test.py:182-190): the outer
-    border of every 8-connected component of 1-pixels, and the border of every hole (a 4-connected
-    0-region that does not reach the image edge; its contour = the 1-pixels with a 4-neighbour in it).
-    A contour's rectangle depends only on the convex hull of its points, so regions are labelled
-    (ocr_mask_cc) and hulled (ocr_min_area_rects / ocr_hole_border_rects) on the GPU without tracing
-    borders.  mask uint8 [h,w].  Returns (rects float32 [k,5], boxes int64 [k,4,2]); outer contours
-    first (components in raster order of their first pixel), then holes — OpenCV's list order differs,
-    the set of boxes does not."""
+    """The boxes test.py:182-190 draws from `cv2.findContours(mask, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)`:
+    one `cv2.minAreaRect` per contour.  A contour is either the outer border of an 8-connected
+    component of 1-pixels or the border of a hole (a 4-connected 0-region that does not reach the
+    image edge; its contour = the surrounding 1-pixels with a 4-neighbour in it).  A contour's
+    rectangle depends only on the convex hull of its points, so regions are labelled (ocr_mask_cc)
+    and hulled (ocr_min_area_rects / ocr_hole_border_rects) on the GPU without tracing borders.
+    mask uint8 [h,w].  Returns (rects float32 [k,5], boxes int64 [k,4,2]) in OpenCV's list order:
+    border following discovers an outer border at its component's first pixel in raster order and a
+    hole border at the hole's first 0-pixel, every new contour becomes the FIRST child of its parent
+    (cvInsertNodeIntoTree), and the list is the pre-order walk of that tree (cvTreeToNodeSeq) — so
+    siblings come newest first, each followed by its own subtree (ocr_contour_parents gives the
+    parent links)."""
     import numpy as np
     g = graph or get_default_graph()
     m = mask if isinstance(mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8))
     m = (m.to(g.device) != 0).to(torch.uint8).contiguous()[None]
     _, h, w = m.shape
-    out_r, out_b = [], []
+    keep = {}
+    nodes = []                                   # (discovery key, kind, index, rect)
     for value, conn in ((1, 8), (0, 4)):
         labels = torch.empty((1, h, w), dtype=torch.int32, device=g.device)
         ncomp = torch.empty((1,), dtype=torch.int32, device=g.device)
@@ -285,6 +289,7 @@ def find_contour_boxes(mask, scale_x=1.0, scale_y=1.0, max_regions=4096, graph=N
         k = int(ncomp[0].item())
         if k > max_regions:
             raise ValueError("more than %d regions" % max_regions)
+        keep[value] = (labels, comps, k)
         if k == 0:
             continue
         hull_n = torch.zeros((1, max_regions), dtype=torch.int32, device=g.device)
@@ -296,12 +301,38 @@ def find_contour_boxes(mask, scale_x=1.0, scale_y=1.0, max_regions=4096, graph=N
             ops.hole_border_rects(m, labels, ncomp, max_regions, float(scale_x), float(scale_y), hull_n, head, cal,
                                   g.workspace())
         hn, hd, cl = hull_n[0, :k].cpu().numpy(), head[0, :k].cpu().numpy(), cal[0, :k].cpu().numpy()
+        first = comps[0, :k, 0].cpu().numpy()
         for i in range(k):
             if hn[i] == 0:                       # a 0-region that reaches the edge: background, no contour
                 continue
-            r = _rotated_rect(int(hn[i]), hd[i], cl[i])
-            out_r.append(r)
-            out_b.append(_box_points(r).astype(np.int64))
+            nodes.append((int(first[i]), value, i, _rotated_rect(int(hn[i]), hd[i], cl[i])))
+    if not nodes:
+        return np.zeros((0, 5), np.float32), np.zeros((0, 4, 2), np.int64)
+    (lab1, comps1, k1), (lab0, comps0, k0) = keep[1], keep[0]
+    par_c = torch.zeros((max(k1, 1),), dtype=torch.int32, device=g.device)
+    par_z = torch.zeros((max(k0, 1),), dtype=torch.int32, device=g.device)
+    ops.contour_parents(lab1, lab0, comps1, k1, comps0, k0, par_c, par_z)
+    par_c, par_z = par_c.cpu().numpy(), par_z.cpu().numpy()
+    holes = {n[2] for n in nodes if n[1] == 0}
+    kids = {}
+    for key, value, i, r in nodes:
+        if value == 1:                           # outer border: child of the hole it lies in, else top level
+            z = int(par_c[i]) - 1
+            parent = (0, z) if z in holes else None
+        else:                                    # hole border: child of the surrounding component
+            parent = (1, int(par_z[i]) - 1)
+        kids.setdefault(parent, []).append((key, (value, i), r))
+    out_r, out_b = [], []
+    stack = [iter(sorted(kids.get(None, []), key=lambda t: -t[0]))]
+    while stack:                                 # pre-order, newest sibling first
+        nxt = next(stack[-1], None)
+        if nxt is None:
+            stack.pop()
+            continue
+        _, nid, r = nxt
+        out_r.append(r)
+        out_b.append(_box_points(r).astype(np.int64))
+        stack.append(iter(sorted(kids.get(nid, []), key=lambda t: -t[0])))
     if not out_r:
         return np.zeros((0, 5), np.float32), np.zeros((0, 4, 2), np.int64)
     return np.stack(out_r), np.stack(out_b)

@@ -9,9 +9,8 @@ heads), softmax scores, the script's own `pixel_detect`, one `cv2.minAreaRect` b
 Same flag names / defaults.  Everything per-pixel runs on the GPU (network, cv2.resize, softmaxes,
 mask, region labelling, convex hulls + rotating calipers); the per-box integer arithmetic of
 :191-199 and `order_points` stay on the host as in the reference.  Forced differences: images are
-decoded with PIL (or .npy), no visualisation images are written (`cv2.imwrite` of score_map.jpg /
-img.jpg / the annotated photo), and boxes are emitted in region order (outer contours in raster
-order, then holes) instead of OpenCV's contour-list order."""
+decoded with PIL (or .npy) and no visualisation images are written (`cv2.imwrite` of score_map.jpg /
+img.jpg / the annotated photo).  Boxes come out in the order of OpenCV's contour list."""
 import argparse
 import os
 import time

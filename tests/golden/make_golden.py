@@ -96,6 +96,10 @@ def cv_geometry():
     mask[18:22, 25:31] = 1
     rects, boxes = OC.contour_boxes(mask)
     out.update(ct_mask=mask, ct_rects=np.stack(rects), ct_boxes=np.stack(boxes))
+    traced = OC.suzuki_contours(mask)
+    out.update(ct_kinds=np.array([k for k, _, _ in traced]), ct_parents=np.array([p for _, _, p in traced], np.int32))
+    cub = np.random.default_rng(22).uniform(size=(12, 20)).astype(np.float32)
+    out.update(cub_src=cub, cub_up=C.resize_cubic_f32(cub * np.float32(255), 45, 80), cub_down=C.resize_cubic_f32(cub, 5, 9))
     np.savez_compressed(os.path.join(HERE, "cv_geometry.npz"), **out)
 
 

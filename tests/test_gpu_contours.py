@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import contours as OC
+from oracle import cvgeom
 
 pytestmark = pytest.mark.gpu
 
@@ -48,11 +49,34 @@ def test_contour_boxes_match_definition(device, h, w, seed):
     rects, boxes = P.find_contour_boxes(m, graph=g)
     orects, oboxes = OC.contour_boxes(m)
     assert len(boxes) == len(oboxes)
-    assert _keyset(boxes) == _keyset(oboxes)
-    assert sorted(r.tobytes() for r in rects) == sorted(r.tobytes() for r in orects)
+    # same boxes in the same ORDER: OpenCV's contour list (newest sibling first, pre-order)
+    assert [tuple(np.asarray(b).ravel().tolist()) for b in boxes] == [tuple(np.asarray(b).ravel().tolist()) for b in oboxes]
+    assert [r.tobytes() for r in rects] == [r.tobytes() for r in orects]
     if seed == 0:
         kinds = [k for k, _ in OC.contour_point_sets(m)]
         assert kinds.count("outer") == 4 and kinds.count("hole") == 1
+
+
+def test_contour_order_of_nested_rings(device):
+    """Rings inside rings with islands and gaps: hole -> island -> hole chains several levels deep.  The
+    order is checked against the LITERAL border-following restatement, not only the label-based one."""
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.tool import pixellink_fn as P
+    g = Graph(device)
+    rng = np.random.default_rng(5)
+    for h, w in ((33, 41), (48, 48), (25, 60)):
+        m = np.zeros((h, w), np.uint8)
+        for k in range(0, min(h, w) // 2, 2):
+            m[k:h - k, k:w - k] = 1
+            m[k + 1:h - k - 1, k + 1:w - k - 1] = 0
+        m ^= (rng.uniform(size=(h, w)) < 0.03).astype(np.uint8)
+        rects, boxes = P.find_contour_boxes(m, graph=g)
+        traced = OC.suzuki_contours(m)
+        assert len(traced) == len(boxes) and max(t[2] for t in traced) >= 3        # real nesting
+        for (is_hole, pts, _), rect, box in zip(traced, rects, boxes):
+            want, _, _ = cvgeom.min_area_rect(np.unique(pts, axis=0))
+            assert rect.tobytes() == np.asarray(want, np.float32).tobytes()
+            assert np.array_equal(box, cvgeom.box_points(want).astype(np.int64))
 
 
 def test_empty_and_full_masks(device):

@@ -136,4 +136,4 @@ def test_east_test_script_end_to_end(device, tmp_path, capsys):
         b[:, 0] = b[:, 0] / rw
         b[:, 1] = b[:, 1] / rh
         want.append(OC.order_points(b))
-    assert len(got) == 3 and sorted(x.ravel().tolist() for x in got) == sorted(x.ravel().tolist() for x in want)
+    assert len(got) == 3 and [x.ravel().tolist() for x in got] == [x.ravel().tolist() for x in want]

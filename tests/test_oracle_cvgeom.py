@@ -247,3 +247,79 @@ def test_golden_cv_geometry_fixture():
     rects, boxes = OC.contour_boxes(g["ct_mask"])
     assert np.array_equal(np.stack(rects), g["ct_rects"]) and np.array_equal(np.stack(boxes), g["ct_boxes"])
     assert len(boxes) == 3 and g["ev_tp"].tolist() == [True, True, False] and g["ev_fp"].tolist() == [False, False, True]
+    traced = OC.suzuki_contours(g["ct_mask"])       # the lower-right block was found last, so it comes first
+    assert [k for k, _, _ in traced] == g["ct_kinds"].tolist() == [False, False, True]
+    assert [p for _, _, p in traced] == g["ct_parents"].tolist() == [-1, -1, 1]
+    assert np.array_equal(C.resize_cubic_f32(g["cub_src"] * np.float32(255), 45, 80), g["cub_up"])
+    assert np.array_equal(C.resize_cubic_f32(g["cub_src"], 5, 9), g["cub_down"])
+
+
+def test_contour_list_order_literal_tracing_equals_label_rule():
+    """oracle/contours.py: `suzuki_contours` follows borders pixel by pixel the way OpenCV's
+    contours.cpp does (transition scan, head insertion, pre-order walk); `contour_order` derives the
+    list from region labels.  Same kinds, same parents, same order; hole contours visit exactly the
+    surrounding component's pixels that touch the hole; an outer contour has its component's hull."""
+    from scipy import ndimage
+    from oracle import contours as OC
+    # a hand-checked case: A (with hole H holding island I) above B; discovery A, H, I, B ->
+    # top level newest first: B, then A followed by its subtree H, I
+    m = np.zeros((12, 12), np.uint8)
+    m[1:8, 1:9] = 1
+    m[2:7, 2:8] = 0
+    m[4, 4] = 1
+    m[9:11, 3:6] = 1
+    got = OC.suzuki_contours(m)
+    assert [(k, p) for k, _, p in got] == [(False, -1), (False, -1), (True, 1), (False, 2)]
+    assert sorted(map(tuple, got[0][1])) == sorted((x, y) for y in (9, 10) for x in (3, 4, 5))
+    assert [tuple(p) for p in got[3][1]] == [(4, 4)]
+    rng = np.random.default_rng(0)
+    total = 0
+    for t in range(120):
+        h, w = int(rng.integers(3, 26)), int(rng.integers(3, 26))
+        m = (rng.uniform(size=(h, w)) < rng.choice([0.3, 0.5, 0.7, 0.85, 0.95])).astype(np.uint8)
+        if t % 4 == 1:
+            m = ndimage.binary_dilation(m).astype(np.uint8)
+        if t % 4 == 2:
+            m[:] = 0
+            for k in range(0, min(h, w) // 2, 2):
+                m[k:h - k, k:w - k] = 1
+                m[k + 1:h - k - 1, k + 1:w - k - 1] = 0
+            m ^= (rng.uniform(size=(h, w)) < 0.03).astype(np.uint8)
+        a, b = OC.suzuki_contours(m), OC.contour_order(m)
+        assert len(a) == len(b)
+        for (hole, pts, par), (kind, dpts, dpar) in zip(a, b):
+            total += 1
+            assert hole == (kind == "hole") and par == dpar
+            sa, sb = set(map(tuple, pts)), set(map(tuple, dpts))
+            if hole:
+                assert sa == sb
+            else:
+                assert sa <= sb
+                assert np.array_equal(C.min_area_rect(np.unique(pts, axis=0))[0], C.min_area_rect(dpts)[0])
+    assert total > 800
+
+
+def test_resize_cubic_known_properties():
+    """cv2.resize INTER_CUBIC restatement: Keys' kernel with A = -0.75 (coefficients at x = 0.5 are
+    -3/32, 19/32, 19/32, -3/32), identity at equal size, constants preserved, clamped borders."""
+    src = np.zeros((1, 8), np.float32)
+    src[0, 3] = 32.0
+    up = C.resize_cubic_f32(src, 1, 16)              # 2x: sample positions k/2 - 0.25 -> fx in {0.75, 0.25}
+    c = np.float32(-0.75)
+    def coeffs(x):
+        x = np.float32(x)
+        c0 = ((c * (x + 1) - 5 * c) * (x + 1) + 8 * c) * (x + 1) - 4 * c
+        c1 = ((c + 2) * x - (c + 3)) * x * x + 1
+        c2 = ((c + 2) * (1 - x) - (c + 3)) * (1 - x) * (1 - x) + 1
+        return np.array([c0, c1, c2, np.float32(1) - c0 - c1 - c2], np.float32)
+    assert np.allclose(coeffs(0.5), [-3 / 32, 19 / 32, 19 / 32, -3 / 32])
+    # dx = 6: fx = 2.75 -> sx = 2, taps 1..4 -> the impulse at 3 meets coefficient 2 of x = 0.75
+    assert up[0, 6] == np.float32(32) * coeffs(0.75)[2]
+    assert up[0, 7] == np.float32(32) * coeffs(0.25)[1]
+    assert up[0, 9] == np.float32(32) * coeffs(0.25)[0]  # dx = 9: sx = 4, tap 0 is column 3
+    rng = np.random.default_rng(1)
+    s = rng.uniform(size=(7, 9)).astype(np.float32)
+    assert np.array_equal(C.resize_cubic_f32(s, 7, 9), s)
+    assert np.abs(C.resize_cubic_f32(np.full((4, 5), 0.3, np.float32), 13, 17) - 0.3).max() < 1e-6
+    one = C.resize_cubic_f32(np.array([[2.0]], np.float32), 3, 3)          # every tap clamps onto the pixel
+    assert np.abs(one - 2.0).max() < 1e-6
