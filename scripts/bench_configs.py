@@ -180,6 +180,14 @@ def east_fwd_config():
         holder["o"] = (a, b)
     net()
     dt_net = timed(net, 2, 10)
+    from tensorflow_ocr_amd.infer import GraphedForward
+
+    def fwd_fn(gr, im):
+        a, b = model.model(im, is_training=False, graph=gr)
+        return a, b
+    graphed = GraphedForward(g, fwd_fn)
+    graphed(x)
+    dt_graph = timed(lambda: graphed(x), 2, 20)
     # decode on a synthetic, well-behaved score map (random-init weights give degenerate maps)
     sc = torch.from_numpy((rng.uniform(size=(1, 128, 128, 1)) < 0.12).astype(np.float32)).to(dev)
     ys, xs = np.mgrid[0:128, 0:128]
@@ -210,6 +218,7 @@ def east_fwd_config():
             O.model_resnet(xi, tp, False)
             cpu = time.perf_counter() - t0
     print(json.dumps({"config": "test.py path, one 512x512 image: model.model inference + EAST-script decode (configs[0])",
+                      "net_ms_hip_graph": round(dt_graph * 1e3, 3),
                       "net_forward_ms": round(dt_net * 1e3, 3), "images_per_sec": round(1 / dt_net, 1),
                       "decode_ms": round(dt_dec * 1e3, 3), "boxes": int(len(holder["b"][1])),
                       "cpu_baseline": None if cpu is None else {"kind": "port", "cores": torch.get_num_threads(),

@@ -117,30 +117,34 @@ def main():
     from tensorflow_ocr_amd import checkpoint
     from tensorflow_ocr_amd.datasets import icdar
     from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.infer import GraphedForward
     from tensorflow_ocr_amd.nets import model
     from tensorflow_ocr_amd.tool import pixellink_fn
     os.makedirs(FLAGS.output_dir, exist_ok=True)
     g = Graph('cuda:0')
     restored = False
+
+    def network(gr, im):      # sess.run([f_score, f_geometry]) + the two softmaxes: one HIP graph per image shape
+        f_score, f_geometry = model.model(im, is_training=False, graph=gr)
+        fg = f_geometry.data if hasattr(f_geometry, 'data') and not isinstance(f_geometry, torch.Tensor) else f_geometry
+        return (pixellink_fn.pixel_scores(f_score, graph=gr),
+                pixellink_fn.pixel_scores(fg.reshape(-1, 2), graph=gr).reshape(fg.shape))
+    forward = GraphedForward(g, network)
     for im_fn in get_images(FLAGS.test_data_path):
         im = icdar.read_image_rgb(im_fn)                      # cv2.imread(im_fn)[:, :, ::-1]
         start_time = time.time()
         im_resized, (ratio_h, ratio_w) = resize_image(im, graph=g)
         x = im_resized[None]
-        f_score, f_geometry = model.model(x, is_training=False, graph=g)
-        g.reset_tape()
+        scores, pixel_score = forward(x)
         if not restored:
             # variable_averages.variables_to_restore(): the EMA shadows (test.py:149-158)
             if os.path.exists(os.path.join(FLAGS.checkpoint_path, 'checkpoint')) or os.path.exists(FLAGS.checkpoint_path + '.index'):
                 sd, _ = checkpoint.load_tf_checkpoint(FLAGS.checkpoint_path, use_moving_averages=True)
                 g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
                 print('Restore from {}'.format(FLAGS.checkpoint_path))
-                f_score, f_geometry = model.model(x, is_training=False, graph=g)
-                g.reset_tape()
+                scores, pixel_score = forward(x)
             restored = True
-        cls_score = pixellink_fn.pixel_scores(f_score, graph=g)[:, :, :, 1:2].contiguous()     # softmax(f_score)[..., 1:2]
-        fg = f_geometry.data if hasattr(f_geometry, 'data') and not isinstance(f_geometry, torch.Tensor) else f_geometry
-        pixel_score = pixellink_fn.pixel_scores(fg.reshape(-1, 2), graph=g).reshape(fg.shape)   # softmax over the pairs
+        cls_score = scores[:, :, :, 1:2].contiguous()           # softmax(f_score)[..., 1:2]; pixel_score: softmax over the pairs
         torch.cuda.synchronize()
         print('net time:' + str((time.time() - start_time) * 1000) + 'ms')
         score_map_res = pixel_detect(score_map=cls_score, geo_map=pixel_score, graph=g)

@@ -43,6 +43,7 @@ def main():
     FLAGS = parse()
     from tensorflow_ocr_amd import checkpoint
     from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.infer import GraphedForward
     from tensorflow_ocr_amd.nets import pixellink
     from tensorflow_ocr_amd.tool import pixellink_fn
     g = Graph('cuda:0')
@@ -54,13 +55,17 @@ def main():
     else:
         items = [(os.path.basename(f).split('.')[0], np.load(f).astype(np.float32)) for f in get_images(FLAGS.test_data_path)]
     loaded = False
+
+    def network(gr, im):      # sess.run of the pixel / link softmaxes: one HIP graph (every image has the eval size)
+        net = pixellink.PixelLinkNet(im, graph=gr)
+        return net.pixel_scores, pixellink_fn.link_scores(net.link_cls, graph=gr)
+    forward = GraphedForward(g, network)
     for name, im in items:
         if im.shape[:2] != (H, W):
             raise SystemExit('%s: expected %dx%d input (resize is a cv2 step, out of scope)' % (name, H, W))
-        x = ((im - 120.0) / 60.0)[None]
+        x = torch.from_numpy(((im - 120.0) / 60.0)[None]).to(g.device)
         t0 = time.time()
-        net = pixellink.PixelLinkNet(x, graph=g)
-        g.reset_tape()
+        pixel_score, link_score = forward(x)                            # [1,h,w,2], [8,1,h,w,2]
         if FLAGS.checkpoint_path and not loaded:
             if FLAGS.checkpoint_path.endswith('.npz'):
                 sd = dict(np.load(FLAGS.checkpoint_path))
@@ -68,10 +73,7 @@ def main():
                 sd, _ = checkpoint.load_tf_checkpoint(FLAGS.checkpoint_path, use_moving_averages=True)
             g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
             loaded = True
-            net = pixellink.PixelLinkNet(x, graph=g)
-            g.reset_tape()
-        pixel_score = net.pixel_scores                                  # [1,h,w,2]
-        link_score = pixellink_fn.link_scores(net.link_cls, graph=g)    # [8,1,h,w,2]
+            pixel_score, link_score = forward(x)
         score_res = pixellink_fn.tf_pixel_detect(pixel_score[..., 1:2].contiguous(), link_score,
                                                  FLAGS.pixel_conf_threshold, FLAGS.link_conf_threshold, graph=g)
         labels, ncomp, comps = pixellink_fn.link_cc_decode(pixel_score[..., 1].contiguous(), link_score,

@@ -103,22 +103,28 @@ def test_full_resolution_decode_matches_oracle(device):
             assert abs(r[0] - (xs.min() + xs.max()) / 2) < max(r[2], r[3]) and abs(r[1] - (ys.min() + ys.max()) / 2) < max(r[2], r[3])
 
 
-def test_full_resolution_script_end_to_end(device, tmp_path, capsys):
+@pytest.mark.parametrize("script", ["test_pixellink", "test_pixellink_fast"])
+def test_decode_scripts_end_to_end(device, tmp_path, capsys, script):
+    """Three images of one size: the forward runs launch by launch, is captured as a HIP graph on the
+    second image and replayed on the third."""
     sys.path.insert(0, ROOT)
-    mod = importlib.import_module("test_pixellink")
+    mod = importlib.import_module(script)
     assert mod.__file__.startswith(ROOT)
     out_dir = os.path.join(tmp_path, "out")
     old = sys.argv
-    sys.argv = ["test_pixellink.py", "--synthetic", "2", "--eval_image_height", "128", "--eval_image_width", "192",
-                "--decode_height", "120", "--decode_width", "192", "--checkpoint_path", os.path.join(tmp_path, "none"),
-                "--output_dir", out_dir]
+    sys.argv = [script + ".py", "--synthetic", "3", "--eval_image_height", "128", "--eval_image_width", "192",
+                "--checkpoint_path", os.path.join(tmp_path, "none"), "--output_dir", out_dir]
+    if script == "test_pixellink":
+        sys.argv += ["--decode_height", "120", "--decode_width", "192"]
+    else:
+        sys.argv[sys.argv.index("--checkpoint_path"):sys.argv.index("--checkpoint_path") + 2] = []
     try:
         mod.main()
     finally:
         sys.argv = old
     out = capsys.readouterr().out
-    assert out.count("groups") == 2
-    assert sorted(os.listdir(out_dir)) == ["res_synthetic_0.txt", "res_synthetic_1.txt"]
+    assert out.count("net+decode") == 3
+    assert sorted(os.listdir(out_dir)) == ["res_synthetic_%d.txt" % i for i in range(3)]
     for fn in os.listdir(out_dir):
         for line in open(os.path.join(out_dir, fn), newline="").read().split("\r\n"):
             assert line == "" or len(line.split(",")) == 8
