@@ -1,0 +1,25 @@
+"""Dev-only: LANMS on bench-like input (MODE=bench) or on pairwise-disjoint quads (MODE=disjoint)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tensorflow_ocr_amd.graph import Graph
+from tensorflow_ocr_amd.tool import lanms
+g = Graph("cuda:0")
+n, K, S = 16, 1024, 1024
+rng = np.random.default_rng(4)
+boxes = np.zeros((n, K, 9), np.float32)
+mode = os.environ.get("MODE", "bench")
+for i in range(n):
+    cx = np.sort(rng.uniform(20, S - 20, K)); cy = rng.uniform(20, S - 20, K)
+    if mode == "disjoint":
+        cy = np.arange(K) * 100.0
+    w = rng.uniform(20, 60, K); h = rng.uniform(10, 30, K)
+    boxes[i, :, 0] = cx - w; boxes[i, :, 1] = cy - h; boxes[i, :, 2] = cx + w; boxes[i, :, 3] = cy - h
+    boxes[i, :, 4] = cx + w; boxes[i, :, 5] = cy + h; boxes[i, :, 6] = cx - w; boxes[i, :, 7] = cy + h
+    boxes[i, :, 8] = rng.uniform(0.5, 1.0, K)
+bt = torch.from_numpy(boxes).to("cuda:0"); ct = torch.full((n,), K, dtype=torch.int32, device="cuda:0")
+for _ in range(6):
+    out = lanms.lanms_batch(bt, ct, 0.2, graph=g)
+torch.cuda.synchronize()
+print(mode, "n_merged", out[1].tolist()[:4], "n_keep", out[3].tolist()[:4])
+

@@ -48,3 +48,40 @@ def test_lanms_bit_exact(device, k):
     one = lanms.merge_quadrangle_n9(boxes[0, :counts[0]], 0.2, graph=g)
     om, ok = OL.lanms(boxes[0, :counts[0]], 0.2)
     assert np.array_equal(one, om[ok])
+
+
+def _scattered(rng, k, span):
+    """Mostly non-overlapping rotated boxes in row-major order: almost nothing merges, so the
+    suppression matrix and the sweep see ~k quads (the bench's regime)."""
+    cx = np.sort(rng.uniform(20, span - 20, k))
+    cy = rng.uniform(20, span - 20, k)
+    out = np.zeros((k, 9), np.float32)
+    for i in range(k):
+        w, h = rng.uniform(20, 60), rng.uniform(10, 30)
+        ang = rng.uniform(-0.5, 0.5)
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        pts = np.array([[-w, -h], [w, -h], [w, h], [-w, h]]) @ R.T + [cx[i], cy[i]]
+        out[i, :8] = pts.ravel()
+        out[i, 8] = rng.choice([0.5, 0.75, 1.0]) if i % 3 else rng.uniform(0.5, 1.0)     # score ties too
+    return out
+
+
+@pytest.mark.parametrize("k,span,thr", [(1024, 1024.0, 0.2), (1024, 500.0, 0.3), (300, 300.0, 0.0005),
+                                        (4200, 1500.0, 0.2), (65, 200.0, 0.2), (64, 200.0, 0.2)])
+def test_lanms_scattered_bit_exact(device, k, span, thr):
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.tool import lanms
+    g = Graph(device)
+    rng = np.random.default_rng(k + int(span))
+    n_img = 2
+    boxes = np.zeros((n_img, k, 9), np.float32)
+    counts = np.array([k, k - k // 3], np.int32)
+    for b in range(n_img):
+        boxes[b, :counts[b]] = _scattered(rng, int(counts[b]), span)
+    merged, n_merged, keep, n_keep = [t.cpu().numpy() for t in lanms.lanms_batch(boxes, counts, thr, graph=g)]
+    for b in range(n_img):
+        om, ok = OL.lanms(boxes[b, :counts[b]], thr)
+        assert n_merged[b] == len(om) and n_keep[b] == len(ok)
+        assert np.array_equal(merged[b, :len(om)], om)
+        assert np.array_equal(keep[b, :len(ok)], ok)
+    assert n_merged[0] > k // 2 and 0 < n_keep[0] < n_merged[0]
