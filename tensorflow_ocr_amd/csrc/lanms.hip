@@ -151,57 +151,54 @@ __device__ float quad_iou_wave(const float* qa, const float* qb, float* scratch,
   load_ccw(qa, a);                               // uniform: computed redundantly by every lane
   load_ccw(qb, b);
   const float area_a = fabsf(signed_area(a, 4)), area_b = fabsf(signed_area(b, 4));
-  pt cur;
-  cur.x = lane < 4 ? a[lane & 3].x : 0.f;
-  cur.y = lane < 4 ? a[lane & 3].y : 0.f;
+  // lane i holds vertex i (`cur`) and its successor (`e`) of the polygon being clipped
+  pt cur = a[lane & 3], e = a[(lane + 1) & 3];
   int n = 4;
-  pt* nxt = reinterpret_cast<pt*>(scratch);      // [16]
-  for (int ce = 0; ce < 4 && n > 0; ++ce) {
-    const pt c1 = b[ce], c2 = b[(ce + 1) & 3];
-    const int nb = (lane + 1 == n) ? 0 : lane + 1;
-    pt e;
-    e.x = __shfl(cur.x, nb, 64);
-    e.y = __shfl(cur.y, nb, 64);
-    int cnt = 0;
-    pt o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
-    if (lane < n) {
-      const pt s = cur;
-      const bool sin = cross3(c1, c2, s) >= 0.f, ein = cross3(c1, c2, e) >= 0.f;
-      if (sin && ein) { o0 = e; cnt = 1; }
-      else if (sin && !ein) { o0 = intersect(s, e, c1, c2); cnt = 1; }
-      else if (!sin && ein) { o0 = intersect(s, e, c1, c2); o1 = e; cnt = 2; }
-    }
-    int pos = cnt;                                // inclusive prefix sum over lanes 0..7
+  const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-      const int t = __shfl_up(pos, o, 64);
-      if (lane >= o) pos += t;
+  for (int ce = 0; ce < 4; ++ce) {
+    if (n > 0) {
+      pt* nxt = reinterpret_cast<pt*>(scratch) + 16 * (ce & 1);     // two buffers: no read/write overlap between stages
+      const pt c1 = b[ce], c2 = b[(ce + 1) & 3];
+      int cnt = 0;
+      pt o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
+      if (lane < n) {
+        const pt s = cur;
+        const bool sin = cross3(c1, c2, s) >= 0.f, ein = cross3(c1, c2, e) >= 0.f;
+        if (sin && ein) { o0 = e; cnt = 1; }
+        else if (sin && !ein) { o0 = intersect(s, e, c1, c2); cnt = 1; }
+        else if (!sin && ein) { o0 = intersect(s, e, c1, c2); o1 = e; cnt = 2; }
+      }
+      // output slots from two ballots (a shuffle prefix sum is four dependent LDS-crossbar trips)
+      const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt == 2);
+      const int pos = __popcll(b1 & lt) + __popcll(b2 & lt);
+      if (cnt >= 1) nxt[pos] = o0;
+      if (cnt == 2) nxt[pos + 1] = o1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      n = __popcll(b1) + __popcll(b2);
+      if (lane < n) {
+        cur = nxt[lane];
+        e = nxt[lane + 1 == n ? 0 : lane + 1];
+      }
     }
-    const int m = __shfl(pos, 7, 64);
-    pos -= cnt;
-    if (cnt >= 1) nxt[pos] = o0;
-    if (cnt == 2) nxt[pos + 1] = o1;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    n = m;
-    if (lane < n) cur = nxt[lane];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   float inter = 0.f;
   if (n >= 3) {
     // shoelace terms per lane, summed in vertex order like signed_area()
-    const int nb = (lane + 1 == n) ? 0 : lane + 1;
-    const float vx = __shfl(cur.x, nb, 64), vy = __shfl(cur.y, nb, 64);
-    float* terms = scratch + 32;
-    if (lane < n) terms[lane] = cur.x * vy - vx * cur.y;
+    float* terms = scratch + 64;
+    if (lane < n) terms[lane] = cur.x * e.y - e.x * cur.y;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = terms[i];   // one batch of broadcast reads, then the dependent adds
     float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc += terms[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < n) acc += t[i];
     inter = fabsf(acc * 0.5f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -209,6 +206,21 @@ __device__ float quad_iou_wave(const float* qa, const float* qb, float* scratch,
   }
   const float uni = area_a + area_b - inter;
   return uni > 0.f ? inter / uni : 0.f;
+}
+
+// p <- (score_g * g + score_p * p) / (score_g + score_p), scores added (EAST's weighted_merge).  p is
+// replicated in every lane; lane j computes coordinate j (one division deep instead of eight) and the
+// eight results are broadcast back.
+__device__ __forceinline__ void weighted_merge(const float* g, float* p, int lane) {
+  const float sg = g[8], sp = p[8], sc = sg + sp;
+  float pj = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if ((lane & 7) == j) pj = p[j];
+  const float qj = (sg * g[lane & 7] + sp * pj) / sc;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qj), j));
+  p[8] = sc;
 }
 
 // Phase 0 (grid = quad blocks x images): verdict[i] = iou(g_{i+1}, g_i) > thr for every pair of
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256) void lanms_merge_kernel(const float* __restric
     dst = s_q + (size_t)k * 9;
   }
 
-  __shared__ float s_scratch[48];
+  __shared__ float s_scratch[80];           // two 16-point clip buffers + 16 area terms
   // While the running quad p is an UNMERGED input quad g_r, the next decision is iou(g_{r+1}, g_r) > thr
   // between two inputs: those k-1 verdicts do not depend on the chain (lanms_flags_kernel).  The chain then jumps over whole runs of non-mergeable neighbours (bulk copy) and walks quad
   // by quad only while p carries merged coordinates.
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(256) void lanms_merge_kernel(const float* __restric
     int m = 0;
     bool have = false;
     int raw = -1;                               // p == input quad `raw` exactly (and i == raw + 1), or -1
-    float p[9], q[9];                           // the running merged quad, replicated in every lane
+    float p[9];                                 // the running merged quad, replicated in every lane
     int i = 0;
     while (i < k) {
       if (STAGE && have && raw >= 0) {
@@ -291,10 +303,7 @@ __global__ __launch_bounds__(256) void lanms_merge_kernel(const float* __restric
         if (!hit) break;
         // flag[j]: g_{j+1} merges into p = g_j
         const float* g = src + 9 * i;
-        const float sg = g[8], sp = p[8], sc = sg + sp;
-        for (int t = 0; t < 8; ++t) q[t] = (sg * g[t] + sp * p[t]) / sc;
-        q[8] = sc;
-        for (int t = 0; t < 9; ++t) p[t] = q[t];
+        weighted_merge(g, p, lane);
         raw = -1;
         ++i;
         continue;
@@ -303,10 +312,7 @@ __global__ __launch_bounds__(256) void lanms_merge_kernel(const float* __restric
       bool mergeable = false;
       if (have && !(thr >= 1e-3f && aabb_disjoint(g, p))) mergeable = quad_iou_wave(g, p, s_scratch, lane) > thr;
       if (mergeable) {
-        const float sg = g[8], sp = p[8], sc = sg + sp;
-        for (int j = 0; j < 8; ++j) q[j] = (sg * g[j] + sp * p[j]) / sc;
-        q[8] = sc;
-        for (int j = 0; j < 9; ++j) p[j] = q[j];
+        weighted_merge(g, p, lane);
         raw = -1;
       } else {
         if (have) {
