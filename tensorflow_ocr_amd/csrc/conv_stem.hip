@@ -182,7 +182,9 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, half_t* __restrict
   out[i] = (half_t)v;
 }
 
-int stem_blocks(int m_tiles) { return m_tiles < 256 ? m_tiles : 256; }
+// two workgroups per CU (76 KB of LDS each): a tile is a chain of 14 barriers with 8 MFMAs between them, so a
+// second resident workgroup fills the stalls (64 x 640^2: 1.09 -> 0.67 ms; 768 / 1024 blocks: 0.85 / 0.74 ms)
+int stem_blocks(int m_tiles) { return m_tiles < 512 ? m_tiles : 512; }
 
 int fill(StemP* p, int n, int h, int w, int cout, int flags) {
   OCR_CHECK_ARG(n > 0 && h > 0 && w > 0);
