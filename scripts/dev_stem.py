@@ -18,3 +18,6 @@ def t(f, it=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
 print(os.environ.get("OCR_STEM_BLOCKS", "256"), "stem wgrad %.3f ms" % t(lambda: ops.conv2d_stem_wgrad(x4, dy, dw, ws)))
+n, h, w = 32, 512, 512
+x4 = torch.randn(n, h, w, 4, device=dev).half(); dy = torch.randn(n, h, w, 64, device=dev).half(); dw = torch.empty(3, 3, 3, 64, device=dev)
+print(os.environ.get("OCR_FIRST_BLOCKS", "256"), "first wgrad %.3f ms" % t(lambda: ops.conv2d_first_wgrad(x4, dy, dw, ws)))
