@@ -47,36 +47,11 @@ __device__ void load_ccw(const float* q, pt* out) {
   }
 }
 
-__device__ float quad_iou(const float* qa, const float* qb) {
-  pt a[4], b[4], cur[16], nxt[16];
-  load_ccw(qa, a);
-  load_ccw(qb, b);
-  const float area_a = fabsf(signed_area(a, 4)), area_b = fabsf(signed_area(b, 4));
-  int n = 4;
-  for (int i = 0; i < 4; ++i) cur[i] = a[i];
-  for (int ce = 0; ce < 4 && n > 0; ++ce) {
-    const pt c1 = b[ce], c2 = b[(ce + 1) % 4];
-    int m = 0;
-    for (int i = 0; i < n; ++i) {
-      const pt s = cur[i], e = cur[(i + 1) % n];
-      const bool sin = cross3(c1, c2, s) >= 0.f, ein = cross3(c1, c2, e) >= 0.f;
-      if (sin && ein) nxt[m++] = e;
-      else if (sin && !ein) nxt[m++] = intersect(s, e, c1, c2);
-      else if (!sin && ein) { nxt[m++] = intersect(s, e, c1, c2); nxt[m++] = e; }
-    }
-    n = m;
-    for (int i = 0; i < m; ++i) cur[i] = nxt[i];
-  }
-  const float inter = n >= 3 ? fabsf(signed_area(cur, n)) : 0.f;
-  const float uni = area_a + area_b - inter;
-  return uni > 0.f ? inter / uni : 0.f;
-}
-
-// The same clipper with its two work polygons in LDS (point i of thread t at [i * 256 + t]: one bank per
-// lane) instead of private arrays, which the compiler places in scratch = global memory: a clip is a
-// chain of dependent indexed reads and writes, ~4x faster against LDS latency.  Identical arithmetic
-// in identical order, so the value equals quad_iou()'s bit for bit.  A quad clipped by four
-// half-planes has at most 8 vertices.
+// IoU of two convex quads by Sutherland-Hodgman clipping (quad_iou of oracle/lanms_oracle.c, operation for
+// operation), one pair per thread.  The two work polygons live in LDS (point i of thread t at [i * 256 + t]:
+// one bank per lane): as private arrays the compiler places them in scratch = global memory, and a clip is a
+// chain of dependent indexed reads and writes (~4x slower).  A quad clipped by four half-planes has at most
+// 8 vertices.
 constexpr int kClipPts = 10;
 __device__ float quad_iou_lds(const float* qa, const float* qb, pt* cur, pt* nxt) {
   pt a[4], b[4];
@@ -118,7 +93,7 @@ __device__ float quad_iou_lds(const float* qa, const float* qb, pt* cur, pt* nxt
 // Phase 1 (one workgroup per image): sequential weighted merge (lane 0), then the stable score
 // ranking of the merged quads (all lanes).
 // Early-out: quads whose axis-aligned bounding boxes are disjoint have an empty intersection (the
-// clipper could at most leave a rounding-sized sliver), so `quad_iou(a, b) > thr` is false for any
+// clipper could at most leave a rounding-sized sliver), so `iou(a, b) > thr` is false for any
 // thr >= 1e-3 without running the clipper.  Only that decision is consumed, so the kept indices stay
 // bit-identical to the oracle; below 1e-3 the clipper always runs.
 __device__ bool aabb_disjoint(const float* a, const float* b) {
@@ -133,11 +108,6 @@ __device__ bool aabb_disjoint(const float* a, const float* b) {
   return ax1 < bx0 || bx1 < ax0 || ay1 < by0 || by1 < ay0;
 }
 
-__device__ bool iou_above(const float* a, const float* b, float thr) {
-  if (thr >= 1e-3f && aabb_disjoint(a, b)) return false;
-  return quad_iou(a, b) > thr;
-}
-
 // Wave-cooperative quad IoU for the merge chain (all 64 lanes of one wave call it with UNIFORM
 // arguments; the result is uniform).  The chain is sequential in the quads, so the parallelism has to
 // come from inside one IoU: lane i owns vertex i of the polygon being clipped (a quad clipped by four
@@ -145,7 +115,7 @@ __device__ bool iou_above(const float* a, const float* b, float thr) {
 // neighbour by shuffle, inside tests and the intersection per lane, output slots by an 8-lane prefix
 // sum, compaction through 16 points of wave-private LDS.  Every lane performs exactly the scalar
 // clipper's arithmetic for its vertex and the areas are summed in vertex order, so the value equals
-// quad_iou()'s bit for bit.
+// quad_iou_lds()'s (and the oracle's) bit for bit.
 __device__ float quad_iou_wave(const float* qa, const float* qb, float* scratch, int lane) {
   pt a[4], b[4];
   load_ccw(qa, a);                               // uniform: computed redundantly by every lane
