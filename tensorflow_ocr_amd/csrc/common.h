@@ -72,3 +72,20 @@ static __global__ void ocr_sum_rows_kernel(const float* __restrict__ partial, fl
   if (lane == 0) out[i] = a * scale;
 }
 static inline unsigned sum_rows_grid(int elems) { return (unsigned)((elems + 3) / 4); }
+// The same sum with the result row split over two destinations (elements [0, n_a) -> out_a, the rest ->
+// out_b; out_b may be null when n_a == elems, a null out_a drops the first part): the row is written where
+// it is wanted instead of being copied there by two more launches.
+static __global__ void ocr_sum_rows_split_kernel(const float* __restrict__ partial, float* __restrict__ out_a,
+                                                 int n_a, float* __restrict__ out_b, int elems, int S,
+                                                 float scale) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= elems) return;
+  float a = 0.f;
+  for (int s = lane; s < S; s += 64) a += partial[(size_t)s * elems + i];
+  a = wave_sum(a);
+  if (lane == 0) {
+    if (i < n_a) { if (out_a) out_a[i] = a * scale; }
+    else if (out_b) out_b[i - n_a] = a * scale;
+  }
+}

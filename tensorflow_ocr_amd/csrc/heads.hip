@@ -631,11 +631,8 @@ extern "C" int ocr_sc_bn_bwd(const void* z, const void* scale, const void* shift
                      P, C, relu, 0.f, static_cast<float*>(partial), (float*)nullptr);
   // partial [T][2][C]: sum rows into dbeta / dgamma (T <= 1024, tiny)
   float* part = static_cast<float*>(partial);
-  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(2 * C)), dim3(256), 0, st, part,
-                     part + (size_t)T * 2 * C, 2 * C, T, 1.f);
-  if (hipMemcpyAsync(dbeta, part + (size_t)T * 2 * C, C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(dgamma, part + (size_t)T * 2 * C + C, C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return OCR_ERR_HIP;
+  hipLaunchKernelGGL(ocr_sum_rows_split_kernel, dim3(sum_rows_grid(2 * C)), dim3(256), 0, st, part,
+                     static_cast<float*>(dbeta), C, static_cast<float*>(dgamma), 2 * C, T, 1.f);
   hipLaunchKernelGGL(sc_bn_bwd_kernel<1>, dim3(T), dim3(256), 0, st, zp,
                      static_cast<const float*>(scale), static_cast<const float*>(shift),
                      static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
@@ -705,7 +702,6 @@ extern "C" int ocr_sc_pointwise_wgrad(const void* x, int ldx, int xo, int cin, c
   const int B = 256;
   const int pairs = cin * cout + cout;
   float* ws = static_cast<float*>(workspace);
-  float* tot = ws + (size_t)B * pairs;
   OCR_CHECK_SHAPE(cin <= 32 && cout <= 32 && pairs <= 512);
   if (cin == 16 && cout == 16)
     hipLaunchKernelGGL(sc_pointwise_wgrad16_kernel, dim3(B), dim3(256), 0, st, static_cast<const float*>(x), ldx,
@@ -717,12 +713,8 @@ extern "C" int ocr_sc_pointwise_wgrad(const void* x, int ldx, int xo, int cin, c
     hipLaunchKernelGGL(sc_pointwise_wgrad_kernel, dim3(B), dim3(256), 0, st,
                        static_cast<const float*>(x), ldx, xo, cin, static_cast<const float*>(dout),
                        ldo, oo, cout, P, ocr_cdiv(P, B), ws);
-  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(pairs)), dim3(256), 0, st, ws, tot,
-                     pairs, B, 1.f);
-  if (hipMemcpyAsync(dw, tot, (size_t)cin * cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return OCR_ERR_HIP;
-  if (db && hipMemcpyAsync(db, tot + cin * cout, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return OCR_ERR_HIP;
+  hipLaunchKernelGGL(ocr_sum_rows_split_kernel, dim3(sum_rows_grid(pairs)), dim3(256), 0, st, ws,
+                     static_cast<float*>(dw), cin * cout, static_cast<float*>(db), pairs, B, 1.f);
   return ocr_launch_status();
 }
 
@@ -735,10 +727,8 @@ extern "C" int ocr_sc_colsum(const void* x, int P, int C, void* out, void* parti
   const int T = sc_blocks(P, C);
   float* part = static_cast<float*>(partial);
   hipLaunchKernelGGL(sc_stats_kernel, dim3(T), dim3(256), 0, st, static_cast<const float*>(x), P, C, part);
-  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(2 * C)), dim3(256), 0, st, part,
-                     part + (size_t)T * 2 * C, 2 * C, T, 1.f);
-  if (hipMemcpyAsync(out, part + (size_t)T * 2 * C, C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return OCR_ERR_HIP;
+  hipLaunchKernelGGL(ocr_sum_rows_split_kernel, dim3(sum_rows_grid(2 * C)), dim3(256), 0, st, part,
+                     static_cast<float*>(out), C, (float*)nullptr, 2 * C, T, 1.f);
   return ocr_launch_status();
 }
 
