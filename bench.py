@@ -119,7 +119,7 @@ def main():
         a[0] += flops
         a[1] += sec
         a[2] += 1
-        if phase == "fwd":          # forward launches: nothing else on the GPU (no side-stream wgrad)
+        if phase == "fwd":          # forward launches
             b = fwd.setdefault(variant, [0.0, 0.0])
             b[0] += flops
             b[1] += sec
@@ -137,9 +137,9 @@ def main():
                 traffic = round(json.load(f)[dom]["hbm_bytes_per_launch"])
         except Exception:
             pass
-        # `achieved` averages EVERY launch of the kernel in the timed region, as rocprofv3 --stats does;
-        # about half of them (the input-gradient launches) run concurrently with the side-stream weight
-        # gradients and are stretched by sharing the chip.  `achieved_alone` = the forward launches only.
+        # `achieved` averages EVERY launch of the kernel in the timed region (forward and input-gradient
+        # launches), as rocprofv3 --stats does; `achieved_alone` = the forward launches only (the
+        # input-gradient ones also carry the fused BN-backward sums in their epilogue).
         alone = round(fwd[dom][0] / fwd[dom][1] / 1e12, 1) if dom in fwd and fwd[dom][1] > 0 else None
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
