@@ -424,6 +424,16 @@ int ocr_pixellink_labels(const void* cover_u32, int n, int h, int w, int new_h, 
 int ocr_quad_iou(const void* dets_i32, int nd, const void* gts_i32, int ng, int verts, int mask_h, int mask_w,
                  void* inter_i32, void* union_i32, void* stream);
 
+/* Strided 3x3 convolutions of ResNet-v1 (nets/resnet_utils.py:85-122 conv2d_same with stride 2) as one
+ * stride-1 2x2 convolution over a space-to-depth copy: xs[n][Y][X][(a*2+b)*c + ch] = x[n][2Y+a][2X+b][ch]
+ * (h, w even; c a multiple of 8), weights w22 f32 [2][2][4c][k] from w33 f32 [3][3][c][k] (zero where a tap
+ * has no source), the weight gradient mapped back tap by tap, the input gradient un-shuffled (optionally added
+ * to an existing gradient). */
+int ocr_space_to_depth_f16(const void* x, int n, int h, int w, int c, void* xs, void* stream);
+int ocr_depth_to_space_f16(const void* xs, int n, int h, int w, int c, void* x, int accumulate, void* stream);
+int ocr_weights_s2d_f32(const void* w33_f32, int cin, int cout, void* w22_f32, void* stream);
+int ocr_weights_s2d_grad_f32(const void* dw22_f32, int cin, int cout, void* dw33_f32, void* stream);
+
 /* cv2.resize(im, dsize=(dw, dh)) (default INTER_LINEAR, 8-bit fixed-point path) + astype(float32):
  * datasets/icdar.py:615,630.  src uint8 [H][W][cn] -> dst f32 [dh][dw][cn]. */
 int ocr_resize_linear_u8(const void* src_u8, int H, int W, int cn, void* dst_f32, int dh, int dw,

@@ -129,6 +129,26 @@ def conv2d_wgrad(d, x, dy, dw, ws):
         L.RECORDER.tag_last(("side",))
 
 
+def space_to_depth(x, xs):
+    n, h, w, c = x.shape
+    L.call("ocr_space_to_depth_f16", ptr(x), c_int(n), c_int(h), c_int(w), c_int(c), ptr(xs), _st())
+
+
+def depth_to_space(xs, x, accumulate):
+    n, h, w, c = x.shape
+    L.call("ocr_depth_to_space_f16", ptr(xs), c_int(n), c_int(h), c_int(w), c_int(c), ptr(x), c_int(int(accumulate)), _st())
+
+
+def weights_s2d(w33, w22):
+    _, _, cin, cout = w33.shape
+    L.call("ocr_weights_s2d_f32", ptr(w33), c_int(cin), c_int(cout), ptr(w22), _st())
+
+
+def weights_s2d_grad(dw22, dw33):
+    _, _, cin, cout = dw33.shape
+    L.call("ocr_weights_s2d_grad_f32", ptr(dw22), c_int(cin), c_int(cout), ptr(dw33), _st())
+
+
 def conv2d_first_num_mtiles(n, h, w):
     return L.call_int("ocr_conv2d_first_num_mtiles", c_int(n), c_int(h), c_int(w))
 

@@ -2,16 +2,20 @@
 convolution, and the bottleneck tail relu(shortcut + bn(conv3)) — reference nets/resnet_v1.py:68-111,
 181-196 and nets/resnet_utils.py:59-122.
 
-Strided 3x3 convolutions use the identity the reference's own docstring states
-(resnet_utils.py:85-93): conv2d_same(x, n, 3, stride=s) == subsample(conv2d(x, n, 3, stride=1,
-SAME), s).  The stride-1 MFMA kernels (forward, input gradient, weight gradient) are reused and the
-sub-sampling is the 1x1/s max-pool kernel; only 3 of ResNet-50's 53 convolutions are strided 3x3
-(+7 % forward FLOPs), so this costs little and keeps one tuned kernel family.
+Strided 3x3 convolutions (three in ResNet-50) reuse the stride-1 MFMA kernels.  For stride 2 on even
+sizes the input is shuffled space-to-depth and the layer becomes ONE stride-1 2x2 convolution over
+4*cin channels (csrc/s2d.hip: 16/9 of the minimal work, output-resolution tiles, fused BN partial
+sums).  Other strides fall back on the identity the reference's own docstring states
+(resnet_utils.py:85-93): conv2d_same(x, n, 3, stride=s) == subsample(conv2d(x, n, 3, stride=1, SAME), s)
+— 4x the work at stride 2 plus a full-resolution intermediate, which is why it is only the fallback.
 """
 from . import ops
 from .graph import Act, F32, constant, variance_scaling
 from .layers import BN_DECAY, BN_EPS, FUSE_BN_REDUCE, _bn_vars, _packs
 from ._lib import CONV_ACCUM_F16, CONV_STATS
+
+
+USE_S2D = __import__("os").environ.get("OCR_RESNET_S2D", "1") == "1"     # measurement switch (A/B against the subsample form)
 
 
 class ConvBN:
@@ -32,14 +36,43 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
         wv = g.get_variable("weights", (k, k, cin, cout), variance_scaling(g.rng), regularized=weight_decay)
         gamma, beta, mm, mv = _bn_vars(g, cout)
     ws = g.workspace()
-    w_fwd, w_dg = _packs(g, wv, False)
-    d = ops.conv_desc((n, h, w, cin), cout, k, k, 1, rate)          # stride-1 SAME
     strided = stride != 1
     if strided and k == 1:
         raise NotImplementedError("strided 1x1 conv (the slim variant in the reference has none)")
-    y_full = g.empty((n, d.oh, d.ow, cout))
-    mt = ops.conv2d_num_mtiles(d)
-    if strided:
+    s2d = strided and stride == 2 and k == 3 and rate == 1 and h % 2 == 0 and w % 2 == 0 and cin % 16 == 0 and USE_S2D
+    if s2d:
+        def mk22(old):
+            t = old if old is not None else g.empty((2, 2, 4 * cin, cout), F32)
+            ops.weights_s2d(wv.data, t)
+            return t
+        w22 = g.packed(wv, "s2d_f32", mk22)
+
+        def mkp(old):
+            if old is None:
+                old = (g.empty((4, cout, 4 * cin)), g.empty((4, 4 * cin, cout)))
+            ops.pack_weights(w22, old[0], old[1])
+            return old
+        w_fwd, w_dg = g.packed(wv, "s2d_kc_ck", mkp)
+        oh, ow = h // 2, w // 2
+        xs = g.empty((n, oh, ow, 4 * cin))
+        ops.space_to_depth(x.data, xs)
+        d = ops.conv_desc((n, oh, ow, 4 * cin), cout, 2, 2, 1, 1, pad=(1, 1), out_hw=(oh, ow))
+        y_full = None
+        y = g.empty((n, oh, ow, cout))
+        T = ops.conv2d_num_mtiles(d)
+        part, stage = g.ws_small.two(T * 2 * cout * 4, ops.bn_reduce_workspace(T, cout))
+        d.flags = CONV_STATS if is_training else 0
+        ops.conv2d(d, xs, w_fwd, y, None, part if is_training else None)
+        x_in = xs
+    else:
+        w_fwd, w_dg = _packs(g, wv, False)
+        d = ops.conv_desc((n, h, w, cin), cout, k, k, 1, rate)          # stride-1 SAME
+        x_in = x.data
+        y_full = g.empty((n, d.oh, d.ow, cout))
+        mt = ops.conv2d_num_mtiles(d)
+    if s2d:
+        pass
+    elif strided:
         d.flags = 0
         ops.conv2d(d, x.data, w_fwd, y_full, None, None)
         oh, ow = -(-h // stride), -(-w // stride)
@@ -67,17 +100,33 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
         ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, c.scale, c.shift)
 
     def backward_from(dy):
-        if strided:
+        if strided and not s2d:
             dy_full = g.empty(y_full.shape)
             ops.maxpool_bwd(y_full, dy, 1, stride, (0, 0), dy_full, False)   # zero insertion
             dy = dy_full
         dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, d.kh, d.kw, 1, d.dilation, d.pad_top,
                           d.pad_left, 0, 0)
-        ops.conv2d_wgrad(dd, x.data, dy, wv.grad, g.ws_wgrad)
+        if s2d:
+            dw22 = g.empty((2, 2, 4 * cin, cout), F32)
+            ops.conv2d_wgrad(dd, x_in, dy, dw22, g.ws_wgrad)
+            ops.weights_s2d_grad(dw22, wv.grad)
+        else:
+            ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad)
         if not x.requires_grad:
             return
         pt = d.dilation * (d.kh - 1) - d.pad_top
         pl = d.dilation * (d.kw - 1) - d.pad_left
+        if s2d:
+            # input gradient in the shuffled layout, then back to full resolution (added to what is there)
+            dxs = g.empty(x_in.shape)
+            dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, 0)
+            ops.conv2d(dg, dy, w_dg, dxs, None, None)
+            had = x.grad is not None
+            if not had:
+                x.grad = g.empty(x.shape)
+            ops.depth_to_space(dxs, x.grad, had)
+            x.bn_partial = None
+            return
         flags = 0
         if x.grad is None:
             x.grad = g.empty(x.shape)

@@ -188,3 +188,65 @@ def test_model_east_merge_branch_dice(device):
     assert cs[0][0] > (0.8 if bf else 0.9)
     big = [c for c, k in cs if grads[k].size >= 4096]
     assert min(big) > (0.85 if bf else 0.9)
+
+
+def test_space_to_depth_ops_exact(device):
+    """csrc/s2d.hip data movement: layouts against numpy, round trip, accumulate, weight maps."""
+    from tensorflow_ocr_amd import _lib, ops
+    F16 = torch.bfloat16 if _lib.STORAGE == "bf16" else torch.float16
+    rng = np.random.default_rng(0)
+    n, h, w, c, k = 2, 6, 10, 16, 8
+    x = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(device).to(F16)
+    xs = torch.empty((n, h // 2, w // 2, 4 * c), dtype=F16, device=device)
+    ops.space_to_depth(x, xs)
+    want = x.reshape(n, h // 2, 2, w // 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, h // 2, w // 2, 4 * c)
+    assert torch.equal(xs, want)
+    back = torch.full_like(x, float("nan"))
+    ops.depth_to_space(xs, back, False)
+    assert torch.equal(back, x)
+    acc = x.clone()
+    ops.depth_to_space(xs, acc, True)
+    assert torch.equal(acc, (x.float() + x.float()).to(F16))
+    w33 = torch.from_numpy(rng.standard_normal((3, 3, c, k)).astype(np.float32)).to(device)
+    w22 = torch.full((2, 2, 4 * c, k), float("nan"), device=device)
+    ops.weights_s2d(w33, w22)
+    w22n = w22.cpu().numpy().reshape(2, 2, 2, 2, c, k)          # [ky2][kx2][a][b][c][k]
+    tap = {(0, 1): 0, (1, 0): 1, (1, 1): 2}
+    for ky2 in range(2):
+        for kx2 in range(2):
+            for a in range(2):
+                for b in range(2):
+                    if (ky2, a) in tap and (kx2, b) in tap:
+                        assert np.array_equal(w22n[ky2, kx2, a, b], w33.cpu().numpy()[tap[(ky2, a)], tap[(kx2, b)]])
+                    else:
+                        assert not w22n[ky2, kx2, a, b].any()
+    dw33 = torch.full((3, 3, c, k), float("nan"), device=device)
+    ops.weights_s2d_grad(w22, dw33)
+    assert torch.equal(dw33, w33)                               # the adjoint gather returns every tap once
+
+
+def test_strided_conv_space_to_depth_equals_subsample_form(device, monkeypatch):
+    """conv2d_same(x, n, 3, stride=2): the space-to-depth form and the stride-1-then-subsample form are the
+    same sums in a different order — outputs, BN statistics, weight and input gradients agree to f16 rounding."""
+    from tensorflow_ocr_amd import resnet_layers as R
+    from tensorflow_ocr_amd.graph import Act, Graph
+    rng = np.random.default_rng(3)
+    n, h, w, cin, cout = 2, 24, 40, 64, 64
+    xin = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    dyv = rng.standard_normal((n, h // 2, w // 2, cout)).astype(np.float32)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(R, "USE_S2D", mode)
+        g = Graph(device, seed=5)
+        x = Act(torch.from_numpy(xin).to(device).to(R.ops.F16), name="x")
+        x.requires_grad = True
+        c = R.conv_bn_raw(g, x, cout, 3, "conv2", stride=2, is_training=True)
+        dy = torch.from_numpy(dyv).to(device).to(R.ops.F16)
+        c.backward_from(dy)
+        torch.cuda.synchronize()
+        res[mode] = [t.float().cpu().numpy() for t in (c.y, c.mean, c.invstd, c.wv.grad, x.grad)]
+    for a, b, tol in zip(res[True], res[False], (2e-2, 2e-3, 2e-3, 2e-2, 2e-2)):
+        assert a.shape == b.shape
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= tol * scale, (np.abs(a - b).max(), scale)
+    assert np.abs(res[True][3]).max() > 0 and np.abs(res[True][4]).max() > 0
