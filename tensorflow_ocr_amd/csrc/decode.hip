@@ -99,24 +99,6 @@ __global__ void cc_init_kernel(CcP p, const float* __restrict__ score, int* __re
   }
 }
 
-__global__ void cc_union_kernel(CcP p, const float* __restrict__ link, int* __restrict__ parent) {
-  const size_t hw = (size_t)p.h * p.w, total = (size_t)p.n * hw;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int img = (int)(i / hw), local = (int)(i % hw);
-    const int y = local / p.w, x = local - y * p.w;
-    if (x < 1 || x > p.w - 2 || y < 1 || y > p.h - 2) continue;
-    int* par = parent + (size_t)img * hw;
-    if (par[local] < 0) continue;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      if (!(link[(((size_t)d * p.n + img) * hw + local) * p.ls + p.lo] > p.tl)) continue;
-      const int q = (y + kDy[d]) * p.w + (x + kDx[d]);
-      if (par[q] < 0) continue;
-      uf_unite(par, local, q);
-    }
-  }
-}
-
 __global__ void cc_root_kernel(CcP p, int* __restrict__ parent, int* __restrict__ root,
                                int* __restrict__ size) {
   const size_t hw = (size_t)p.h * p.w, total = (size_t)p.n * hw;
@@ -226,21 +208,77 @@ __global__ void cc_init_mask_kernel(CcP p, const unsigned char* __restrict__ mas
   }
 }
 
-__global__ void cc_union_mask_kernel(CcP p, int conn8, int* __restrict__ parent) {
-  const size_t hw = (size_t)p.h * p.w, total = (size_t)p.n * hw;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int img = (int)(i / hw), local = (int)(i % hw);
-    const int y = local / p.w, x = local - y * p.w;
-    int* par = parent + (size_t)img * hw;
-    if (par[local] < 0) continue;
-    // right, down (4-connectivity) + down-left, down-right (8): every undirected edge once
-    if (x + 1 < p.w && par[local + 1] >= 0) uf_unite(par, local, local + 1);
-    if (y + 1 < p.h) {
-      if (par[local + p.w] >= 0) uf_unite(par, local, local + p.w);
-      if (conn8) {
-        if (x > 0 && par[local + p.w - 1] >= 0) uf_unite(par, local, local + p.w - 1);
-        if (x + 1 < p.w && par[local + p.w + 1] >= 0) uf_unite(par, local, local + p.w + 1);
+// ---- tiled linking -----------------------------------------------------------------------------
+// The kernels above unite every edge with global atomics.  Most edges join pixels of the same 32x32 tile:
+// those are united in LDS first (same union-find, LDS atomics), each pixel then points at its tile's root
+// (the smallest index of its tile-local set, written as a global index), and a second launch unites only
+// the edges that cross a tile border.  Roots are still the smallest pixel index of each component, so
+// labels do not change.  MODE 0: link-gated 8 directions on interior pixels; 1 / 2: 4- / 8-connected mask.
+__device__ __forceinline__ int lds_find(volatile int* lp, int i) {
+  for (;;) {
+    const int p = lp[i];
+    if (p == i) return i;
+    i = p;
+  }
+}
+__device__ __forceinline__ void lds_unite(int* lp, int a, int b) {
+  for (int guard = 0; guard < (1 << 20); ++guard) {
+    a = lds_find(lp, a);
+    b = lds_find(lp, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(lp + a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+template <int MODE, bool BORDER>
+__global__ __launch_bounds__(1024) void cc_union_tile_kernel(CcP p, const float* __restrict__ link,
+                                                             int* __restrict__ parent) {
+  __shared__ int lp[1024];
+  const int hw = p.h * p.w;
+  const int img = blockIdx.y;
+  const int tiles_x = (p.w + 31) >> 5;
+  const int tx0 = (blockIdx.x % tiles_x) << 5, ty0 = (blockIdx.x / tiles_x) << 5;
+  const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
+  const int x = tx0 + lx, y = ty0 + ly;
+  const bool inimg = x < p.w && y < p.h;
+  const int local = y * p.w + x;
+  int* par = parent + (size_t)img * hw;
+  const bool seg = inimg && par[local] >= 0;
+  if (!BORDER) {
+    lp[tid] = seg ? tid : -1;
+    __syncthreads();
+  }
+  if (seg) {
+    constexpr int ND = MODE == 0 ? 8 : (MODE == 1 ? 2 : 4);
+    const bool active = MODE != 0 || (x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2);
+    if (active) {
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        int dx, dy;
+        if (MODE == 0) { dx = kDx[d]; dy = kDy[d]; }
+        else { dx = d == 0 ? 1 : (d == 1 ? 0 : (d == 2 ? -1 : 1)); dy = d == 0 ? 0 : 1; }   // right, down, down-left, down-right
+        const int nx = x + dx, ny = y + dy;
+        if (MODE != 0 && (nx < 0 || nx >= p.w || ny >= p.h)) continue;
+        const bool inside = (nx >> 5) == (x >> 5) && (ny >> 5) == (y >> 5);
+        if (inside == BORDER) continue;
+        if (MODE == 0 && !(link[(((size_t)d * p.n + img) * hw + local) * p.ls + p.lo] > p.tl)) continue;
+        const int q = ny * p.w + nx;
+        if (BORDER) {
+          if (par[q] >= 0) uf_unite(par, local, q);
+        } else if (lp[(ly + dy) * 32 + lx + dx] >= 0) {
+          lds_unite(lp, tid, (ly + dy) * 32 + lx + dx);
+        }
       }
+    }
+  }
+  if (!BORDER) {
+    __syncthreads();
+    if (seg) {
+      const int r = lds_find(lp, tid);
+      par[local] = (ty0 + (r >> 5)) * p.w + tx0 + (r & 31);
     }
   }
 }
@@ -341,7 +379,10 @@ extern "C" int ocr_link_cc(const void* pixel_score, const void* link_score, int 
   CcP p{n, h, w, min_size, pixel_thresh, link_thresh, link_elem_stride, link_elem_offset};
   hipLaunchKernelGGL(cc_init_kernel, dim3(dgrid(total)), dim3(256), 0, st, p,
                      static_cast<const float*>(pixel_score), parent, size);
-  hipLaunchKernelGGL(cc_union_kernel, dim3(dgrid(total)), dim3(256), 0, st, p,
+  const dim3 tgrid((unsigned)(((w + 31) / 32) * ((h + 31) / 32)), (unsigned)n);
+  hipLaunchKernelGGL((cc_union_tile_kernel<0, false>), tgrid, dim3(1024), 0, st, p,
+                     static_cast<const float*>(link_score), parent);
+  hipLaunchKernelGGL((cc_union_tile_kernel<0, true>), tgrid, dim3(1024), 0, st, p,
                      static_cast<const float*>(link_score), parent);
   hipLaunchKernelGGL(cc_root_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, parent, root, size);
   cc_number(p, root, size, ids, blkcnt, static_cast<int*>(labels_i32), static_cast<int*>(ncomp_i32),
@@ -365,7 +406,14 @@ extern "C" int ocr_mask_cc(const void* mask_u8, int value, int connectivity, int
   CcP p{n, h, w, 0, 0.f, 0.f, 1, 0};
   hipLaunchKernelGGL(cc_init_mask_kernel, dim3(dgrid(total)), dim3(256), 0, st, p,
                      static_cast<const unsigned char*>(mask_u8), value, parent, size);
-  hipLaunchKernelGGL(cc_union_mask_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, connectivity == 8 ? 1 : 0, parent);
+  const dim3 tgrid((unsigned)(((w + 31) / 32) * ((h + 31) / 32)), (unsigned)n);
+  if (connectivity == 8) {
+    hipLaunchKernelGGL((cc_union_tile_kernel<2, false>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent);
+    hipLaunchKernelGGL((cc_union_tile_kernel<2, true>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent);
+  } else {
+    hipLaunchKernelGGL((cc_union_tile_kernel<1, false>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent);
+    hipLaunchKernelGGL((cc_union_tile_kernel<1, true>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent);
+  }
   hipLaunchKernelGGL(cc_root_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, parent, root, size);
   cc_number(p, root, size, ids, blkcnt, static_cast<int*>(labels_i32), static_cast<int*>(ncomp_i32),
             static_cast<int*>(comps_i32), max_comps, st);
