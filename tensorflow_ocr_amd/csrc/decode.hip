@@ -100,7 +100,7 @@ __global__ void cc_init_kernel(CcP p, const float* __restrict__ score, int* __re
 }
 
 __global__ void cc_root_kernel(CcP p, int* __restrict__ parent, int* __restrict__ root,
-                               int* __restrict__ size) {
+                               int* __restrict__ size, const int* __restrict__ tcnt) {
   const size_t hw = (size_t)p.h * p.w, total = (size_t)p.n * hw;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int img = (int)(i / hw), local = (int)(i % hw);
@@ -108,7 +108,8 @@ __global__ void cc_root_kernel(CcP p, int* __restrict__ parent, int* __restrict_
     int r = -1;
     if (par[local] >= 0) {
       r = uf_find(par, local);
-      atomicAdd(size + (size_t)img * hw + r, 1);
+      const int c = tcnt[i];                      // > 0 only at the root of a tile-local set
+      if (c > 0) atomicAdd(size + (size_t)img * hw + r, c);
     }
     root[i] = r;
   }
@@ -235,8 +236,9 @@ __device__ __forceinline__ void lds_unite(int* lp, int a, int b) {
 
 template <int MODE, bool BORDER>
 __global__ __launch_bounds__(1024) void cc_union_tile_kernel(CcP p, const float* __restrict__ link,
-                                                             int* __restrict__ parent) {
+                                                             int* __restrict__ parent, int* __restrict__ tcnt) {
   __shared__ int lp[1024];
+  __shared__ int lcnt[1024];
   const int hw = p.h * p.w;
   const int img = blockIdx.y;
   const int tiles_x = (p.w + 31) >> 5;
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(1024) void cc_union_tile_kernel(CcP p, const float*
   const bool seg = inimg && par[local] >= 0;
   if (!BORDER) {
     lp[tid] = seg ? tid : -1;
+    lcnt[tid] = 0;
     __syncthreads();
   }
   if (seg) {
@@ -276,10 +279,16 @@ __global__ __launch_bounds__(1024) void cc_union_tile_kernel(CcP p, const float*
   }
   if (!BORDER) {
     __syncthreads();
+    int r = -1;
     if (seg) {
-      const int r = lds_find(lp, tid);
+      r = lds_find(lp, tid);
       par[local] = (ty0 + (r >> 5)) * p.w + tx0 + (r & 31);
+      atomicAdd(lcnt + r, 1);
     }
+    __syncthreads();
+    // pixels per tile-local set, kept at the set's root: the size pass then needs one global atomic per
+    // tile-local set instead of one per pixel
+    if (inimg) tcnt[(size_t)img * hw + local] = lcnt[tid];
   }
 }
 
@@ -381,10 +390,10 @@ extern "C" int ocr_link_cc(const void* pixel_score, const void* link_score, int 
                      static_cast<const float*>(pixel_score), parent, size);
   const dim3 tgrid((unsigned)(((w + 31) / 32) * ((h + 31) / 32)), (unsigned)n);
   hipLaunchKernelGGL((cc_union_tile_kernel<0, false>), tgrid, dim3(1024), 0, st, p,
-                     static_cast<const float*>(link_score), parent);
+                     static_cast<const float*>(link_score), parent, ids);
   hipLaunchKernelGGL((cc_union_tile_kernel<0, true>), tgrid, dim3(1024), 0, st, p,
-                     static_cast<const float*>(link_score), parent);
-  hipLaunchKernelGGL(cc_root_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, parent, root, size);
+                     static_cast<const float*>(link_score), parent, ids);
+  hipLaunchKernelGGL(cc_root_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, parent, root, size, ids);
   cc_number(p, root, size, ids, blkcnt, static_cast<int*>(labels_i32), static_cast<int*>(ncomp_i32),
             static_cast<int*>(comps_i32), max_comps, st);
   return ocr_launch_status();
@@ -408,13 +417,13 @@ extern "C" int ocr_mask_cc(const void* mask_u8, int value, int connectivity, int
                      static_cast<const unsigned char*>(mask_u8), value, parent, size);
   const dim3 tgrid((unsigned)(((w + 31) / 32) * ((h + 31) / 32)), (unsigned)n);
   if (connectivity == 8) {
-    hipLaunchKernelGGL((cc_union_tile_kernel<2, false>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent);
-    hipLaunchKernelGGL((cc_union_tile_kernel<2, true>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent);
+    hipLaunchKernelGGL((cc_union_tile_kernel<2, false>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent, ids);
+    hipLaunchKernelGGL((cc_union_tile_kernel<2, true>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent, ids);
   } else {
-    hipLaunchKernelGGL((cc_union_tile_kernel<1, false>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent);
-    hipLaunchKernelGGL((cc_union_tile_kernel<1, true>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent);
+    hipLaunchKernelGGL((cc_union_tile_kernel<1, false>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent, ids);
+    hipLaunchKernelGGL((cc_union_tile_kernel<1, true>), tgrid, dim3(1024), 0, st, p, (const float*)nullptr, parent, ids);
   }
-  hipLaunchKernelGGL(cc_root_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, parent, root, size);
+  hipLaunchKernelGGL(cc_root_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, parent, root, size, ids);
   cc_number(p, root, size, ids, blkcnt, static_cast<int*>(labels_i32), static_cast<int*>(ncomp_i32),
             static_cast<int*>(comps_i32), max_comps, st);
   return ocr_launch_status();
