@@ -304,7 +304,8 @@ __global__ void east_mask_first_kernel(const float* __restrict__ score, const fl
     mask[i] = score[i] > ts ? 1 : 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
-      if (link16[(size_t)i * 16 + 2 * c + 1] < tl) atomicMin(first + c, i);
+      if (link16[(size_t)i * 16 + 2 * c + 1] < tl && i < __hip_atomic_load(first + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(first + c, i);          // the minimum only falls: a read that already covers i proves the atomic a no-op
   }
 }
 __global__ void east_second_kernel(const float* __restrict__ link16, int hw, float tl, const int* __restrict__ first,
@@ -312,7 +313,9 @@ __global__ void east_second_kernel(const float* __restrict__ link16, int hw, flo
   for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
 #pragma unroll
     for (int c = 0; c < 8; ++c)
-      if (i > first[c] && link16[(size_t)i * 16 + 2 * c + 1] < tl) atomicMin(second + c, i);
+      if (i > first[c] && link16[(size_t)i * 16 + 2 * c + 1] < tl &&
+          i < __hip_atomic_load(second + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(second + c, i);
   }
 }
 __global__ void zero_pixels_kernel(unsigned char* __restrict__ mask, const int* __restrict__ idx, int count) {
