@@ -82,15 +82,24 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const half_t* __rest
 }
 
 // dx[p][ci] (+)= sum_co dz[p][co] * w[ci][co]     (w_ck f16 [cin][32], cols >= cout zero)
+// One wave = 32 pixels; the accumulator holds, per lane, 4-channel pieces of ONE pixel, so written directly every
+// store touches 32 different lines with 8 bytes each.  Two 32-channel blocks are parked in the wave's LDS tile
+// ([32 px][64 ch], row stride 144 B) and leave as whole 128-byte lines (8 lanes per pixel row); the
+// accumulate form reads the old gradient the same way.
 __global__ __launch_bounds__(256) void conv1x1_small_dgrad_kernel(const float* __restrict__ dz,
                                                                   const half_t* __restrict__ w_ck,
                                                                   int P, int cin, int cout,
                                                                   half_t* __restrict__ dx,
                                                                   int accumulate, float gscale) {
+  constexpr int RS = 64 * 4 + 16;                           // f32 staging: the result is rounded once, after the add
+  __shared__ __attribute__((aligned(16))) char s_o[4][32 * RS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int p = (blockIdx.x * 4 + wave) * 32 + r;
+  const int p0 = (blockIdx.x * 4 + wave) * 32;
+  const int p = p0 + r;
   const bool ok = p < P;
+  char* so = s_o[wave];
+  const int lrow = lane >> 3, lc = lane & 7;
   half8_t b[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -99,31 +108,50 @@ __global__ __launch_bounds__(256) void conv1x1_small_dgrad_kernel(const float* _
       const int co = ks * 16 + 8 * hh + j;
       b[ks][j] = (half_t)((ok && co < cout) ? dz[(size_t)p * cout + co] * gscale : 0.f);
     }
-  for (int ct = 0; ct < cin / 32; ++ct) {
-    f32x16 acc;
+  for (int c0 = 0; c0 < cin; c0 += 64) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int t = 0; t < 2; ++t) {
+      const int ct = c0 + t * 32;
+      if (ct >= cin) break;
+      f32x16 acc;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8_t a = *reinterpret_cast<const half8_t*>(w_ck + (size_t)(ct * 32 + r) * 32 + ks * 16 + 8 * hh);
-      acc = OCR_MFMA_32x32x16(a, b[ks], acc, 0, 0, 0);
-    }
-    if (ok) {
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        half8_t a = *reinterpret_cast<const half8_t*>(w_ck + (size_t)(ct + r) * 32 + ks * 16 + 8 * hh);
+        acc = OCR_MFMA_32x32x16(a, b[ks], acc, 0, 0, 0);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        half_t* dst = dx + (size_t)p * cin + ct * 32 + q * 8 + 4 * hh;
-        half4_t o;
-        if (accumulate) {
-          half4_t old = *reinterpret_cast<const half4_t*>(dst);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)(acc[q * 4 + e] + (float)old[e]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)acc[q * 4 + e];
-        }
-        *reinterpret_cast<half4_t*>(dst) = o;
+        f32x4 o = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+        *reinterpret_cast<f32x4*>(so + r * RS + (t * 32 + q * 8 + 4 * hh) * 4) = o;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lrow + 8 * i, pp = p0 + row;
+      if (pp < P && c0 + lc * 8 < cin) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(so + row * RS + lc * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(so + row * RS + lc * 32 + 16);
+        float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        half_t* dst = dx + (size_t)pp * cin + c0 + lc * 8;
+        half8_t o;
+        if (accumulate) {
+          const half8_t old = *reinterpret_cast<const half8_t*>(dst);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (half_t)(f[e] + (float)old[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
+        }
+        *reinterpret_cast<half8_t*>(dst) = o;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
