@@ -3,7 +3,7 @@
 backward + gradient all-reduce + Adam/EMA) of the VGG-16 detector at 512x512, batch 32 per GPU
 (BASELINE.json configs[1]; the graph is nets/model_vgg_16.py: model_vgg + loss).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
@@ -60,7 +60,17 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "gloo lets several ranks share one GPU for a functional check")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (functional check only)")
+    ap.add_argument("--force-pg", action="store_true", help="N=1 only: create a one-rank process group and run "
+                    "the bucketed gradient exchange anyway (RCCL stream ordering on a one-GPU box)")
     args = ap.parse_args()
+
+    # Plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and
+    # relays rank 0's JSON line; it returns here only as a rank (WORLD_SIZE set) or for N = 1.
+    # Nothing above this line has touched HIP.
+    from tensorflow_ocr_amd import launch
+    rc = launch.self_launch(args.gpus)
+    if rc is not None:
+        sys.exit(rc)
 
     from tensorflow_ocr_amd import _lib, dist, ops, synthetic
     from tensorflow_ocr_amd.graph import Graph
@@ -70,7 +80,7 @@ def main():
 
     if args.share_gpu:
         os.environ["LOCAL_RANK"] = "0"
-    rank, world, local = dist.init_process_group_from_env(args.backend)
+    rank, world, local = dist.init_process_group_from_env(args.backend, force=args.force_pg)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     device = torch.device("cuda", local)
@@ -85,10 +95,11 @@ def main():
         f_score, f_geometry = M.model_vgg(im, is_training=True, graph=gr)
         return M.loss(px, f_score, lk, f_geometry, mk, graph=gr)
 
-    step = TrainStep(g, forward_loss, lambda gr: AdamOptimizer(gr, learning_rate=1e-4), world_size=world)
+    step = TrainStep(g, forward_loss, lambda gr: AdamOptimizer(gr, learning_rate=1e-4), world_size=world,
+                     force_reduce=args.force_pg)
 
     def barrier():
-        if world > 1:
+        if td.is_initialized():
             td.barrier()
         torch.cuda.synchronize()
 
@@ -105,11 +116,39 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+    dt = max_over_ranks(dt)
     loss_val = loss.item()
+
+    # the exchange itself, outside the timed region: (1) a collective that proves every rank is in the
+    # RCCL communicator, (2) the same K steps with the gradient exchange switched off — the difference
+    # is the communication the backward pass did NOT hide.  (The towers' weights drift apart in (2);
+    # nothing is measured after it.)
+    comm = None
+    if td.is_available() and td.is_initialized():
+        ones = torch.ones(1, dtype=torch.float32, device=device)
+        td.all_reduce(ones)
+        red = step.reducer
+        red.enabled = False
+        for _ in range(2):
+            step(*batch)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(*batch)
+        barrier()
+        dt_off = max_over_ranks(time.perf_counter() - t1)
+        red.enabled = True
+        comm = {"backend": td.get_backend(), "rccl_ranks": int(round(ones.item())),
+                "bucket_bytes": red.bucket_nbytes(), "grad_bytes": int(g.store.flat_grad.numel() * 4),
+                "ms_per_step_no_exchange": round(dt_off / args.steps * 1e3, 3),
+                "comm_exposed_ms": round((dt - dt_off) / args.steps * 1e3, 3)}
 
     # dominant kernel: the conv_igemm instantiation with the most accumulated time
     per, fwd = {}, {}
@@ -162,10 +201,12 @@ def main():
             "train_tflops": round(value * TRAIN_GFLOP_PER_IMG / 1e3 * (args.size / 512.0) ** 2, 1),
             "roofline": roof,
         }
+        if comm is not None:
+            out["exchange"] = comm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if td.is_available() and td.is_initialized():
         td.barrier()
         td.destroy_process_group()
 

@@ -144,6 +144,11 @@ int ocr_pack_weights_small_f16(const void* w_f32, int cin, int cout, void* w_kc3
  * ------------------------------------------------------------------------- */
 int ocr_prep_images_f16(const void* images_f32, int64_t npix, float m0, float m1, float m2,
                         void* out_f16x4, void* stream);
+/* The PixelLink input pipeline's normalisation folded into the same pass: (x - m) / div (IEEE
+ * division) — the `ssd_vgg_preprocessing` output train_pixellink.py:150-154 hands the queue; the
+ * counterparts use (120, 120, 120) / 60. */
+int ocr_prep_images_norm_f16(const void* images_f32, int64_t npix, float m0, float m1, float m2,
+                             float div, void* out_f16x4, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * slim.batch_norm (decay .997, eps 1e-5, scale; nets/resnet_utils.py:232-246,
@@ -305,6 +310,13 @@ int ocr_softmax_loss_fwd(const ocr_softmax_loss_desc* d, const void* pixel_logit
                          const void* link_logits, const void* pixel_labels, const void* link_labels,
                          void* ohnm_threshold, void* sums34, void* loss10, void* workspace,
                          size_t ws_bytes, void* stream);
+/* mask_u8 [n*hw] = 1 where the pixel CE term counts (positives + mined negatives): the
+ * `selected` map of OHNM_batch (nets/model.py:186-197).  The mining score P(neg) is a fixed
+ * sequence of IEEE f32 operations (loss_softmax.hip: det_exp) shared with the CPU checker, so the
+ * threshold and this mask are bit-exact index outputs. */
+int ocr_softmax_loss_selected(const ocr_softmax_loss_desc* d, const void* pixel_logits,
+                              const void* pixel_labels, const void* ohnm_threshold, void* mask_u8,
+                              void* stream);
 int ocr_softmax_loss_bwd(const ocr_softmax_loss_desc* d, const void* pixel_logits,
                          const void* link_logits, const void* pixel_labels, const void* link_labels,
                          const void* ohnm_threshold, const void* sums34, float grad_scale,
@@ -457,6 +469,13 @@ int ocr_adam_step(void* w, const void* g, void* m, void* v, void* ema, int64_t n
 int ocr_momentum_step(void* w, const void* g, void* accum, void* ema, int64_t n,
                       int64_t n_regularized, float lr, float momentum, float weight_decay,
                       float inv_loss_scale, float ema_decay, void* stream);
+/* out_f32[0] = scale * sum(x[i]^2), f64 accumulation in a fixed order (bitwise reproducible): the
+ * REGULARIZATION_LOSSES term of `total_loss` (multigpu_train.py:36,183-184) is
+ * weight_decay/2 * sum(w^2) over the regularised range (slim.l2_regularizer, nets/model.py:103).
+ * x must be 16-byte aligned. */
+size_t ocr_sum_squares_workspace(int64_t n);
+int ocr_sum_squares_f32(const void* x, int64_t n, float scale, void* out_f32, void* workspace,
+                        size_t ws_bytes, void* stream);
 int ocr_scale_f32(void* x, int64_t n, float s, void* stream);
 int ocr_fill_f32(void* x, int64_t n, float value, void* stream);   /* n 4-byte words */
 

@@ -3,6 +3,7 @@
 loop :169-194) on the MI355X path: one process per GPU
 
     python multigpu_train.py --gpu_list 0 --batch_size_per_gpu 14 --input_size 512
+    python multigpu_train.py --gpu_list 0,1           (starts one rank per listed GPU itself)
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 multigpu_train.py --gpu_list 0,1
 
 Same flag names and defaults; `--net` selects the graph (`model` = nets/model.py ResNet-50 +
@@ -55,17 +56,26 @@ def build_forward_loss(net):
             return model_vgg_16.loss(sm, a, gm, b, tm, graph=g)
     else:
         def f(g, im, sm, gm, tm):
-            n = pixellink.PixelLinkNet(im, graph=g)        # input normalised by _train_loop, before the step
+            # raw images in; the pipeline's (x - 120) / 60 runs inside the image-preparation kernel
+            n = pixellink.PixelLinkNet(im, graph=g, input_norm=(120.0, 60.0))
             return n.build_loss(sm[..., 0], gm)
     return f
 
 
 def main():
     FLAGS = parse()
+    gpus = FLAGS.gpu_list.split(',')
+    # os.environ['CUDA_VISIBLE_DEVICES'] = FLAGS.gpu_list (multigpu_train.py:90) + one tower per entry
+    # (:118-130).  Started plainly, this process either IS the single tower or becomes the launcher of
+    # len(gpus) ranks; nothing has touched HIP yet.
+    from tensorflow_ocr_amd import launch
+    if 'WORLD_SIZE' not in os.environ:
+        if len(gpus) > 1:
+            raise SystemExit(launch.self_launch(len(gpus), visible=FLAGS.gpu_list))
+        os.environ.setdefault('HIP_VISIBLE_DEVICES', FLAGS.gpu_list)
     from tensorflow_ocr_amd import checkpoint, dist, synthetic
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.train import AdamOptimizer, TrainStep
-    gpus = FLAGS.gpu_list.split(',')
     rank, world, local = dist.init_process_group_from_env()
     if world not in (1, len(gpus)):
         raise SystemExit("gpu_list has %d entries but WORLD_SIZE=%d" % (len(gpus), world))
@@ -96,44 +106,64 @@ def main():
             feeder.close()
 
 
+def _next_batch(FLAGS, feeder, rng, device):
+    from tensorflow_ocr_amd import synthetic
+    if feeder is not None:
+        images, _, score_maps, geo_maps, training_masks = next(feeder)
+        return [images, score_maps, geo_maps, training_masks]
+    data = synthetic.make_batch(rng, FLAGS.batch_size_per_gpu, FLAGS.input_size)
+    return [torch.from_numpy(a).to(device, non_blocking=True) for a in data]
+
+
 def _train_loop(FLAGS, g, step, feeder, rng, rank, world, device, start):
-    from tensorflow_ocr_amd import checkpoint, synthetic
-    for it in range(FLAGS.max_steps):
-        if feeder is not None:
-            images, _, score_maps, geo_maps, training_masks = next(feeder)
-            batch = [images, score_maps, geo_maps, training_masks]
+    from tensorflow_ocr_amd import checkpoint, dist
+    batch = _next_batch(FLAGS, feeder, rng, device)
+    # variables, optimiser slots and EMA shadows exist before the first update, so a checkpoint is
+    # restored (:153-158) / the pretrained backbone loaded (:149-151,161-162) BEFORE it, as in the reference
+    step.build(*batch)
+    opt = step.opt
+    src = FLAGS.checkpoint_path if FLAGS.restore else FLAGS.pretrained_model_path
+    if src:
+        if not (os.path.isdir(src) and os.path.exists(os.path.join(src, 'checkpoint')) or os.path.exists(src + '.index')
+                or os.path.isfile(src)):
+            raise FileNotFoundError('no checkpoint at %s' % src)
+        if FLAGS.restore:
+            checkpoint.restore_training_state(src, g, opt)
+            if rank == 0:
+                print('continue training from previous checkpoint')
         else:
-            data = synthetic.make_batch(rng, FLAGS.batch_size_per_gpu, FLAGS.input_size)
-            batch = [torch.from_numpy(a).to(device, non_blocking=True) for a in data]
-        if FLAGS.net == 'pixellink':
-            batch[0] = (batch[0] - 120.0) / 60.0           # PixelLinkNet takes preprocessed input
+            sd, _ = checkpoint.load_tf_checkpoint(src)        # variables only (slim.assign_from_checkpoint_fn)
+            g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
+            if opt.ema is not None:
+                opt.ema.copy_(g.store.flat)
+            if rank == 0:
+                print('loaded ' + src)
+    first = opt.global_step
+    for it in range(first, FLAGS.max_steps):
+        if it > first:
+            batch = _next_batch(FLAGS, feeder, rng, device)
         loss = step(*batch)
-        if it == 0:
-            # variables exist after the first step: restore (:145-148) or load the pretrained backbone (:149-151)
-            src = FLAGS.checkpoint_path if FLAGS.restore else FLAGS.pretrained_model_path
-            if src and (os.path.isdir(src) and os.path.exists(os.path.join(src, 'checkpoint')) or os.path.exists(src + '.index')
-                        or os.path.isfile(src)):
-                sd, _ = checkpoint.load_tf_checkpoint(src)
-                g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
-                if rank == 0:
-                    print('continue training from previous checkpoint' if FLAGS.restore else 'loaded ' + src)
         if it % 10 == 0:
             ml = loss.item()
-            if np.isnan(ml):
-                print('Loss diverged, stop training')
+            # the stop decision is collective: a rank leaving alone would strand the others in the
+            # next gradient all-reduce
+            if dist.any_rank(bool(np.isnan(ml))):
+                if rank == 0:
+                    print('Loss diverged, stop training')
                 break
             avg_time_per_step = (time.time() - start) / 10
             avg_examples_per_second = (10 * FLAGS.batch_size_per_gpu * world) / (time.time() - start)
             start = time.time()
             if rank == 0:
-                tl = ml        # the L2 regulariser enters through the optimiser, not the reported loss
+                # total_loss = model_loss + sum(REGULARIZATION_LOSSES) (multigpu_train.py:36)
+                tl = ml + opt.regularization_loss().item()
                 print('Step {:06d}, model loss {:.4f}, total loss {:.4f}, {:.2f} seconds/step, {:.2f} examples/second'.format(
                     it, ml, tl, avg_time_per_step, avg_examples_per_second), flush=True)
-        if rank == 0 and it % FLAGS.save_checkpoint_steps == 0 and it > 0:
-            # saver.save(sess, FLAGS.checkpoint_path + 'model.ckpt', global_step=global_step) (:188-189):
-            # a TensorFlow V2 bundle with the reference's variable names + the EMA shadows
-            checkpoint.save_tf_checkpoint(FLAGS.checkpoint_path, it, checkpoint.internal_to_tf(g.store.state_dict()),
-                                          checkpoint.internal_to_tf(step.opt.shadow_state_dict()) if step.opt.ema is not None else None)
+        if rank == 0 and it % FLAGS.save_checkpoint_steps == 0 and it > first:
+            # saver.save(sess, FLAGS.checkpoint_path + 'model.ckpt', global_step=global_step) (:186-187):
+            # a TensorFlow V2 bundle of Saver(tf.global_variables()) — variables, EMA shadows, Adam slots
+            checkpoint.save_training_state(FLAGS.checkpoint_path, g, opt)
+
 
 if __name__ == '__main__':
     main()

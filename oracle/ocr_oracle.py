@@ -343,6 +343,19 @@ def adam_update(w, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     return w, m, v
 
 
+def momentum_update(w, g, acc, lr, momentum=0.9):
+    """tf.train.MomentumOptimizer(lr, momentum) (train_pixellink.py:243), use_nesterov=False:
+    accum = momentum * accum + grad; var -= lr * accum."""
+    acc = momentum * acc + g
+    w = w - lr * acc
+    return w, acc
+
+
+def pixellink_lr(step, base_lr=0.01):
+    """train_pixellink.py:222-237: base_lr * tf.case{step<20k: .1, <40k: .01, <60k: .001, default 1}."""
+    return base_lr * (0.1 if step < 20000 else 0.01 if step < 40000 else 0.001 if step < 60000 else 1.0)
+
+
 def ema_decay(decay, num_updates):
     """tf.train.ExponentialMovingAverage(decay, num_updates): min(d, (1+n)/(10+n))."""
     return min(decay, (1.0 + num_updates) / (10.0 + num_updates))
@@ -393,6 +406,29 @@ def _ce2(logits, labels):
     return lse - torch.gather(logits, -1, labels.long().unsqueeze(-1)).squeeze(-1)
 
 
+def det_exp_f32(x):
+    """exp(x) as a fixed sequence of IEEE float32 operations (Cody-Waite reduction, degree-6 Taylor,
+    2^n scaling; ~1 ulp).  The device evaluates the SAME sequence (loss_softmax.hip: det_exp), so the
+    OHNM mining scores — and the threshold / mask that follow, which are index work — are bit-exact
+    on both sides.  TF's own softmax bits are out of reach either way (parity unpinned)."""
+    f = np.float32
+    x = np.clip(np.asarray(x, dtype=f), f(-80.0), f(80.0))
+    n = np.rint(x * f(1.44269504))
+    r = x - n * f(0.693145751953125)
+    r = r - n * f(1.42860677e-06)
+    p = np.full_like(r, f(1.3888889e-03))
+    for c in (8.3333338e-03, 4.1666668e-02, 1.6666667e-01, 0.5, 1.0, 1.0):
+        p = p * r + f(c)
+    return np.ldexp(p, n.astype(np.int32)).astype(f)
+
+
+def neg_score_f32(l0, l1):
+    """softmax(logits)[..., 0] = 1 / (1 + exp(l1 - l0)) in float32 (nets/model.py:216-217)."""
+    f = np.float32
+    l0, l1 = np.asarray(l0, dtype=f), np.asarray(l1, dtype=f)
+    return (f(1.0) / (f(1.0) + det_exp_f32(l1 - l0))).astype(f)
+
+
 def ohnm_single_image(scores, n_pos, neg_mask, ratio=3):
     """nets/model.py:161-184.  scores: P(neg) per pixel (numpy 1-D), neg_mask bool.
     Returns the selected-negative mask (float).  n_pos > 0 with no negatives raises in TF
@@ -421,7 +457,8 @@ def model_loss_ohnm(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, traini
     n = y_pred_pixel.shape[0]
     label = y_true_pixel.reshape(n, -1)
     pred = y_pred_pixel.reshape(n, -1, 2)
-    scores = torch.softmax(pred, dim=-1)[..., 0].detach().numpy()
+    pn = pred.detach().numpy()
+    scores = neg_score_f32(pn[..., 0], pn[..., 1])
     pos = (label == 1).numpy()
     neg = (label == 0).numpy()
     sel = torch.from_numpy(ohnm_batch(scores, pos, neg))

@@ -77,20 +77,27 @@ class Recorder:
 
     def __init__(self):
         self.entries = []     # ("c", fn, args, name, tag) | ("py", callable)
+        # only the thread that created the recorder is recorded (the feeder thread launches its own
+        # resize / label kernels concurrently); the owner is part of the object, so it is set before
+        # the recorder can be seen through `RECORDER`
+        self.owner = threading.get_ident()
+
+    def mine(self):
+        return self.owner == threading.get_ident()
 
     def c(self, fn, args, name):
         self.entries.append(["c", fn, args, name, None])
 
     def py(self, fn):
-        self.entries.append(["py", fn])
+        if self.mine():
+            self.entries.append(["py", fn])
 
     def tag_last(self, tag):
-        self.entries[-1][4] = tag
+        if self.mine():
+            self.entries[-1][4] = tag
 
 
 RECORDER = None
-RECORDER_THREAD = None    # only the thread that installed the recorder is recorded (the feeder thread
-                          # launches its own kernels concurrently)
 _fn_cache = {}
 _STREAM = None
 
@@ -131,8 +138,9 @@ def call(name, *args):
     rc = fn(*args)
     if rc != 0:
         check(rc, name)
-    if RECORDER is not None and (RECORDER_THREAD is None or RECORDER_THREAD == threading.get_ident()):
-        RECORDER.c(fn, args, name)
+    rec = RECORDER
+    if rec is not None and rec.mine():
+        rec.c(fn, args, name)
     return rc
 
 

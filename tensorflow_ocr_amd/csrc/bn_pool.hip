@@ -12,11 +12,13 @@
 namespace {
 
 // ---------------------------------------------------------------- image prep
+// (x - mean) / div, IEEE division (hipcc's default is the correctly rounded one), so the f16 values
+// equal those of a host-side `(images - 120) / 60` followed by the cast; div = 1 is exact.
 __global__ void prep_images_kernel(const float* __restrict__ img, half_t* __restrict__ out,
-                                   size_t npix, float m0, float m1, float m2) {
+                                   size_t npix, float m0, float m1, float m2, float div) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
-  float r = img[i * 3 + 0] - m0, g = img[i * 3 + 1] - m1, b = img[i * 3 + 2] - m2;
+  float r = (img[i * 3 + 0] - m0) / div, g = (img[i * 3 + 1] - m1) / div, b = (img[i * 3 + 2] - m2) / div;
   half4_t o = {(half_t)r, (half_t)g, (half_t)b, (half_t)0.f};
   *reinterpret_cast<half4_t*>(out + i * 4) = o;
 }
@@ -903,13 +905,18 @@ bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
 
-extern "C" int ocr_prep_images_f16(const void* images_f32, int64_t npix, float m0, float m1,
-                                   float m2, void* out_f16x4, void* stream) {
-  OCR_CHECK_ARG(images_f32 && out_f16x4 && npix > 0);
+extern "C" int ocr_prep_images_norm_f16(const void* images_f32, int64_t npix, float m0, float m1,
+                                        float m2, float div, void* out, void* stream) {
+  OCR_CHECK_ARG(images_f32 && out && npix > 0 && div != 0.f);
   hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const float*>(images_f32),
-                     static_cast<half_t*>(out_f16x4), (size_t)npix, m0, m1, m2);
+                     static_cast<half_t*>(out), (size_t)npix, m0, m1, m2, div);
   return ocr_launch_status();
+}
+
+extern "C" int ocr_prep_images_f16(const void* images_f32, int64_t npix, float m0, float m1,
+                                   float m2, void* out, void* stream) {
+  return ocr_prep_images_norm_f16(images_f32, npix, m0, m1, m2, 1.0f, out, stream);
 }
 
 extern "C" size_t ocr_bn_reduce_workspace(int T, int C) {

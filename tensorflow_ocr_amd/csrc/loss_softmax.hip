@@ -29,8 +29,31 @@ struct SlP {
 __device__ __forceinline__ bool is_pos(float label, int rule) { return rule ? label > 0.f : label == 1.f; }
 __device__ __forceinline__ bool is_neg(float label, int rule) { return rule ? !(label > 0.f) : label == 0.f; }
 
-// P(class 0) of a 2-way softmax
-__device__ __forceinline__ float neg_score(float l0, float l1) { return 1.f / (1.f + expf(l1 - l0)); }
+// exp(x) as a FIXED sequence of IEEE f32 operations (no FMA contraction, no library call): the
+// CPU checker evaluates the same sequence in numpy float32, so the mining scores — and with them the
+// k-th-smallest threshold and the mined mask, which are index work — agree bit for bit.
+// Range reduction x = n ln2 + r (Cody-Waite), degree-6 Taylor in r (|r| <= 0.347: ~1 ulp), 2^n scale.
+__device__ __forceinline__ float det_exp(float x) {
+#pragma clang fp contract(off)
+  x = fminf(fmaxf(x, -80.f), 80.f);
+  const float n = rintf(x * 1.44269504f);
+  float r = x - n * 0.693145751953125f;
+  r = r - n * 1.42860677e-06f;
+  float p = 1.3888889e-03f;
+  p = p * r + 8.3333338e-03f;
+  p = p * r + 4.1666668e-02f;
+  p = p * r + 1.6666667e-01f;
+  p = p * r + 0.5f;
+  p = p * r + 1.0f;
+  p = p * r + 1.0f;
+  return ldexpf(p, (int)n);
+}
+
+// P(class 0) of a 2-way softmax, = exp(l0) / (exp(l0) + exp(l1))
+__device__ __forceinline__ float neg_score(float l0, float l1) {
+#pragma clang fp contract(off)
+  return 1.f / (1.f + det_exp(l1 - l0));
+}
 
 // 2-class CE and softmax of logits (l0, l1) for class t
 __device__ __forceinline__ float ce2(float l0, float l1, int t, float* p1) {
@@ -261,6 +284,17 @@ __global__ __launch_bounds__(256) void sl_bwd_kernel(SlP p, const float* __restr
   }
 }
 
+// the pixel-term weight map W as bytes (1 = positive or mined negative): what `OHNM_batch` returns
+// (nets/model.py:186-197), straight from the expression the loss kernels use
+__global__ void sl_selected_kernel(SlP p, const float* __restrict__ pl, const float* __restrict__ plab,
+                                   const float* __restrict__ thr, unsigned char* __restrict__ mask) {
+  const size_t total = (size_t)p.n * p.hw;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int img = (int)(i / p.hw);
+    mask[i] = pixel_weight(p, plab[i], pl[2 * i], pl[2 * i + 1], p.pixel_rule == 0 ? thr[img] : 0.f) != 0.f;
+  }
+}
+
 int sl_blocks(size_t total) {
   size_t b = (total + 256 * 4 - 1) / (256 * 4);
   if (b > 1024) b = 1024;
@@ -308,6 +342,20 @@ extern "C" int ocr_softmax_loss_fwd(const ocr_softmax_loss_desc* d, const void* 
   hipLaunchKernelGGL(sl_finalize_kernel, dim3(1), dim3(256), 0, st, p,
                      static_cast<const float*>(workspace), T, static_cast<float*>(sums34),
                      static_cast<float*>(loss10));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_softmax_loss_selected(const ocr_softmax_loss_desc* d, const void* pixel_logits,
+                                         const void* pixel_labels, const void* ohnm_threshold,
+                                         void* mask_u8, void* stream) {
+  SlP p;
+  int rc = fill(d, &p);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(pixel_logits && pixel_labels && ohnm_threshold && mask_u8);
+  hipLaunchKernelGGL(sl_selected_kernel, dim3(sl_blocks((size_t)p.n * p.hw)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, static_cast<const float*>(pixel_logits),
+                     static_cast<const float*>(pixel_labels), static_cast<const float*>(ohnm_threshold),
+                     static_cast<unsigned char*>(mask_u8));
   return ocr_launch_status();
 }
 

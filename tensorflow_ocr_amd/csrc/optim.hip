@@ -104,6 +104,48 @@ __global__ void fill_kernel(float* __restrict__ x, long long n, float v) {
     x[i] = v;
 }
 
+// scale * sum(x^2): slim.l2_regularizer(s)(w) = s * tf.nn.l2_loss(w) = s * sum(w^2) / 2 over the
+// regularised variables (the REGULARIZATION_LOSSES term of `total_loss`, multigpu_train.py:36).
+// Two launches, f64 partial per block and a fixed-order final sum: bitwise reproducible.
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ void sumsq_partial_kernel(const float* __restrict__ x, long long n, double* __restrict__ partial) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  const long long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = x4[i];
+    acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = x[(n4 << 2) + threadIdx.x];
+    acc += (double)v * v;
+  }
+  const double t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ void sumsq_final_kernel(const double* __restrict__ partial, int g, double scale, float* __restrict__ out) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < g; i += 256) acc += partial[i];
+  const double t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) out[0] = (float)(scale * t);
+}
+
+unsigned sumsq_grid(long long n) {
+  long long b = (n / 4 + 255) / 256;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
 unsigned ogrid(long long n) {
   long long b = (n + 255) / 256;
   if (b > 4096) b = 4096;
@@ -153,6 +195,21 @@ extern "C" int ocr_pack_weights_small_f16(const void* w_f32, int cin, int cout, 
   hipLaunchKernelGGL(pack_small_kernel, dim3(ocr_cdiv(cin * 32, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const float*>(w_f32), cin, cout,
                      static_cast<half_t*>(w_kc32), static_cast<half_t*>(w_ck32));
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_sum_squares_workspace(int64_t n) { return (size_t)sumsq_grid(n) * sizeof(double); }
+
+extern "C" int ocr_sum_squares_f32(const void* x, int64_t n, float scale, void* out_f32, void* workspace,
+                                   size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(x && out_f32 && workspace && n > 0 && ((uintptr_t)x & 15) == 0);
+  const unsigned g = sumsq_grid(n);
+  if (ws_bytes < (size_t)g * sizeof(double)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(g), dim3(256), 0, st, static_cast<const float*>(x),
+                     (long long)n, static_cast<double*>(workspace));
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, static_cast<const double*>(workspace),
+                     (int)g, (double)scale, static_cast<float*>(out_f32));
   return ocr_launch_status();
 }
 

@@ -17,14 +17,22 @@ import torch
 import torch.distributed as td
 
 
-def init_process_group_from_env(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run contract)."""
+def init_process_group_from_env(backend=None, force=False):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run contract; also what
+    `launch.self_launch` sets).  A single tower needs no group; `force=True` (or OCR_FORCE_PG=1)
+    creates a ONE-rank group anyway, so the RCCL bucket path can be exercised on a one-GPU box."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    force = force or os.environ.get("OCR_FORCE_PG", "0") == "1"
+    if world == 1 and not force:
         return 0, 1, 0
-    rank = int(os.environ["RANK"])
+    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", rank))
+    if world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            from .launch import free_port
+            os.environ["MASTER_PORT"] = str(free_port())
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
@@ -69,10 +77,18 @@ def plan_buckets(var_ranges, total, bucket_elems):
 
 
 class GradientAllReduce:
-    def __init__(self, store, world_size, bucket_bytes=32 << 20, op="mean", group=None, fold_mean=False):
-        """fold_mean: leave the SUM in the buffer and let the optimiser apply `grad_scale` (= 1/world)
-        inside its own pass instead of one more sweep over the gradients."""
+    def __init__(self, store, world_size, bucket_bytes=32 << 20, op="mean", group=None, fold_mean=False,
+                 force=False):
+        """op: "mean" = `average_gradients` (multigpu_train.py:70-85); "sum" = `sum_gradients`
+        (train_pixellink.py:179-194: the caller has already divided its loss by num_clones).
+        fold_mean: leave the SUM in the buffer and let the optimiser apply `grad_scale` (= 1/world)
+        inside its own pass instead of one more sweep over the gradients.
+        force: run the bucket / comm-stream / wait path at world 1 too (a one-rank group must exist).
+        `enabled = False` turns every hook into a no-op (bench.py's comm-exposed A/B: the step without
+        its exchange)."""
         self.store = store
+        self.active = world_size > 1 or force
+        self.enabled = True
         self.fold_mean = fold_mean
         self.grad_scale = (1.0 / world_size) if (fold_mean and op == "mean") else 1.0
         self.world = world_size
@@ -104,8 +120,11 @@ class GradientAllReduce:
         self.handles = []
         self.fired = [False] * len(self.buckets)
 
+    def bucket_nbytes(self):
+        return [(e - s) * 4 for s, e in self.buckets]
+
     def on_grads_ready(self, variables):
-        if self.world == 1:
+        if not self.active or not self.enabled:
             return
         for v in variables:
             bi = self.bucket_of.get(v.name)
@@ -134,7 +153,7 @@ class GradientAllReduce:
     def finish(self):
         """Fire whatever has not been fired (variables without a gradient this step), wait for all
         buckets, and turn the sum into the tower mean (multigpu_train.py:80-81)."""
-        if self.world == 1:
+        if not self.active or not self.enabled:
             self.reset()
             return
         for bi in range(len(self.buckets)):
@@ -149,3 +168,16 @@ class GradientAllReduce:
             else:
                 self.store.flat_grad.mul_(1.0 / self.world)
         self.reset()
+
+
+def any_rank(flag, device=None):
+    """True on EVERY rank iff `flag` is true on ANY rank (all-reduce MAX of one int).  The stop
+    decision of the training loops (`np.isnan(loss)` -> break, multigpu_train.py:175-177) must be
+    collective: a rank that leaves the loop alone strands the others in the next all-reduce."""
+    if not td.is_initialized() or td.get_world_size() == 1:
+        return bool(flag)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return bool(t.item())

@@ -58,7 +58,9 @@ class VariableStore:
         if self.flat is not None:
             raise RuntimeError("variable %s created after the store was materialised" % name)
         init = np.ascontiguousarray(np.asarray(initializer(tuple(shape)), dtype=np.float32).reshape(shape))
-        v = Variable(name, shape, None, trainable, regularized)
+        # non-trainables (BN moving statistics: small vectors) keep their initial value so that a
+        # variable-creating dry run can be undone (train.TrainStep.build)
+        v = Variable(name, shape, None if trainable else init, trainable, regularized)
         v.data = torch.from_numpy(init).to(self.device)
         if trainable:
             v.grad = torch.zeros_like(v.data)
@@ -103,6 +105,34 @@ class VariableStore:
 
     def trainable(self):
         return [self.vars[n] for n in self.order if self.vars[n].trainable]
+
+    def reset_non_trainable(self):
+        """Moving statistics back to their initial values (0 / 1)."""
+        for n in self.order:
+            v = self.vars[n]
+            if not v.trainable and v.init is not None:
+                v.data.copy_(torch.from_numpy(v.init))
+
+    def by_variable(self, flat_like):
+        """{variable name: numpy copy} of a buffer laid out like `flat` (gradients, optimiser slots, EMA)."""
+        base = self.flat.data_ptr()
+        out = {}
+        for v in self.trainable():
+            off = (v.data.data_ptr() - base) // 4
+            out[v.name] = flat_like[off:off + v.size].view(v.shape).detach().cpu().numpy().copy()
+        return out
+
+    def load_by_variable(self, flat_like, sd):
+        """Inverse of `by_variable` for the names present in `sd`; returns the names loaded."""
+        base = self.flat.data_ptr()
+        done = []
+        for v in self.trainable():
+            if v.name in sd:
+                off = (v.data.data_ptr() - base) // 4
+                a = np.asarray(sd[v.name], dtype=np.float32).reshape(v.shape)
+                flat_like[off:off + v.size].view(v.shape).copy_(torch.from_numpy(a))
+                done.append(v.name)
+        return done
 
     def state_dict(self):
         return {n: self.vars[n].data.detach().cpu().numpy().copy() for n in self.order}
@@ -153,6 +183,7 @@ class Graph:
         self.tape = []
         self.scope = []
         self.loss_scale = float(loss_scale)
+        self.loss_div = 1.0          # train_pixellink.py:264: each clone's loss is divided by num_clones
         self.rng = np.random.default_rng(seed)
         self.ws = None
         self.ws_small = None
@@ -176,6 +207,11 @@ class Graph:
 
     def get_variable(self, name, shape, initializer, trainable=True, regularized=False):
         return self.store.get(self.full_name(name), shape, initializer, trainable, regularized)
+
+    def seed_scale(self):
+        """d(loss)/d(loss) the loss kernels start the backward pass from: the f16 loss scale, over
+        the clone count when the caller pre-divides its loss (grad_op="sum")."""
+        return self.loss_scale / self.loss_div
 
     # --- device memory ---
     def workspace(self):

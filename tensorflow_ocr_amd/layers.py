@@ -232,16 +232,19 @@ def max_pool2d(g, x, k, stride, scope="pool"):
     return out
 
 
-def prep_images(g, images, means=(123.68, 116.78, 103.94)):
-    """mean_image_subtraction (nets/model.py:18-31) + f16 cast into the [n,h,w,4] layout."""
+def prep_images(g, images, means=(123.68, 116.78, 103.94), div=1.0):
+    """mean_image_subtraction (nets/model.py:18-31) + f16 cast into the [n,h,w,4] layout; `div`
+    folds the PixelLink pipeline's `(x - 120) / 60` into the same pass."""
     if images.shape[-1] != len(means):
         raise ValueError("len(means) must match the number of channels")
     if g.precision == "f32":
         from . import layers_f32
+        if div != 1.0:
+            raise NotImplementedError("input normalisation is folded into the f16 path only")
         return layers_f32.prep_images(g, images, means)
     n, h, w, _ = images.shape
     x4 = g.empty((n, h, w, 4))
-    ops.prep_images(images, x4, means)
+    ops.prep_images(images, x4, means, div)
     return Act(x4, requires_grad=False, name="images")
 
 

@@ -47,10 +47,17 @@ def softmax_loss(g, pixel_logits, link_logits, pixel_labels, link_labels, *, pix
     def backward():
         pixel_logits.grad = g.empty(pixel_logits.data.shape, F32)
         link_logits.grad = g.empty(link_logits.data.shape, F32)
-        ops.softmax_loss_bwd(d, pixel_logits.data, link_logits.data, pl, ll, thr, sums, g.loss_scale,
+        ops.softmax_loss_bwd(d, pixel_logits.data, link_logits.data, pl, ll, thr, sums, g.seed_scale(),
                              pixel_logits.grad, link_logits.grad)
     g.record(backward)
     res = Scalar(out)
     res.ohnm_threshold = thr
+
+    def selected_mask():
+        """uint8 [n,h,w]: pixels whose CE counts — positives and mined negatives (OHNM_batch's `selected`)."""
+        m = g.empty((n, h, w), torch.uint8)
+        ops.softmax_loss_selected(d, pixel_logits.data, pl, thr, m)
+        return m
+    res.selected_mask = selected_mask
     g.collections["losses"].append(res)
     return res

@@ -124,7 +124,7 @@ def loss(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mask, gr
     def backward():
         y_pred_pixel.grad = g.empty(y_pred_pixel.data.shape, F32)
         y_pred_link.grad = g.empty(y_pred_link.data.shape, F32)
-        ops.dice_loss_bwd(ytp, ytl, m, sums, g.loss_scale, y_pred_pixel.grad, y_pred_link.grad)
+        ops.dice_loss_bwd(ytp, ytl, m, sums, g.seed_scale(), y_pred_pixel.grad, y_pred_link.grad)
     g.record(backward)
     res = Scalar(out)
     g.collections["losses"].append(res)

@@ -33,11 +33,15 @@ class _LossTerm:
 
 class PixelLinkNet(object):
     def __init__(self, inputs, weight_decay=None, basenet_type='vgg', data_format='NHWC',
-                 weights_initializer=None, biases_initializer=None, graph=None):
+                 weights_initializer=None, biases_initializer=None, graph=None, input_norm=None):
+        """input_norm=(mean, std): `inputs` are RAW images and the input pipeline's normalisation
+        `(x - mean) / std` (what the reference's queue applies before the net, train_pixellink.py:150-154)
+        runs inside the image-preparation kernel; None: `inputs` are already preprocessed."""
         if data_format != 'NHWC':
             raise ValueError("only NHWC is implemented (the reference default)")
         self.g = graph or get_default_graph()
         self.inputs = inputs
+        self.input_norm = input_norm
         self.weight_decay = weight_decay
         self.basenet_type = basenet_type
         self.data_format = data_format
@@ -61,7 +65,11 @@ class PixelLinkNet(object):
         x = self.inputs
         if isinstance(x, torch.Tensor) or not hasattr(x, "requires_grad"):
             x = losses.to_device(g, x)
-            x = layers.prep_images(g, x, means=(0.0, 0.0, 0.0))   # PixelLinkNet takes preprocessed input
+            if self.input_norm is None:
+                x = layers.prep_images(g, x, means=(0.0, 0.0, 0.0))   # PixelLinkNet takes preprocessed input
+            else:
+                m, sd = self.input_norm
+                x = layers.prep_images(g, x, means=(m, m, m), div=sd)
         with g.variable_scope(self.basenet_type):
             basenet, end_points = vgg.basenet(x, graph=g, normalizer=None,
                                               initializer=self.weights_initializer)

@@ -34,9 +34,13 @@ class Workspace:
     def __init__(self, device, nbytes=64 << 20):
         self.device = device
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.retired = []
 
     def get(self, nbytes):
         if nbytes > self.buf.numel():
+            # a recorded step plan or a captured HIP graph may hold raw pointers into the old arena:
+            # it stays allocated (never handed back to the caching allocator) for the tower's lifetime
+            self.retired.append(self.buf)
             self.buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
         return self.buf
 
@@ -208,10 +212,18 @@ def pack_weights_small(w, w_kc32, w_ck32):
 
 
 # ------------------------------------------------------------------- image / BN / pool
-def prep_images(images_f32, out_f16x4, means=(123.68, 116.78, 103.94)):
+def prep_images(images_f32, out_f16x4, means=(123.68, 116.78, 103.94), div=1.0):
     npix = images_f32.numel() // 3
-    L.call("ocr_prep_images_f16", ptr(images_f32), c_int64(npix), c_float(means[0]),
-           c_float(means[1]), c_float(means[2]), ptr(out_f16x4), _st())
+    L.call("ocr_prep_images_norm_f16", ptr(images_f32), c_int64(npix), c_float(means[0]),
+           c_float(means[1]), c_float(means[2]), c_float(div), ptr(out_f16x4), _st())
+
+
+def sum_squares(x, scale, out, ws):
+    """out[0] = scale * sum(x^2) (f64 accumulation, fixed order)."""
+    n = x.numel()
+    nbytes = L.call_size("ocr_sum_squares_workspace", c_int64(n))
+    buf = ws.get(nbytes)
+    L.call("ocr_sum_squares_f32", ptr(x), c_int64(n), c_float(scale), ptr(out), ptr(buf), c_size_t(nbytes), _st())
 
 
 def bn_finalize(partial, T, C, count, gamma, beta, eps, decay, moving_mean, moving_var, scale, shift,
@@ -443,6 +455,10 @@ def softmax_loss_fwd(desc, pixel_logits, link_logits, pixel_labels, link_labels,
     buf = ws.get(nbytes)
     L.call("ocr_softmax_loss_fwd", byref(desc), ptr(pixel_logits), ptr(link_logits), ptr(pixel_labels),
            ptr(link_labels), ptr(thr), ptr(sums34), ptr(loss10), ptr(buf), c_size_t(nbytes), _st())
+
+
+def softmax_loss_selected(desc, pixel_logits, pixel_labels, thr, mask_u8):
+    L.call("ocr_softmax_loss_selected", byref(desc), ptr(pixel_logits), ptr(pixel_labels), ptr(thr), ptr(mask_u8), _st())
 
 
 def softmax_loss_bwd(desc, pixel_logits, link_logits, pixel_labels, link_labels, thr, sums34, grad_scale,

@@ -8,6 +8,7 @@ One process drives one GPU ("tower"); the cross-tower gradient mean of `average_
 """
 import math
 
+import numpy as np
 import torch
 
 from . import ops
@@ -31,6 +32,19 @@ def pixellink_lr(global_step, base_lr=0.01):
     else:
         f = 1.0
     return base_lr * f
+
+
+def _regularization_loss(opt):
+    """Sum of tf.GraphKeys.REGULARIZATION_LOSSES (multigpu_train.py:36): slim.l2_regularizer(wd) on
+    every regularised variable = wd/2 * sum(w^2) over the head of the flat buffer.  One device
+    reduction; returns a 1-element f32 device tensor (read it with .item() where the loss is logged)."""
+    st = opt.g.store
+    if getattr(opt, "_reg_out", None) is None:
+        opt._reg_out = torch.zeros(1, dtype=F32, device=st.flat.device)
+    if st.n_reg > 0 and opt.wd:
+        opt.g.workspace()
+        ops.sum_squares(st.flat[:st.n_reg], 0.5 * opt.wd, opt._reg_out, opt.g.ws_small)
+    return opt._reg_out
 
 
 class AdamOptimizer:
@@ -66,13 +80,33 @@ class AdamOptimizer:
 
     def shadow_state_dict(self):
         """EMA shadows by variable name (what test.py:149-150 restores)."""
+        return self.g.store.by_variable(self.ema)
+
+    # `tf.train.Saver(tf.global_variables())` (multigpu_train.py:144) also saves the optimiser's slot
+    # variables `<var>/Adam`, `<var>/Adam_1`, the scalars `beta1_power`, `beta2_power` and
+    # `global_step`; a resumed run continues the LR staircase, the bias correction and the EMA warm-up
+    SLOTS = ("Adam", "Adam_1")
+
+    def slot_state_dict(self):
         st = self.g.store
-        base = st.flat.data_ptr()
-        out = {}
-        for v in st.trainable():
-            off = (v.data.data_ptr() - base) // 4
-            out[v.name] = self.ema[off:off + v.size].view(v.shape).detach().cpu().numpy().copy()
-        return out
+        return {"Adam": st.by_variable(self.m), "Adam_1": st.by_variable(self.v)}
+
+    def scalar_state_dict(self):
+        t = self.global_step
+        return {"beta1_power": np.float32(self.b1 ** (t + 1)), "beta2_power": np.float32(self.b2 ** (t + 1))}
+
+    def load_state(self, global_step=None, slots=None, ema=None):
+        st = self.g.store
+        if slots:
+            st.load_by_variable(self.m, slots.get("Adam", {}))
+            st.load_by_variable(self.v, slots.get("Adam_1", {}))
+        if ema and self.ema is not None:
+            st.load_by_variable(self.ema, ema)
+        if global_step is not None:
+            self.global_step = int(global_step)
+
+    def regularization_loss(self):
+        return _regularization_loss(self)
 
 
 class MomentumOptimizer:
@@ -89,6 +123,29 @@ class MomentumOptimizer:
 
     def learning_rate(self):
         return pixellink_lr(self.global_step, self.base_lr)
+
+    SLOTS = ("Momentum",)
+
+    def shadow_state_dict(self):
+        return self.g.store.by_variable(self.ema)
+
+    def slot_state_dict(self):
+        return {"Momentum": self.g.store.by_variable(self.acc)}
+
+    def scalar_state_dict(self):
+        return {}
+
+    def load_state(self, global_step=None, slots=None, ema=None):
+        st = self.g.store
+        if slots:
+            st.load_by_variable(self.acc, slots.get("Momentum", {}))
+        if ema and self.ema is not None:
+            st.load_by_variable(self.ema, ema)
+        if global_step is not None:
+            self.global_step = int(global_step)
+
+    def regularization_loss(self):
+        return _regularization_loss(self)
 
     def apply_gradients(self, grad_scale=1.0):
         st = self.g.store
@@ -147,8 +204,18 @@ class TrainStep:
     audit that raises if a torch operator touched device memory inside `forward_loss`."""
 
     def __init__(self, graph, forward_loss, optimizer_factory, world_size=1, bucket_bytes=32 << 20,
-                 replay=True):
+                 replay=True, grad_op="mean", force_reduce=False):
+        """grad_op: "mean" = multigpu_train.py's `average_gradients` (each tower differentiates its own
+        loss, the gradients are averaged); "sum" = train_pixellink.py's `sum_gradients`: each clone
+        differentiates loss / num_clones (:264) and the gradients are summed (:179-194).
+        force_reduce: run the bucketed exchange at world 1 too (needs a one-rank process group)."""
+        if grad_op not in ("mean", "sum"):
+            raise ValueError("grad_op must be 'mean' or 'sum'")
         self.g = graph
+        self.grad_op = grad_op
+        self.force_reduce = force_reduce
+        if grad_op == "sum":
+            graph.loss_div = float(world_size)       # total_clone_loss = sum(losses) / num_clones
         self.forward_loss = forward_loss
         self.optimizer_factory = optimizer_factory
         self.world = world_size
@@ -167,6 +234,24 @@ class TrainStep:
         # than overlap, and every overlapped launch is stretched); off by default, kept as a switch
         self.use_side_stream = __import__("os").environ.get("OCR_SIDE_STREAM", "0") == "1"
 
+    def build(self, *batch):
+        """Create the variables, the flat buffers, the optimiser and the reducer WITHOUT taking a
+        step: one forward pass on `batch` whose side effects (BN moving-statistics update) are undone.
+        After it `graph.store` / `self.opt` can be restored from a checkpoint before the first update
+        (the reference restores before its first `sess.run(train_op)`, multigpu_train.py:153-158)."""
+        if self.opt is not None:
+            return self
+        from .dist import GradientAllReduce
+        g = self.g
+        g.reset_tape()
+        self.forward_loss(g, *batch)
+        g.reset_tape()
+        self.opt = self.optimizer_factory(g)
+        g.store.reset_non_trainable()
+        self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, op=self.grad_op,
+                                         fold_mean=True, force=self.force_reduce)
+        return self
+
     # -- eager / recording path --------------------------------------------------------------
     def _eager(self, batch, record):
         from . import _lib
@@ -175,7 +260,6 @@ class TrainStep:
         if record:
             rec = _lib.Recorder()
             _lib.RECORDER = rec
-            _lib.RECORDER_THREAD = __import__("threading").get_ident()
             g.keepalive = []
         audit = _record_audit() if record else __import__("contextlib").nullcontext()
         try:
@@ -188,8 +272,9 @@ class TrainStep:
             if self.opt is None:
                 from .dist import GradientAllReduce
                 self.opt = self.optimizer_factory(g)           # materialises the flat buffers
-                self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, fold_mean=True)
-            g.backward(self.reducer.on_grads_ready if self.world > 1 else None)
+                self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, op=self.grad_op,
+                                                 fold_mean=True, force=self.force_reduce)
+            g.backward(self.reducer.on_grads_ready if self.reducer.active else None)
         finally:
             _lib.RECORDER = None
         self.reducer.finish()
@@ -237,7 +322,7 @@ class TrainStep:
                 if rc != 0:
                     _lib.check(rc, e[3])
             else:
-                if side_used and (self.world == 1 or e[1] == self.reducer.finish):
+                if side_used and (not self.reducer.active or e[1] == self.reducer.finish):
                     main.wait_stream(side)       # optimiser / end of step: weight gradients done
                     side_used = False
                 e[1]()

@@ -138,11 +138,14 @@ def main():
         scores, pixel_score = forward(x)
         if not restored:
             # variable_averages.variables_to_restore(): the EMA shadows (test.py:149-158)
-            if os.path.exists(os.path.join(FLAGS.checkpoint_path, 'checkpoint')) or os.path.exists(FLAGS.checkpoint_path + '.index'):
-                sd, _ = checkpoint.load_tf_checkpoint(FLAGS.checkpoint_path, use_moving_averages=True)
-                g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
-                print('Restore from {}'.format(FLAGS.checkpoint_path))
-                scores, pixel_score = forward(x)
+            if not (os.path.exists(os.path.join(FLAGS.checkpoint_path, 'checkpoint')) or os.path.exists(FLAGS.checkpoint_path + '.index')):
+                # the reference dies here too (`ckpt_state.model_checkpoint_path` on None, test.py:155-157):
+                # never write boxes produced by randomly initialised weights
+                raise FileNotFoundError('no checkpoint under --checkpoint_path %r' % FLAGS.checkpoint_path)
+            sd, _ = checkpoint.load_tf_checkpoint(FLAGS.checkpoint_path, use_moving_averages=True)
+            g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
+            print('Restore from {}'.format(FLAGS.checkpoint_path))
+            scores, pixel_score = forward(x)
             restored = True
         cls_score = scores[:, :, :, 1:2].contiguous()           # softmax(f_score)[..., 1:2]; pixel_score: softmax over the pairs
         torch.cuda.synchronize()

@@ -52,16 +52,26 @@ def test_multigpu_train_on_icdar_directory(device, tmp_path, capsys):
     # saver.save every --save_checkpoint_steps: TF V2 bundles with the reference's names + EMA shadows
     from tensorflow_ocr_amd import checkpoint, tf_bundle
     ck = os.path.join(d, "ckpt")
-    assert tf_bundle.get_checkpoint_state(ck).endswith("model.ckpt-10")
+    # numbered by the global_step VARIABLE (multigpu_train.py:186-187): 11 updates after loop index 10
+    assert tf_bundle.get_checkpoint_state(ck).endswith("model.ckpt-11")
     sd, step = checkpoint.load_tf_checkpoint(ck)
-    assert step == 10 and sd["conv1/conv1_1/weights"].shape == (3, 3, 3, 64)
+    assert step == 11 and sd["conv1/conv1_1/weights"].shape == (3, 3, 3, 64)
+    assert not any(k.endswith("/Adam") or k == "beta1_power" for k in sd)      # variables only
     assert "conv5/conv5_3/BatchNorm/moving_variance" in sd
     keys = [k.decode() for k, _ in tf_bundle.read_table(tf_bundle.get_checkpoint_state(ck) + ".index")]
     assert "conv1/conv1_1/weights/ExponentialMovingAverage" in keys and "global_step" in keys
+    # Saver(tf.global_variables()) also holds the Adam slots and beta powers (multigpu_train.py:144)
+    assert "conv1/conv1_1/weights/Adam" in keys and "conv1/conv1_1/weights/Adam_1" in keys and "beta1_power" in keys
+    assert "total loss" in lines[0]
+    tot = [float(l.split("total loss ")[1].split(",")[0]) for l in lines]
+    assert all(t > m for t, m in zip(tot, losses))            # + sum(REGULARIZATION_LOSSES), > 0
     out = _run("multigpu_train", ["--gpu_list", "0", "--batch_size_per_gpu", "2", "--input_size", "128",
-                                  "--max_steps", "1", "--net", "model_vgg", "--num_readers", "0", "--restore",
+                                  "--max_steps", "21", "--net", "model_vgg", "--num_readers", "0", "--restore",
                                   "--training_data_path", os.path.join(d, "none"), "--checkpoint_path", ck], capsys)
     assert "continue training from previous checkpoint" in out
+    # the resumed run continues at the restored global step (11): its only log line is Step 000020
+    lines = [l for l in out.splitlines() if l.startswith("Step ")]
+    assert len(lines) == 1 and lines[0].startswith("Step 000020"), lines
 
 
 def test_train_pixellink_on_icdar_directory(device, tmp_path, capsys):

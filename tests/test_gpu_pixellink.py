@@ -54,3 +54,18 @@ def test_pixellinknet_forward_loss_backward(device):
     assert worst > 0.98
     ps = net.pixel_scores.cpu().numpy()
     assert np.allclose(ps.sum(-1), 1.0, atol=1e-5)
+
+
+def test_input_normalisation_inside_the_prep_kernel(device):
+    """`(x - 120) / 60` of the PixelLink input pipeline folded into ocr_prep_images_norm_f16 (IEEE
+    division): the net sees the same f16 pixels as with a host-side normalisation, bit for bit."""
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import pixellink
+    rng = np.random.default_rng(1)
+    images, _, _, _ = O.synthetic_batch(rng, 2, 64)
+    x = ((images - np.float32(120.0)) / np.float32(60.0)).astype(np.float32)
+    ga, gb = Graph(device, seed=7), Graph(device, seed=7)
+    a = pixellink.PixelLinkNet(x, graph=ga)
+    b = pixellink.PixelLinkNet(images, graph=gb, input_norm=(120.0, 60.0))
+    torch.cuda.synchronize()
+    assert torch.equal(a.pixel_cls.data, b.pixel_cls.data) and torch.equal(a.link_cls.data, b.link_cls.data)

@@ -180,3 +180,165 @@ def test_data_parallel_two_ranks_stay_in_sync(device, tmp_path):
     assert outs is not None, "two-rank rendezvous timed out twice"
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-2000:]
+
+
+def test_momentum_update_matches_oracle(device):
+    """a18: tf.train.MomentumOptimizer + slim L2 5e-4 on the regularised range
+    (train_pixellink.py:222-243,267-269) as `ocr_momentum_step` applies it to the device gradients."""
+    g, step = _make_pixellink(device, False)
+    b = _pixellink_batch(device, 3)
+    b[0] = (b[0] - 120.0) / 60.0
+    step(*b)                                   # creates variables + optimiser, first update
+    st, opt = g.store, step.opt
+    assert opt.wd == 5e-4 and opt.momentum == 0.9
+    for it in range(2):
+        w0, a0 = st.flat.cpu().numpy().copy(), opt.acc.cpu().numpy().copy()
+        step(*b)
+        grad = st.flat_grad.cpu().numpy() / g.loss_scale
+        grad[:st.n_reg] += 5e-4 * w0[:st.n_reg]
+        w1, a1 = O.momentum_update(w0, grad, a0, O.pixellink_lr(opt.global_step - 1, 1e-3), 0.9)
+        assert np.allclose(opt.acc.cpu().numpy(), a1, rtol=1e-5, atol=1e-8)
+        assert np.allclose(st.flat.cpu().numpy(), w1, rtol=1e-6, atol=1e-8)
+    assert np.abs(a1).max() > 0
+
+
+def test_regularization_loss_term(device):
+    """total loss = model loss + sum(REGULARIZATION_LOSSES) (multigpu_train.py:36): wd/2 * sum(w^2)
+    over the regularised variables, one device reduction."""
+    g, batch, step = _make(device, False)
+    step(*batch)
+    st = g.store
+    w = st.flat[:st.n_reg].cpu().numpy().astype(np.float64)
+    ref = 0.5 * 1e-5 * float((w * w).sum())
+    got = step.opt.regularization_loss().item()
+    assert ref > 0 and abs(got - ref) < 1e-6 * ref + 1e-12
+    assert step.opt.regularization_loss().item() == got          # fixed summation order
+
+
+def test_checkpoint_resume_restores_optimizer_state(device, tmp_path):
+    """`Saver(tf.global_variables())` holds the Adam slots, the EMA shadows and
+    global_step; a resumed tower continues bit for bit where the saved one stood."""
+    from tensorflow_ocr_amd import checkpoint
+    g, batch, step = _make(device, False)
+    for _ in range(3):
+        step(*batch)
+    prefix = checkpoint.save_training_state(str(tmp_path), g, step.opt)
+    assert prefix.endswith("model.ckpt-3")
+    for _ in range(2):
+        step(*batch)
+    g2, batch2, step2 = _make(device, False)
+    step2.build(*batch2)                               # variables + optimiser, no update taken
+    assert step2.opt.global_step == 0 and float(step2.opt.m.abs().max()) == 0.0
+    mv = [v for n, v in g2.store.vars.items() if n.endswith("moving_variance")]
+    assert mv and all(torch.equal(v.data, torch.ones_like(v.data)) for v in mv)     # dry run left no trace
+    assert checkpoint.restore_training_state(str(tmp_path), g2, step2.opt) == 3
+    assert step2.opt.global_step == 3
+    for _ in range(2):
+        step2(*batch2)
+    assert torch.equal(g.store.flat, g2.store.flat) and torch.equal(g.store.flat_aux, g2.store.flat_aux)
+    assert torch.equal(step.opt.m, step2.opt.m) and torch.equal(step.opt.v, step2.opt.v)
+    assert torch.equal(step.opt.ema, step2.opt.ema)
+
+
+def test_build_then_step_equals_plain_steps(device):
+    g1, b1, s1 = _make(device, True)
+    g2, b2, s2 = _make(device, True)
+    s2.build(*b2)
+    for _ in range(5):
+        s1(*b1)
+        s2(*b2)
+    assert torch.equal(g1.store.flat, g2.store.flat) and torch.equal(g1.store.flat_aux, g2.store.flat_aux)
+
+
+_RCCL1_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as td
+from tensorflow_ocr_amd import dist, synthetic
+from tensorflow_ocr_amd.graph import Graph
+from tensorflow_ocr_amd.nets import model_vgg_16 as M
+from tensorflow_ocr_amd.train import AdamOptimizer, TrainStep
+rank, world, local = dist.init_process_group_from_env("nccl", force=True)      # ONE-rank RCCL communicator
+assert (rank, world) == (0, 1) and td.get_backend() == "nccl"
+dev = torch.device("cuda:0")
+ones = torch.ones(4, device=dev); td.all_reduce(ones); assert ones.tolist() == [1.0] * 4
+def make(force):
+    g = Graph(dev, loss_scale=1024.0, seed=3)
+    rng = np.random.default_rng(50)
+    batch = [torch.from_numpy(a).to(dev) for a in synthetic.make_batch(rng, 2, 64)]
+    def fl(gr, im, px, lk, mk):
+        a, b = M.model_vgg(im, graph=gr)
+        return M.loss(px, a, lk, b, mk, graph=gr)
+    return g, batch, TrainStep(g, fl, lambda gr: AdamOptimizer(gr, learning_rate=1e-3), world_size=world,
+                               bucket_bytes=8 << 20, force_reduce=force)
+g0, b0, s0 = make(False)
+g1, b1, s1 = make(True)
+fired = []
+for i in range(7):                                   # 2 eager + 1 recorded + 4 replayed
+    s0(*b0)
+    s1(*b1)
+    fired.append(len(s1.reducer.handles))
+torch.cuda.synchronize()
+red = s1.reducer
+assert s1.plan is not None and red.active and len(red.buckets) >= 2 and red.comm_stream is not None
+assert not s0.reducer.active
+# every bucket went through RCCL on the comm stream and was waited for before the optimiser
+# (an all-reduce over one rank is the identity: the two towers must agree bit for bit)
+assert torch.equal(g0.store.flat, g1.store.flat), (g0.store.flat - g1.store.flat).abs().max().item()
+assert torch.equal(s0.opt.m, s1.opt.m) and torch.isfinite(g1.store.flat).all()
+n_py = sum(1 for e in s1.plan if e[0] == "py")
+assert n_py >= len(red.buckets) + 2, n_py            # bucket hooks + finish + optimiser are in the replayed plan
+td.barrier(); td.destroy_process_group()
+print("rccl-1 ok buckets", red.bucket_nbytes())
+"""
+
+
+def test_rccl_one_rank_group_through_trainstep(device, tmp_path):
+    """The `nccl` (= RCCL) path of dist.GradientAllReduce — comm stream, event from the compute
+    stream, async all_reduce handles, `h.wait()` before the replayed optimiser launch — executed on
+    hardware with the one GPU this box has: a ONE-rank communicator (multigpu_train.py:70-85,118-133)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl1.py"
+    script.write_text(_RCCL1_WORKER % root)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=540)
+    assert r.returncode == 0 and b"rccl-1 ok" in r.stdout, r.stdout.decode()[-3000:]
+
+
+def _bench(args, timeout=540):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks(device):
+    """`python bench.py --gpus 2` from a clean shell (no WORLD_SIZE): the parent spawns the ranks
+    before touching the GPU and relays rank 0's single JSON line.  Two ranks share this box's one
+    GPU through gloo (RCCL refuses two ranks on one device); the driver's SCALE run uses nccl."""
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "64",
+                  "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    ex = out["exchange"]
+    assert ex["backend"] == "gloo" and ex["rccl_ranks"] == 2 and sum(ex["bucket_bytes"]) == ex["grad_bytes"]
+    assert out["value"] > 0 and "comm_exposed_ms" in ex and out["scaling"] == "weak"
+
+
+def test_bench_one_rank_rccl_exchange(device):
+    out = _bench(["--gpus", "1", "--force-pg", "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "64",
+                  "--no-cpu-baseline"])
+    ex = out["exchange"]
+    assert ex["backend"] == "nccl" and ex["rccl_ranks"] == 1 and len(ex["bucket_bytes"]) >= 2
+    assert out["n_gpus"] == 1 and np.isfinite(out["loss"])

@@ -170,3 +170,155 @@ def test_gradient_allreduce_world2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+# ------------------------------------------------------------------ self-launch (one process per GPU)
+_LAUNCH_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+from tensorflow_ocr_amd import launch
+n = int(sys.argv[1]); mode = sys.argv[2]
+rc = launch.self_launch(n)            # launcher: returns the job's exit code; rank: returns None
+if rc is not None:
+    sys.exit(rc)
+import torch, torch.distributed as td
+from tensorflow_ocr_amd import dist
+rank, world, local = dist.init_process_group_from_env("gloo")
+assert world == n and local == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+if mode == "fail" and rank == 1:
+    sys.exit(7)                       # one tower dies before the collective: the others must not hang
+t = torch.ones(1); td.all_reduce(t)
+stop = dist.any_rank(rank == world - 1)            # only the LAST rank saw a NaN: everybody stops
+none = dist.any_rank(False)
+print("noise from rank", rank) if rank else None   # non-zero ranks' stdout goes to stderr
+if rank == 0:
+    print(json.dumps({"ranks": int(t.item()), "stop": stop, "none": none}))
+td.barrier(); td.destroy_process_group()
+"""
+
+
+def _run_launcher(tmp_path, n, mode, timeout=240):
+    script = tmp_path / "selflaunch.py"
+    script.write_text(_LAUNCH_SCRIPT % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    return subprocess.run([sys.executable, str(script), str(n), mode], env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=timeout)
+
+
+def test_self_launch_spawns_ranks_and_relays_rank0(tmp_path):
+    """`python bench.py --gpus N` from a clean shell: the parent spawns N ranks (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their env), only rank 0's stdout reaches the parent's stdout, exit 0."""
+    import json
+    r = _run_launcher(tmp_path, 2, "ok")
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    # (gloo itself prints a "[Gloo] Rank 0 is connected ..." banner on stdout; RCCL does not)
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip() and not l.startswith("[Gloo]")]
+    assert len(lines) == 1, lines                       # the ONE JSON line
+    out = json.loads(lines[0])
+    assert out == {"ranks": 2, "stop": True, "none": False}
+    assert b"noise from rank 1" in r.stderr
+
+
+def test_self_launch_fails_when_a_rank_fails(tmp_path):
+    r = _run_launcher(tmp_path, 2, "fail", timeout=120)
+    assert r.returncode == 7
+    assert b"rank 1 exited with code 7" in r.stderr and b"{" not in r.stdout
+
+
+def test_self_launch_is_a_noop_for_ranks_and_single_tower(monkeypatch):
+    from tensorflow_ocr_amd import launch
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert launch.self_launch(1) is None
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert launch.self_launch(4) is None
+    env = launch.child_env(3, 8, 1234, visible="0,1,2,3,4,5,6,7", base={"CUDA_VISIBLE_DEVICES": "5"})
+    assert env["RANK"] == "3" and env["LOCAL_RANK"] == "3" and env["WORLD_SIZE"] == "8"
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "1234"
+    assert env["HIP_VISIBLE_DEVICES"] == "0,1,2,3,4,5,6,7" and "CUDA_VISIBLE_DEVICES" not in env
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+_SUM_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as td
+from tensorflow_ocr_amd import dist
+from tensorflow_ocr_amd.graph import VariableStore, constant
+rank, world, _ = dist.init_process_group_from_env("gloo")
+st = VariableStore(torch.device("cpu"))
+a = st.get("a/weights", (3, 3, 2, 4), constant(1.0), regularized=True)
+b = st.get("b/biases", (6,), constant(0.0))
+st.materialise()
+# train_pixellink.py:179-194,264: every clone differentiates loss / num_clones, the gradients are SUMMED
+red = dist.GradientAllReduce(st, world, bucket_bytes=64 * 4, op="sum", fold_mean=True)
+assert red.grad_scale == 1.0 and red.active
+a.grad.fill_((rank + 1) / world); b.grad.fill_(10.0 * (rank + 1) / world)
+red.on_grads_ready([b]); red.on_grads_ready([a]); red.finish()
+mean = (1 + world) / 2.0
+assert torch.allclose(a.grad, torch.full_like(a.grad, mean)) and torch.allclose(b.grad, torch.full_like(b.grad, 10 * mean))
+# disabled (bench.py's comm-exposed A/B): hooks are no-ops, the local gradient stays
+red.enabled = False
+a.grad.fill_(float(rank)); red.on_grads_ready([a, b]); red.finish()
+assert torch.allclose(a.grad, torch.full_like(a.grad, float(rank)))
+assert sum(red.bucket_nbytes()) == st.flat.numel() * 4
+td.barrier(); td.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_gradient_sum_semantics_world2_gloo(tmp_path):
+    script = tmp_path / "s.py"
+    script.write_text(_SUM_WORKER % ROOT)
+    from tensorflow_ocr_amd import launch
+    port = launch.free_port()
+    ps = [subprocess.Popen([sys.executable, str(script)], env=launch.child_env(r, 2, port), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT) for r in range(2)]
+    outs = []
+    for p in ps:
+        try:
+            outs.append(p.communicate(timeout=120)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in ps:
+                q.kill()
+            raise
+    for p, o in zip(ps, outs):
+        assert p.returncode == 0 and "ok" in o, o[-2000:]
+
+
+def test_one_rank_group_can_be_forced(tmp_path):
+    """OCR_FORCE_PG / force=True: a ONE-rank group (what the 1-GPU RCCL test uses) and a reducer that
+    runs its bucket path at world 1."""
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import torch, torch.distributed as td
+from tensorflow_ocr_amd import dist
+from tensorflow_ocr_amd.graph import VariableStore, constant
+assert dist.init_process_group_from_env("gloo") == (0, 1, 0) and not td.is_initialized()
+rank, world, local = dist.init_process_group_from_env("gloo", force=True)
+assert (rank, world, local) == (0, 1, 0) and td.is_initialized() and td.get_world_size() == 1
+st = VariableStore(torch.device("cpu"))
+a = st.get("a/weights", (8,), constant(1.0)); st.materialise()
+red = dist.GradientAllReduce(st, 1, fold_mean=True, force=True)
+assert red.active
+a.grad.fill_(3.0); red.on_grads_ready([a]); assert red.fired == [True]; red.finish()
+assert torch.allclose(a.grad, torch.full_like(a.grad, 3.0))
+assert not dist.GradientAllReduce(st, 1).active
+td.destroy_process_group(); print("ok")
+""" % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "OCR_FORCE_PG")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stdout.decode()[-2000:]
+
+
+def test_recorder_only_records_its_owner_thread():
+    """a feeder-thread C-ABI call must never land in the training plan."""
+    import threading
+    from tensorflow_ocr_amd import _lib
+    rec = _lib.Recorder()
+    assert rec.mine()
+    seen = []
+    t = threading.Thread(target=lambda: (seen.append(rec.mine()), rec.py(lambda: None)))
+    t.start(); t.join()
+    assert seen == [False] and rec.entries == []
+    rec.py(lambda: None)
+    assert len(rec.entries) == 1

@@ -3,6 +3,7 @@ SURVEY.md §3.5 stated as hand-computed cases, and the committed golden fixtures
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import ocr_oracle as O
@@ -99,3 +100,51 @@ def test_golden_model_vgg_small():
     assert np.allclose(px.detach().numpy(), g["pixel_cls"], atol=2e-4)
     assert np.allclose(lk.detach().numpy(), g["link_cls"], atol=2e-4)
     assert abs(L.item() - float(g["loss"])) < 1e-4
+
+
+def test_momentum_update_and_pixellink_lr():
+    """tf.train.MomentumOptimizer (train_pixellink.py:243) and the tf.case LR factors (:222-237)."""
+    w, g, acc = np.array([1.0, -2.0]), np.array([0.5, 0.25]), np.array([0.1, -0.2])
+    w1, a1 = O.momentum_update(w, g, acc, lr=0.1, momentum=0.9)
+    assert np.allclose(a1, [0.59, 0.07]) and np.allclose(w1, [1.0 - 0.059, -2.0 - 0.007])
+    assert [O.pixellink_lr(s) for s in (0, 19999, 20000, 40000, 60000)] == pytest.approx([1e-3, 1e-3, 1e-4, 1e-5, 1e-2])
+
+
+def test_det_exp_is_an_accurate_f32_exp_and_scores_are_a_softmax():
+    x = np.linspace(-30, 30, 100001).astype(np.float32)
+    e = O.det_exp_f32(x)
+    assert e.dtype == np.float32
+    assert np.max(np.abs(e - np.exp(x.astype(np.float64))) / np.exp(x.astype(np.float64))) < 4e-7
+    l = (np.random.default_rng(0).standard_normal((4096, 2)) * 3).astype(np.float32)
+    s = O.neg_score_f32(l[:, 0], l[:, 1])
+    assert np.abs(s - torch.softmax(torch.from_numpy(l), -1)[:, 0].numpy()).max() < 3e-7
+    # example.py:13-21 (the reference's only known answer): softmax([1, 2])[0] = 0.268941
+    assert abs(float(O.neg_score_f32(np.float32(1), np.float32(2))) - 0.268941) < 1e-6
+
+
+def test_link_cc_union_vs_reference_dfs_on_asymmetric_links():
+    """a15: the product's weakly-connected components against the reference's directed DFS
+    (test_pixellink_fast.py:153-178, ascending key order) on ASYMMETRIC link predictions.  They differ
+    only in fragments around the size filter (a pixel the DFS reaches from one side but not the
+    other); pixels labelled by both always fall in the same groups.  Measured on 4 x 128^2 maps:
+    0 / 19823 segment pixels at the survey's logit strength 3.0, 17 / 19226 (0.09 %) at 2.0,
+    45 / 17367 (0.26 %) at 1.5."""
+    def sm(l):
+        e = np.exp(l - l.max(-1, keepdims=True))
+        return e / e.sum(-1, keepdims=True)
+    for strength, bound in ((3.0, 0.0), (1.5, 0.01)):          # 12 / 2132 on these two 64^2 maps
+        rng = np.random.default_rng(0)
+        pl, ll = O.synthetic_decode_maps(rng, 2, 64, strength)
+        tot = differs = 0
+        for b in range(2):
+            ps = sm(pl[b])[..., 1]
+            ls = [sm(ll[b][..., 2 * d:2 * d + 2])[..., 1] for d in range(8)]
+            A = O.link_cc_reference_dfs(ps, ls, 0.8, 0.9, 10)
+            B, _ = O.link_cc_union(ps, ls, 0.8, 0.9, 10)
+            seg = ps > 0.8
+            tot += int(seg.sum())
+            differs += int(((A > 0) != (B > 0))[seg].sum())
+            both = (A > 0) & (B > 0)
+            for a in np.unique(A[both]):                 # every DFS group lies inside ONE union-find group
+                assert len(np.unique(B[both & (A == a)])) == 1
+        assert differs <= bound * tot, (strength, differs, tot)

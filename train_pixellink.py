@@ -3,11 +3,13 @@
 :196-283) on the MI355X path: one process per GPU ("clone")
 
     python train_pixellink.py --dataset_dir /data/icdar2015/train --batch_size 32 --num_gpus 1
+    python train_pixellink.py --num_gpus 2 ...        (starts the two clones itself)
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 train_pixellink.py --num_gpus 2 ...
 
 Same flag names and defaults where they bear on the step: `PixelLinkNet` + `build_loss`
-(nets/pixellink.py), each clone's loss divided by num_clones and the gradients SUMMED
-(`sum_gradients`, :179-194) = the all-reduce mean `TrainStep` folds into the optimiser, Momentum 0.9,
+(nets/pixellink.py), each clone's loss divided by num_clones (:264) and the gradients SUMMED
+(`sum_gradients`, :179-194: `TrainStep(grad_op="sum")` seeds the backward pass with 1/num_clones and
+all-reduces with SUM), Momentum 0.9,
 `tf.case` staircase on --lr_breakpoints / --lr_decays (:222-237), weight decay 5e-4.
 
 Data: the reference reads TFRecords through `datasets.dataset_factory` / `ssd_vgg_preprocessing`,
@@ -55,10 +57,9 @@ def staircase_lr(step, base, breakpoints, decays):
     return base * 1.0
 
 
-def preprocess(images):
-    """The input normalisation of the reference's pipeline (train_pixellink.py:150-154 hands the queue
-    `ssd_vgg_preprocessing` output); done where the reference does it — before the step."""
-    return (images - 120.0) / 60.0
+# The input normalisation of the reference's pipeline (train_pixellink.py:150-154 hands the queue
+# `ssd_vgg_preprocessing` output): (x - 120) / 60, applied by the net's image-preparation kernel
+INPUT_NORM = (120.0, 60.0)
 
 
 def dataset_batches(FLAGS, g, batch, rank):
@@ -93,12 +94,16 @@ def dataset_batches(FLAGS, g, batch, rank):
                 else:
                     raise SystemExit('square train size only (resize_images)')
                 score, link, _ = pixellink_fn.generate_rbox_batch(H, W, xs_l, ys_l, bb_l, ig_l, graph=g)
-                yield preprocess(images), score, link
+                yield images, score, link
                 ims, xs_l, ys_l, bb_l, ig_l = [], [], [], [], []
 
 
 def main():
     FLAGS = parse()
+    from tensorflow_ocr_amd import launch
+    rc = launch.self_launch(FLAGS.num_gpus)          # plain start with --num_gpus N: become the launcher
+    if rc is not None:
+        raise SystemExit(rc)
     from tensorflow_ocr_amd import checkpoint, dist, synthetic
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.nets import pixellink
@@ -118,7 +123,7 @@ def main():
     g = Graph(device, seed=1)
 
     def forward_loss(gr, im, pixel_labels, link_labels):
-        net = pixellink.PixelLinkNet(im, graph=gr)                       # preprocessed input
+        net = pixellink.PixelLinkNet(im, graph=gr, input_norm=INPUT_NORM)   # raw images in
         return net.build_loss(pixel_labels, link_labels)                 # 2*pixel + link (two LOSSES, :263)
 
     def make_opt(gr):
@@ -127,7 +132,7 @@ def main():
                                 moving_average_decay=FLAGS.moving_average_decay if FLAGS.using_moving_average else None)
         opt.learning_rate = lambda: staircase_lr(opt.global_step, FLAGS.learning_rate, bps, dcs)
         return opt
-    step = TrainStep(g, forward_loss, make_opt, world_size=world)
+    step = TrainStep(g, forward_loss, make_opt, world_size=world, grad_op="sum")
 
     feeder = None
     if FLAGS.dataset_dir and os.path.isdir(FLAGS.dataset_dir):
@@ -143,7 +148,6 @@ def main():
         else:
             im, px, lk, _ = synthetic.make_batch(rng, batch_size_per_gpu, FLAGS.train_image_height)
             images, pixel, link = [torch.from_numpy(a).to(device, non_blocking=True) for a in (im, px[..., 0], lk)]
-            images = preprocess(images)
         loss = step(images, pixel, link)
         if it % FLAGS.log_every_n_steps == 0:
             v = loss.item()
@@ -152,10 +156,10 @@ def main():
             if rank == 0:
                 print('global step %d: loss = %.4f (%.3f sec/step), lr %.6f' % (
                     it, v, dt, staircase_lr(it, FLAGS.learning_rate, bps, dcs)), flush=True)
-            if np.isnan(v):
+            if dist.any_rank(bool(np.isnan(v))):     # collective: no rank leaves the all-reduce alone
                 break
         if FLAGS.train_dir and rank == 0 and it > 0 and it % 1000 == 0:
-            checkpoint.save_tf_checkpoint(FLAGS.train_dir, it, checkpoint.internal_to_tf(g.store.state_dict()))
+            checkpoint.save_training_state(FLAGS.train_dir, g, step.opt)
     if feeder is not None:
         feeder.close()
 
