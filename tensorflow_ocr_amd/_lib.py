@@ -62,6 +62,31 @@ def load():
     return lib
 
 
+VERIFY_LIB_PATH = os.path.join(_HERE, "libocr_verify.so")
+_verify = None
+
+
+def load_verify():
+    """libocr_verify.so (include/ocr_verify.h): the f32 VERIFICATION kernels.  Test infrastructure —
+    only `Graph(precision="f32")` (layers_f32.py) reaches it; the product path never does."""
+    global _verify
+    if _verify is None:
+        import torch  # noqa: F401
+        if not os.path.exists(VERIFY_LIB_PATH):
+            raise OcrHipError("libocr_verify.so is not built: run `make -C tensorflow_ocr_amd/csrc`")
+        _verify = ctypes.CDLL(VERIFY_LIB_PATH)
+    return _verify
+
+
+def call_verify(name, *args, restype=ctypes.c_int):
+    fn = getattr(load_verify(), name)
+    fn.restype = restype
+    rc = fn(*args)
+    if restype is ctypes.c_int and rc < 0:
+        check(rc, name)
+    return rc
+
+
 def check(status, what=""):
     if status != 0:
         lib = load()

@@ -10,6 +10,7 @@
 // (nets/model_vgg_16.py:144), slim.max_pool2d (nets/vgg.py:16-32), mean_image_subtraction
 // (nets/model_vgg_16.py:19-32).
 #include "common.h"
+#include "../../include/ocr_verify.h"
 
 namespace {
 

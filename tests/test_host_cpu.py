@@ -14,8 +14,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "ocr_hip.h")).read()
+def _declared_symbols(header="ocr_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(ocr_[a-z0-9_]+)\s*\(", txt)))
 
@@ -41,6 +41,20 @@ def test_library_exports_every_declared_symbol():
     assert not [n for n in names if not hasattr(bf, n)]
     bf.ocr_storage_dtype.restype = ctypes.c_char_p
     assert bf.ocr_storage_dtype() == b"bf16"
+
+
+def test_verification_kernels_live_in_their_own_library():
+    """The f32 verification kernels (include/ocr_verify.h) are test infrastructure: libocr_verify.so
+    exports them, the product libraries export none of them."""
+    from tensorflow_ocr_amd import _lib
+    names = _declared_symbols("ocr_verify.h")
+    assert len(names) == 8 and all(n.endswith("_f32") or "_f32_" in n for n in names)
+    ver = ctypes.CDLL(_lib.VERIFY_LIB_PATH)
+    assert not [n for n in names if not hasattr(ver, n)]
+    for path in (_lib.LIB_PATH, os.path.join(os.path.dirname(_lib.LIB_PATH), "libocr_hip_bf16.so")):
+        prod = ctypes.CDLL(path)
+        assert not [n for n in names if hasattr(prod, n)], path
+    assert not set(names) & set(_declared_symbols())
 
 
 def test_abi_rejects_bad_arguments_without_touching_the_gpu():
