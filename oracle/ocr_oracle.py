@@ -217,24 +217,40 @@ def _conv_block(x, p, name, rate, normalizer, mixed, updates, bn_training=True):
     return a
 
 
-def vgg_basenet(x, p, prefix="", normalizer="bn", mixed=False, updates=None):
-    """nets/vgg.py:6-42.  x: mean-subtracted NHWC image.  Returns (net, end_points)."""
+def vgg_basenet(x, p, prefix="", normalizer="bn", mixed=False, updates=None, taps=None):
+    """nets/vgg.py:6-42.  x: mean-subtracted NHWC image.  Returns (net, end_points).
+    taps (dict, optional): per conv layer `name -> {"x": input, "a": relu(bn(conv)) output,
+    "pool": the 2x2-pooled output where one follows}`, every tensor with its gradient retained —
+    what a layer-by-layer check of the device path needs (tests/test_gpu_fullsize_nets.py)."""
     updates = {} if updates is None else updates
     end_points = {}
+
+    def keep(t):
+        if taps is not None and t.requires_grad:
+            t.retain_grad()
+        return t
+
+    def block(net, name, rate, first=False):
+        xin = net if first else keep(qg(net, mixed))
+        a = keep(_conv_block(xin, p, name, rate, normalizer, mixed, updates))
+        if taps is not None:
+            taps[name] = {"x": xin, "a": a}
+        return a
     net = q(x, mixed)
-    for bi, (block, reps, _) in enumerate(VGG_CFG):
+    for bi, (blk, reps, _) in enumerate(VGG_CFG):
         for r in range(1, reps + 1):
-            name = "%s%s/%s_%d" % (prefix, block, block, r)
-            net = _conv_block(qg(net, mixed) if not (bi == 0 and r == 1) else net, p, name, 1,
-                              normalizer, mixed, updates)
-        end_points["%s_%d" % (block, reps)] = net
+            name = "%s%s/%s_%d" % (prefix, blk, blk, r)
+            net = block(net, name, 1, first=(bi == 0 and r == 1))
+        end_points["%s_%d" % (blk, reps)] = net
         if bi < 4:
-            net = max_pool(net, 2, 2)
+            net = keep(max_pool(net, 2, 2))
+            if taps is not None:
+                taps[name]["pool"] = net
         else:
             net = max_pool(net, 3, 1)
-    net = _conv_block(qg(net, mixed), p, prefix + "fc6", 6, normalizer, mixed, updates)
+    net = block(net, prefix + "fc6", 6)
     end_points["fc6"] = net
-    net = _conv_block(qg(net, mixed), p, prefix + "fc7", 1, normalizer, mixed, updates)
+    net = block(net, prefix + "fc7", 1)
     end_points["fc7"] = net
     return net, end_points
 
@@ -286,11 +302,11 @@ def _head_f32(x, p, nm, is_training, updates):
     return torch.relu(z)
 
 
-def model_vgg(images, p, is_training=True, mixed=False, updates=None):
+def model_vgg(images, p, is_training=True, mixed=False, updates=None, taps=None):
     """nets/model_vgg_16.py:138-177.  Returns (pixel_cls, link_cls, end_points)."""
     updates = {} if updates is None else updates
     x = mean_image_subtraction(images)
-    _, ep = vgg_basenet(x, p, "", "bn", mixed, updates)
+    _, ep = vgg_basenet(x, p, "", "bn", mixed, updates, taps)
     outs = []
     for base, c in ((0, 2), (5, 16)):
         def nm(i):
@@ -603,6 +619,42 @@ def link_cc_union(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, m
         if len(members) > min_size:
             comps.append((int(r), len(members)))
             labels[members] = len(comps)
+    return labels.reshape(h, w), comps
+
+
+def link_cc_union_fast(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, min_size=10):
+    """`link_cc_union` for maps too large for its Python loops (16 x 256^2, BASELINE configs[4]): the
+    same edge set built with NumPy, weakly-connected components by scipy.sparse.csgraph, the same
+    canonical numbering (ascending smallest pixel index, size filter).  Held equal to link_cc_union
+    on small maps by tests/test_oracle.py."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    h, w = pixel_score.shape
+    seg = pixel_score > pixel_thresh
+    idx = np.arange(h * w).reshape(h, w)
+    src, dst = [], []
+    inner = np.zeros((h, w), bool)
+    inner[1:h - 1, 1:w - 1] = True
+    for d, (dx, dy) in enumerate(LINK_OFFSETS):
+        nb_seg = np.zeros((h, w), bool)
+        nb_seg[1:h - 1, 1:w - 1] = seg[1 + dy:h - 1 + dy, 1 + dx:w - 1 + dx]
+        e = inner & seg & (link_scores[d] > link_thresh) & nb_seg
+        src.append(idx[e])
+        dst.append(idx[e] + dy * w + dx)
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    ncomp, lab = connected_components(coo_matrix((np.ones(len(src), np.int8), (src, dst)), shape=(h * w, h * w)),
+                                      directed=True, connection="weak")
+    segf = seg.ravel()
+    first = np.full(ncomp, h * w, np.int64)
+    np.minimum.at(first, lab[segf], np.nonzero(segf)[0])
+    size = np.bincount(lab[segf], minlength=ncomp)
+    order = [c for c in np.argsort(first, kind="stable") if first[c] < h * w and size[c] > min_size]
+    new_id = np.zeros(ncomp, np.int32)
+    comps = []
+    for c in order:
+        comps.append((int(first[c]), int(size[c])))
+        new_id[c] = len(comps)
+    labels = np.where(segf, new_id[lab], 0).astype(np.int32)
     return labels.reshape(h, w), comps
 
 

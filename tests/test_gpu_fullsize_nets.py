@@ -1,0 +1,269 @@
+"""GPU: the NETWORKS at the sizes BASELINE.json quotes them on, against the CPU oracle.
+
+* configs[1]  model_vgg + dice + backward at 512x512 (n = 2 against the oracle: end to end AND layer by
+  layer on the oracle's own layer inputs, so the tight single-layer bars of test_gpu_layers.py hold at
+  full resolution; then n = 32 with that pair replicated 16x, which must reproduce the n = 2 results —
+  batch statistics are identical under replication — and drags every tile variant the benchmark selects
+  at batch 32 through the same comparison: conv_c64_persist on 512-row maps, XCD swizzle, multi-round
+  split-K weight gradients, the pooled-BN index path on 1 GiB tensors).
+* configs[3]  full-depth ResNet-v1-50 EAST at 640x640, n = 1, in the bfloat16 build (child interpreter).
+* configs[4]  PixelLinkNet forward at 1024x1024, n = 1, and the link-CC decode of 16 x 256^2 maps
+  against the union-find oracle (bit-exact labels).
+
+The oracle runs these sizes in seconds on the GPU box's host cores (the same cost bench.py's
+cpu_baseline leg pays)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ocr_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+S = 1024.0
+BF = O.STORAGE == torch.bfloat16
+TOL = 8.0 if BF else 1.0
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-20))
+
+
+def _cos(a, b):
+    a, b = np.asarray(a).ravel().astype(np.float64), np.asarray(b).ravel().astype(np.float64)
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+def _device_model_vgg(device, p, images, pixel, link, mask):
+    from tensorflow_ocr_amd import checkpoint
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model_vgg_16 as M
+    g = Graph(device, loss_scale=S)
+    M.model_vgg(images[:1], graph=g)                      # creates the variables
+    g.reset_tape()
+    g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, p))
+    px, lk = M.model_vgg(images, graph=g)
+    L = M.loss(pixel, px, link, lk, mask, graph=g)
+    g.backward()
+    torch.cuda.synchronize()
+    grads = checkpoint.internal_to_tf({n: (v.grad / S).cpu().numpy() for n, v in g.store.vars.items() if v.trainable})
+    return px.data.cpu().numpy(), lk.data.cpu().numpy(), L.item(), grads
+
+
+@pytest.fixture(scope="module")
+def vgg512():
+    """Oracle (f16-storage mode) forward + loss + backward of model_vgg on two 512x512 images, with
+    every conv layer's input / output / pooled output and their gradients kept."""
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    rng = np.random.default_rng(0)
+    p = O.init_model_vgg_params(rng)
+    images, pixel, link, mask = O.synthetic_batch(rng, 2, 512)
+    tp = O.to_torch_params(p)
+    taps = {}
+    px, lk, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=True, taps=taps)
+    L = O.dice_loss(torch.from_numpy(pixel), px, torch.from_numpy(link), lk, torch.from_numpy(mask))
+    (L * S).backward()
+    return dict(p=p, tp=tp, taps=taps, images=images, pixel=pixel, link=link, mask=mask,
+                px=px.detach().numpy(), lk=lk.detach().numpy(), loss=float(L))
+
+
+def test_model_vgg_512_end_to_end(device, vgg512):
+    """configs[1] at its real resolution: loss, score maps and weight gradients vs the oracle."""
+    o = vgg512
+    dpx, dlk, dL, dgr = _device_model_vgg(device, o["p"], o["images"], o["pixel"], o["link"], o["mask"])
+    assert dpx.shape == (2, 128, 128, 2) and dlk.shape == (2, 128, 128, 16)
+    ogr = {k: (v.grad / S).numpy() for k, v in o["tp"].items() if v.grad is not None}
+    dmean = np.abs(dpx - o["px"]).mean()
+    cs = sorted((_cos(dgr[k], ogr[k]), k) for k in ogr if ogr[k].size >= 64)
+    glob = _cos(np.concatenate([dgr[k].ravel() for k in sorted(ogr)]), np.concatenate([ogr[k].ravel() for k in sorted(ogr)]))
+    print("512^2 n=2: loss %.5f vs %.5f | mean|d pixel_cls| %.3e Linf %.3e | lowest cosines %s | global %.4f" % (
+        dL, o["loss"], dmean, np.abs(dpx - o["px"]).max(), cs[:3], glob))
+    assert abs(dL - o["loss"]) < 5e-3 * TOL and dmean < 1e-2 * TOL
+    assert cs[0][0] > (0.6 if BF else 0.9) and glob > (0.8 if BF else 0.95)
+
+
+def test_model_vgg_512_layer_by_layer(device, vgg512):
+    """Every VGG conv (+BN+ReLU, + 2x2 pool where one follows) at 512-row resolution, fed the ORACLE's
+    own input of that layer and the oracle's gradient of its output: outputs to 2e-3, BN gradients to
+    5e-3, weight / input gradients to 1e-2 of the tensor's max — the single-layer bars, at full size."""
+    from tensorflow_ocr_amd import layers
+    from tensorflow_ocr_amd.graph import Act, Graph
+    o = vgg512
+    p, tp, taps = o["p"], o["tp"], o["taps"]
+    worst = {}
+    for name, t in taps.items():
+        first = name.endswith("conv1_1")
+        pool = 2 if "pool" in t else 0
+        rate = 6 if name == "fc6" else 1
+        w = p[name + "/weights"]
+        k, cout = w.shape[0], w.shape[3]
+        g = Graph(device, loss_scale=1.0)
+        if first:
+            xa = layers.prep_images(g, torch.from_numpy(o["images"]).to(device))
+        else:
+            xa = Act(t["x"].detach().to(O.STORAGE).to(device))
+        sd = {"L/weights": w}
+        for s in ("gamma", "beta", "moving_mean", "moving_variance"):
+            sd["L/BatchNorm/" + s] = p[name + "/BatchNorm/" + s]
+        kw = dict(rate=rate, pool=pool, first=first, keep_full=(not pool) or name.startswith(("conv3", "conv4")))
+        layers.conv2d(g, xa, cout, k, "L", **kw)
+        g.reset_tape()
+        g.store.load_state_dict(sd)
+        full, pooled = layers.conv2d(g, xa, cout, k, "L", **kw)
+        out = pooled if pool else full
+        ref = (t["pool"] if pool else t["a"])
+        # gradient of the layer's output(s) as the oracle's backward pass delivered it (x loss scale)
+        if pool:
+            pooled.grad = t["pool"].grad.to(O.STORAGE).to(device)
+            if full is not None:
+                # conv3_3 / conv4_3 are also end points: the gradient reaching `a` directly (heads) is
+                # a.grad minus what came back through the pool
+                a2 = t["a"].detach().requires_grad_(True)
+                through = torch.autograd.grad(O.max_pool(a2, 2, 2), a2, t["pool"].grad)[0]
+                full.grad = (t["a"].grad - through).to(O.STORAGE).to(device)
+        else:
+            full.grad = t["a"].grad.to(O.STORAGE).to(device)
+        g.backward()
+        torch.cuda.synchronize()
+        e_out = np.abs(out.data.float().cpu().numpy() - ref.detach().numpy()).max() / max(1.0, float(ref.abs().max()))
+        dv = g.store.vars
+        e_dw = _rel(dv["L/weights"].grad.cpu().numpy(), tp[name + "/weights"].grad.numpy())
+        e_dg = _rel(dv["L/BatchNorm/gamma"].grad.cpu().numpy(), tp[name + "/BatchNorm/gamma"].grad.numpy())
+        e_db = _rel(dv["L/BatchNorm/beta"].grad.cpu().numpy(), tp[name + "/BatchNorm/beta"].grad.numpy())
+        e_dx = 0.0 if first else _rel(xa.grad.float().cpu().numpy(), t["x"].grad.numpy())
+        worst[name] = (e_out, e_dw, e_dg, e_db, e_dx)
+        print("%-16s out %.2e dw %.2e dgamma %.2e dbeta %.2e dx %.2e" % ((name,) + worst[name]))
+        del g, xa, full, pooled
+        torch.cuda.empty_cache()
+    for name, (e_out, e_dw, e_dg, e_db, e_dx) in worst.items():
+        assert e_out <= (4e-3 if name.endswith("conv1_1") else 2e-3) * TOL, (name, "out", e_out)
+        assert e_dw < 1e-2 * TOL and e_dx < 1e-2 * TOL, (name, e_dw, e_dx)
+        assert e_dg < 5e-3 * TOL and e_db < 5e-3 * TOL, (name, e_dg, e_db)
+
+
+def test_model_vgg_512_batch32_replicated_equals_n2(device, vgg512):
+    """The benchmark's batch (32 x 512^2): the n = 2 pair replicated 16 times has the same batch
+    statistics and the same dice ratios, so loss, per-image outputs and weight gradients must come out
+    as at n = 2 — through the tile variants and split-K schedules only batch 32 selects."""
+    o = vgg512
+    px2, lk2, L2, g2 = _device_model_vgg(device, o["p"], o["images"], o["pixel"], o["link"], o["mask"])
+    rep = lambda a: np.ascontiguousarray(np.concatenate([a] * 16, axis=0))
+    px32, lk32, L32, g32 = _device_model_vgg(device, o["p"], rep(o["images"]), rep(o["pixel"]), rep(o["link"]), rep(o["mask"]))
+    assert px32.shape == (32, 128, 128, 2)
+    d = np.abs(px32.reshape(16, 2, 128, 128, 2) - px2[None])
+    same = np.abs(px32.reshape(16, 2, 128, 128, 2) - px32[:2][None]).max()
+    cs = sorted((_cos(g32[k], g2[k]), k) for k in g2 if g2[k].size >= 64)
+    print("n=32 vs n=2: loss %.6f vs %.6f | pixel_cls mean|d| %.3e Linf %.3e | replicas among themselves Linf %.3e | "
+          "lowest gradient cosines %s" % (L32, L2, d.mean(), d.max(), same, cs[:3]))
+    assert abs(L32 - L2) < 2e-3 * TOL and d.mean() < 3e-3 * TOL
+    assert cs[0][0] > (0.8 if BF else 0.97)
+    # against the oracle directly too
+    assert abs(L32 - o["loss"]) < 5e-3 * TOL and np.abs(px32[:2] - o["px"]).mean() < 1e-2 * TOL
+
+
+def test_pixellinknet_1024_forward(device):
+    """configs[4]'s network at its size: PixelLinkNet (bias VGG, no BN) forward on one 1024x1024 image."""
+    from tensorflow_ocr_amd import checkpoint
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import pixellink
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    rng = np.random.default_rng(0)
+    p = O.init_pixellink_params(rng)
+    images, _, _, _ = O.synthetic_batch(rng, 1, 1024)
+    x = ((images - np.float32(120.0)) / np.float32(60.0)).astype(np.float32)
+    g = Graph(device)
+    pixellink.PixelLinkNet(x[:, :64, :64], graph=g)
+    g.reset_tape()
+    g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, p))
+    net = pixellink.PixelLinkNet(images, graph=g, input_norm=(120.0, 60.0))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        opx, olk, _ = O.pixellink_net(torch.from_numpy(x), O.to_torch_params(p, requires_grad=False), mixed=True)
+    dpx, dlk = net.pixel_cls.data.cpu().numpy(), net.link_cls.data.cpu().numpy()
+    assert dpx.shape == (1, 256, 256, 2) and dlk.shape == (1, 256, 256, 16)
+    sc = max(1.0, float(opx.abs().max()))
+    # what the decode consumes: softmax scores
+    sp = torch.softmax(torch.from_numpy(dpx), -1)[..., 1].numpy()
+    so = torch.softmax(opx, -1)[..., 1].numpy()
+    print("1024^2: pixel_cls Linf %.3e (logit scale %.2f)  link_cls Linf %.3e | pixel score Linf %.3e mean %.3e" % (
+        np.abs(dpx - opx.numpy()).max(), sc, np.abs(dlk - olk.numpy()).max(), np.abs(sp - so).max(), np.abs(sp - so).mean()))
+    assert np.abs(dpx - opx.numpy()).max() < 2e-2 * sc * TOL and np.abs(dlk - olk.numpy()).max() < 2e-2 * sc * TOL
+    assert np.abs(sp - so).max() < 1e-2 * TOL
+
+
+def test_link_cc_decode_16x256_bit_exact(device):
+    """configs[4]'s decode at its size: 16 maps of 256x256, labels / counts / component table bit-exact
+    against the union-find oracle (NumPy edge set + scipy components, held equal to the loop version on
+    small maps by tests/test_oracle.py), on asymmetric predictions at two noise levels."""
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.tool import pixellink_fn as PF
+    g = Graph(device)
+    for seed, strength in ((0, 3.0), (1, 1.5)):
+        rng = np.random.default_rng(seed)
+        n, q = 16, 256
+        pl, ll = O.synthetic_decode_maps(rng, n, q, strength)
+        ps = PF.pixel_scores(torch.from_numpy(pl), graph=g)
+        ls = PF.link_scores(torch.from_numpy(ll), graph=g)
+        ps_np, ls_np = ps.cpu().numpy(), ls.cpu().numpy()
+        labels, ncomp, comps = PF.link_cc_decode(ps[..., 1].contiguous(), ls, 0.8, 0.9, min_size=10, graph=g)
+        labels, ncomp, comps = labels.cpu().numpy(), ncomp.cpu().numpy(), comps.cpu().numpy()
+        total = 0
+        for b in range(n):
+            ol, oc = O.link_cc_union_fast(ps_np[b, :, :, 1], ls_np[:, b, :, :, 1], 0.8, 0.9, 10)
+            assert np.array_equal(labels[b], ol), (seed, b)
+            assert ncomp[b] == len(oc) and [tuple(c) for c in comps[b, :ncomp[b]]] == oc
+            total += len(oc)
+        assert total > 16
+
+
+def test_resnet50_east_640_full_depth_bf16(device):
+    """configs[3]'s per-GPU graph at its size and dtype: full-depth ResNet-v1-50 + EAST merge branch +
+    dice, 640x640, n = 1, bfloat16 storage (libocr_hip_bf16.so) — in a child interpreter, since the
+    storage type is a process-wide choice."""
+    if os.environ.get("OCR_FULLSIZE_CHILD") == "1":
+        _east_640_body(device)
+        return
+    env = dict(os.environ, OCR_STORAGE="bf16", OCR_FULLSIZE_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_fullsize_nets.py") + "::test_resnet50_east_640_full_depth_bf16"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    print(tail)
+    assert r.returncode == 0 and "1 passed" in r.stdout, tail
+
+
+def _east_640_body(device):
+    from tensorflow_ocr_amd import _lib, checkpoint
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model_vgg_16 as M
+    assert _lib.STORAGE == "bf16" and BF
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    rng = np.random.default_rng(4)
+    p = O.init_model_east_params(rng)                     # full depth: [3, 4, 6, 3] units
+    images, pixel, link, mask = O.synthetic_batch(rng, 1, 640)
+    g = Graph(device, loss_scale=S)
+    M.model(images[:, :64, :64], graph=g)
+    g.reset_tape()
+    g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, p))
+    fs, geo = M.model(images, graph=g)
+    assert fs.data.shape == (1, 160, 160, 1) and geo.data.shape == (1, 160, 160, 8)
+    L = M.loss(pixel, fs, link, geo, mask, graph=g)
+    g.backward()
+    torch.cuda.synchronize()
+    grads = checkpoint.internal_to_tf({n: (v.grad / S).cpu().numpy() for n, v in g.store.vars.items() if v.trainable})
+    tp = O.to_torch_params(p)
+    ofs, ogeo, _ = O.model_east(torch.from_numpy(images), tp, True, mixed=True)
+    oL = O.dice_loss(torch.from_numpy(pixel), ofs, torch.from_numpy(link), ogeo, torch.from_numpy(mask))
+    (oL * S).backward()
+    d = np.abs(fs.data.cpu().numpy() - ofs.detach().numpy())
+    dg = np.abs(geo.data.cpu().numpy() - ogeo.detach().numpy())
+    cs = sorted((_cos(grads[k], (tp[k].grad / S).numpy()), k) for k in grads if grads[k].size >= 4096)
+    print("R50-EAST 640^2 bf16: loss %.5f vs %.5f | F_score Linf %.3e mean %.3e | geo mean %.3e | lowest gradient cosines %s" % (
+        L.item(), float(oL), d.max(), d.mean(), dg.mean(), cs[:3]))
+    assert np.isfinite(L.item()) and abs(L.item() - float(oL)) < 4e-2 and d.mean() < 4e-2 and dg.mean() < 4e-2
+    assert cs[0][0] > 0.6 and float(np.median([c for c, _ in cs])) > 0.9

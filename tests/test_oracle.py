@@ -148,3 +148,31 @@ def test_link_cc_union_vs_reference_dfs_on_asymmetric_links():
             for a in np.unique(A[both]):                 # every DFS group lies inside ONE union-find group
                 assert len(np.unique(B[both & (A == a)])) == 1
         assert differs <= bound * tot, (strength, differs, tot)
+
+
+def test_link_cc_union_fast_equals_the_loop_version():
+    def sm(l):
+        e = np.exp(l - l.max(-1, keepdims=True))
+        return e / e.sum(-1, keepdims=True)
+    for seed, strength in ((0, 3.0), (1, 1.5), (2, 0.8)):
+        rng = np.random.default_rng(seed)
+        pl, ll = O.synthetic_decode_maps(rng, 1, 48, strength)
+        ps = sm(pl[0])[..., 1]
+        ls = [sm(ll[0][..., 2 * d:2 * d + 2])[..., 1] for d in range(8)]
+        a, ca = O.link_cc_union(ps, ls, 0.8, 0.9, 10)
+        b, cb = O.link_cc_union_fast(ps, ls, 0.8, 0.9, 10)
+        assert np.array_equal(a, b) and ca == cb and (strength < 1 or len(ca) > 0)
+
+
+def test_vgg_taps_do_not_change_the_forward():
+    rng = np.random.default_rng(3)
+    p = O.init_model_vgg_params(rng, width_div=8)
+    images, _, _, _ = O.synthetic_batch(rng, 1, 32)
+    tp = O.to_torch_params(p)
+    a, b, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=True)
+    taps = {}
+    c, d, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=True, taps=taps)
+    assert torch.equal(a, c) and torch.equal(b, d)
+    assert len(taps) == 15 and "pool" in taps["conv1/conv1_2"] and "pool" not in taps["conv5/conv5_3"]
+    (c.sum() + d.sum()).backward()
+    assert taps["conv3/conv3_2"]["a"].grad is not None and taps["conv3/conv3_2"]["x"].grad is not None
