@@ -25,6 +25,41 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 #define OCR_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define OCR_STORAGE_NAME "f16"
 #endif
+// ---- in-kernel clock stamps: DIAGNOSTIC BUILD ONLY (libocr_hip_diag.so, -DOCR_DIAG_CLOCK) --------------
+// MI355X_MICROARCH.md "DVFS give-back" item 6: the clock a kernel really runs at is
+// d(s_memtime) / d(s_memrealtime) x 100 MHz, stamped once around its main loop.  The stamps go to a
+// buffer of their own that nothing else reads; in the product libraries none of this is compiled.
+#ifdef OCR_DIAG_CLOCK
+#define OCR_DIAG_SLOTS 4096
+struct OcrDiagStamp { unsigned long long t0, r0; };
+#define OCR_DIAG_DECLARE(name) static __device__ unsigned long long name[OCR_DIAG_SLOTS][2];
+#define OCR_DIAG_BEGIN()                                              \
+  OcrDiagStamp diag_;                                                 \
+  diag_.t0 = __builtin_amdgcn_s_memtime();                            \
+  diag_.r0 = __builtin_amdgcn_s_memrealtime();                        \
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#define OCR_DIAG_END(name)                                            \
+  {                                                                   \
+    const unsigned long long t1_ = __builtin_amdgcn_s_memtime();      \
+    const unsigned long long r1_ = __builtin_amdgcn_s_memrealtime();  \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                               \
+    if (threadIdx.x == 0) {                                           \
+      name[blockIdx.x % OCR_DIAG_SLOTS][0] = t1_ - diag_.t0;          \
+      name[blockIdx.x % OCR_DIAG_SLOTS][1] = r1_ - diag_.r0;          \
+    }                                                                 \
+  }
+#define OCR_DIAG_READER(fn, name)                                                        \
+  extern "C" int fn(void* host_out, int slots) {                                         \
+    if (!host_out || slots <= 0 || slots > OCR_DIAG_SLOTS) return OCR_ERR_INVALID_ARG;   \
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(name), (size_t)slots * 16) == hipSuccess ? OCR_OK : OCR_ERR_HIP; \
+  }
+#else
+#define OCR_DIAG_DECLARE(name)
+#define OCR_DIAG_BEGIN()
+#define OCR_DIAG_END(name)
+#define OCR_DIAG_READER(fn, name)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -41,6 +41,8 @@ struct ConvP {
 
 // LDS pixel / weight-row stride: CK f16 + padding that makes the 16-byte fragment reads
 // conflict-free for the lane->(row, k-group) map of the MFMA shape in use.
+OCR_DIAG_DECLARE(ocr_diag_conv)
+
 constexpr int conv_pstr(int ck, bool m16) { return ck * 2 + (m16 ? 32 : 16); }
 
 // Weight slices go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
   };
 
   int wb = 0;
+  OCR_DIAG_BEGIN()
   if (prefetch) halo_load(0);
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();  // previous chunk's halo fully consumed
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
     }
   }
 
+  OCR_DIAG_END(ocr_diag_conv)
   // ---- epilogue: accumulators -> LDS [256 px][<=128 couts] f16 -> coalesced rows, in passes of
   // 8 tile rows x <=128 couts (the waves owning that slice are the active ones) ----
   constexpr int EP = TH / 8;          // 8-row passes
@@ -855,6 +859,8 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
 }
 
 }  // namespace
+
+OCR_DIAG_READER(ocr_diag_read_conv, ocr_diag_conv)
 
 extern "C" int ocr_conv2d_num_mtiles(const ocr_conv_desc* d) {
   if (!d) return OCR_ERR_INVALID_ARG;

@@ -34,6 +34,8 @@ struct WgP {
   int tiles_x, tiles_y, m_tiles, HT, WT, splits, tiles_per_split, nci, nco;
 };
 
+OCR_DIAG_DECLARE(ocr_diag_wgrad)
+
 constexpr int TILE_H = 8;
 constexpr int TILE_W = 32;
 constexpr int CIB = 64;
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
     }
   };
 
+  OCR_DIAG_BEGIN()
   if (mt_begin < mt_end) {
     load_tile(mt_begin);
     store_tile(0);
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
     __syncthreads();
   }
 
+  OCR_DIAG_END(ocr_diag_wgrad)
   // D blocks: lane (li, g) holds rows (ci) 4g..4g+3 of column (co) li
 #pragma unroll
   for (int t = 0; t < MAXTAPS; ++t) {
@@ -472,6 +476,8 @@ int fill(const ocr_conv_desc* d, WgP* p) {
 }
 
 }  // namespace
+
+OCR_DIAG_READER(ocr_diag_read_wgrad, ocr_diag_wgrad)
 
 extern "C" size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d) {
   if (!d) return 0;
