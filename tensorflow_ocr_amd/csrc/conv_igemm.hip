@@ -696,6 +696,234 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / dilation 1 layers with cin % 64 == 0: FOUR waves per workgroup, ONE per SIMD, each
+// with the whole 512-entry register file (wave tile 128 couts x 128 pixels = 256 accumulator registers,
+// fragments of the next k-step double-buffered in the remaining VGPRs).
+//
+// Why: PMC + in-kernel clock stamps on the 8-wave kernel above (profiles/r02_clock_diag.json,
+// r02_pmc_mfma.json): its main loop keeps the matrix pipe busy 63 % of its cycles (47 % of the launch)
+// with the two waves of a SIMD running the same read -> wait -> MFMA program in lockstep behind one
+// barrier per tap, and it issues 0.375 ds_read_b128 per MFMA.  Here
+//   * a "step" = one tap x 32 input channels = 64 MFMAs (16x16x32) per wave; the 8 weight + 8 pixel
+//     fragments of step s+1 are read WHILE the MFMAs of step s issue (0.25 ds_read_b128 per MFMA),
+//     every LDS address is a per-lane base register + an immediate (taps fully unrolled): no address
+//     arithmetic in the loop;
+//   * BOTH operands arrive by LDS-DMA (global_load_lds_dwordx4): the halo tile of a 64-channel chunk
+//     ([10][34] pixels x 128 B, chunk index XOR (pixel & 7): conflict-free for every tap shift) is
+//     double-buffered and fetched under the previous chunk's 18 steps; the [256][32] weight slice of
+//     a step goes through a 4-deep ring, fetched 3 steps ahead; waits are COUNTED (s_waitcnt vmcnt(N),
+//     never 0 in the loop) and the one barrier per step is a raw s_barrier placed where the wave
+//     already holds the fragments of the step it is about to issue, so a barrier costs its skew only;
+//   * out-of-image halo pixels read a zero page; the tail issues clamped (redundant) DMAs so that the
+//     vmcnt arithmetic is the same in every step.
+// Same tile geometry (8 x 32 pixels x 256 couts), weight pack, epilogue and batch-norm partials as
+// conv_igemm_kernel<256,64,4,true,8>: a drop-in for that instantiation.
+template <int N> struct IC { static constexpr int value = N; };
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IC<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// In-place accumulate on an accumulator-file (AGPR) quad.  With all 256 accumulator registers live hipcc's
+// builtin form picks a destination different from the C operand and shuffles quads through
+// v_accvgpr_read/write around every MFMA (968 such moves per 1152 MFMAs in the first build of this
+// kernel); the asm form pins D = C.  The accumulators are read again only in the epilogue, far beyond
+// the MFMA -> accvgpr_read hazard window (an explicit s_nop block precedes it anyway).
+__device__ __forceinline__ void mfma16_acc(f32x4& c, const half8_t& a, const half8_t& b) {
+#ifdef OCR_BF16
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#else
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#endif
+}
+
+constexpr int W4_HT = 10, W4_WT = 34;
+constexpr int W4_HSLOTS = ((W4_HT * W4_WT * 8 + 255) / 256) * 256;   // 16-byte slots per halo buffer (2816)
+constexpr int W4_HBYTES = W4_HSLOTS * 16;                            // 45056
+constexpr int W4_NH = W4_HSLOTS / 256;                               // halo DMA rounds per chunk (11)
+constexpr int W4_WSTEP = 256 * 64;                                   // bytes of one step's weight slice
+constexpr int W4_RING = 4, W4_AHEAD = 3;
+constexpr int W4_LDS = 2 * W4_HBYTES + W4_RING * W4_WSTEP;           // 155648
+
+__global__ __launch_bounds__(256) void conv3x3_w4_kernel(
+    ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
+    const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
+  constexpr int BN = 256, TH = 8, WT = W4_WT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wbuf = smem + 2 * W4_HBYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave & 1, wpx = wave >> 1;        // cout half (128), pixel half (4 rows)
+  const int L = lane & 15, kg = lane >> 4;
+
+  int bid = blockIdx.x;
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+  const int nt = bid % p.n_tiles;
+  int mt = bid / p.n_tiles;
+  const int txi = mt % p.tiles_x;
+  const int tmp = mt / p.tiles_x;
+  const int tyi = tmp % p.tiles_y;
+  const int img = tmp / p.tiles_y;
+  const int co0 = nt * BN;
+  const int iy0 = tyi * TH - p.pt, ix0 = txi * TILE_W - p.pl;
+  const int nchunks = p.cin / 64;
+
+  // ---- per-lane DMA sources -------------------------------------------------------------------
+  const half_t* const xb = x + (size_t)img * p.h * p.w * p.cin;
+  const __attribute__((address_space(1))) void* const zero =
+      (const __attribute__((address_space(1))) void*)(&ocr_conv_zero_page[0]);
+  int hoff[W4_NH];                                   // element offset of this lane's halo slot, -1 = zero page
+#pragma unroll
+  for (int u = 0; u < W4_NH; ++u) {
+    const int idx = u * 256 + tid;
+    const int hp = idx >> 3, sl = idx & 7;
+    const int hy = hp / WT, hx = hp - hy * WT;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    hoff[u] = (hp < W4_HT * WT && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+                  ? (iy * p.w + ix) * p.cin + ((sl ^ (hp & 7)) << 3)
+                  : -1;
+  }
+  // weights: slot idx = u*256 + tid -> row u*64 + (tid>>2), stored chunk tid&3 holds logical chunk c ^ swz
+  const int wrow = tid >> 2;
+  const int woff = wrow * p.cin + (((tid & 3) ^ (((wrow >> 3) & 1) << 1)) << 3);
+
+  auto dma_halo = [&](int cc, int hb, int u) {
+    const __attribute__((address_space(1))) void* src =
+        hoff[u] >= 0 ? (const __attribute__((address_space(1))) void*)(xb + hoff[u] + cc * 64) : zero;
+    __builtin_amdgcn_global_load_lds(
+        src, (__attribute__((address_space(3))) void*)(smem + hb * W4_HBYTES + (u * 256 + wave * 64) * 16), 16, 0, 0);
+  };
+  auto dma_w = [&](int cc, int tap, int ks, int ring) {
+    const int tapw = p.flip ? (8 - tap) : tap;
+    const half_t* src = w + ((size_t)tapw * p.cout + co0) * p.cin + cc * 64 + ks * 32 + woff;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + (size_t)u * 64 * p.cin),
+          (__attribute__((address_space(3))) void*)(wbuf + ring * W4_WSTEP + (u * 256 + wave * 64) * 16), 16, 0, 0);
+  };
+
+  // ---- per-lane LDS read bases ------------------------------------------------------------------
+  // pixel fragment of tile t at tap (ky,kx): halo pixel hp = (wpx*4 + (t>>1) + ky)*34 + (t&1)*16 + kx + L,
+  // 16-byte chunk (ks*4 + kg) ^ (hp & 7); hp & 7 = (L + u) & 7 with u = (2*((t>>1)+ky) + kx) & 7 STATIC
+  // (wpx*4*34 and 16 are multiples of 8): 16 per-lane bases (2 k-halves x 8 values of u), the rest is
+  // an immediate offset.
+  unsigned tb[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      tb[ks][u] = (unsigned)((wpx * 4 * WT + L) * 128 + (((ks * 4 + kg) ^ ((L + u) & 7)) << 4));
+  // weight fragment of cout tile i: row wco*128 + i*16 + L of the step's slice, chunk kg ^ swz(row)
+  const unsigned a_lane = (unsigned)(2 * W4_HBYTES + (wco * 128 + L) * 64 + ((kg ^ (((L >> 3) & 1) << 1)) << 4));
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  half8_t fa[2][8], fb[2][8];
+
+  OCR_DIAG_BEGIN()
+  // ---- prologue: halo of chunk 0, weight slices of steps 0..2 -----------------------------------
+#pragma unroll
+  for (int u = 0; u < W4_NH; ++u) dma_halo(0, 0, u);
+  dma_w(0, 0, 0, 0);
+  dma_w(0, 0, 1, 1);
+  dma_w(0, 1, 0, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    // fragments of step 0 (tap 0, ks 0) into set 0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[0][i] = *reinterpret_cast<const half8_t*>(smem + (a_lane + i * 1024));
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int u = (2 * (t >> 1)) & 7;
+      fb[0][t] = *reinterpret_cast<const half8_t*>(smem + (tb[0][u] + ((t >> 1) * WT + (t & 1) * 16) * 128));
+    }
+  }
+
+  int hsel = 0;                                   // halo buffer of the chunk being computed
+  for (int cc = 0; cc < nchunks; ++cc) {
+    const int s0 = cc * 18;                       // global step index of this chunk's step 0
+    const int ccn = cc + 1 < nchunks ? cc + 1 : cc;   // clamped: the tail re-fetches (harmless)
+    static_for<0, 18>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int P = j & 1, Q = P ^ 1;
+      // next step (whose fragments are read during this one)
+      constexpr int jn = (j + 1) % 18;
+      constexpr int tapn = jn >> 1, ksn = jn & 1, kyn = tapn / 3, kxn = tapn % 3;
+      // step whose weight slice is fetched during this one
+      constexpr int jd = (j + W4_AHEAD) % 18;
+      constexpr bool dnext = j + W4_AHEAD >= 18;
+      // weights of step s+1 landed (own share): everything older than the 4 DMAs of step s+2 and the
+      // halo DMA issued in step s-1
+      constexpr int jp = (j + 17) % 18;
+      constexpr int nh_prev = (jp >= 1 && jp <= W4_NH) ? 1 : 0;
+      if constexpr (nh_prev) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // DMA (behind the first MFMA groups, below): halo piece of the next chunk (steps 1..11), then the
+      // weight slice of step s+3
+      const int sd_ring = (s0 + j + W4_AHEAD) & (W4_RING - 1);
+      const int d_cc = dnext ? ccn : cc;
+      const int d_tapw = p.flip ? (8 - (jd >> 1)) : (jd >> 1);
+      const half_t* const wsrc = w + ((size_t)d_tapw * p.cout + co0) * p.cin + d_cc * 64 + (jd & 1) * 32 + woff;
+      auto dma_w1 = [&](int u) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wsrc + (size_t)u * 64 * p.cin),
+            (__attribute__((address_space(3))) void*)(wbuf + sd_ring * W4_WSTEP + (u * 256 + wave * 64) * 16), 16, 0, 0);
+      };
+      if constexpr (j == 17) {
+        hsel ^= 1;                                // the prefetched fragments belong to the next chunk
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) tb[ks][u] = hsel ? tb[ks][u] + W4_HBYTES : tb[ks][u] - W4_HBYTES;
+      }
+      const unsigned abase = a_lane + (unsigned)(((s0 + j + 1) & (W4_RING - 1)) * W4_WSTEP);
+      // 64 MFMAs of this step from set P; the 16 fragment reads of the next step go into set Q BEHIND the
+      // MFMA groups (pixel fragments first: all eight are needed by the next step's first group; none
+      // behind the last group, so every fragment is >= 8 MFMAs old when the next step starts)
+      auto read_b = [&](int t) {
+        const int u = (2 * ((t >> 1) + kyn) + kxn) & 7;
+        fb[Q][t] = *reinterpret_cast<const half8_t*>(smem + (tb[ksn][u] + (((t >> 1) + kyn) * WT + (t & 1) * 16 + kxn) * 128));
+      };
+      auto read_a = [&](int i) { fa[Q][i] = *reinterpret_cast<const half8_t*>(smem + (abase + i * 1024)); };
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) mfma16_acc(acc[g][t], fa[P][g], fb[P][t]);
+        if (g == 0) { if constexpr (j >= 1 && j <= W4_NH) dma_halo(ccn, hsel ^ 1, j - 1); dma_w1(0); read_b(0); read_b(1); }
+        if (g == 1) { dma_w1(1); read_b(2); read_b(3); read_b(4); }
+        if (g == 2) { dma_w1(2); read_b(5); read_b(6); read_b(7); }
+        if (g == 3) { dma_w1(3); read_a(0); read_a(1); }
+        if (g == 4) { read_a(2); read_a(3); }
+        if (g == 5) { read_a(4); read_a(5); }
+        if (g == 6) { read_a(6); read_a(7); }
+      }
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the tail's redundant DMAs must not land in the epilogue's LDS
+  OCR_DIAG_END(ocr_diag_conv)
+
+  // ---- epilogue: two passes of 128 couts (the waves holding that half are the active ones) ----
+  const int mt8 = (img * p.tiles_y + tyi) * p.tiles_x + txi;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+    conv_epilogue16<128, 4, 4, 1, 256>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt8, co0 + h * 128, p.oh, p.ow,
+                                       p.cout, 0, wpx, wco == h, p.br.y ? &p.br : nullptr);
+  }
+}
+
 template <int BN, int WCO>
 int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
               hipStream_t st) {
@@ -776,6 +1004,33 @@ static int launch_c64(const ConvP& p, const void* x, const void* w, const void* 
   hipLaunchKernelGGL(kern, dim3((unsigned)(per * p.n_tiles)), dim3(512), lds, st, p, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats), (int)area);
+  return ocr_launch_status();
+}
+
+// 4-wave kernel: 3x3 / stride 1 / dilation 1, 64-channel chunks, 256-cout tiles, 16x16x32 MFMA
+static bool conv_w4_ok(const ConvP& p) {
+  static const int on = [] { const char* e = getenv("OCR_CONV_W4"); return e ? atoi(e) : 1; }();
+  return on && p.m16 && p.kh == 3 && p.kw == 3 && p.dil == 1 && p.stride == 1 && p.cin % 64 == 0 && p.cout % 256 == 0;
+}
+
+static int launch_w4(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
+                     hipStream_t st) {
+  auto kern = conv3x3_w4_kernel;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(160 * 1024)) != hipSuccess)
+      return OCR_ERR_HIP;
+    configured = true;
+  }
+  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
+  dim3 grid((unsigned)(m_tiles * p.n_tiles));
+  static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 2; }();
+  ConvP q = p;
+  q.xcd_swizzle = (swz & 1) && grid.x % 8 == 0;
+  hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)W4_LDS, st, q, static_cast<const half_t*>(x),
+                     static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
+                     static_cast<float*>(stats));
   return ocr_launch_status();
 }
 
@@ -879,6 +1134,10 @@ extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap)
     return OCR_OK;
   }
   const int wco = c.bn == 256 ? 4 : c.bn == 32 ? 1 : 2;
+  if (c.bn == 256 && c.ck == 64 && c.th == 8 && conv_w4_ok(p)) {
+    snprintf(out, cap, "conv3x3_w4_kernel");
+    return OCR_OK;
+  }
   if (c.bn == 64 && c.ck == 64 && c.th == 8 && conv_c64_ok(p)) {
     snprintf(out, cap, "conv_c64_persist_kernel<64>");
     return OCR_OK;
@@ -896,7 +1155,9 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
   }
   const int key = c.bn * 10000 + c.ck * 100 + c.th;
   switch (key) {
-    case 2566408: return launch<256, 64, 4>(p, x, w_kc, bias, y, stats, st);
+    case 2566408:
+      if (conv_w4_ok(p)) return launch_w4(p, x, w_kc, bias, y, stats, st);
+      return launch<256, 64, 4>(p, x, w_kc, bias, y, stats, st);
     case 2563208: return launch<256, 32, 4>(p, x, w_kc, bias, y, stats, st);
     case 1286416: return launch<128, 64, 2, 16>(p, x, w_kc, bias, y, stats, st);
     case 1283216: return launch<128, 32, 2, 16>(p, x, w_kc, bias, y, stats, st);

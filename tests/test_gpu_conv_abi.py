@@ -41,6 +41,9 @@ SHAPES = [
     (2, 100, 130, 64, 64, 3, 1),     # persistent weight-stationary 64-channel kernel: 130 ragged pixel tiles
     (1, 128, 256, 64, 128, 3, 1),    # ... two cout tiles, workgroups split between them
     (9, 64, 64, 64, 64, 3, 1),       # ... more images than tiles per image
+    (2, 33, 70, 128, 256, 3, 1),     # 4-wave 3x3 kernel (conv3x3_w4): ragged rows and columns, 2 chunks
+    (1, 16, 64, 512, 512, 3, 1),     # ... 8 chunks x 18 steps, two cout tiles
+    (3, 8, 32, 64, 256, 3, 1),       # ... one chunk (prologue + tail only), several images
 ]
 
 
@@ -94,12 +97,14 @@ def test_conv_fwd_dgrad_wgrad(device, n, h, w, cin, cout, k, dil):
     assert e_y < tol and e_dx < tol and e_dw < 5e-6
 
 
-def test_persistent_c64_kernel_is_selected_and_emits_stats(device):
-    """The 64-channel large-map layers (conv1_2 class) run the persistent weight-stationary kernel;
-    its per-tile batch-norm partials (sum, sum of squares of the STORED 16-bit values) add up to the
-    tensor's own sums, and the fused BN-backward variant's partials to (sum dz, sum dz*xhat)."""
+@pytest.mark.parametrize("n,h,w,c,variant", [(2, 100, 130, 64, "conv_c64_persist_kernel<64>"),
+                                             (2, 37, 70, 256, "conv3x3_w4_kernel")])
+def test_special_kernels_are_selected_and_emit_stats(device, n, h, w, c, variant):
+    """The 64-channel large-map layers (conv1_2 class) run the persistent weight-stationary kernel, the
+    3x3 layers with 256-cout tiles the 4-wave kernel; their per-tile batch-norm partials (sum, sum of
+    squares of the STORED 16-bit values) add up to the tensor's own sums, and the fused BN-backward
+    variant's partials to (sum dz, sum dz*xhat)."""
     from tensorflow_ocr_amd import ops
-    n, h, w, c = 2, 100, 130, 64
     rng = np.random.default_rng(5)
     x = _h(rng.standard_normal((n, h, w, c)))
     wt = _h(rng.standard_normal((3, 3, c, c)) * np.sqrt(2.0 / (9 * c)))
@@ -109,7 +114,7 @@ def test_persistent_c64_kernel_is_selected_and_emits_stats(device):
     w_ck = torch.empty((9, c, c), dtype=O.STORAGE, device=device)
     ops.pack_weights(wm, w_kc, w_ck)
     d = ops.conv_desc((n, h, w, c), c, 3, 3, 1, 1)
-    assert ops.conv2d_variant(d) == "conv_c64_persist_kernel<64>"
+    assert ops.conv2d_variant(d) == variant
     d.flags = ops.CONV_STATS
     T = ops.conv2d_num_mtiles(d)
     y = torch.empty((n, h, w, c), dtype=O.STORAGE, device=device)

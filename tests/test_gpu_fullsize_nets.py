@@ -136,6 +136,22 @@ def test_model_vgg_512_layer_by_layer(device, vgg512):
         e_dg = _rel(dv["L/BatchNorm/gamma"].grad.cpu().numpy(), tp[name + "/BatchNorm/gamma"].grad.numpy())
         e_db = _rel(dv["L/BatchNorm/beta"].grad.cpu().numpy(), tp[name + "/BatchNorm/beta"].grad.numpy())
         e_dx = 0.0 if first else _rel(xa.grad.float().cpu().numpy(), t["x"].grad.numpy())
+        if e_dx > 2e-3:          # where does the input-gradient error sit?
+            dd = np.abs(xa.grad.float().cpu().numpy() - t["x"].grad.numpy())
+            mx = float(np.abs(t["x"].grad.numpy()).max())
+            big = dd > 1e-3 * mx
+            am = np.unravel_index(int(dd.argmax()), dd.shape)
+            # 2x2 windows of this layer's activation whose maximum is attained twice (a tie the pooling
+            # gradient has to break)
+            ties = -1
+            if pool:
+                a4 = t["a"].detach().numpy()
+                n_, h_, w_, c_ = a4.shape
+                win = a4.reshape(n_, h_ // 2, 2, w_ // 2, 2, c_).transpose(0, 1, 3, 5, 2, 4).reshape(n_, h_ // 2, w_ // 2, c_, 4)
+                mxw = win.max(-1, keepdims=True)
+                ties = int((((win == mxw).sum(-1) > 1) & (mxw[..., 0] > 0)).sum())
+            print("   dx error: %d of %d elements above 1e-3 of max (%.2e); worst at %s; tied positive 2x2 maxima: %d" % (
+                int(big.sum()), dd.size, mx, am, ties))
         worst[name] = (e_out, e_dw, e_dg, e_db, e_dx)
         print("%-16s out %.2e dw %.2e dgamma %.2e dbeta %.2e dx %.2e   (max|dx| %.2e, max|d out| %.2e)" % (
             (name,) + worst[name] + (0.0 if first else float(t["x"].grad.abs().max()),
