@@ -741,6 +741,11 @@ __device__ __forceinline__ void mfma16_acc(f32x4& c, const half8_t& a, const hal
 #endif
 }
 
+// dev ablations (never in a shipped library): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop,
+// 4 = no barrier, 8 = no fragment reads, 16 = no vmcnt wait
+#ifndef W4_ABL
+#define W4_ABL 0
+#endif
 constexpr int W4_HT = 10, W4_WT = 34;
 constexpr int W4_HSLOTS = ((W4_HT * W4_WT * 8 + 255) / 256) * 256;   // 16-byte slots per halo buffer (2816)
 constexpr int W4_HBYTES = W4_HSLOTS * 16;                            // 45056
@@ -867,9 +872,11 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
       // halo DMA issued in step s-1
       constexpr int jp = (j + 17) % 18;
       constexpr int nh_prev = (jp >= 1 && jp <= W4_NH) ? 1 : 0;
-      if constexpr (nh_prev) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(W4_ABL & 16)) {
+        if constexpr (nh_prev) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      if constexpr (!(W4_ABL & 4)) __builtin_amdgcn_s_barrier();
       // DMA (behind the first MFMA groups, below): halo piece of the next chunk (steps 1..11), then the
       // weight slice of step s+3
       const int sd_ring = (s0 + j + W4_AHEAD) & (W4_RING - 1);
@@ -877,6 +884,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
       const int d_tapw = p.flip ? (8 - (jd >> 1)) : (jd >> 1);
       const half_t* const wsrc = w + ((size_t)d_tapw * p.cout + co0) * p.cin + d_cc * 64 + (jd & 1) * 32 + woff;
       auto dma_w1 = [&](int u) {
+        if constexpr (W4_ABL & 1) return;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(wsrc + (size_t)u * 64 * p.cin),
             (__attribute__((address_space(3))) void*)(wbuf + sd_ring * W4_WSTEP + (u * 256 + wave * 64) * 16), 16, 0, 0);
@@ -893,15 +901,19 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
       // MFMA groups (pixel fragments first: all eight are needed by the next step's first group; none
       // behind the last group, so every fragment is >= 8 MFMAs old when the next step starts)
       auto read_b = [&](int t) {
+        if constexpr (W4_ABL & 8) return;
         const int u = (2 * ((t >> 1) + kyn) + kxn) & 7;
         fb[Q][t] = *reinterpret_cast<const half8_t*>(smem + (tb[ksn][u] + (((t >> 1) + kyn) * WT + (t & 1) * 16 + kxn) * 128));
       };
-      auto read_a = [&](int i) { fa[Q][i] = *reinterpret_cast<const half8_t*>(smem + (abase + i * 1024)); };
+      auto read_a = [&](int i) {
+        if constexpr (W4_ABL & 8) return;
+        fa[Q][i] = *reinterpret_cast<const half8_t*>(smem + (abase + i * 1024));
+      };
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) mfma16_acc(acc[g][t], fa[P][g], fb[P][t]);
-        if (g == 0) { if constexpr (j >= 1 && j <= W4_NH) dma_halo(ccn, hsel ^ 1, j - 1); dma_w1(0); read_b(0); read_b(1); }
+        if (g == 0) { if constexpr (j >= 1 && j <= W4_NH && !(W4_ABL & 2)) dma_halo(ccn, hsel ^ 1, j - 1); dma_w1(0); read_b(0); read_b(1); }
         if (g == 1) { dma_w1(1); read_b(2); read_b(3); read_b(4); }
         if (g == 2) { dma_w1(2); read_b(5); read_b(6); read_b(7); }
         if (g == 3) { dma_w1(3); read_a(0); read_a(1); }
@@ -914,13 +926,117 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the tail's redundant DMAs must not land in the epilogue's LDS
   OCR_DIAG_END(ocr_diag_conv)
 
-  // ---- epilogue: two passes of 128 couts (the waves holding that half are the active ones) ----
-  const int mt8 = (img * p.tiles_y + tyi) * p.tiles_x + txi;
+  // ---- epilogue, WAVE-PRIVATE: a wave owns 128 couts of 128 pixels, i.e. whole 256-byte pieces of 128
+  // output rows.  16 rounds of (16 pixels x 64 couts): accumulator quads -> this wave's 2 KB staging rows
+  // (16-byte chunk index XOR (pixel & 7)) -> 128-byte coalesced row pieces, batch-norm partials (of the
+  // STORED 16-bit values; with `br` the producing layer's BN-backward sums) accumulated per lane over the
+  // rounds and folded over the wave at the end.  No block barrier after the first one, no shared
+  // staging: the block-staged epilogue of the 8-wave kernel cost this kernel 16 % of its run time
+  // (4 waves doing two block-wide passes).  Partials go to row 2 * tile + pixel-half (the two waves of
+  // a pixel half own disjoint couts): ocr_conv2d_num_mtiles reports twice the tile count for this kernel.
+  __syncthreads();                                   // every wave's DMAs have landed: the LDS is free
+  {
+    const int mt8 = (img * p.tiles_y + tyi) * p.tiles_x + txi;
+    char* const stage = smem + wave * 2048;
+    const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
+    const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
+    const BnRed* br = p.br.y ? &p.br : nullptr;
+    const int g4 = lane >> 4;                        // accumulator layout: pixel L, couts 4*g4..+3 of a 16x16 tile
+    const int c8 = lane & 7, pg = lane >> 3;         // read-back layout: 16-byte chunk of a pixel's 64 couts, pixel
+    const int cow = co0 + wco * 128;
+    float s[2][8], q2[2][8];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();
-    conv_epilogue16<128, 4, 4, 1, 256>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt8, co0 + h * 128, p.oh, p.ow,
-                                       p.cout, 0, wpx, wco == h, p.br.y ? &p.br : nullptr);
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[hf][e] = 0.f; q2[hf][e] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int oy = tyi * TH + wpx * 4 + (t >> 1);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = hf * 4 + ii;
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (has_bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = bias[cow + i * 16 + g4 * 4 + e];
+          }
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][t][e] + bv[e];
+            if (relu) v = v > 0.f ? v : 0.f;
+            o[e] = (half_t)v;
+          }
+          *reinterpret_cast<half4_t*>(stage + L * 128 + (((ii * 2 + (g4 >> 1)) ^ (L & 7)) << 4) + (g4 & 1) * 8) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int px = k * 8 + pg;
+          const int ox = txi * TILE_W + (t & 1) * 16 + px;
+          if (oy < p.oh && ox < p.ow) {
+            half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
+            const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + cow + hf * 64 + c8 * 8;
+            if (accum) {
+              const half8_t old = *reinterpret_cast<const half8_t*>(y + off);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+            }
+            *reinterpret_cast<half8_t*>(y + off) = v;
+            if (do_stats) {
+              if (br != nullptr) {
+                const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const int cc = cow + hf * 64 + c8 * 8 + e;
+                  const float yf = (float)yv[e];
+                  const float z = (float)(half_t)(yf * br->scale[cc] + br->shift[cc]);
+                  const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
+                  s[hf][e] += dz;
+                  q2[hf][e] += dz * ((yf - br->mean[cc]) * br->invstd[cc]);
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float f = (float)v[e];
+                  s[hf][e] += f;
+                  q2[hf][e] += f * f;
+                }
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // the next round's writes come after these reads (in-order LDS)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    if (do_stats) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) {         // the 8 pixel lanes of a chunk, fixed order
+            s[hf][e] += __shfl_xor(s[hf][e], o, 64);
+            q2[hf][e] += __shfl_xor(q2[hf][e], o, 64);
+          }
+        }
+      if (pg == 0) {
+        float* row = stats + ((size_t)(mt8 * 2 + wpx) * 2) * p.cout + cow + c8 * 8;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            row[hf * 64 + e] = s[hf][e];
+            row[p.cout + hf * 64 + e] = q2[hf][e];
+          }
+      }
+    }
   }
 }
 
@@ -1120,7 +1236,12 @@ OCR_DIAG_READER(ocr_diag_read_conv, ocr_diag_conv)
 extern "C" int ocr_conv2d_num_mtiles(const ocr_conv_desc* d) {
   if (!d) return OCR_ERR_INVALID_ARG;
   if (conv_is_pw(d)) return (int)(((long long)d->n * d->oh * d->ow + 255) / 256);   // flat 256-pixel tiles
-  return d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
+  const int tiles = d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
+  ConvP p;
+  TileCfg c;
+  // the 4-wave kernel emits one partial row per pixel half of a tile
+  if (fill_params(d, &p, &c) == OCR_OK && c.bn == 256 && c.ck == 64 && c.th == 8 && conv_w4_ok(p)) return 2 * tiles;
+  return tiles;
 }
 
 extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap) {
