@@ -34,6 +34,11 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-20))
 
 
+def _l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
 def _cos(a, b):
     a, b = np.asarray(a).ravel().astype(np.float64), np.asarray(b).ravel().astype(np.float64)
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
@@ -89,8 +94,9 @@ def test_model_vgg_512_end_to_end(device, vgg512):
 
 def test_model_vgg_512_layer_by_layer(device, vgg512):
     """Every VGG conv (+BN+ReLU, + 2x2 pool where one follows) at 512-row resolution, fed the ORACLE's
-    own input of that layer and the oracle's gradient of its output: outputs to 2e-3, BN gradients to
-    5e-3, weight / input gradients to 1e-2 of the tensor's max — the single-layer bars, at full size."""
+    own input of that layer and the oracle's gradient of its output: outputs to 2e-3 and BN gradients to
+    5e-3 of the tensor's max (the single-layer bars, at full size); weight / input gradients by relative
+    L2 and the share of elements a flipped ReLU / argmax decision moved (see the comment at the bars)."""
     from tensorflow_ocr_amd import layers
     from tensorflow_ocr_amd.graph import Act, Graph
     o = vgg512
@@ -132,36 +138,35 @@ def test_model_vgg_512_layer_by_layer(device, vgg512):
         torch.cuda.synchronize()
         e_out = np.abs(out.data.float().cpu().numpy() - ref.detach().numpy()).max() / max(1.0, float(ref.abs().max()))
         dv = g.store.vars
-        e_dw = _rel(dv["L/weights"].grad.cpu().numpy(), tp[name + "/weights"].grad.numpy())
         e_dg = _rel(dv["L/BatchNorm/gamma"].grad.cpu().numpy(), tp[name + "/BatchNorm/gamma"].grad.numpy())
         e_db = _rel(dv["L/BatchNorm/beta"].grad.cpu().numpy(), tp[name + "/BatchNorm/beta"].grad.numpy())
-        e_dx = 0.0 if first else _rel(xa.grad.float().cpu().numpy(), t["x"].grad.numpy())
-        if e_dx > 2e-3:          # where does the input-gradient error sit?
-            dd = np.abs(xa.grad.float().cpu().numpy() - t["x"].grad.numpy())
-            mx = float(np.abs(t["x"].grad.numpy()).max())
-            big = dd > 1e-3 * mx
-            am = np.unravel_index(int(dd.argmax()), dd.shape)
-            # 2x2 windows of this layer's activation whose maximum is attained twice (a tie the pooling
-            # gradient has to break)
-            ties = -1
-            if pool:
-                a4 = t["a"].detach().numpy()
-                n_, h_, w_, c_ = a4.shape
-                win = a4.reshape(n_, h_ // 2, 2, w_ // 2, 2, c_).transpose(0, 1, 3, 5, 2, 4).reshape(n_, h_ // 2, w_ // 2, c_, 4)
-                mxw = win.max(-1, keepdims=True)
-                ties = int((((win == mxw).sum(-1) > 1) & (mxw[..., 0] > 0)).sum())
-            print("   dx error: %d of %d elements above 1e-3 of max (%.2e); worst at %s; tied positive 2x2 maxima: %d" % (
-                int(big.sum()), dd.size, mx, am, ties))
-        worst[name] = (e_out, e_dw, e_dg, e_db, e_dx)
-        print("%-16s out %.2e dw %.2e dgamma %.2e dbeta %.2e dx %.2e   (max|dx| %.2e, max|d out| %.2e)" % (
-            (name,) + worst[name] + (0.0 if first else float(t["x"].grad.abs().max()),
-                                     float((t["pool"] if pool else t["a"]).grad.abs().max()))))
+        dwd, dwo = dv["L/weights"].grad.cpu().numpy(), tp[name + "/weights"].grad.numpy()
+        e_dw, l2_dw = _rel(dwd, dwo), _l2(dwd, dwo)
+        e_dx = l2_dx = bad = 0.0
+        if not first:
+            dxd, dxo = xa.grad.float().cpu().numpy(), t["x"].grad.numpy()
+            e_dx, l2_dx = _rel(dxd, dxo), _l2(dxd, dxo)
+            bad = float((np.abs(dxd - dxo) > 2e-3 * TOL * np.abs(dxo).max()).mean())
+        worst[name] = (e_out, e_dw, l2_dw, e_dg, e_db, e_dx, l2_dx, bad)
+        print("%-16s out %.2e | dw Linf %.2e L2 %.2e | dgamma %.2e dbeta %.2e | dx Linf %.2e L2 %.2e, %.1e of the elements off" % (
+            (name,) + worst[name]))
         del g, xa, full, pooled
         torch.cuda.empty_cache()
-    for name, (e_out, e_dw, e_dg, e_db, e_dx) in worst.items():
+    # Outputs and BN gradients: element-wise bars.  Weight / input gradients pass through this layer's ReLU
+    # mask and (pooled layers) the pooling argmax, which are DECISIONS on 16-bit values: where the device's
+    # conv output differs from the oracle's by one 16-bit ulp (different f32 summation order: ~1e-3 of the
+    # elements) a value next to zero or two near-equal window maxima decide the other way, and the whole
+    # gradient of that element moves.  Measured at 512^2: 3e-5 .. 1.4e-3 of the input-gradient elements
+    # (sparse, up to 5 % of the tensor's max each) on the pooled layers and on conv2_1; everywhere else
+    # every element agrees to 5e-4.  So: L-inf where no decision flipped, relative L2 + the fraction of
+    # affected elements for all.
+    for name, (e_out, e_dw, l2_dw, e_dg, e_db, e_dx, l2_dx, bad) in worst.items():
         assert e_out <= (4e-3 if name.endswith("conv1_1") else 2e-3) * TOL, (name, "out", e_out)
-        assert e_dw < 1e-2 * TOL and e_dx < 1e-2 * TOL, (name, e_dw, e_dx)
         assert e_dg < 5e-3 * TOL and e_db < 5e-3 * TOL, (name, e_dg, e_db)
+        assert l2_dw < 2e-2 * TOL and l2_dx < 3e-2 * TOL and bad < 3e-3, (name, l2_dw, l2_dx, bad)
+        if e_dx < 2e-3 * TOL and e_dw < 2e-3 * TOL:
+            continue                      # this layer saw no flipped decision at all
+        assert e_dw < 6e-2 * TOL and e_dx < 8e-2 * TOL, (name, e_dw, e_dx)
 
 
 def test_model_vgg_512_batch32_replicated_equals_n2(device, vgg512):
