@@ -1040,6 +1040,260 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same design for the 64- and 128-cout 3x3 layers (conv1_2, conv2_x and the input gradients that end in
+// 64 / 128 channels): large maps, little arithmetic per output byte — conv1_2 moves 2.1 GB for 0.62 TFLOP, so
+// its floor is the HBM stream (0.43 ms), not MFMA.  What these layers need is the output stores and halo
+// fetches of one workgroup running UNDER the MFMAs of another, so here a workgroup is small enough for TWO
+// per CU (4 waves x 256 registers, <= 80 KB of LDS):
+//   * tile 8 x 32 pixels x BN couts (BN = 64 or 128), wave w owns tile rows 2w, 2w+1 (64 pixels) x all couts;
+//   * 32-channel halo chunks ([10][34] pixels x 64 B, chunk index XOR ((p & 3) ^ ((p >> 1) & 3)): conflict-free
+//     for every tap shift), double-buffered, one step = one tap (K = 32) = BN/16 x 4 MFMAs per wave; the
+//     loop body is a PAIR of chunks (18 steps, fragment-set parity and halo buffer static);
+//   * weight slices [BN][32] through the same 4-deep LDS-DMA ring, counted vmcnt, one raw barrier per step;
+//   * the same wave-private epilogue; one partial row per WAVE (ocr_conv2d_num_mtiles: 4 x tiles).
+constexpr int W4S_HSLOTS = ((W4_HT * W4_WT * 4 + 255) / 256) * 256;   // 16-byte slots per halo buffer (1536)
+constexpr int W4S_HBYTES = W4S_HSLOTS * 16;                          // 24576
+constexpr int W4S_NH = W4S_HSLOTS / 256;                             // halo DMA rounds per chunk (6)
+__device__ __forceinline__ int w4s_swz(int hp) { return (hp & 3) ^ ((hp >> 1) & 3); }
+constexpr int w4s_lds(int bn) { return 2 * W4S_HBYTES + W4_RING * bn * 64; }
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
+    ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
+    const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
+  constexpr int TH = 8, WT = W4_WT, AI = BN / 16, AT = 4, NW = BN / 64, WSTEP = BN * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wbuf = smem + 2 * W4S_HBYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = pixel quarter: tile rows 2w, 2w+1
+  const int L = lane & 15, kg = lane >> 4;
+
+  int bid = blockIdx.x;
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+  const int nt = bid % p.n_tiles;
+  int mt = bid / p.n_tiles;
+  const int txi = mt % p.tiles_x;
+  const int tmp = mt / p.tiles_x;
+  const int tyi = tmp % p.tiles_y;
+  const int img = tmp / p.tiles_y;
+  const int co0 = nt * BN;
+  const int iy0 = tyi * TH - p.pt, ix0 = txi * TILE_W - p.pl;
+  const int npairs = p.cin / 64;                                 // pairs of 32-channel chunks
+
+  const half_t* const xb = x + (size_t)img * p.h * p.w * p.cin;
+  const __attribute__((address_space(1))) void* const zero =
+      (const __attribute__((address_space(1))) void*)(&ocr_conv_zero_page[0]);
+  int hoff[W4S_NH];
+#pragma unroll
+  for (int u = 0; u < W4S_NH; ++u) {
+    const int idx = u * 256 + tid;
+    const int hp = idx >> 2, sl = idx & 3;
+    const int hy = hp / WT, hx = hp - hy * WT;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    hoff[u] = (hp < W4_HT * WT && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+                  ? (iy * p.w + ix) * p.cin + ((sl ^ w4s_swz(hp)) << 3)
+                  : -1;
+  }
+  const int wrow = tid >> 2;
+  const int woff = wrow * p.cin + (((tid & 3) ^ (((wrow >> 3) & 1) << 1)) << 3);
+
+  auto dma_halo = [&](int q, int hb, int u) {       // 32-channel chunk q of this tile -> halo buffer hb
+    const __attribute__((address_space(1))) void* src =
+        hoff[u] >= 0 ? (const __attribute__((address_space(1))) void*)(xb + hoff[u] + q * 32) : zero;
+    __builtin_amdgcn_global_load_lds(
+        src, (__attribute__((address_space(3))) void*)(smem + hb * W4S_HBYTES + (u * 256 + wave * 64) * 16), 16, 0, 0);
+  };
+  auto dma_w = [&](int q, int tap, int ring) {
+    const int tapw = p.flip ? (8 - tap) : tap;
+    const half_t* src = w + ((size_t)tapw * p.cout + co0) * p.cin + q * 32 + woff;
+#pragma unroll
+    for (int u = 0; u < NW; ++u)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + (size_t)u * 64 * p.cin),
+          (__attribute__((address_space(3))) void*)(wbuf + ring * WSTEP + (u * 256 + wave * 64) * 16), 16, 0, 0);
+  };
+
+  // pixel fragment of tile t at tap (ky,kx): hp = (2*wave + (t>>1) + ky)*34 + (t&1)*16 + kx + L; the swizzle
+  // key hp & 7 = (L + 4*(wave&1) + u) & 7 with u = (2*((t>>1)+ky) + kx) & 7 static
+  unsigned tb[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    tb[u] = (unsigned)((wave * 2 * WT + L) * 64 + ((kg ^ w4s_swz((L + 4 * (wave & 1) + u) & 7)) << 4));
+  const unsigned a_lane = (unsigned)(2 * W4S_HBYTES + L * 64 + ((kg ^ (((L >> 3) & 1) << 1)) << 4));
+
+  f32x4 acc[AI][AT];
+#pragma unroll
+  for (int i = 0; i < AI; ++i)
+#pragma unroll
+    for (int t = 0; t < AT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  half8_t fa[AI], fb[2][AT];      // weight fragments: each is re-read right behind the only MFMA group that uses it
+
+#pragma unroll
+  for (int u = 0; u < W4S_NH; ++u) dma_halo(0, 0, u);
+  dma_w(0, 0, 0);
+  dma_w(0, 1, 1);
+  dma_w(0, 2, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < AI; ++i) fa[i] = *reinterpret_cast<const half8_t*>(smem + (a_lane + i * 1024));
+#pragma unroll
+  for (int t = 0; t < AT; ++t)
+    fb[0][t] = *reinterpret_cast<const half8_t*>(smem + (tb[(2 * (t >> 1)) & 7] + ((t >> 1) * WT + (t & 1) * 16) * 64));
+
+  for (int pr = 0; pr < npairs; ++pr) {
+    const int s0 = pr * 18;
+    const int q0 = pr * 2;                          // this pair's first 32-channel chunk
+    const int qlast = 2 * npairs - 1;
+    static_for<0, 18>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int P = j & 1, Q = P ^ 1;
+      constexpr int c = j / 9;                      // chunk of the pair = halo buffer
+      constexpr int jn = (j + 1) % 18, cn = jn / 9, tapn = jn % 9, kyn = tapn / 3, kxn = tapn % 3;
+      constexpr int jd = (j + W4_AHEAD) % 18, cd = jd / 9, tapd = jd % 9;
+      constexpr bool dnext = j + W4_AHEAD >= 18;
+      constexpr int jp = (j + 17) % 18;
+      constexpr bool nh_prev = (jp % 9) >= 1 && (jp % 9) <= W4S_NH;
+      if constexpr (nh_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const int sd_ring = (s0 + j + W4_AHEAD) & (W4_RING - 1);
+      int qd = q0 + cd + (dnext ? 2 : 0);
+      qd = qd > qlast ? qlast : qd;                 // tail: redundant re-fetch keeps the vmcnt arithmetic uniform
+      int qh = q0 + c + 1;
+      qh = qh > qlast ? qlast : qh;
+      const unsigned abase = a_lane + (unsigned)(((s0 + j + 1) & (W4_RING - 1)) * WSTEP);
+      auto read_b = [&](int t) {
+        const int u = (2 * ((t >> 1) + kyn) + kxn) & 7;
+        fb[Q][t] = *reinterpret_cast<const half8_t*>(
+            smem + (tb[u] + cn * W4S_HBYTES + (((t >> 1) + kyn) * WT + (t & 1) * 16 + kxn) * 64));
+      };
+      auto read_a = [&](int i) { fa[i] = *reinterpret_cast<const half8_t*>(smem + (abase + i * 1024)); };
+#pragma unroll
+      for (int g = 0; g < AI; ++g) {
+#pragma unroll
+        for (int t = 0; t < AT; ++t) mfma16_acc(acc[g][t], fa[g], fb[P][t]);
+        if (g == 0) {
+          if constexpr ((j % 9) >= 1 && (j % 9) <= W4S_NH) dma_halo(qh, c ^ 1, (j % 9) - 1);
+          dma_w(qd, tapd, sd_ring);
+        }
+        // the next step's fragments: weight fragment g right behind its group, the four pixel fragments
+        // (all needed by the next step's first group) behind the first two groups
+        if (g == 0) { read_b(0); read_b(1); }
+        if (g == 1) { read_b(2); read_b(3); }
+        read_a(g);
+      }
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  __syncthreads();                                   // every wave's DMAs have landed: the LDS is free
+  {
+    const int mt8 = (img * p.tiles_y + tyi) * p.tiles_x + txi;
+    char* const stage = smem + wave * 2048;
+    const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
+    const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
+    const BnRed* br = p.br.y ? &p.br : nullptr;
+    const int g4 = lane >> 4;
+    const int c8 = lane & 7, pg = lane >> 3;
+    float s[NW][8], q2[NW][8];
+#pragma unroll
+    for (int hf = 0; hf < NW; ++hf)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[hf][e] = 0.f; q2[hf][e] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < AT; ++t) {
+      const int oy = tyi * TH + wave * 2 + (t >> 1);
+#pragma unroll
+      for (int hf = 0; hf < NW; ++hf) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = hf * 4 + ii;
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (has_bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + i * 16 + g4 * 4 + e];
+          }
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][t][e] + bv[e];
+            if (relu) v = v > 0.f ? v : 0.f;
+            o[e] = (half_t)v;
+          }
+          *reinterpret_cast<half4_t*>(stage + L * 128 + (((ii * 2 + (g4 >> 1)) ^ (L & 7)) << 4) + (g4 & 1) * 8) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int px = k * 8 + pg;
+          const int ox = txi * TILE_W + (t & 1) * 16 + px;
+          if (oy < p.oh && ox < p.ow) {
+            half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
+            const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + hf * 64 + c8 * 8;
+            if (accum) {
+              const half8_t old = *reinterpret_cast<const half8_t*>(y + off);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+            }
+            *reinterpret_cast<half8_t*>(y + off) = v;
+            if (do_stats) {
+              if (br != nullptr) {
+                const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const int cc = co0 + hf * 64 + c8 * 8 + e;
+                  const float yf = (float)yv[e];
+                  const float z = (float)(half_t)(yf * br->scale[cc] + br->shift[cc]);
+                  const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
+                  s[hf][e] += dz;
+                  q2[hf][e] += dz * ((yf - br->mean[cc]) * br->invstd[cc]);
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float f = (float)v[e];
+                  s[hf][e] += f;
+                  q2[hf][e] += f * f;
+                }
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    if (do_stats) {
+#pragma unroll
+      for (int hf = 0; hf < NW; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) {
+            s[hf][e] += __shfl_xor(s[hf][e], o, 64);
+            q2[hf][e] += __shfl_xor(q2[hf][e], o, 64);
+          }
+        }
+      if (pg == 0) {
+        float* row = stats + ((size_t)(mt8 * 4 + wave) * 2) * p.cout + co0 + c8 * 8;
+#pragma unroll
+        for (int hf = 0; hf < NW; ++hf)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            row[hf * 64 + e] = s[hf][e];
+            row[p.cout + hf * 64 + e] = q2[hf][e];
+          }
+      }
+    }
+  }
+}
+
 template <int BN, int WCO>
 int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
               hipStream_t st) {
@@ -1150,6 +1404,38 @@ static int launch_w4(const ConvP& p, const void* x, const void* w, const void* b
   return ocr_launch_status();
 }
 
+// small-tile variant: two workgroups per CU; couts in 64- or 128-wide tiles (the 256-multiples go to conv3x3_w4)
+static int conv_w4s_bn(const ConvP& p) {
+  static const int on = [] { const char* e = getenv("OCR_CONV_W4S"); return e ? atoi(e) : 1; }();
+  if (!(on && p.m16 && p.kh == 3 && p.kw == 3 && p.dil == 1 && p.stride == 1 && p.cin % 64 == 0)) return 0;
+  if (p.cout % 256 == 0) return 0;
+  return p.cout % 128 == 0 ? 128 : p.cout % 64 == 0 ? 64 : 0;
+}
+
+template <int BN>
+static int launch_w4s(const ConvP& p0, const void* x, const void* w, const void* bias, void* y, void* stats,
+                      hipStream_t st) {
+  auto kern = conv3x3_w4s_kernel<BN>;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(160 * 1024)) != hipSuccess)
+      return OCR_ERR_HIP;
+    configured = true;
+  }
+  ConvP p = p0;
+  p.tiles_y = ocr_cdiv(p.oh, 8);                 // (the tile configuration may have chosen 16-row tiles)
+  p.n_tiles = p.cout / BN;
+  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
+  dim3 grid((unsigned)(m_tiles * p.n_tiles));
+  static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 2; }();
+  p.xcd_swizzle = (swz & 1) && grid.x % 8 == 0;
+  hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)w4s_lds(BN), st, p, static_cast<const half_t*>(x),
+                     static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
+                     static_cast<float*>(stats));
+  return ocr_launch_status();
+}
+
 template <int BN, int CK, int WCO, int TH = 8>
 int launch(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
            hipStream_t st) {
@@ -1239,8 +1525,10 @@ extern "C" int ocr_conv2d_num_mtiles(const ocr_conv_desc* d) {
   const int tiles = d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
   ConvP p;
   TileCfg c;
-  // the 4-wave kernel emits one partial row per pixel half of a tile
-  if (fill_params(d, &p, &c) == OCR_OK && c.bn == 256 && c.ck == 64 && c.th == 8 && conv_w4_ok(p)) return 2 * tiles;
+  // the 4-wave kernels emit one partial row per pixel half (256-cout tiles) / per wave (64-, 128-cout tiles)
+  if (fill_params(d, &p, &c) != OCR_OK) return tiles;
+  if (conv_w4s_bn(p)) return 4 * tiles;
+  if (c.bn == 256 && c.ck == 64 && c.th == 8 && conv_w4_ok(p)) return 2 * tiles;
   return tiles;
 }
 
@@ -1255,6 +1543,10 @@ extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap)
     return OCR_OK;
   }
   const int wco = c.bn == 256 ? 4 : c.bn == 32 ? 1 : 2;
+  if (const int bn = conv_w4s_bn(p)) {
+    snprintf(out, cap, "conv3x3_w4s_kernel<%d>", bn);
+    return OCR_OK;
+  }
   if (c.bn == 256 && c.ck == 64 && c.th == 8 && conv_w4_ok(p)) {
     snprintf(out, cap, "conv3x3_w4_kernel");
     return OCR_OK;
@@ -1274,6 +1566,8 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     if (c.bn == 128) return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
     return launch_pw<64, 1>(p, x, w_kc, bias, y, stats, st);
   }
+  if (const int bn = conv_w4s_bn(p))
+    return bn == 128 ? launch_w4s<128>(p, x, w_kc, bias, y, stats, st) : launch_w4s<64>(p, x, w_kc, bias, y, stats, st);
   const int key = c.bn * 10000 + c.ck * 100 + c.th;
   switch (key) {
     case 2566408:

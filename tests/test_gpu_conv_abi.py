@@ -38,9 +38,11 @@ SHAPES = [
     (2, 24, 40, 256, 256, 1, 1),     # pointwise GEMM kernel: 7.5 flat tiles, 256-cout tile
     (1, 16, 32, 64, 64, 1, 1),       # ... 64-cout tile, one K stage
     (1, 32, 32, 1024, 128, 1, 1),    # ... 128-cout tile, 16 K stages
-    (2, 100, 130, 64, 64, 3, 1),     # persistent weight-stationary 64-channel kernel: 130 ragged pixel tiles
-    (1, 128, 256, 64, 128, 3, 1),    # ... two cout tiles, workgroups split between them
+    (2, 100, 130, 64, 64, 3, 1),     # small-tile 4-wave kernel (conv3x3_w4s<64>): 130 ragged pixel tiles, one chunk pair
+    (1, 128, 256, 64, 128, 3, 1),    # ... <128>
     (9, 64, 64, 64, 64, 3, 1),       # ... more images than tiles per image
+    (2, 40, 64, 256, 128, 3, 1),     # ... <128>, four chunk pairs
+    (1, 24, 40, 192, 64, 3, 1),      # ... <64>, three chunk pairs (odd)
     (2, 33, 70, 128, 256, 3, 1),     # 4-wave 3x3 kernel (conv3x3_w4): ragged rows and columns, 2 chunks
     (1, 16, 64, 512, 512, 3, 1),     # ... 8 chunks x 18 steps, two cout tiles
     (3, 8, 32, 64, 256, 3, 1),       # ... one chunk (prologue + tail only), several images
@@ -97,11 +99,12 @@ def test_conv_fwd_dgrad_wgrad(device, n, h, w, cin, cout, k, dil):
     assert e_y < tol and e_dx < tol and e_dw < 5e-6
 
 
-@pytest.mark.parametrize("n,h,w,c,variant", [(2, 100, 130, 64, "conv_c64_persist_kernel<64>"),
+@pytest.mark.parametrize("n,h,w,c,variant", [(2, 100, 130, 64, "conv3x3_w4s_kernel<64>"),
+                                             (2, 50, 70, 128, "conv3x3_w4s_kernel<128>"),
                                              (2, 37, 70, 256, "conv3x3_w4_kernel")])
 def test_special_kernels_are_selected_and_emit_stats(device, n, h, w, c, variant):
-    """The 64-channel large-map layers (conv1_2 class) run the persistent weight-stationary kernel, the
-    3x3 layers with 256-cout tiles the 4-wave kernel; their per-tile batch-norm partials (sum, sum of
+    """The 3x3 layers run the 4-wave kernels (64- / 128-cout tiles: two small workgroups per CU; 256-cout
+    tiles: one wave per SIMD with the whole register file); their per-tile batch-norm partials (sum, sum of
     squares of the STORED 16-bit values) add up to the tensor's own sums, and the fused BN-backward
     variant's partials to (sum dz, sum dz*xhat)."""
     from tensorflow_ocr_amd import ops
