@@ -15,7 +15,7 @@ def case(hw, cin, cout):
     x = torch.randn(B, hw, hw, cin, device=dev).half(); w = (torch.randn(9, cout, cin, device=dev) * 0.05).half()
     d = L.ConvDesc(B, hw, hw, cin, hw, hw, cout, 3, 3, 1, 1, 1, 1, 0, L.CONV_STATS)
     y = torch.empty(B, hw, hw, cout, dtype=torch.half, device=dev)
-    st = torch.zeros(B * (hw // 8) * (hw // 32), 2, cout, device=dev)
+    st = torch.zeros(4 * B * (hw // 8) * (hw // 32), 2, cout, device=dev)
     sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     res = {k: [] for k in libs}
     def f(lib):
@@ -32,7 +32,7 @@ def case(hw, cin, cout):
             e1.record(); torch.cuda.synchronize()
             res[k].append(e0.elapsed_time(e1) / 20)
     fl = 2.0 * B * hw * hw * cout * cin * 9
-    ideal = (cin // 64) * 18 * 1024
+    ideal = (cin // 64) * 18 * 1024 * min(cout, 256) // 256
     for k, lib in libs.items():
         buf = (ctypes.c_ulonglong * (2 * 1024))()
         lib.ocr_diag_read_conv(buf, ctypes.c_int(1024))
@@ -42,5 +42,5 @@ def case(hw, cin, cout):
         print("%d:%d>%d abl=%-3s %.3f ms %5.0f TF | main loop %7.0f cyc (ideal %d: %.0f%%) clock %.2f GHz" % (
             hw, cin, cout, k, ms, fl / ms / 1e9, np.median(a[ok, 0]), ideal, 100 * ideal / np.median(a[ok, 0]),
             np.median(a[ok, 0] / a[ok, 1] * 0.1)), flush=True)
-for hw, cin, cout in [(64, 512, 512), (128, 256, 256)]:
+for hw, cin, cout in [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(64, 512, 512), (128, 256, 256)]:
     case(hw, cin, cout)

@@ -1056,13 +1056,22 @@ constexpr int W4S_HSLOTS = ((W4_HT * W4_WT * 4 + 255) / 256) * 256;   // 16-byte
 constexpr int W4S_HBYTES = W4S_HSLOTS * 16;                          // 24576
 constexpr int W4S_NH = W4S_HSLOTS / 256;                             // halo DMA rounds per chunk (6)
 __device__ __forceinline__ int w4s_swz(int hp) { return (hp & 3) ^ ((hp >> 1) & 3); }
-constexpr int w4s_lds(int bn) { return 2 * W4S_HBYTES + W4_RING * bn * 64; }
+// weight ring depth: a step is only BN/16 x 4 MFMAs (256 cycles for BN = 64), an LDS-DMA takes 500+ cycles under
+// load to land: the 4 KB slices of the 64-cout variant are fetched 6 steps ahead (8 slots), the 8 KB slices
+// of the 128-cout variant 3 ahead (4 slots); both rings are 32 KB -> 80 KB with the two halo buffers
+constexpr int w4s_ring(int bn) { return bn == 64 ? 8 : 4; }
+constexpr int w4s_ahead(int bn) { return bn == 64 ? 6 : 3; }
+constexpr int w4s_lds(int bn) { return 2 * W4S_HBYTES + w4s_ring(bn) * bn * 64; }
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
   constexpr int TH = 8, WT = W4_WT, AI = BN / 16, AT = 4, NW = BN / 64, WSTEP = BN * 64;
+  constexpr int RING = w4s_ring(BN), AHEAD = w4s_ahead(BN);
+  // halo pieces of the next chunk: two per step in the chunk's first three steps (6 pieces), so that the last
+  // one has five steps to land before the fragments of the next chunk's first step are read (step 8)
+  constexpr int HPS = 2, HSTEPS = W4S_NH / HPS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wbuf = smem + 2 * W4S_HBYTES;
 
@@ -1101,12 +1110,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
   const int woff = wrow * p.cin + (((tid & 3) ^ (((wrow >> 3) & 1) << 1)) << 3);
 
   auto dma_halo = [&](int q, int hb, int u) {       // 32-channel chunk q of this tile -> halo buffer hb
+    if constexpr ((W4_ABL & 2) != 0) { if (q > 0) return; }
     const __attribute__((address_space(1))) void* src =
         hoff[u] >= 0 ? (const __attribute__((address_space(1))) void*)(xb + hoff[u] + q * 32) : zero;
     __builtin_amdgcn_global_load_lds(
         src, (__attribute__((address_space(3))) void*)(smem + hb * W4S_HBYTES + (u * 256 + wave * 64) * 16), 16, 0, 0);
   };
-  auto dma_w = [&](int q, int tap, int ring) {
+  auto dma_w = [&](int q, int tap, int ring, bool in_loop = false) {
+    if constexpr ((W4_ABL & 1) != 0) { if (in_loop) return; }
     const int tapw = p.flip ? (8 - tap) : tap;
     const half_t* src = w + ((size_t)tapw * p.cout + co0) * p.cin + q * 32 + woff;
 #pragma unroll
@@ -1131,11 +1142,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     for (int t = 0; t < AT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   half8_t fa[AI], fb[2][AT];      // weight fragments: each is re-read right behind the only MFMA group that uses it
 
+  OCR_DIAG_BEGIN()
 #pragma unroll
   for (int u = 0; u < W4S_NH; ++u) dma_halo(0, 0, u);
-  dma_w(0, 0, 0);
-  dma_w(0, 1, 1);
-  dma_w(0, 2, 2);
+#pragma unroll
+  for (int sI = 0; sI < AHEAD; ++sI) dma_w(sI / 9, sI % 9, sI);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -1153,32 +1164,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
       constexpr int P = j & 1, Q = P ^ 1;
       constexpr int c = j / 9;                      // chunk of the pair = halo buffer
       constexpr int jn = (j + 1) % 18, cn = jn / 9, tapn = jn % 9, kyn = tapn / 3, kxn = tapn % 3;
-      constexpr int jd = (j + W4_AHEAD) % 18, cd = jd / 9, tapd = jd % 9;
-      constexpr bool dnext = j + W4_AHEAD >= 18;
-      constexpr int jp = (j + 17) % 18;
-      constexpr bool nh_prev = (jp % 9) >= 1 && (jp % 9) <= W4S_NH;
-      if constexpr (nh_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 1) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
-      __builtin_amdgcn_s_barrier();
-      const int sd_ring = (s0 + j + W4_AHEAD) & (W4_RING - 1);
+      constexpr int jd = (j + AHEAD) % 18, cd = jd / 9, tapd = jd % 9;
+      constexpr bool dnext = j + AHEAD >= 18;
+      // the weight slice of step s+1 (own share) has landed once nothing older than the DMAs of the steps
+      // s-AHEAD+2 .. s-1 (slices of s+2 .. s+AHEAD-1 and the halo pieces issued in those steps) is outstanding
+      constexpr int outstanding = [] {
+        int n = 0;
+        for (int k = 1; k <= AHEAD - 2; ++k) {
+          const int jk = (j + 18 - k) % 18;
+          n += NW + ((jk % 9) < HSTEPS ? HPS : 0);
+        }
+        return n;
+      }();
+      if constexpr (!(W4_ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(outstanding) : "memory");
+      if constexpr (!(W4_ABL & 4)) __builtin_amdgcn_s_barrier();
+      const int sd_ring = (s0 + j + AHEAD) & (RING - 1);
       int qd = q0 + cd + (dnext ? 2 : 0);
       qd = qd > qlast ? qlast : qd;                 // tail: redundant re-fetch keeps the vmcnt arithmetic uniform
       int qh = q0 + c + 1;
       qh = qh > qlast ? qlast : qh;
-      const unsigned abase = a_lane + (unsigned)(((s0 + j + 1) & (W4_RING - 1)) * WSTEP);
+      const unsigned abase = a_lane + (unsigned)(((s0 + j + 1) & (RING - 1)) * WSTEP);
       auto read_b = [&](int t) {
+        if constexpr ((W4_ABL & 8) != 0) return;
         const int u = (2 * ((t >> 1) + kyn) + kxn) & 7;
         fb[Q][t] = *reinterpret_cast<const half8_t*>(
             smem + (tb[u] + cn * W4S_HBYTES + (((t >> 1) + kyn) * WT + (t & 1) * 16 + kxn) * 64));
       };
-      auto read_a = [&](int i) { fa[i] = *reinterpret_cast<const half8_t*>(smem + (abase + i * 1024)); };
+      auto read_a = [&](int i) {
+        if constexpr ((W4_ABL & 8) != 0) return;
+        fa[i] = *reinterpret_cast<const half8_t*>(smem + (abase + i * 1024));
+      };
 #pragma unroll
       for (int g = 0; g < AI; ++g) {
 #pragma unroll
         for (int t = 0; t < AT; ++t) mfma16_acc(acc[g][t], fa[g], fb[P][t]);
         if (g == 0) {
-          if constexpr ((j % 9) >= 1 && (j % 9) <= W4S_NH) dma_halo(qh, c ^ 1, (j % 9) - 1);
-          dma_w(qd, tapd, sd_ring);
+          if constexpr ((j % 9) < HSTEPS) {
+#pragma unroll
+            for (int hp_ = 0; hp_ < HPS; ++hp_) dma_halo(qh, c ^ 1, (j % 9) * HPS + hp_);
+          }
+          dma_w(qd, tapd, sd_ring, true);
         }
         // the next step's fragments: weight fragment g right behind its group, the four pixel fragments
         // (all needed by the next step's first group) behind the first two groups
@@ -1189,7 +1214,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     });
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  OCR_DIAG_END(ocr_diag_conv)
   __syncthreads();                                   // every wave's DMAs have landed: the LDS is free
+  if constexpr ((W4_ABL & 32) != 0) {
+    if (acc[0][0][0] == 12345.f) y[0] = (half_t)1;     // keeps the accumulators alive
+    return;
+  }
   {
     const int mt8 = (img * p.tiles_y + tyi) * p.tiles_x + txi;
     char* const stage = smem + wave * 2048;
@@ -1409,6 +1439,10 @@ static int conv_w4s_bn(const ConvP& p) {
   static const int on = [] { const char* e = getenv("OCR_CONV_W4S"); return e ? atoi(e) : 1; }();
   if (!(on && p.m16 && p.kh == 3 && p.kw == 3 && p.dil == 1 && p.stride == 1 && p.cin % 64 == 0)) return 0;
   if (p.cout % 256 == 0) return 0;
+  // cin = cout = 64 on large maps (conv1_2): 72 KB of weight slices per 32 KB of output make the streamed-weight
+  // form no faster than the weight-stationary persistent kernel (0.93 vs 0.91 ms at 32 x 512^2; ablations in
+  // DESIGN.md) — that layer keeps conv_c64_persist_kernel
+  if (p.cin == 64 && p.cout == 64 && conv_c64_ok(p)) return 0;
   return p.cout % 128 == 0 ? 128 : p.cout % 64 == 0 ? 64 : 0;
 }
 

@@ -38,9 +38,10 @@ SHAPES = [
     (2, 24, 40, 256, 256, 1, 1),     # pointwise GEMM kernel: 7.5 flat tiles, 256-cout tile
     (1, 16, 32, 64, 64, 1, 1),       # ... 64-cout tile, one K stage
     (1, 32, 32, 1024, 128, 1, 1),    # ... 128-cout tile, 16 K stages
-    (2, 100, 130, 64, 64, 3, 1),     # small-tile 4-wave kernel (conv3x3_w4s<64>): 130 ragged pixel tiles, one chunk pair
-    (1, 128, 256, 64, 128, 3, 1),    # ... <128>
-    (9, 64, 64, 64, 64, 3, 1),       # ... more images than tiles per image
+    (2, 100, 130, 64, 64, 3, 1),     # persistent weight-stationary 64-channel kernel: 130 ragged pixel tiles
+    (1, 128, 256, 64, 128, 3, 1),    # small-tile 4-wave kernel (conv3x3_w4s<128>), one chunk pair
+    (9, 64, 64, 64, 64, 3, 1),       # persistent kernel: more images than tiles per image
+    (2, 16, 40, 128, 64, 3, 1),      # conv3x3_w4s<64>, two chunk pairs
     (2, 40, 64, 256, 128, 3, 1),     # ... <128>, four chunk pairs
     (1, 24, 40, 192, 64, 3, 1),      # ... <64>, three chunk pairs (odd)
     (2, 33, 70, 128, 256, 3, 1),     # 4-wave 3x3 kernel (conv3x3_w4): ragged rows and columns, 2 chunks
@@ -99,7 +100,7 @@ def test_conv_fwd_dgrad_wgrad(device, n, h, w, cin, cout, k, dil):
     assert e_y < tol and e_dx < tol and e_dw < 5e-6
 
 
-@pytest.mark.parametrize("n,h,w,c,variant", [(2, 100, 130, 64, "conv3x3_w4s_kernel<64>"),
+@pytest.mark.parametrize("n,h,w,c,variant", [(2, 100, 130, 64, "conv_c64_persist_kernel<64>"),
                                              (2, 50, 70, 128, "conv3x3_w4s_kernel<128>"),
                                              (2, 37, 70, 256, "conv3x3_w4_kernel")])
 def test_special_kernels_are_selected_and_emit_stats(device, n, h, w, c, variant):
