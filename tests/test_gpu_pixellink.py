@@ -44,7 +44,9 @@ def test_pixellinknet_forward_loss_backward(device):
     assert np.abs(dlk - olk.detach().numpy()).max() < 2e-2 * sc
     assert abs(L.item() - float(p2 + ltot)) < 5e-3
     l2p, llink = [t.item() for t in g.collections["losses"]]
-    assert abs(l2p - float(p2)) < 2e-3 and abs(llink - float(ltot)) < 5e-3
+    # (f16 bars; bfloat16 storage rounds 8x coarser at every storage point: tests/test_gpu_bf16.py)
+    tol = 8.0 if O.STORAGE == torch.bfloat16 else 1.0
+    assert abs(l2p - float(p2)) < 2e-3 * tol and abs(llink - float(ltot)) < 5e-3 * tol
 
     def cos(a, b):
         a, b = a.ravel().astype(np.float64), b.ravel().astype(np.float64)
