@@ -60,10 +60,32 @@ struct OcrDiagStamp { unsigned long long t0, r0; };
 #define OCR_DIAG_READER(fn, name)
 #endif
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// In-place accumulate on an accumulator-file (AGPR) quad.  With all 256 accumulator registers live hipcc's
+// builtin form picks a destination different from the C operand and shuffles quads through
+// v_accvgpr_read/write around every MFMA (968 such moves per 1152 MFMAs in the first build of
+// conv3x3_w4_kernel); the asm form pins D = C.  The accumulators are read again only in the epilogue, far beyond
+// the MFMA -> accvgpr_read hazard window (an explicit s_nop block precedes it anyway).
+__device__ __forceinline__ void mfma16_acc(f32x4& c, const half8_t& a, const half8_t& b) {
+#ifdef OCR_BF16
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#else
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#endif
+}
+
+// the same with the accumulator quad in the vector-register half (kernels with more than 256 accumulators)
+__device__ __forceinline__ void mfma16_acc_v(f32x4& c, const half8_t& a, const half8_t& b) {
+#ifdef OCR_BF16
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#else
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
+}
 
 #define OCR_CHECK_ARG(cond)                 \
   do {                                      \

@@ -728,19 +728,6 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// In-place accumulate on an accumulator-file (AGPR) quad.  With all 256 accumulator registers live hipcc's
-// builtin form picks a destination different from the C operand and shuffles quads through
-// v_accvgpr_read/write around every MFMA (968 such moves per 1152 MFMAs in the first build of this
-// kernel); the asm form pins D = C.  The accumulators are read again only in the epilogue, far beyond
-// the MFMA -> accvgpr_read hazard window (an explicit s_nop block precedes it anyway).
-__device__ __forceinline__ void mfma16_acc(f32x4& c, const half8_t& a, const half8_t& b) {
-#ifdef OCR_BF16
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#else
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#endif
-}
-
 // dev ablations (never in a shipped library): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop,
 // 4 = no barrier, 8 = no fragment reads, 16 = no vmcnt wait
 #ifndef W4_ABL

@@ -421,6 +421,219 @@ __global__ __launch_bounds__(512) void wgrad2_kernel(Wg2P p, const half_t* __res
 }
 
 
+// ---------------------------------------------------------------------------
+// v3: the same tiling as v2 (64 ci x 128 co x taps per workgroup, 4 x 32-pixel tiles double-buffered in
+// LDS, permuted-K transposing reads) on FOUR waves, one per SIMD, with the whole register file: wave tile
+// 32 ci x 64 co x taps = 288 accumulator registers.  v2's eight waves own 32 x 32 x taps each and issue
+// 40 transposing reads per 36 MFMAs (every shifted x fragment feeds 2 MFMAs): 142 B/clk of LDS reads
+// per CU, MFMA pipe busy 43 % (profiles/r02_pmc_mfma.json).  Here a shifted x fragment feeds 4 MFMAs and
+// a dy fragment 18: 44 reads per 72 MFMAs, i.e. 0.55x the LDS bytes per MFMA.  Accumulators are pinned
+// in place (mfma16_acc); the staging registers of the next tile (60 per lane) fit beside them.
+template <int N> struct WgIC { static constexpr int value = N; };
+template <typename F>
+__device__ __forceinline__ void static_for4(F&& f) {
+  f(WgIC<0>{});
+  f(WgIC<1>{});
+  f(WgIC<2>{});
+  f(WgIC<3>{});
+}
+
+template <int MAXTAPS>
+__global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __restrict__ x,
+                                                      const half_t* __restrict__ dy,
+                                                      float* __restrict__ slab) {
+  constexpr int NT = 256, COB2 = 128;
+  constexpr int DSTR2 = COB2 * 2 + 32;
+  constexpr int DCH = COB2 / 8;
+  constexpr int NDY = 128 * DCH / NT;      // 8
+  constexpr int XPP = NT / 8;              // 32 halo pixels per pass
+  constexpr int NXMAX = (224 + XPP - 1) / XPP;   // 7
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int halo_px = p.HT * p.WT;
+  const int halo_bytes = halo_px * X2STR;
+  const int stage_bytes = halo_bytes + 128 * DSTR2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ciw = wave >> 1, cow = wave & 1;       // 32-ci half, 64-co half
+  const int li = lane & 15, g = lane >> 4;
+  const int q = li >> 2, pp = li & 3;
+
+  int bid = blockIdx.x;
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+  const int cob = bid % p.nco;
+  bid /= p.nco;
+  const int cib = bid % p.nci;
+  const int split = bid / p.nci;
+  const int ci0 = cib * CIB, co0 = cob * COB2;
+  const int ntaps = p.kh * p.kw;
+
+  f32x4 acc[MAXTAPS][2][4];      // [tap][ci half of 16][co quarter of 16]
+#pragma unroll
+  for (int t = 0; t < MAXTAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_lane = ((4 * g + q) * p.stride) * X2STR + (ciw * 32 + 4 * pp) * 2;
+  const int a_half = 16 * p.stride * X2STR;
+  const int b_lane = (4 * g + q) * DSTR2 + (cow * 64 + 4 * pp) * 2;
+  const int b_half = 16 * DSTR2;
+
+  int xpos[NXMAX];
+  const int xc = tid & 7;
+#pragma unroll
+  for (int u = 0; u < NXMAX; ++u) {
+    const int hp = u * XPP + (tid >> 3);
+    xpos[u] = -1;
+    if (hp < halo_px) {
+      const int hy = hp / p.WT;
+      xpos[u] = (hy << 16) | (hp - hy * p.WT);
+    }
+  }
+
+  const int mt_begin = split * p.tiles_per_split;
+  int mt_end = mt_begin + p.tiles_per_split;
+  if (mt_end > p.m_tiles) mt_end = p.m_tiles;
+
+  u32x4 xr[NXMAX], dr[NDY];
+  auto load_tile = [&](int mt) {
+    const int txi = mt % p.tiles_x;
+    const int tmp = mt / p.tiles_x;
+    const int tyi = tmp % p.tiles_y;
+    const int img = tmp / p.tiles_y;
+    const int iy0 = tyi * T2_H * p.stride - p.pt;
+    const int ix0 = txi * TILE_W * p.stride - p.pl;
+    const half_t* xb = x + (size_t)img * p.h * p.w * p.cin + ci0 + xc * 8;
+#pragma unroll
+    for (int u = 0; u < NXMAX; ++u) {
+      xr[u] = u32x4{0u, 0u, 0u, 0u};
+      if (xpos[u] >= 0) {
+        const int iy = iy0 + (xpos[u] >> 16), ix = ix0 + (xpos[u] & 0xffff);
+        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w && ci0 + xc * 8 < p.cin)
+          xr[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin);
+      }
+    }
+    const half_t* db = dy + (size_t)img * p.oh * p.ow * p.cout + co0;
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int idx = u * NT + tid;
+      const int px = idx / DCH, c = idx % DCH;
+      const int oy = tyi * T2_H + (px >> 5), ox = txi * TILE_W + (px & 31);
+      dr[u] = u32x4{0u, 0u, 0u, 0u};
+      if (oy < p.oh && ox < p.ow && co0 + c * 8 < p.cout)
+        dr[u] = *reinterpret_cast<const u32x4*>(db + ((size_t)oy * p.ow + ox) * p.cout + c * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* xh = smem + buf * stage_bytes;
+    char* dyt = xh + halo_bytes;
+#pragma unroll
+    for (int u = 0; u < NXMAX; ++u)
+      if (xpos[u] >= 0)
+        *reinterpret_cast<u32x4*>(xh + (u * XPP + (tid >> 3)) * X2STR + xc * 16) = xr[u];
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int idx = u * NT + tid;
+      *reinterpret_cast<u32x4*>(dyt + (idx / DCH) * DSTR2 + (idx % DCH) * 16) = dr[u];
+    }
+  };
+
+  // Software pipeline over k-steps (one 32-pixel tile row = 72 MFMAs per wave), fully unrolled per tile:
+  //   step ty:   the 8 dy fragments and the first x fragment pair of step ty+1 are read behind this step's
+  //              taps, the x fragment pair of tap t+1 behind tap t's MFMAs (LDS latency under MFMAs: with
+  //              one wave per SIMD nothing else would cover it);
+  //   ty == 1:   barrier (every wave is done with the other buffer), the next tile goes registers -> LDS,
+  //              the global loads of the tile after it are issued;
+  //   ty == 2:   barrier (next tile visible), so step 3 can prefetch the next tile's first fragments.
+  // 3x3, stride 1, dilation 1 only (all LDS offsets are immediates); other shapes run v2.
+  constexpr int WT_ = 34;
+  OCR_DIAG_BEGIN()
+  if (mt_begin < mt_end) {
+    load_tile(mt_begin);
+    store_tile(0);
+    if (mt_begin + 1 < mt_end) load_tile(mt_begin + 1);
+  }
+  __syncthreads();
+  half8_t bq[2][4], an[2];
+  auto read_b = [&](int set, const char* dyt, int ty) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq[set][j] = tr_pair(dyt + b_lane + ty * 32 * DSTR2 + j * 32, b_half);
+  };
+  auto read_a = [&](const char* xh, int ty, int t) {
+    const int ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) an[i] = tr_pair(xh + a_lane + ((ty + ky) * WT_ + kx) * X2STR + i * 32, a_half);
+  };
+  if (mt_begin < mt_end) {
+    read_b(0, smem + halo_bytes, 0);
+    read_a(smem, 0, 0);
+  }
+  for (int mt = mt_begin; mt < mt_end; ++mt) {
+    const int buf = (mt - mt_begin) & 1;
+    const bool more = mt + 1 < mt_end;
+    const char* xh = smem + buf * stage_bytes;
+    const char* dyt = xh + halo_bytes;
+    const char* xh_n = smem + (buf ^ 1) * stage_bytes;
+    static_for4([&](auto TY) {
+      constexpr int ty = decltype(TY)::value;
+      constexpr int S = ty & 1;                        // dy fragment set of this step
+      if constexpr (ty == 1) {
+        __builtin_amdgcn_s_barrier();                  // all reads of the other buffer are complete
+        if (more) {
+          store_tile(buf ^ 1);
+          if (mt + 2 < mt_end) load_tile(mt + 2);
+        }
+      }
+      if constexpr (ty == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes of the next tile are done
+        __builtin_amdgcn_s_barrier();
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        half8_t a0 = an[0], a1 = an[1];
+        if (t < 8) read_a(xh, ty, t + 1);
+        else if (ty < 3) read_a(xh, ty + 1, 0);
+        else read_a(xh_n, 0, 0);                       // next tile (garbage past the last one: unused)
+        if (t == 4) {
+          if (ty < 3) read_b(S ^ 1, dyt, ty + 1);
+          else read_b(S ^ 1, xh_n + halo_bytes, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (t < 8) mfma16_acc(acc[t][0][j], a0, bq[S][j]);
+          else mfma16_acc_v(acc[t][0][j], a0, bq[S][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (t < 8) mfma16_acc(acc[t][1][j], a1, bq[S][j]);
+          else mfma16_acc_v(acc[t][1][j], a1, bq[S][j]);
+        }
+      }
+    });
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA results settle before the accumulators are read
+  OCR_DIAG_END(ocr_diag_wgrad)
+
+  // D blocks: lane (li, g) holds rows (ci) 4g..4g+3 of column (co) li
+#pragma unroll
+  for (int t = 0; t < MAXTAPS; ++t) {
+    if (t < ntaps) {
+      float* dst = slab + (((size_t)split * ntaps + t) * p.cin + ci0 + ciw * 32 + 4 * g) * p.cout +
+                   co0 + cow * 64 + li;
+      if (ci0 + ciw * 32 < p.cin && co0 + cow * 64 < p.cout) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(size_t)(i * 16 + e) * p.cout + j * 16] = acc[t][i][j][e];
+      }
+    }
+  }
+}
+
 // returns OCR_OK when v2 applies (and fills p / cob), OCR_ERR_UNSUPPORTED otherwise
 int fill2(const ocr_conv_desc* d, Wg2P* p, int* cob) {
   if (d->cin % 32 || d->cout % 32 || d->kh * d->kw > 9) return OCR_ERR_UNSUPPORTED;
@@ -524,7 +737,10 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
     const unsigned grid = (unsigned)(p2.splits * p2.nci * p2.nco);
     static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 2; }();
     p2.xcd_swizzle = (swz & 2) && grid % 8 == 0;
-    if (cob == 128)
+    static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();
+    if (cob == 128 && ntaps == 9 && v3 && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1)
+      rc = launch_wg(wgrad3_kernel<9>, p2, grid, lds, x, dy, workspace, st, 256);
+    else if (cob == 128)
       rc = ntaps == 1 ? launch_wg(wgrad2_kernel<128, 1>, p2, grid, lds, x, dy, workspace, st, 512)
                       : launch_wg(wgrad2_kernel<128, 9>, p2, grid, lds, x, dy, workspace, st, 512);
     else
