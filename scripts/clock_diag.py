@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """In-kernel clock of the two dominant MFMA kernels, on random and on all-zero operands
-(MI355X_MICROARCH.md "DVFS give-back" item 6).
+(MI355X_MICROARCH.md "DVFS give-back" item 6).  OCR_CONV_W4=0 / OCR_CONV_W4S=0 /
+OCR_WGRAD3=0 select the round-1 kernels (conv_igemm_kernel<...>, wgrad2_kernel<...>) for comparison.
 
 Uses the DIAGNOSTIC library libocr_hip_diag.so (same sources, -DOCR_DIAG_CLOCK: s_memtime /
 s_memrealtime stamped once around the main loop of conv_igemm_kernel and wgrad2_kernel, written to a
@@ -56,13 +57,15 @@ def run_case(kind, hw, cin, cout, zero):
         f = lambda: L.call("ocr_conv2d_f16", ctypes.byref(d), L.ptr(x), L.ptr(w), L.ptr(None), L.ptr(y), L.ptr(st), L.stream_ptr())
         name = ctypes.create_string_buffer(128)
         L.load().ocr_conv2d_variant(ctypes.byref(d), name, ctypes.c_size_t(128))
-        variant, reader, slots = name.value.decode(), "ocr_diag_read_conv", min(4096, mt * (cout // 256 if cout >= 256 else 1))
+        variant, reader, slots = name.value.decode(), "ocr_diag_read_conv", 1024
     else:
         nbytes = L.call_size("ocr_conv2d_wgrad_workspace", ctypes.byref(d))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         dw = torch.empty(3, 3, cin, cout, device=dev)
         f = lambda: L.call("ocr_conv2d_wgrad_f16", ctypes.byref(d), L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(ws), ctypes.c_size_t(nbytes), L.stream_ptr())
-        variant, reader, slots = "wgrad2_kernel<%d,9>" % (128 if cout % 128 == 0 else 64), "ocr_diag_read_wgrad", 256
+        v3 = os.environ.get("OCR_WGRAD3", "1") != "0" and cout % 128 == 0 and cin % 64 == 0
+        variant = "wgrad3_kernel<9>" if v3 else "wgrad2_kernel<%d,9>" % (128 if cout % 128 == 0 else 64)
+        reader, slots = "ocr_diag_read_wgrad", 256
     f()
     torch.cuda.synchronize()
     t0 = time.time()

