@@ -919,8 +919,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
   // STORED 16-bit values; with `br` the producing layer's BN-backward sums) accumulated per lane over the
   // rounds and folded over the wave at the end.  No block barrier after the first one, no shared
   // staging: the block-staged epilogue of the 8-wave kernel cost this kernel 16 % of its run time
-  // (4 waves doing two block-wide passes).  Partials go to row 2 * tile + pixel-half (the two waves of
-  // a pixel half own disjoint couts): ocr_conv2d_num_mtiles reports twice the tile count for this kernel.
+  // (4 waves doing two block-wide passes).  The per-wave partials are summed through LDS at the end.
   __syncthreads();                                   // every wave's DMAs have landed: the LDS is free
   {
     const int mt8 = (img * p.tiles_y + tyi) * p.tiles_x + txi;
@@ -1013,16 +1012,21 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
             q2[hf][e] += __shfl_xor(q2[hf][e], o, 64);
           }
         }
+      // the two pixel halves of a cout range meet in LDS (fixed order: deterministic), one partial row per tile
+      float* const red = reinterpret_cast<float*>(smem + 4 * 2048);     // [2 pixel halves][2][256]
       if (pg == 0) {
-        float* row = stats + ((size_t)(mt8 * 2 + wpx) * 2) * p.cout + cow + c8 * 8;
+        float* row = red + wpx * 512 + wco * 128 + c8 * 8;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             row[hf * 64 + e] = s[hf][e];
-            row[p.cout + hf * 64 + e] = q2[hf][e];
+            row[256 + hf * 64 + e] = q2[hf][e];
           }
       }
+      __syncthreads();
+      for (int i = tid; i < 512; i += 256)
+        stats[((size_t)mt8 * 2 + (i >> 8)) * p.cout + co0 + (i & 255)] = red[i] + red[512 + i];
     }
   }
 }
@@ -1038,7 +1042,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
 //     for every tap shift), double-buffered, one step = one tap (K = 32) = BN/16 x 4 MFMAs per wave; the
 //     loop body is a PAIR of chunks (18 steps, fragment-set parity and halo buffer static);
 //   * weight slices [BN][32] through the same 4-deep LDS-DMA ring, counted vmcnt, one raw barrier per step;
-//   * the same wave-private epilogue; one partial row per WAVE (ocr_conv2d_num_mtiles: 4 x tiles).
+//   * the same wave-private epilogue (per-wave batch-norm partials summed through LDS at the end).
 constexpr int W4S_HSLOTS = ((W4_HT * W4_WT * 4 + 255) / 256) * 256;   // 16-byte slots per halo buffer (1536)
 constexpr int W4S_HBYTES = W4S_HSLOTS * 16;                          // 24576
 constexpr int W4S_NH = W4S_HSLOTS / 256;                             // halo DMA rounds per chunk (6)
@@ -1297,16 +1301,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
             q2[hf][e] += __shfl_xor(q2[hf][e], o, 64);
           }
         }
+      // the four waves (pixel quarters) meet in LDS, summed in wave order: one partial row per tile
+      float* const red = reinterpret_cast<float*>(smem + 4 * 2048);     // [4 waves][2][BN]
       if (pg == 0) {
-        float* row = stats + ((size_t)(mt8 * 4 + wave) * 2) * p.cout + co0 + c8 * 8;
+        float* row = red + wave * 2 * BN + c8 * 8;
 #pragma unroll
         for (int hf = 0; hf < NW; ++hf)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             row[hf * 64 + e] = s[hf][e];
-            row[p.cout + hf * 64 + e] = q2[hf][e];
+            row[BN + hf * 64 + e] = q2[hf][e];
           }
       }
+      __syncthreads();
+      if (tid < 2 * BN)
+        stats[((size_t)mt8 * 2 + tid / BN) * p.cout + co0 + tid % BN] =
+            ((red[tid] + red[2 * BN + tid]) + red[4 * BN + tid]) + red[6 * BN + tid];
     }
   }
 }
@@ -1543,14 +1553,7 @@ OCR_DIAG_READER(ocr_diag_read_conv, ocr_diag_conv)
 extern "C" int ocr_conv2d_num_mtiles(const ocr_conv_desc* d) {
   if (!d) return OCR_ERR_INVALID_ARG;
   if (conv_is_pw(d)) return (int)(((long long)d->n * d->oh * d->ow + 255) / 256);   // flat 256-pixel tiles
-  const int tiles = d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
-  ConvP p;
-  TileCfg c;
-  // the 4-wave kernels emit one partial row per pixel half (256-cout tiles) / per wave (64-, 128-cout tiles)
-  if (fill_params(d, &p, &c) != OCR_OK) return tiles;
-  if (conv_w4s_bn(p)) return 4 * tiles;
-  if (c.bn == 256 && c.ck == 64 && c.th == 8 && conv_w4_ok(p)) return 2 * tiles;
-  return tiles;
+  return d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
 }
 
 extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap) {
