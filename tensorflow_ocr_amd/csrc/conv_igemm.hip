@@ -935,6 +935,19 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[hf][e] = 0.f; q2[hf][e] = 0.f; }
+    // this lane's 2 x 8 couts are fixed over the rounds: the producing layer's BN parameters once, up front
+    // (scale / shift decide the ReLU mask per element; mean / invstd enter linearly and are applied to the
+    // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
+    float bsc[2][8], bsh[2][8];
+    if (br != nullptr) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int cc = cow + hf * 64 + c8 * 8 + e;
+          bsc[hf][e] = br->scale[cc]; bsh[hf][e] = br->shift[cc];
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int oy = tyi * TH + wpx * 4 + (t >> 1);
@@ -978,12 +991,11 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
                 const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  const int cc = cow + hf * 64 + c8 * 8 + e;
                   const float yf = (float)yv[e];
-                  const float z = (float)(half_t)(yf * br->scale[cc] + br->shift[cc]);
+                  const float z = (float)(half_t)(yf * bsc[hf][e] + bsh[hf][e]);
                   const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
                   s[hf][e] += dz;
-                  q2[hf][e] += dz * ((yf - br->mean[cc]) * br->invstd[cc]);
+                  q2[hf][e] += dz * yf;
                 }
               } else {
 #pragma unroll
@@ -1002,6 +1014,15 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
       }
     }
     if (do_stats) {
+      if (br != nullptr) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int cc = cow + hf * 64 + c8 * 8 + e;
+            q2[hf][e] = (q2[hf][e] - br->mean[cc] * s[hf][e]) * br->invstd[cc];
+          }
+      }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -1224,6 +1245,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     for (int hf = 0; hf < NW; ++hf)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[hf][e] = 0.f; q2[hf][e] = 0.f; }
+    // (scale / shift decide the ReLU mask per element; mean / invstd enter linearly and are applied to the
+    // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
+    float bsc[NW][8], bsh[NW][8];
+    if (br != nullptr) {
+#pragma unroll
+      for (int hf = 0; hf < NW; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int cc = co0 + hf * 64 + c8 * 8 + e;
+          bsc[hf][e] = br->scale[cc]; bsh[hf][e] = br->shift[cc];
+        }
+    }
 #pragma unroll
     for (int t = 0; t < AT; ++t) {
       const int oy = tyi * TH + wave * 2 + (t >> 1);
@@ -1267,12 +1300,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
                 const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  const int cc = co0 + hf * 64 + c8 * 8 + e;
                   const float yf = (float)yv[e];
-                  const float z = (float)(half_t)(yf * br->scale[cc] + br->shift[cc]);
+                  const float z = (float)(half_t)(yf * bsc[hf][e] + bsh[hf][e]);
                   const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
                   s[hf][e] += dz;
-                  q2[hf][e] += dz * ((yf - br->mean[cc]) * br->invstd[cc]);
+                  q2[hf][e] += dz * yf;
                 }
               } else {
 #pragma unroll
@@ -1291,6 +1323,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
       }
     }
     if (do_stats) {
+      if (br != nullptr) {
+#pragma unroll
+        for (int hf = 0; hf < NW; ++hf)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int cc = co0 + hf * 64 + c8 * 8 + e;
+            q2[hf][e] = (q2[hf][e] - br->mean[cc] * s[hf][e]) * br->invstd[cc];
+          }
+      }
 #pragma unroll
       for (int hf = 0; hf < NW; ++hf)
 #pragma unroll
