@@ -78,6 +78,26 @@ __device__ __forceinline__ void mfma16_acc(f32x4& c, const half8_t& a, const hal
 #endif
 }
 
+// The LAST MFMA statement of a loop body (and of the kernel) carries its own drain: hipcc does not know that
+// the asm MFMAs wrote the accumulator quads a few cycles ago, and the copies it places at a loop exit
+// (v_accvgpr_read / v_accvgpr_mov re-shuffling the quads for the epilogue, spills) may sit directly behind
+// the last asm statement — they did once the epilogue grew, and the quads of the last two MFMAs came out
+// stale.  With the wait states inside the statement nothing can get between the MFMA and its drain.
+__device__ __forceinline__ void mfma16_acc_drain(f32x4& c, const half8_t& a, const half8_t& b) {
+#ifdef OCR_BF16
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" : "+a"(c) : "v"(a), "v"(b));
+#else
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" : "+a"(c) : "v"(a), "v"(b));
+#endif
+}
+__device__ __forceinline__ void mfma16_acc_v_drain(f32x4& c, const half8_t& a, const half8_t& b) {
+#ifdef OCR_BF16
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(c) : "v"(a), "v"(b));
+#else
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(c) : "v"(a), "v"(b));
+#endif
+}
+
 // the same with the accumulator quad in the vector-register half (kernels with more than 256 accumulators)
 __device__ __forceinline__ void mfma16_acc_v(f32x4& c, const half8_t& a, const half8_t& b) {
 #ifdef OCR_BF16

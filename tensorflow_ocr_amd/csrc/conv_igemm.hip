@@ -899,7 +899,10 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) mfma16_acc(acc[g][t], fa[P][g], fb[P][t]);
+        for (int t = 0; t < 8; ++t) {
+          if (j == 17 && g == 7 && t == 7) mfma16_acc_drain(acc[g][t], fa[P][g], fb[P][t]);   // see common.h
+          else mfma16_acc(acc[g][t], fa[P][g], fb[P][t]);
+        }
         if (g == 0) { if constexpr (j >= 1 && j <= W4_NH && !(W4_ABL & 2)) dma_halo(ccn, hsel ^ 1, j - 1); dma_w1(0); read_b(0); read_b(1); }
         if (g == 1) { dma_w1(1); read_b(2); read_b(3); read_b(4); }
         if (g == 2) { dma_w1(2); read_b(5); read_b(6); read_b(7); }
@@ -1209,7 +1212,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
 #pragma unroll
       for (int g = 0; g < AI; ++g) {
 #pragma unroll
-        for (int t = 0; t < AT; ++t) mfma16_acc(acc[g][t], fa[g], fb[P][t]);
+        for (int t = 0; t < AT; ++t) {
+          if (j == 17 && g == AI - 1 && t == AT - 1) mfma16_acc_drain(acc[g][t], fa[g], fb[P][t]);   // see common.h
+          else mfma16_acc(acc[g][t], fa[g], fb[P][t]);
+        }
         if (g == 0) {
           if constexpr ((j % 9) < HSTEPS) {
 #pragma unroll

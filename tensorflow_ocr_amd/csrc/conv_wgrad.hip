@@ -608,12 +608,12 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (t < 8) mfma16_acc(acc[t][1][j], a1, bq[S][j]);
+          else if (ty == 3 && j == 3) mfma16_acc_v_drain(acc[t][1][j], a1, bq[S][j]);   // last MFMA of the tile loop body
           else mfma16_acc_v(acc[t][1][j], a1, bq[S][j]);
         }
       }
     });
   }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA results settle before the accumulators are read
   OCR_DIAG_END(ocr_diag_wgrad)
 
   // D blocks: lane (li, g) holds rows (ci) 4g..4g+3 of column (co) li
