@@ -34,10 +34,15 @@ def short(name):
     m = re.match(r"(?:void )?([A-Za-z0-9_]+)(<[^>]*>)?", name)
     if m and not name.startswith("_Z"):
         return m.group(1) + (m.group(2) or "")
-    m = re.search(r"_ZN\d+_GLOBAL__N_1\d+([a-z0-9_]+?)(I[A-Za-z0-9_]*?E)?(?:Ev|vNS)", name)
-    if m:
-        args = re.findall(r"L[ib](\d+)E", m.group(2) or "")
-        return m.group(1) + ("<" + ",".join(args) + ">" if args else "")
+    m = re.match(r"_ZN\d+_GLOBAL__N_1(\d+)", name)
+    if m:                                   # Itanium mangling: <len><identifier>[I<template args>E]...
+        n0 = m.end()
+        ident = name[n0:n0 + int(m.group(1))]
+        rest = name[n0 + int(m.group(1)):]
+        args = []
+        if rest.startswith("I"):
+            args = re.findall(r"L[ib](\d+)E", rest[:rest.find("EEv") + 1] if "EEv" in rest else rest)
+        return ident + ("<" + ",".join(args) + ">" if args else "")
     return name[:80]
 
 
