@@ -410,24 +410,25 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   const int b_half = 16 * p.stride * PSTR;
   const int b_row = p.stride * WT * PSTR;
 
+  // halo loads are BUFFER loads whose range check supplies the zero padding (offset beyond the descriptor ->
+  // zeros): no branch, no per-load wait (see wgrad3_kernel); the launcher keeps tensors under 2 GiB here
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(x), 0, (int)((size_t)p.n * p.h * p.w * p.cin * 2), 0x00020000);
   u32x4 hreg[NH];
   auto halo_load = [&](int mt) {
     const int txi = mt % p.tiles_x;
     const int tmp = mt / p.tiles_x;
     const int tyi = tmp % p.tiles_y, img = tmp / p.tiles_y;
     const int iy0 = tyi * TH * p.stride - p.pt, ix0 = txi * TILE_W * p.stride - p.pl;
-    const half_t* xb = x + (size_t)img * p.h * p.w * p.cin;
 #pragma unroll
     for (int u = 0; u < NH; ++u) {
       const int idx = u * NT + tid;
-      hreg[u] = u32x4{0u, 0u, 0u, 0u};
-      if (idx < halo_total) {
-        const int hp = idx / CPP, c = idx % CPP;
-        const int hy = hp / WT, hx = hp - hy * WT;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
-          hreg[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin + c * 8);
-      }
+      const int hp = idx / CPP, c = idx % CPP;
+      const int hy = hp / WT, hx = hp - hy * WT;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = idx < halo_total && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+      const unsigned off = ok ? (unsigned)((((img * p.h + iy) * p.w + ix) * p.cin + c * 8) * 2) : 0xfffffff0u;
+      hreg[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
     }
   };
 
@@ -1422,7 +1423,8 @@ static bool conv_c64_ok(const ConvP& p) {
   static const int on = [] { const char* e = getenv("OCR_CONV_PERSIST"); return e ? atoi(e) : 1; }();
   const int ntaps = p.kh * p.kw;
   return on && p.m16 && p.cin == 64 && ntaps > 1 && ntaps <= 9 && p.HT * p.WT * 8 <= 6 * 512 &&
-         p.n * p.tiles_x * p.tiles_y >= 128;        // enough pixel tiles to amortise the weight staging
+         p.n * p.tiles_x * p.tiles_y >= 128 &&      // enough pixel tiles to amortise the weight staging
+         (size_t)p.n * p.h * p.w * p.cin < (1u << 30);   // 32-bit buffer offsets
 }
 
 static int launch_c64(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,

@@ -497,6 +497,16 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
   int mt_end = mt_begin + p.tiles_per_split;
   if (mt_end > p.m_tiles) mt_end = p.m_tiles;
 
+  // Tile staging loads are BUFFER loads with the range check doing the zero padding: a halo pixel outside the
+  // image (or a channel block past cin / cout) gets an offset beyond the descriptor's size and reads as
+  // zero.  With ordinary loads under `if (inside)` hipcc branches around every one of the 15 loads and
+  // waits for each before the next (measured: 39 % of this kernel's main loop, with one wave per SIMD
+  // nothing hides it).  Both tensors are < 2 GiB (checked by the launcher).
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(x), 0, (int)((size_t)p.n * p.h * p.w * p.cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(dy), 0, (int)((size_t)p.n * p.oh * p.ow * p.cout * 2), 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
   u32x4 xr[NXMAX], dr[NDY];
   auto load_tile = [&](int mt) {
     const int txi = mt % p.tiles_x;
@@ -505,25 +515,22 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
     const int img = tmp / p.tiles_y;
     const int iy0 = tyi * T2_H * p.stride - p.pt;
     const int ix0 = txi * TILE_W * p.stride - p.pl;
-    const half_t* xb = x + (size_t)img * p.h * p.w * p.cin + ci0 + xc * 8;
+    const bool cok = ci0 + xc * 8 < p.cin;
 #pragma unroll
     for (int u = 0; u < NXMAX; ++u) {
-      xr[u] = u32x4{0u, 0u, 0u, 0u};
-      if (xpos[u] >= 0) {
-        const int iy = iy0 + (xpos[u] >> 16), ix = ix0 + (xpos[u] & 0xffff);
-        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w && ci0 + xc * 8 < p.cin)
-          xr[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin);
-      }
+      const int iy = iy0 + (xpos[u] >> 16), ix = ix0 + (xpos[u] & 0xffff);
+      const bool ok = xpos[u] >= 0 && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w && cok;
+      const unsigned off = ok ? (unsigned)((((img * p.h + iy) * p.w + ix) * p.cin + ci0 + xc * 8) * 2) : OOB;
+      xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
     }
-    const half_t* db = dy + (size_t)img * p.oh * p.ow * p.cout + co0;
 #pragma unroll
     for (int u = 0; u < NDY; ++u) {
       const int idx = u * NT + tid;
       const int px = idx / DCH, c = idx % DCH;
       const int oy = tyi * T2_H + (px >> 5), ox = txi * TILE_W + (px & 31);
-      dr[u] = u32x4{0u, 0u, 0u, 0u};
-      if (oy < p.oh && ox < p.ow && co0 + c * 8 < p.cout)
-        dr[u] = *reinterpret_cast<const u32x4*>(db + ((size_t)oy * p.ow + ox) * p.cout + c * 8);
+      const bool ok = oy < p.oh && ox < p.ow && co0 + c * 8 < p.cout;
+      const unsigned off = ok ? (unsigned)((((img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8) * 2) : OOB;
+      dr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0));
     }
   };
   auto store_tile = [&](int buf) {
@@ -556,19 +563,25 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
     if (mt_begin + 1 < mt_end) load_tile(mt_begin + 1);
   }
   __syncthreads();
-  half8_t bq[2][4], an[2];
+#ifndef WG3_ABL
+#define WG3_ABL 0      // dev ablations: 1 no tile staging in the loop, 2 no barriers, 4 no x fragment reads, 8 no dy fragment reads
+#endif
+  half8_t bq[2][4], af[3][2];        // x fragment pairs of taps t, t+1, t+2 (slot = tap % 3; 9 taps per step)
   auto read_b = [&](int set, const char* dyt, int ty) {
+    if constexpr ((WG3_ABL & 8) != 0) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) bq[set][j] = tr_pair(dyt + b_lane + ty * 32 * DSTR2 + j * 32, b_half);
   };
-  auto read_a = [&](const char* xh, int ty, int t) {
+  auto read_a = [&](int slot, const char* xh, int ty, int t) {
+    if constexpr ((WG3_ABL & 4) != 0) return;
     const int ky = t / 3, kx = t - ky * 3;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) an[i] = tr_pair(xh + a_lane + ((ty + ky) * WT_ + kx) * X2STR + i * 32, a_half);
+    for (int i = 0; i < 2; ++i) af[slot][i] = tr_pair(xh + a_lane + ((ty + ky) * WT_ + kx) * X2STR + i * 32, a_half);
   };
   if (mt_begin < mt_end) {
     read_b(0, smem + halo_bytes, 0);
-    read_a(smem, 0, 0);
+    read_a(0, smem, 0, 0);
+    read_a(1, smem, 0, 1);
   }
   for (int mt = mt_begin; mt < mt_end; ++mt) {
     const int buf = (mt - mt_begin) & 1;
@@ -580,37 +593,38 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
       constexpr int ty = decltype(TY)::value;
       constexpr int S = ty & 1;                        // dy fragment set of this step
       if constexpr (ty == 1) {
-        __builtin_amdgcn_s_barrier();                  // all reads of the other buffer are complete
+        if constexpr (!(WG3_ABL & 2)) __builtin_amdgcn_s_barrier();                  // all reads of the other buffer are complete
+        if constexpr (!(WG3_ABL & 1)) {
         if (more) {
           store_tile(buf ^ 1);
           if (mt + 2 < mt_end) load_tile(mt + 2);
         }
+        }
       }
       if constexpr (ty == 2) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes of the next tile are done
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(WG3_ABL & 2)) __builtin_amdgcn_s_barrier();
       }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        half8_t a0 = an[0], a1 = an[1];
-        if (t < 8) read_a(xh, ty, t + 1);
-        else if (ty < 3) read_a(xh, ty + 1, 0);
-        else read_a(xh_n, 0, 0);                       // next tile (garbage past the last one: unused)
+        // the x fragment pair two taps ahead (LDS latency under 16 MFMAs), into the slot tap t-1 just freed
+        const int t2 = t + 2;
+        if (t2 < 9) read_a(t2 % 3, xh, ty, t2);
+        else if (ty < 3) read_a(t2 % 3, xh, ty + 1, t2 - 9);
+        else read_a(t2 % 3, xh_n, 0, t2 - 9);          // next tile (garbage past the last one: unused)
         if (t == 4) {
           if (ty < 3) read_b(S ^ 1, dyt, ty + 1);
           else read_b(S ^ 1, xh_n + halo_bytes, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (t < 8) mfma16_acc(acc[t][0][j], a0, bq[S][j]);
-          else mfma16_acc_v(acc[t][0][j], a0, bq[S][j]);
-        }
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (t < 8) mfma16_acc(acc[t][1][j], a1, bq[S][j]);
-          else if (ty == 3 && j == 3) mfma16_acc_v_drain(acc[t][1][j], a1, bq[S][j]);   // last MFMA of the tile loop body
-          else mfma16_acc_v(acc[t][1][j], a1, bq[S][j]);
-        }
+          for (int j = 0; j < 4; ++j) {
+            // 288 accumulators: taps 0..7 fill the 256 accumulator-file registers, tap 8 lives in VGPRs
+            if (t < 8) mfma16_acc(acc[t][i][j], af[t % 3][i], bq[S][j]);
+            else if (ty == 3 && i == 1 && j == 3) mfma16_acc_v_drain(acc[t][i][j], af[t % 3][i], bq[S][j]);   // last MFMA of the loop body
+            else mfma16_acc_v(acc[t][i][j], af[t % 3][i], bq[S][j]);
+          }
       }
     });
   }
@@ -738,7 +752,8 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
     static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 2; }();
     p2.xcd_swizzle = (swz & 2) && grid % 8 == 0;
     static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();
-    if (cob == 128 && ntaps == 9 && v3 && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1)
+    const bool small = (size_t)d->n * d->h * d->w * d->cin < (1u << 30) && (size_t)d->n * d->oh * d->ow * d->cout < (1u << 30);   // < 2 GiB each
+    if (cob == 128 && ntaps == 9 && v3 && small && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1)
       rc = launch_wg(wgrad3_kernel<9>, p2, grid, lds, x, dy, workspace, st, 256);
     else if (cob == 128)
       rc = ntaps == 1 ? launch_wg(wgrad2_kernel<128, 1>, p2, grid, lds, x, dy, workspace, st, 512)
