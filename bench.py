@@ -167,15 +167,27 @@ def main():
     if dom:
         fl, sec, cnt = per[dom]
         ach = fl / sec / 1e12
-        # HBM bytes per launch of this kernel from the committed PMC passes (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE on this same command, summarised by scripts/pmc_traffic.py with
-        # the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md §HBM); null when absent
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = round(json.load(f)[dom]["hbm_bytes_per_launch"])
-        except Exception:
-            pass
+        # HBM bytes per launch of this kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE on this same command, summarised by scripts/pmc_traffic.py with the gfx950 FETCH_SIZE x2
+        # correction of MI355X_MICROARCH.md §HBM); MFMA-pipe occupancy from the SQ counter pass
+        # (scripts/pmc_mfma.py) and the in-kernel clock on random operands from the diagnostic build's
+        # s_memtime / s_memrealtime stamps (scripts/clock_diag.py).  null when the file is absent.
+        def committed(fname, *keys):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as f:
+                    v = json.load(f)
+                for k in keys:
+                    v = v[k]
+                return v
+            except Exception:
+                return None
+        traffic = committed("r02_pmc_traffic.json", dom, "hbm_bytes_per_launch")
+        mfma_busy = committed("r02_pmc_mfma.json", dom, "mfma_busy_frac")
+        clock = None
+        cd = committed("r02_clock_diag.json") or {}
+        ck = [v["clock_ghz_median"] for v in cd.values() if v.get("kernel") == dom and v.get("operands") == "random"]
+        if ck:
+            clock = round(sum(ck) / len(ck), 3)
         # `achieved` averages EVERY launch of the kernel in the timed region (forward and input-gradient
         # launches), as rocprofv3 --stats does; `achieved_alone` = the forward launches only (the
         # input-gradient ones also carry the fused BN-backward sums in their epilogue).
@@ -184,7 +196,8 @@ def main():
                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": cnt // args.steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
                 "share_of_step": round(sec / dt, 3), "achieved_alone": alone,
-                "frac_alone": round(alone / MFMA_F16_PEAK_TFLOPS, 4) if alone else None}
+                "frac_alone": round(alone / MFMA_F16_PEAK_TFLOPS, 4) if alone else None,
+                "clock_ghz": clock, "mfma_busy": mfma_busy}
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
