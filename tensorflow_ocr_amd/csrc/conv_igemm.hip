@@ -1369,268 +1369,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// cin = cout = 64 on large maps (conv1_2 forward / input gradient; 2.1 GB of activations for 0.62 TFLOP: the
-// floor is the HBM stream, 0.43 ms at 5 TB/s, not MFMA).  conv_c64_persist_kernel above keeps the weights in LDS
-// but runs its 8 waves through load-wait -> MFMA -> store in lockstep: 0.35 ms of main loop and 0.40-0.54 ms of
-// epilogue run back to back (0.91 ms), and conv3x3_w4s_kernel<64> pays an LDS-DMA issue per 16 MFMAs for the
-// 72 KB of weight slices it re-fetches per tile (0.93 ms).  This kernel PING-PONGS two groups of four waves
-// inside one persistent workgroup:
-//   * all 9 x [64][64] weight slices stay in LDS (72 KB, staged once);
-//   * each group owns one halo buffer (64-channel halo of an 8 x 32 tile, 44 KB, LDS-DMA, zero page outside
-//     the image) and alternates roles every PHASE: COMPUTE (18 k-steps of 16 MFMAs per wave from LDS
-//     alone: no DMA, no waits on memory) | IO (wave-private epilogue of the tile it has just computed,
-//     staged through its own — now dead — halo buffer; then the halo DMA of its next tile into that buffer);
-//   * so one group's output stores and halo fetches run under the other group's MFMAs; two workgroup
-//     barriers per phase (mid-phase: the IO group's staging is finished before its DMAs may land on it;
-//     end of phase: the DMA'd halo is visible).  Both paths execute the same barriers.
-// The 64 accumulator registers per wave live in VGPRs ("+v"): hipcc splits the register file 128 / 128 as soon
-// as one accumulator-file register is named, and 128 vector registers do not hold both paths.
-// Batch-norm partials: one row per WAVE (ocr_conv2d_num_mtiles: 4 x tiles for this kernel) — the groups have
-// no private barrier to combine them behind.
-constexpr int PP_WBYTES = 9 * 64 * 128;                           // 73728
-constexpr int PP_LDS = 2 * W4_HBYTES + PP_WBYTES;                 // 163840 = the whole LDS
-
-__global__ __launch_bounds__(512) void conv_c64_pp_kernel(
-    ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
-    const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
-  constexpr int TH = 8, WT = W4_WT, AI = 4, AT = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const wst = smem + 2 * W4_HBYTES;            // [9][64 couts][128 B], chunk ^ ((row >> 1) & 7)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wv = wave & 3;          // group, wave in group = tile rows 2wv, 2wv+1
-  const int gtid = tid & 255;
-  const int L = lane & 15, kg = lane >> 4;
-  char* const hbuf = smem + grp * W4_HBYTES;         // this group's halo buffer / epilogue staging
-
-  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
-  const int G = gridDim.x;
-  const int b = blockIdx.x;
-  const int ntile = b < m_tiles ? (m_tiles - b + G - 1) / G : 0;   // tiles of this workgroup: b, b+G, ...
-
-  const __attribute__((address_space(1))) void* const zero =
-      (const __attribute__((address_space(1))) void*)(&ocr_conv_zero_page[0]);
-
-  // weights -> LDS, once: slot idx = tap*512 + tid -> row tid>>3, stored chunk tid&7 holds logical chunk c ^ swz
-  {
-    const int rr = tid >> 3, c = tid & 7;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int tapw = p.flip ? (8 - tap) : tap;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(w + ((size_t)tapw * p.cout + rr) * p.cin + ((c ^ ((rr >> 1) & 7)) << 3)),
-          (__attribute__((address_space(3))) void*)(wst + tap * 8192 + (tid & ~63) * 16), 16, 0, 0);
-    }
-  }
-
-  auto tile_of = [&](int k, int& img, int& tyi, int& txi) {       // k-th tile of this workgroup
-    const int mt = b + k * G;
-    txi = mt % p.tiles_x;
-    const int tmp = mt / p.tiles_x;
-    tyi = tmp % p.tiles_y;
-    img = tmp / p.tiles_y;
-  };
-  // halo DMA of tile k into this group's buffer (4 waves: 11 rounds of 256 slots)
-  auto dma_tile = [&](int k) {
-    int img, tyi, txi;
-    tile_of(k, img, tyi, txi);
-    const int iy0 = tyi * TH - p.pt, ix0 = txi * TILE_W - p.pl;
-    const half_t* const xb = x + (size_t)img * p.h * p.w * p.cin;
-#pragma unroll
-    for (int u = 0; u < W4_NH; ++u) {
-      const int idx = u * 256 + gtid;
-      const int hp = idx >> 3, sl = idx & 7;
-      const int hy = hp / WT, hx = hp - hy * WT;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      const bool ok = hp < W4_HT * WT && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-      const __attribute__((address_space(1))) void* src =
-          ok ? (const __attribute__((address_space(1))) void*)(xb + (iy * p.w + ix) * p.cin + ((sl ^ (hp & 7)) << 3)) : zero;
-      __builtin_amdgcn_global_load_lds(
-          src, (__attribute__((address_space(3))) void*)(hbuf + (u * 256 + wv * 64) * 16), 16, 0, 0);
-    }
-  };
-
-  unsigned tb[2][8];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      tb[ks][u] = (unsigned)(grp * W4_HBYTES + (wv * 2 * WT + L) * 128 + (((ks * 4 + kg) ^ ((L + 4 * (wv & 1) + u) & 7)) << 4));
-  unsigned ab[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-    ab[ks] = (unsigned)(2 * W4_HBYTES + L * 128 + (((ks * 4 + kg) ^ ((L >> 1) & 7)) << 4));
-
-  f32x4 acc[AI][AT];
-  half8_t fa[AI], fb[2][AT];
-
-  if (grp == 0 && ntile > 0) dma_tile(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
-  const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
-  const BnRed* br = p.br.y ? &p.br : nullptr;
-
-  // phase ph: group (ph & 1) computes tile ph; the other group stores tile ph-1 and fetches tile ph+1
-  for (int ph = 0; ph <= ntile; ++ph) {
-    if ((ph & 1) == grp) {
-      // ------------------------------------------------------------ COMPUTE
-      if (ph < ntile) {
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-#pragma unroll
-          for (int t = 0; t < AT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < AI; ++i) fa[i] = *reinterpret_cast<const half8_t*>(smem + (ab[0] + i * 2048));
-#pragma unroll
-        for (int t = 0; t < AT; ++t)
-          fb[0][t] = *reinterpret_cast<const half8_t*>(smem + (tb[0][(2 * (t >> 1)) & 7] + ((t >> 1) * WT + (t & 1) * 16) * 128));
-      }
-      static_for<0, 18>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        constexpr int P = j & 1, Q = P ^ 1;
-        constexpr int jn = (j + 1) % 18, tapn = jn >> 1, ksn = jn & 1, kyn = tapn / 3, kxn = tapn % 3;
-        if constexpr (j == 10) __builtin_amdgcn_s_barrier();       // mid-phase (see the IO path)
-        if (ph < ntile) {
-          auto read_b = [&](int t) {
-            const int u = (2 * ((t >> 1) + kyn) + kxn) & 7;
-            fb[Q][t] = *reinterpret_cast<const half8_t*>(
-                smem + (tb[ksn][u] + (((t >> 1) + kyn) * WT + (t & 1) * 16 + kxn) * 128));
-          };
-          auto read_a = [&](int i) {
-            fa[i] = *reinterpret_cast<const half8_t*>(smem + (ab[ksn] + tapn * 8192 + i * 2048));
-          };
-#pragma unroll
-          for (int g = 0; g < AI; ++g) {
-#pragma unroll
-            for (int t = 0; t < AT; ++t) {
-              if (j == 17 && g == AI - 1 && t == AT - 1) mfma16_acc_v_drain(acc[g][t], fa[g], fb[P][t]);
-              else mfma16_acc_v(acc[g][t], fa[g], fb[P][t]);
-            }
-            if constexpr (j < 17) {
-              if (g == 0) { read_b(0); read_b(1); }
-              if (g == 1) { read_b(2); read_b(3); }
-              read_a(g);
-            }
-          }
-        }
-      });
-      __builtin_amdgcn_s_barrier();                                  // end of phase
-    } else {
-      // ------------------------------------------------------------ IO
-      if (ph >= 1) {
-        // epilogue of tile ph-1 (computed by this group in the previous phase), staged in its own halo buffer
-        int img, tyi, txi;
-        tile_of(ph - 1, img, tyi, txi);
-        const int mt8 = b + (ph - 1) * G;                            // = (img*tiles_y + tyi)*tiles_x + txi
-        char* const stage = hbuf + wv * 2048;
-        const int g4 = lane >> 4;
-        const int c8 = lane & 7, pg = lane >> 3;
-        float s[8], q2[8], bsc[8], bsh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
-        if (br != nullptr) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { bsc[e] = br->scale[c8 * 8 + e]; bsh[e] = br->shift[c8 * 8 + e]; }
-        }
-#pragma unroll
-        for (int t = 0; t < AT; ++t) {
-          const int oy = tyi * TH + wv * 2 + (t >> 1);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (has_bias) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) bv[e] = bias[i * 16 + g4 * 4 + e];
-            }
-            half4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v = acc[i][t][e] + bv[e];
-              if (relu) v = v > 0.f ? v : 0.f;
-              o[e] = (half_t)v;
-            }
-            *reinterpret_cast<half4_t*>(stage + L * 128 + (((i * 2 + (g4 >> 1)) ^ (L & 7)) << 4) + (g4 & 1) * 8) = o;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int px = k * 8 + pg;
-            const int ox = txi * TILE_W + (t & 1) * 16 + px;
-            if (oy < p.oh && ox < p.ow) {
-              half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
-              const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + c8 * 8;
-              if (accum) {
-                const half8_t old = *reinterpret_cast<const half8_t*>(y + off);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
-              }
-              *reinterpret_cast<half8_t*>(y + off) = v;
-              if (do_stats) {
-                if (br != nullptr) {
-                  const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) {
-                    const float yf = (float)yv[e];
-                    const float z = (float)(half_t)(yf * bsc[e] + bsh[e]);
-                    const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
-                    s[e] += dz;
-                    q2[e] += dz * yf;
-                  }
-                } else {
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
-                    s[e] += f;
-                    q2[e] += f * f;
-                  }
-                }
-              }
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        if (do_stats) {
-          if (br != nullptr) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              q2[e] = (q2[e] - br->mean[c8 * 8 + e] * s[e]) * br->invstd[c8 * 8 + e];
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int o = 8; o < 64; o <<= 1) {
-              s[e] += __shfl_xor(s[e], o, 64);
-              q2[e] += __shfl_xor(q2[e], o, 64);
-            }
-          }
-          if (pg == 0) {
-            float* row = stats + ((size_t)(mt8 * 4 + wv) * 2) * p.cout + c8 * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              row[e] = s[e];
-              row[p.cout + e] = q2[e];
-            }
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // own staging reads are done
-      __builtin_amdgcn_s_barrier();                                  // mid-phase: nobody in this group still stages
-      if (ph + 1 < ntile) dma_tile(ph + 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                  // end of phase: the halo is visible
-    }
-  }
-}
-
 template <int BN, int WCO>
 int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
               hipStream_t st) {
@@ -1712,37 +1450,6 @@ static int launch_c64(const ConvP& p, const void* x, const void* w, const void* 
   hipLaunchKernelGGL(kern, dim3((unsigned)(per * p.n_tiles)), dim3(512), lds, st, p, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats), (int)area);
-  return ocr_launch_status();
-}
-
-// ping-pong variant of the 64 -> 64 channel kernel (two 4-wave groups alternate compute / store+fetch)
-static bool conv_c64_pp_ok(const ConvP& p) {
-  static const int on = [] { const char* e = getenv("OCR_CONV_PP"); return e ? atoi(e) : 1; }();
-  return on && p.m16 && p.cin == 64 && p.cout == 64 && p.kh == 3 && p.kw == 3 && p.dil == 1 && p.stride == 1 &&
-         p.n * ocr_cdiv(p.ow, TILE_W) * ocr_cdiv(p.oh, TILE_H) >= 512;       // at least two tiles per workgroup
-}
-
-static int launch_c64_pp(const ConvP& p0, const void* x, const void* w, const void* bias, void* y, void* stats,
-                         hipStream_t st) {
-  auto kern = conv_c64_pp_kernel;
-  static int cus = 0;
-  if (!cus) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(160 * 1024)) != hipSuccess)
-      return OCR_ERR_HIP;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OCR_ERR_HIP;
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  ConvP p = p0;
-  p.tiles_y = ocr_cdiv(p.oh, 8);
-  p.n_tiles = 1;
-  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
-  const int grid = cus < m_tiles ? cus : m_tiles;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), (size_t)PP_LDS, st, p, static_cast<const half_t*>(x),
-                     static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
-                     static_cast<float*>(stats));
   return ocr_launch_status();
 }
 
@@ -1895,12 +1602,7 @@ OCR_DIAG_READER(ocr_diag_read_conv, ocr_diag_conv)
 extern "C" int ocr_conv2d_num_mtiles(const ocr_conv_desc* d) {
   if (!d) return OCR_ERR_INVALID_ARG;
   if (conv_is_pw(d)) return (int)(((long long)d->n * d->oh * d->ow + 255) / 256);   // flat 256-pixel tiles
-  const int tiles = d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
-  ConvP p;
-  TileCfg c;
-  // the ping-pong 64-channel kernel emits one partial row per wave of a tile's group
-  if (fill_params(d, &p, &c) == OCR_OK && conv_c64_pp_ok(p)) return 4 * tiles;
-  return tiles;
+  return d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
 }
 
 extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap) {
@@ -1914,10 +1616,6 @@ extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap)
     return OCR_OK;
   }
   const int wco = c.bn == 256 ? 4 : c.bn == 32 ? 1 : 2;
-  if (conv_c64_pp_ok(p)) {
-    snprintf(out, cap, "conv_c64_pp_kernel");
-    return OCR_OK;
-  }
   if (const int bn = conv_w4s_bn(p)) {
     snprintf(out, cap, "conv3x3_w4s_kernel<%d>", bn);
     return OCR_OK;
@@ -1941,7 +1639,6 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     if (c.bn == 128) return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
     return launch_pw<64, 1>(p, x, w_kc, bias, y, stats, st);
   }
-  if (conv_c64_pp_ok(p)) return launch_c64_pp(p, x, w_kc, bias, y, stats, st);
   if (const int bn = conv_w4s_bn(p))
     return bn == 128 ? launch_w4s<128>(p, x, w_kc, bias, y, stats, st) : launch_w4s<64>(p, x, w_kc, bias, y, stats, st);
   const int key = c.bn * 10000 + c.ck * 100 + c.th;

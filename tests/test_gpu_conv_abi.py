@@ -41,6 +41,7 @@ SHAPES = [
     (2, 100, 130, 64, 64, 3, 1),     # persistent weight-stationary 64-channel kernel: 130 ragged pixel tiles
     (1, 128, 256, 64, 128, 3, 1),    # small-tile 4-wave kernel (conv3x3_w4s<128>), one chunk pair
     (9, 64, 64, 64, 64, 3, 1),       # persistent kernel: more images than tiles per image
+    (3, 203, 230, 64, 64, 3, 1),     # ... 624 ragged tiles, 2 or 3 per workgroup
     (2, 16, 40, 128, 64, 3, 1),      # conv3x3_w4s<64>, two chunk pairs
     (2, 40, 64, 256, 128, 3, 1),     # ... <128>, four chunk pairs
     (1, 24, 40, 192, 64, 3, 1),      # ... <64>, three chunk pairs (odd)
