@@ -481,111 +481,168 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
   const int b_lane = (4 * g + q) * DSTR2 + (cow * 64 + 4 * pp) * 2;
   const int b_half = 16 * DSTR2;
 
-  int xpos[NXMAX];
-  const int xc = tid & 7;
-#pragma unroll
-  for (int u = 0; u < NXMAX; ++u) {
-    const int hp = u * XPP + (tid >> 3);
-    xpos[u] = -1;
-    if (hp < halo_px) {
-      const int hy = hp / p.WT;
-      xpos[u] = (hy << 16) | (hp - hy * p.WT);
-    }
-  }
-
   const int mt_begin = split * p.tiles_per_split;
   int mt_end = mt_begin + p.tiles_per_split;
   if (mt_end > p.m_tiles) mt_end = p.m_tiles;
 
-  // Tile staging loads are BUFFER loads with the range check doing the zero padding: a halo pixel outside the
-  // image (or a channel block past cin / cout) gets an offset beyond the descriptor's size and reads as
-  // zero.  With ordinary loads under `if (inside)` hipcc branches around every one of the 15 loads and
-  // waits for each before the next (measured: 39 % of this kernel's main loop, with one wave per SIMD
-  // nothing hides it).  Both tensors are < 2 GiB (checked by the launcher).
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<half_t*>(x), 0, (int)((size_t)p.n * p.h * p.w * p.cin * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<half_t*>(dy), 0, (int)((size_t)p.n * p.oh * p.ow * p.cout * 2), 0x00020000);
+  // Tile staging: 15 PIECES per tile (7 passes over the 6 x 34-pixel x halo, 8 over the 128 dy pixels), each
+  // one 16-byte buffer load per lane and, a tile later, one 16-byte LDS store.  With one wave per SIMD every
+  // instruction between two MFMAs costs issue cycles unless it is (nearly) alone in the gap, so the pieces
+  // are built to be SHORT and are handed out one per MFMA gap by the main loop:
+  //   * zero padding by the buffer range check with a PER-IMAGE descriptor: rows above / below the image
+  //     fall outside [0, image bytes) on their own (negative offsets wrap), only the column needs a compare;
+  //   * per-lane constants (column, relative byte offset) are set up once; the tile's origin is scalar and
+  //     advances incrementally (no divisions in the loop);
+  //   * a piece is two halves — offset (add, compare, select, add) | load — issued in consecutive gaps.
+  // Both tensors are < 2 GiB (checked by the launcher).  Measured (ablation, conv4_2): staging issued as
+  // one block per tile cost 2,800 of 8,700 cycles per tile.
   constexpr unsigned OOB = 0xfffffff0u;
-  u32x4 xr[NXMAX], dr[NDY];
-  auto load_tile = [&](int mt) {
-    const int txi = mt % p.tiles_x;
-    const int tmp = mt / p.tiles_x;
-    const int tyi = tmp % p.tiles_y;
-    const int img = tmp / p.tiles_y;
-    const int iy0 = tyi * T2_H * p.stride - p.pt;
-    const int ix0 = txi * TILE_W * p.stride - p.pl;
-    const bool cok = ci0 + xc * 8 < p.cin;
+  constexpr int WT_ = 34, HALO_PX = 6 * WT_;             // 3x3, stride 1: 6 x 34 halo pixels per 4 x 32 tile
+  const int xc = tid & 7;
+  int hxv[NXMAX];                                        // halo column of piece u (huge = never valid)
+  unsigned relx[NXMAX];                                  // byte offset relative to the tile's halo origin
 #pragma unroll
-    for (int u = 0; u < NXMAX; ++u) {
-      const int iy = iy0 + (xpos[u] >> 16), ix = ix0 + (xpos[u] & 0xffff);
-      const bool ok = xpos[u] >= 0 && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w && cok;
-      const unsigned off = ok ? (unsigned)((((img * p.h + iy) * p.w + ix) * p.cin + ci0 + xc * 8) * 2) : OOB;
-      xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+  for (int u = 0; u < NXMAX; ++u) {
+    const int hp = u * XPP + (tid >> 3);
+    const int hy = hp / WT_, hx = hp - hy * WT_;
+    hxv[u] = (hp < HALO_PX && ci0 + xc * 8 < p.cin) ? hx : 0x40000000;
+    relx[u] = (unsigned)(((hy * p.w + hx) * p.cin + ci0 + xc * 8) * 2);
+  }
+  const int dc = tid % DCH, dprow = tid / DCH;           // dy piece u: pixel u*16 + dprow = row u>>1, column (u&1)*16 + dprow
+  int colv[2];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) colv[h2] = (co0 + dc * 8 < p.cout) ? h2 * 16 + dprow : 0x40000000;
+  const unsigned reld = (unsigned)((dprow * p.cout + co0 + dc * 8) * 2);
+
+  // the tile whose pieces are being loaded: scalar state
+  int l_mt = mt_begin;
+  int l_txi = l_mt % p.tiles_x, l_tyi = (l_mt / p.tiles_x) % p.tiles_y, l_img = l_mt / (p.tiles_x * p.tiles_y);
+  int s_ix0 = 0, s_orgx = 0, s_ox0 = 0, s_orgd = 0;
+  __amdgpu_buffer_rsrc_t xrs, drs;
+  auto load_setup = [&]() {
+    s_ix0 = l_txi * TILE_W - p.pl;
+    s_orgx = ((l_tyi * T2_H - p.pt) * p.w + s_ix0) * p.cin * 2;
+    s_ox0 = l_txi * TILE_W;
+    s_orgd = ((l_tyi * T2_H) * p.ow + s_ox0) * p.cout * 2;
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(x) + (size_t)l_img * p.h * p.w * p.cin, 0,
+                                            p.h * p.w * p.cin * 2, 0x00020000);
+    drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(dy) + (size_t)l_img * p.oh * p.ow * p.cout, 0,
+                                            p.oh * p.ow * p.cout * 2, 0x00020000);
+  };
+  auto load_advance = [&]() {                            // next tile of this split; stays on the last one
+    if (l_mt + 1 < mt_end) {
+      ++l_mt;
+      if (++l_txi == p.tiles_x) {
+        l_txi = 0;
+        if (++l_tyi == p.tiles_y) {
+          l_tyi = 0;
+          ++l_img;
+        }
+      }
     }
-#pragma unroll
-    for (int u = 0; u < NDY; ++u) {
-      const int idx = u * NT + tid;
-      const int px = idx / DCH, c = idx % DCH;
-      const int oy = tyi * T2_H + (px >> 5), ox = txi * TILE_W + (px & 31);
-      const bool ok = oy < p.oh && ox < p.ow && co0 + c * 8 < p.cout;
-      const unsigned off = ok ? (unsigned)((((img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8) * 2) : OOB;
-      dr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0));
+    load_setup();
+  };
+  u32x4 xr[NXMAX], dr[NDY];
+  unsigned offp = 0;
+  auto load_half = [&](int hh) {                          // hh = 2 * piece + (0: offset | 1: load)
+    const int k = hh >> 1;
+    if (k >= NXMAX + NDY) return;
+    if (k < NXMAX) {
+      if (!(hh & 1)) {
+        const int ix = hxv[k] + s_ix0;
+        offp = (unsigned)ix < (unsigned)p.w ? relx[k] + (unsigned)s_orgx : OOB;
+      } else {
+        xr[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, offp, 0, 0));
+      }
+    } else {
+      const int u = k - NXMAX;
+      if (!(hh & 1)) {
+        const int ox = colv[u & 1] + s_ox0;
+        offp = (unsigned)ox < (unsigned)p.ow ? reld + (unsigned)(s_orgd + ((u >> 1) * p.ow + (u & 1) * 16) * p.cout * 2) : OOB;
+      } else {
+        dr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, offp, 0, 0));
+      }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_piece = [&](int buf, int k) {
     char* xh = smem + buf * stage_bytes;
-    char* dyt = xh + halo_bytes;
-#pragma unroll
-    for (int u = 0; u < NXMAX; ++u)
-      if (xpos[u] >= 0)
-        *reinterpret_cast<u32x4*>(xh + (u * XPP + (tid >> 3)) * X2STR + xc * 16) = xr[u];
-#pragma unroll
-    for (int u = 0; u < NDY; ++u) {
-      const int idx = u * NT + tid;
-      *reinterpret_cast<u32x4*>(dyt + (idx / DCH) * DSTR2 + (idx % DCH) * 16) = dr[u];
+    if (k < NXMAX) {
+      if (k * XPP + XPP <= HALO_PX || k * XPP + (tid >> 3) < HALO_PX)
+        *reinterpret_cast<u32x4*>(xh + (k * XPP + (tid >> 3)) * X2STR + xc * 16) = xr[k];
+    } else if (k < NXMAX + NDY) {
+      const int u = k - NXMAX;
+      *reinterpret_cast<u32x4*>(xh + halo_bytes + (u * 16 + dprow) * DSTR2 + dc * 16) = dr[u];
     }
+  };
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int hh = 0; hh < 2 * (NXMAX + NDY); ++hh) load_half(hh);
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NXMAX + NDY; ++k) store_piece(buf, k);
   };
 
   // Software pipeline over k-steps (one 32-pixel tile row = 72 MFMAs per wave), fully unrolled per tile:
   //   step ty:   the 8 dy fragments and the first x fragment pair of step ty+1 are read behind this step's
   //              taps, the x fragment pair of tap t+1 behind tap t's MFMAs (LDS latency under MFMAs: with
   //              one wave per SIMD nothing else would cover it);
-  //   ty == 1:   barrier (every wave is done with the other buffer), the next tile goes registers -> LDS,
-  //              the global loads of the tile after it are issued;
-  //   ty == 2:   barrier (next tile visible), so step 3 can prefetch the next tile's first fragments.
+  //   ty == 1:   barrier (every wave is done with the other buffer); the next tile goes registers -> LDS, one
+  //              piece per free MFMA gap, and the loads of the tile after it start behind them;
+  //   ty == 2:   barrier (next tile visible), so step 3 can prefetch the next tile's first fragments; the
+  //              rest of the loads (each has more than two steps to land).  Past the split's last tile the
+  //              loads re-fetch that tile and the stores fill the unused buffer: no branches in the loop.
   // 3x3, stride 1, dilation 1 only (all LDS offsets are immediates); other shapes run v2.
-  constexpr int WT_ = 34;
   OCR_DIAG_BEGIN()
   if (mt_begin < mt_end) {
-    load_tile(mt_begin);
+    load_setup();
+    load_tile();
     store_tile(0);
-    if (mt_begin + 1 < mt_end) load_tile(mt_begin + 1);
+    load_advance();
+    load_tile();
   }
   __syncthreads();
 #ifndef WG3_ABL
 #define WG3_ABL 0      // dev ablations: 1 no tile staging in the loop, 2 no barriers, 4 no x fragment reads, 8 no dy fragment reads
 #endif
-  half8_t bq[2][4], af[3][2];        // x fragment pairs of taps t, t+1, t+2 (slot = tap % 3; 9 taps per step)
-  auto read_b = [&](int set, const char* dyt, int ty) {
-    if constexpr ((WG3_ABL & 8) != 0) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bq[set][j] = tr_pair(dyt + b_lane + ty * 32 * DSTR2 + j * 32, b_half);
+  // Fragments are kept as their two transposing reads (k = 0..3 | 4..7 of the lane's eight), so that the loop
+  // can issue ONE LDS read behind each MFMA: with one wave per SIMD an instruction between two MFMAs costs
+  // its issue cycles unless it is alone in the gap (measured: 4 reads + a wait behind every 4th MFMA cost
+  // 6.4 cycles per read, 19 % of the loop).  x fragment pairs: slot = running tap index & 3 (36 taps per
+  // tile), fetched two taps ahead; dy fragments: two sets, the next step's fetched behind taps 4 and 5.
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  short4v al[4][2], ah[4][2], bl[2][4], bh[2][4];
+  auto rd = [&](const char* a) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(a)); };
+  auto frag = [&](const short4v& lo, const short4v& hi) {
+    short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(half8_t, v);
   };
-  auto read_a = [&](int slot, const char* xh, int ty, int t) {
+  // read k (0..7) of the dy fragments of step ty: fragment j = k >> 1, half k & 1
+  auto read_b1 = [&](int set, const char* dyt, int ty, int k) {
+    if constexpr ((WG3_ABL & 8) != 0) return;
+    const char* a = dyt + b_lane + ty * 32 * DSTR2 + (k >> 1) * 32 + ((k & 1) ? b_half : 0);
+    if (k & 1) bh[set][k >> 1] = rd(a);
+    else bl[set][k >> 1] = rd(a);
+  };
+  // read k (0..3) of the x fragment pair of tap t of step ty: fragment i = k >> 1, half k & 1
+  auto read_a1 = [&](int slot, const char* xh, int ty, int t, int k) {
     if constexpr ((WG3_ABL & 4) != 0) return;
     const int ky = t / 3, kx = t - ky * 3;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) af[slot][i] = tr_pair(xh + a_lane + ((ty + ky) * WT_ + kx) * X2STR + i * 32, a_half);
+    const char* a = xh + a_lane + ((ty + ky) * WT_ + kx) * X2STR + (k >> 1) * 32 + ((k & 1) ? a_half : 0);
+    if (k & 1) ah[slot][k >> 1] = rd(a);
+    else al[slot][k >> 1] = rd(a);
   };
   if (mt_begin < mt_end) {
-    read_b(0, smem + halo_bytes, 0);
-    read_a(0, smem, 0, 0);
-    read_a(1, smem, 0, 1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) read_b1(0, smem + halo_bytes, 0, k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      read_a1(0, smem, 0, 0, k);
+      read_a1(1, smem, 0, 1, k);
+    }
   }
   for (int mt = mt_begin; mt < mt_end; ++mt) {
     const int buf = (mt - mt_begin) & 1;
-    const bool more = mt + 1 < mt_end;
     const char* xh = smem + buf * stage_bytes;
     const char* dyt = xh + halo_bytes;
     const char* xh_n = smem + (buf ^ 1) * stage_bytes;
@@ -594,36 +651,44 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
       constexpr int S = ty & 1;                        // dy fragment set of this step
       if constexpr (ty == 1) {
         if constexpr (!(WG3_ABL & 2)) __builtin_amdgcn_s_barrier();                  // all reads of the other buffer are complete
-        if constexpr (!(WG3_ABL & 1)) {
-        if (more) {
-          store_tile(buf ^ 1);
-          if (mt + 2 < mt_end) load_tile(mt + 2);
-        }
-        }
       }
+      if constexpr (ty == 1) load_advance();
       if constexpr (ty == 2) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own LDS writes of the next tile are done
         if constexpr (!(WG3_ABL & 2)) __builtin_amdgcn_s_barrier();
       }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        // the x fragment pair two taps ahead (LDS latency under 16 MFMAs), into the slot tap t-1 just freed
         const int t2 = t + 2;
-        if (t2 < 9) read_a(t2 % 3, xh, ty, t2);
-        else if (ty < 3) read_a(t2 % 3, xh, ty + 1, t2 - 9);
-        else read_a(t2 % 3, xh_n, 0, t2 - 9);          // next tile (garbage past the last one: unused)
-        if (t == 4) {
-          if (ty < 3) read_b(S ^ 1, dyt, ty + 1);
-          else read_b(S ^ 1, xh_n + halo_bytes, 0);
-        }
+        const int cur = (ty * 9 + t) & 3, nxt = (ty * 9 + t + 2) & 3;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
+            const half8_t fa = frag(al[cur][i], ah[cur][i]), fb = frag(bl[S][j], bh[S][j]);
             // 288 accumulators: taps 0..7 fill the 256 accumulator-file registers, tap 8 lives in VGPRs
-            if (t < 8) mfma16_acc(acc[t][i][j], af[t % 3][i], bq[S][j]);
-            else if (ty == 3 && i == 1 && j == 3) mfma16_acc_v_drain(acc[t][i][j], af[t % 3][i], bq[S][j]);   // last MFMA of the loop body
-            else mfma16_acc_v(acc[t][i][j], af[t % 3][i], bq[S][j]);
+            if (t < 8) mfma16_acc(acc[t][i][j], fa, fb);
+            else if (ty == 3 && i == 1 && j == 3) mfma16_acc_v_drain(acc[t][i][j], fa, fb);   // last MFMA of the loop body
+            else mfma16_acc_v(acc[t][i][j], fa, fb);
+            const int m = i * 4 + j;                   // one LDS read behind this MFMA
+            if (m < 4) {
+              // x fragment pair two taps ahead (next step / next tile past this one's; garbage past the last tile: unused)
+              if (t2 < 9) read_a1(nxt, xh, ty, t2, m);
+              else if (ty < 3) read_a1(nxt, xh, ty + 1, t2 - 9, m);
+              else read_a1(nxt, xh_n, 0, t2 - 9, m);
+            } else if (t == 4 || t == 5) {
+              const int k = (t - 4) * 4 + (m - 4);
+              if (ty < 3) read_b1(S ^ 1, dyt, ty + 1, k);
+              else read_b1(S ^ 1, xh_n + halo_bytes, 0, k);
+            } else if constexpr (!(WG3_ABL & 1)) {
+              // free gap f (28 per step): step 1 = the 15 stores, then load halves 0..12; step 2 = load halves 13..29
+              const int f = (t < 4 ? t * 4 : (t - 2) * 4) + (m - 4);
+              if constexpr (ty == 1) {
+                if (f < NXMAX + NDY) store_piece(buf ^ 1, f);
+                else load_half(f - (NXMAX + NDY));
+              }
+              if constexpr (ty == 2) load_half(f + 28 - (NXMAX + NDY));
+            }
           }
       }
     });
