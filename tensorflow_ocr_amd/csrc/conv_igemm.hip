@@ -768,38 +768,46 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
   const int nchunks = p.cin / 64;
 
   // ---- per-lane DMA sources -------------------------------------------------------------------
-  const half_t* const xb = x + (size_t)img * p.h * p.w * p.cin;
-  const __attribute__((address_space(1))) void* const zero =
-      (const __attribute__((address_space(1))) void*)(&ocr_conv_zero_page[0]);
-  int hoff[W4_NH];                                   // element offset of this lane's halo slot, -1 = zero page
+  // LDS-DMA by BUFFER loads (buffer_load_dwordx4 ... lds): the per-lane part of every address is a constant
+  // 32-bit offset, the part that changes from DMA to DMA (channel chunk, tap, cout quarter) is scalar, so
+  // a DMA costs no vector instruction; a halo slot outside the image carries an offset beyond the
+  // descriptor's range and the range check writes zeros into its LDS slot (no zero page, no select).
+  // With one wave per SIMD every instruction between two MFMAs costs issue cycles (see the main loop).
+  constexpr unsigned OOB = 0x80000000u;              // + any scalar offset of a < 2 GiB tensor: still out of range
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(x) + (size_t)img * p.h * p.w * p.cin, 0, p.h * p.w * p.cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(w), 0, 9 * p.cout * p.cin * 2, 0x00020000);
+  unsigned hvo[W4_NH];                               // byte offset of this lane's halo slot in the image
 #pragma unroll
   for (int u = 0; u < W4_NH; ++u) {
     const int idx = u * 256 + tid;
     const int hp = idx >> 3, sl = idx & 7;
     const int hy = hp / WT, hx = hp - hy * WT;
     const int iy = iy0 + hy, ix = ix0 + hx;
-    hoff[u] = (hp < W4_HT * WT && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
-                  ? (iy * p.w + ix) * p.cin + ((sl ^ (hp & 7)) << 3)
-                  : -1;
+    hvo[u] = (hp < W4_HT * WT && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+                 ? (unsigned)(((iy * p.w + ix) * p.cin + ((sl ^ (hp & 7)) << 3)) * 2)
+                 : OOB;
   }
   // weights: slot idx = u*256 + tid -> row u*64 + (tid>>2), stored chunk tid&3 holds logical chunk c ^ swz
   const int wrow = tid >> 2;
-  const int woff = wrow * p.cin + (((tid & 3) ^ (((wrow >> 3) & 1) << 1)) << 3);
+  const unsigned wvo = (unsigned)((wrow * p.cin + (((tid & 3) ^ (((wrow >> 3) & 1) << 1)) << 3)) * 2);
 
   auto dma_halo = [&](int cc, int hb, int u) {
-    const __attribute__((address_space(1))) void* src =
-        hoff[u] >= 0 ? (const __attribute__((address_space(1))) void*)(xb + hoff[u] + cc * 64) : zero;
-    __builtin_amdgcn_global_load_lds(
-        src, (__attribute__((address_space(3))) void*)(smem + hb * W4_HBYTES + (u * 256 + wave * 64) * 16), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        xrs, (__attribute__((address_space(3))) void*)(smem + hb * W4_HBYTES + (u * 256 + wave * 64) * 16), 16,
+        hvo[u], cc * 128, 0, 0);
+  };
+  // quarter u (64 couts) of the [256 couts][32 channels] slice of (chunk cc, tap, k-half ks) -> ring slot
+  auto dma_wq = [&](int cc, int tap, int ks, int ring, int u) {
+    const int tapw = p.flip ? (8 - tap) : tap;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        wrs, (__attribute__((address_space(3))) void*)(wbuf + ring * W4_WSTEP + (u * 256 + wave * 64) * 16), 16,
+        wvo, (((tapw * p.cout + co0 + u * 64) * p.cin) + cc * 64 + ks * 32) * 2, 0, 0);
   };
   auto dma_w = [&](int cc, int tap, int ks, int ring) {
-    const int tapw = p.flip ? (8 - tap) : tap;
-    const half_t* src = w + ((size_t)tapw * p.cout + co0) * p.cin + cc * 64 + ks * 32 + woff;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + (size_t)u * 64 * p.cin),
-          (__attribute__((address_space(3))) void*)(wbuf + ring * W4_WSTEP + (u * 256 + wave * 64) * 16), 16, 0, 0);
+    for (int u = 0; u < 4; ++u) dma_wq(cc, tap, ks, ring, u);
   };
 
   // ---- per-lane LDS read bases ------------------------------------------------------------------
@@ -865,17 +873,12 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       }
       if constexpr (!(W4_ABL & 4)) __builtin_amdgcn_s_barrier();
-      // DMA (behind the first MFMA groups, below): halo piece of the next chunk (steps 1..11), then the
-      // weight slice of step s+3
+      // DMA: halo piece of the next chunk (steps 1..11), then the weight slice of step s+3
       const int sd_ring = (s0 + j + W4_AHEAD) & (W4_RING - 1);
       const int d_cc = dnext ? ccn : cc;
-      const int d_tapw = p.flip ? (8 - (jd >> 1)) : (jd >> 1);
-      const half_t* const wsrc = w + ((size_t)d_tapw * p.cout + co0) * p.cin + d_cc * 64 + (jd & 1) * 32 + woff;
       auto dma_w1 = [&](int u) {
         if constexpr (W4_ABL & 1) return;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(wsrc + (size_t)u * 64 * p.cin),
-            (__attribute__((address_space(3))) void*)(wbuf + sd_ring * W4_WSTEP + (u * 256 + wave * 64) * 16), 16, 0, 0);
+        dma_wq(d_cc, jd >> 1, jd & 1, sd_ring, u);
       };
       if constexpr (j == 17) {
         hsel ^= 1;                                // the prefetched fragments belong to the next chunk
@@ -885,9 +888,11 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
           for (int u = 0; u < 8; ++u) tb[ks][u] = hsel ? tb[ks][u] + W4_HBYTES : tb[ks][u] - W4_HBYTES;
       }
       const unsigned abase = a_lane + (unsigned)(((s0 + j + 1) & (W4_RING - 1)) * W4_WSTEP);
-      // 64 MFMAs of this step from set P; the 16 fragment reads of the next step go into set Q BEHIND the
-      // MFMA groups (pixel fragments first: all eight are needed by the next step's first group; none
-      // behind the last group, so every fragment is >= 8 MFMAs old when the next step starts)
+      // 64 MFMAs of this step from set P.  Everything else is handed out ONE OPERATION PER MFMA GAP: with one
+      // wave per SIMD an instruction between two MFMAs is free only when it is (nearly) alone there — clustered
+      // behind every 8th MFMA the same reads and DMAs cost 5.7 cycles per instruction (18 % of the loop).
+      // Odd gaps 1..31: the 16 fragment reads of the next step into set Q (pixel fragments first: all eight are
+      // needed by the next step's first group); gap 32: the halo DMA; gaps 36..48: the four weight DMAs.
       auto read_b = [&](int t) {
         if constexpr (W4_ABL & 8) return;
         const int u = (2 * ((t >> 1) + kyn) + kxn) & 7;
@@ -903,14 +908,16 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
         for (int t = 0; t < 8; ++t) {
           if (j == 17 && g == 7 && t == 7) mfma16_acc_drain(acc[g][t], fa[P][g], fb[P][t]);   // see common.h
           else mfma16_acc(acc[g][t], fa[P][g], fb[P][t]);
+          const int m = g * 8 + t;
+          if (m & 1) {
+            if (m < 16) read_b(m >> 1);
+            else if (m < 32) read_a((m >> 1) - 8);
+          } else if (m == 32) {
+            if constexpr (j >= 1 && j <= W4_NH && !(W4_ABL & 2)) dma_halo(ccn, hsel ^ 1, j - 1);
+          } else if (m >= 36 && m <= 48 && (m & 3) == 0) {
+            dma_w1((m - 36) >> 2);
+          }
         }
-        if (g == 0) { if constexpr (j >= 1 && j <= W4_NH && !(W4_ABL & 2)) dma_halo(ccn, hsel ^ 1, j - 1); dma_w1(0); read_b(0); read_b(1); }
-        if (g == 1) { dma_w1(1); read_b(2); read_b(3); read_b(4); }
-        if (g == 2) { dma_w1(2); read_b(5); read_b(6); read_b(7); }
-        if (g == 3) { dma_w1(3); read_a(0); read_a(1); }
-        if (g == 4) { read_a(2); read_a(3); }
-        if (g == 5) { read_a(4); read_a(5); }
-        if (g == 6) { read_a(6); read_a(7); }
       }
     });
   }
