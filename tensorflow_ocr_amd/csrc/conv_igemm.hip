@@ -1115,39 +1115,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
   const int iy0 = tyi * TH - p.pt, ix0 = txi * TILE_W - p.pl;
   const int npairs = p.cin / 64;                                 // pairs of 32-channel chunks
 
-  const half_t* const xb = x + (size_t)img * p.h * p.w * p.cin;
-  const __attribute__((address_space(1))) void* const zero =
-      (const __attribute__((address_space(1))) void*)(&ocr_conv_zero_page[0]);
-  int hoff[W4S_NH];
+  // LDS-DMA by buffer loads, as in conv3x3_w4_kernel: per-lane offsets are constants, the moving part of every
+  // address is scalar, the range check zero-fills halo slots outside the image
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(x) + (size_t)img * p.h * p.w * p.cin, 0, p.h * p.w * p.cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(w), 0, 9 * p.cout * p.cin * 2, 0x00020000);
+  unsigned hvo[W4S_NH];
 #pragma unroll
   for (int u = 0; u < W4S_NH; ++u) {
     const int idx = u * 256 + tid;
     const int hp = idx >> 2, sl = idx & 3;
     const int hy = hp / WT, hx = hp - hy * WT;
     const int iy = iy0 + hy, ix = ix0 + hx;
-    hoff[u] = (hp < W4_HT * WT && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
-                  ? (iy * p.w + ix) * p.cin + ((sl ^ w4s_swz(hp)) << 3)
-                  : -1;
+    hvo[u] = (hp < W4_HT * WT && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
+                 ? (unsigned)(((iy * p.w + ix) * p.cin + ((sl ^ w4s_swz(hp)) << 3)) * 2)
+                 : OOB;
   }
   const int wrow = tid >> 2;
-  const int woff = wrow * p.cin + (((tid & 3) ^ (((wrow >> 3) & 1) << 1)) << 3);
+  const unsigned wvo = (unsigned)((wrow * p.cin + (((tid & 3) ^ (((wrow >> 3) & 1) << 1)) << 3)) * 2);
 
   auto dma_halo = [&](int q, int hb, int u) {       // 32-channel chunk q of this tile -> halo buffer hb
     if constexpr ((W4_ABL & 2) != 0) { if (q > 0) return; }
-    const __attribute__((address_space(1))) void* src =
-        hoff[u] >= 0 ? (const __attribute__((address_space(1))) void*)(xb + hoff[u] + q * 32) : zero;
-    __builtin_amdgcn_global_load_lds(
-        src, (__attribute__((address_space(3))) void*)(smem + hb * W4S_HBYTES + (u * 256 + wave * 64) * 16), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        xrs, (__attribute__((address_space(3))) void*)(smem + hb * W4S_HBYTES + (u * 256 + wave * 64) * 16), 16,
+        hvo[u], q * 64, 0, 0);
   };
-  auto dma_w = [&](int q, int tap, int ring, bool in_loop = false) {
-    if constexpr ((W4_ABL & 1) != 0) { if (in_loop) return; }
+  // 64-cout part u of the [BN couts][32 channels] slice of (chunk q, tap) -> ring slot
+  auto dma_wq = [&](int q, int tap, int ring, int u) {
     const int tapw = p.flip ? (8 - tap) : tap;
-    const half_t* src = w + ((size_t)tapw * p.cout + co0) * p.cin + q * 32 + woff;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        wrs, (__attribute__((address_space(3))) void*)(wbuf + ring * WSTEP + (u * 256 + wave * 64) * 16), 16, wvo,
+        (((tapw * p.cout + co0 + u * 64) * p.cin) + q * 32) * 2, 0, 0);
+  };
+  auto dma_w = [&](int q, int tap, int ring) {
 #pragma unroll
-    for (int u = 0; u < NW; ++u)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + (size_t)u * 64 * p.cin),
-          (__attribute__((address_space(3))) void*)(wbuf + ring * WSTEP + (u * 256 + wave * 64) * 16), 16, 0, 0);
+    for (int u = 0; u < NW; ++u) dma_wq(q, tap, ring, u);
   };
 
   // pixel fragment of tile t at tap (ky,kx): hp = (2*wave + (t>>1) + ky)*34 + (t&1)*16 + kx + L; the swizzle
@@ -1217,25 +1221,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
         if constexpr ((W4_ABL & 8) != 0) return;
         fa[i] = *reinterpret_cast<const half8_t*>(smem + (abase + i * 1024));
       };
+      // one operation per MFMA gap (see conv3x3_w4_kernel): pixel fragments behind the first MFMAs of groups 0
+      // and 1, the halo pieces behind their third, the weight DMAs in groups 2.., weight fragment g (single
+      // buffered) behind the last MFMA of the only group that uses it
 #pragma unroll
       for (int g = 0; g < AI; ++g) {
 #pragma unroll
         for (int t = 0; t < AT; ++t) {
           if (j == 17 && g == AI - 1 && t == AT - 1) mfma16_acc_drain(acc[g][t], fa[g], fb[P][t]);   // see common.h
           else mfma16_acc(acc[g][t], fa[g], fb[P][t]);
-        }
-        if (g == 0) {
-          if constexpr ((j % 9) < HSTEPS) {
-#pragma unroll
-            for (int hp_ = 0; hp_ < HPS; ++hp_) dma_halo(qh, c ^ 1, (j % 9) * HPS + hp_);
+          if (t == AT - 1) {
+            read_a(g);
+          } else if (g < 2) {
+            if (t < 2) read_b(g * 2 + t);
+            else if constexpr ((j % 9) < HSTEPS) dma_halo(qh, c ^ 1, (j % 9) * HPS + g);
+          } else if (t == 1 && g - 2 < NW) {
+            if constexpr (!(W4_ABL & 1)) dma_wq(qd, tapd, sd_ring, g - 2);
           }
-          dma_w(qd, tapd, sd_ring, true);
         }
-        // the next step's fragments: weight fragment g right behind its group, the four pixel fragments
-        // (all needed by the next step's first group) behind the first two groups
-        if (g == 0) { read_b(0); read_b(1); }
-        if (g == 1) { read_b(2); read_b(3); }
-        read_a(g);
       }
     });
   }
