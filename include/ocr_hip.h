@@ -92,6 +92,17 @@ int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc
                          const void* bn_y, const void* bn_scale, const void* bn_shift,
                          const void* bn_mean, const void* bn_invstd, int bn_relu, void* stream);
 
+/* Input-gradient convolution into the OUTPUT of a ResNet bottleneck, out = relu(shortcut + bn(bn_y))
+ * (nets/resnet_v1.py:108-110), as the LAST contribution to that output's gradient (OCR_CONV_ACCUM_F16 adds
+ * what the other consumers left in y): the stored value is dz = [tail_out > 0] * gradient — the gradient
+ * past the ReLU, i.e. of the shortcut and of bn(bn_y) alike — and `partial` [ocr_conv2d_num_mtiles][2][cout]
+ * receives (sum dz, sum dz*xhat(bn_y)) for ocr_bn_relu_bwd_apply_f16 (relu = 0).  Replaces one masking pass
+ * and the reduction pass over the bottleneck's widest tensors.  1x1 and generic 3x3 tile kernels only:
+ * OCR_ERR_UNSUPPORTED never occurs for 1x1 convolutions. */
+int ocr_conv2d_bnred_tail_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y, void* partial,
+                              const void* bn_y, const void* bn_mean, const void* bn_invstd,
+                              const void* tail_out, void* stream);
+
 /* First-layer convolution (cin = 3, images [n,h,w,4] f16 with channel 3 zero,
  * produced by ocr_prep_images): 3x3 stride 1, pad 1.
  *   w_first [3][cout][16] f16: for tap row ky, k = kx*4 + c (kx<3, c<3), else 0.

@@ -16,13 +16,21 @@ struct BnRed {
   const half_t* y;
   const float *scale, *shift, *mean, *invstd;
   int relu;
+  // TAIL mode (ResNet bottleneck output, relu(shortcut + bn(y))): `mask` is that OUTPUT; the value this
+  // convolution stores becomes dz = [mask > 0] * value — the gradient past the ReLU, replacing the separate
+  // mask pass — and the sums are (sum dz, sum dz * xhat(y)).  Only kernels that end in conv_epilogue_store
+  // implement it (ocr_conv2d_bnred_tail_f16 routes accordingly).
+  const half_t* mask;
 };
 
 // LDS needed by the epilogue for a BN-wide tile.
 constexpr size_t conv_epilogue_lds(int bn, int nt = 256) { return 256 * (bn * 2 + 16) + nt * 16 * sizeof(float); }
 
 // Second half of the epilogue, shared by both accumulator layouts: LDS [256 px][BN] f16 -> HBM rows.
-template <int BN, int NT>
+// BATCH: the variant for kernels launched WITH global operands in the epilogue (ACCUM / BN-backward / tail):
+// it requests a batch's operands ahead of the batch's stores at the price of ~40 registers, which the
+// memory-bound forward launches of the same kernels cannot afford (occupancy) — they keep the serial loop.
+template <int BN, int NT, bool BATCH = false>
 __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_t* __restrict__ y,
                                                     float* __restrict__ stats, int img, int tyi, int txi,
                                                     int mt, int co0, int oh, int ow, int cout,
@@ -41,44 +49,124 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
   float s[8], q2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
-#pragma unroll 4
-  for (int k = 0; k < PPT; ++k) {
-    const int px = rg + k * RG;
-    const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
-    if (oy < oh && ox < ow) {
-      half8_t v = *reinterpret_cast<const half8_t*>(otile + px * OSTR + c * 16);
-      half_t* dst = y + (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
-      if (accum) {
-        half8_t old = *reinterpret_cast<const half8_t*>(dst);
+  // Pixels in batches of four: every global operand of the batch (the old gradient under ACCUM, the tail
+  // mask, the BN-backward operand) is requested BEFORE the batch's first store — the stores may alias those
+  // tensors as far as the compiler knows, and a load placed behind one waits for it (measured on the
+  // 1x1 input-gradient kernels of ResNet-50: three dependent loads per pixel made the fused tail 2x slower
+  // than the separate element-wise passes it replaces).
+  const bool tail = br != nullptr && br->mask != nullptr;
+  // this thread's 8 couts are fixed: the ReLU-mask coefficients once, up front; mean / invstd enter the sums
+  // linearly and are applied at the end (sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
+  float bsc[8], bsh[8];
+  const bool remask = do_stats && br != nullptr && !tail && br->relu;
+  if (remask) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+    for (int e = 0; e < 8; ++e) { bsc[e] = br->scale[co0 + c * 8 + e]; bsh[e] = br->shift[co0 + c * 8 + e]; }
+  }
+  if constexpr (BATCH) {
+    constexpr int UB = PPT < 4 ? PPT : 4;
+    static_assert(PPT % UB == 0, "pixels per thread");
+    for (int k0 = 0; k0 < PPT; k0 += UB) {
+      half8_t v[UB], old[UB], mk[UB], yv[UB];
+      size_t off[UB];
+      bool ok[UB];
+  #pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int px = rg + (k0 + u) * RG;
+        const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
+        ok[u] = oy < oh && ox < ow;
+        off[u] = (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
+        v[u] = *reinterpret_cast<const half8_t*>(otile + px * OSTR + c * 16);
+        if (ok[u]) {
+          if (accum) old[u] = *reinterpret_cast<const half8_t*>(y + off[u]);
+          if (tail) mk[u] = *reinterpret_cast<const half8_t*>(br->mask + off[u]);
+          if (do_stats && br != nullptr) yv[u] = *reinterpret_cast<const half8_t*>(br->y + off[u]);
+        }
       }
-      *reinterpret_cast<half8_t*>(dst) = v;
-      if (do_stats) {
-        if (br != nullptr) {
-          const size_t off = (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
-          half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int cc = co0 + c * 8 + e;
-            const float yf = (float)yv[e];
-            const float z = (float)(half_t)(yf * br->scale[cc] + br->shift[cc]);
-            const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
-            s[e] += dz;
-            q2[e] += dz * ((yf - br->mean[cc]) * br->invstd[cc]);
+  #pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (!ok[u]) continue;
+        half8_t w = v[u];
+        if (accum) {
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)old[u][e]);
+        }
+        if (tail) {
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = (float)mk[u][e] > 0.f ? w[e] : (half_t)0.f;
+        }
+        *reinterpret_cast<half8_t*>(y + off[u]) = w;
+        if (do_stats) {
+          if (br != nullptr) {
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float yf = (float)yv[u][e];
+              bool pass = true;                      // tail mode: w is dz already
+              if (remask) pass = (float)(half_t)(yf * bsc[e] + bsh[e]) > 0.f;
+              const float dz = pass ? (float)w[e] : 0.f;
+              s[e] += dz;
+              q2[e] += dz * yf;
+            }
+          } else {
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float f = (float)w[e];
+              s[e] += f;
+              q2[e] += f * f;
+            }
           }
-        } else {
+        }
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (int k = 0; k < PPT; ++k) {
+      const int px = rg + k * RG;
+      const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
+      if (oy < oh && ox < ow) {
+        half8_t w = *reinterpret_cast<const half8_t*>(otile + px * OSTR + c * 16);
+        const size_t off = (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
+        if (accum) {
+          const half8_t old = *reinterpret_cast<const half8_t*>(y + off);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float f = (float)v[e];
-            s[e] += f;
-            q2[e] += f * f;
+          for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)old[e]);
+        }
+        if (tail) {
+          const half8_t mk = *reinterpret_cast<const half8_t*>(br->mask + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = (float)mk[e] > 0.f ? w[e] : (half_t)0.f;
+        }
+        *reinterpret_cast<half8_t*>(y + off) = w;
+        if (do_stats) {
+          if (br != nullptr) {
+            const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float yf = (float)yv[e];
+              bool pass = true;                    // tail mode: w is dz already
+              if (remask) pass = (float)(half_t)(yf * bsc[e] + bsh[e]) > 0.f;
+              const float dz = pass ? (float)w[e] : 0.f;
+              s[e] += dz;
+              q2[e] += dz * yf;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = (float)w[e];
+              s[e] += f;
+              q2[e] += f * f;
+            }
           }
         }
       }
     }
   }
   if (do_stats) {
+    if (br != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        q2[e] = (q2[e] - br->mean[co0 + c * 8 + e] * s[e]) * br->invstd[co0 + c * 8 + e];
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       red[(rg * NC + c) * 16 + e] = s[e];
@@ -139,7 +227,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* sme
 
 // Same epilogue for 16x16 accumulator tiles (v_mfma_f32_16x16x32_f16): lane l holds couts
 // 4*(l>>4)..+3 of pixel l&15 of each tile; acc[i][t] covers couts i*16.., pixels t*16.. of the wave.
-template <int BN, int TCO, int TPX, int WCO, int NT = 256>
+template <int BN, int TCO, int TPX, int WCO, int NT = 256, bool BATCH = false>
 __device__ __forceinline__ void conv_epilogue16(f32x4 (&acc)[TCO * 2][TPX * 2], char* smem, int flags,
                                                 const float* __restrict__ bias,
                                                 half_t* __restrict__ y, float* __restrict__ stats,
@@ -175,5 +263,5 @@ __device__ __forceinline__ void conv_epilogue16(f32x4 (&acc)[TCO * 2][TPX * 2], 
       }
     }
   }
-  conv_epilogue_store<BN, NT>(smem, flags, y, stats, img, tyi, txi, mt, co0, oh, ow, cout, br);
+  conv_epilogue_store<BN, NT, BATCH>(smem, flags, y, stats, img, tyi, txi, mt, co0, oh, ow, cout, br);
 }

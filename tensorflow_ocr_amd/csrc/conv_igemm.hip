@@ -585,7 +585,7 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
 // page.  Same epilogue (and batch-norm statistics per 256-pixel tile) as the kernel above.
 __device__ const u32x4 ocr_conv_zero_page[4] = {};
 
-template <int BN, int WCO>
+template <int BN, int WCO, bool EPI_LOADS>
 __global__ __launch_bounds__(512) void conv_pw_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
   for (int h = 0; h < BN / EBN; ++h) {
     __syncthreads();
     const bool active = BN <= 128 || (wco >> 1) == h;
-    conv_epilogue16<EBN, TCO, TPX, EWCO, NT>(acc, smem, p.flags, bias, y, stats, 0, mt, 0, mt, co0 + h * EBN,
+    conv_epilogue16<EBN, TCO, TPX, EWCO, NT, EPI_LOADS>(acc, smem, p.flags, bias, y, stats, 0, mt, 0, mt, co0 + h * EBN,
                                              rows, 32, p.cout, BN > 128 ? (wco & 1) : wco, wpx, active,
                                              p.br.y ? &p.br : nullptr);
   }
@@ -1385,13 +1385,16 @@ int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, vo
   const size_t main_bytes = 2 * ((size_t)BN * 128 + 256 * 128);
   const size_t epi_bytes = conv_epilogue_lds(BN > 128 ? 128 : BN, 512);
   const size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
-  auto kern = conv_pw_kernel<BN, WCO>;
-  static bool configured = false;
-  if (!configured) {
+  // two instantiations: the epilogue with global operands (ACCUM / BN-backward / tail) batches its loads
+  // ahead of its stores (conv_epilogue.h) and needs ~40 more registers than the store-only one
+  const bool epi_loads = (p.flags & OCR_CONV_ACCUM_F16) != 0 || p.br.y != nullptr;
+  auto kern = epi_loads ? conv_pw_kernel<BN, WCO, true> : conv_pw_kernel<BN, WCO, false>;
+  static bool configured[2] = {false, false};
+  if (!configured[epi_loads]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(160 * 1024)) != hipSuccess)
       return OCR_ERR_HIP;
-    configured = true;
+    configured[epi_loads] = true;
   }
   const unsigned m_tiles = (unsigned)((p.npix + 255) / 256);
   hipLaunchKernelGGL(kern, dim3(m_tiles * p.n_tiles), dim3(512), lds, st, p, static_cast<const half_t*>(x),
@@ -1649,12 +1652,13 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     if (c.bn == 128) return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
     return launch_pw<64, 1>(p, x, w_kc, bias, y, stats, st);
   }
-  if (const int bn = conv_w4s_bn(p))
+  const bool tail = p.br.mask != nullptr;          // only the kernels ending in conv_epilogue_store implement it
+  if (const int bn = tail ? 0 : conv_w4s_bn(p))
     return bn == 128 ? launch_w4s<128>(p, x, w_kc, bias, y, stats, st) : launch_w4s<64>(p, x, w_kc, bias, y, stats, st);
   const int key = c.bn * 10000 + c.ck * 100 + c.th;
   switch (key) {
     case 2566408:
-      if (conv_w4_ok(p)) return launch_w4(p, x, w_kc, bias, y, stats, st);
+      if (!tail && conv_w4_ok(p)) return launch_w4(p, x, w_kc, bias, y, stats, st);
       return launch<256, 64, 4>(p, x, w_kc, bias, y, stats, st);
     case 2563208: return launch<256, 32, 4>(p, x, w_kc, bias, y, stats, st);
     case 1286416: return launch<128, 64, 2, 16>(p, x, w_kc, bias, y, stats, st);
@@ -1662,7 +1666,7 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     case 1286408: return launch<128, 64, 2>(p, x, w_kc, bias, y, stats, st);
     case 1283208: return launch<128, 32, 2>(p, x, w_kc, bias, y, stats, st);
     case 646408:
-      if (conv_c64_ok(p)) return launch_c64(p, x, w_kc, bias, y, stats, st);
+      if (!tail && conv_c64_ok(p)) return launch_c64(p, x, w_kc, bias, y, stats, st);
       return launch<64, 64, 2>(p, x, w_kc, bias, y, stats, st);
     case 643208: return launch<64, 32, 2>(p, x, w_kc, bias, y, stats, st);
     case 326408: return launch<32, 64, 1>(p, x, w_kc, bias, y, stats, st);
@@ -1697,5 +1701,20 @@ extern "C" int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const
   p.br = BnRed{static_cast<const half_t*>(bn_y), static_cast<const float*>(bn_scale),
                static_cast<const float*>(bn_shift), static_cast<const float*>(bn_mean),
                static_cast<const float*>(bn_invstd), bn_relu};
+  return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ocr_conv2d_bnred_tail_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y,
+                                         void* partial, const void* bn_y, const void* bn_mean,
+                                         const void* bn_invstd, const void* tail_out, void* stream) {
+  ConvP p;
+  TileCfg cfg;
+  int rc = fill_params(d, &p, &cfg);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x && w_kc && y && partial && bn_y && bn_mean && bn_invstd && tail_out);
+  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_BIAS | OCR_CONV_RELU)));
+  p.flags |= OCR_CONV_STATS;
+  p.br = BnRed{static_cast<const half_t*>(bn_y), nullptr, nullptr, static_cast<const float*>(bn_mean),
+               static_cast<const float*>(bn_invstd), 0, static_cast<const half_t*>(tail_out)};
   return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }

@@ -152,7 +152,8 @@ class VariableStore:
 class Act:
     """Activation handle: device tensor + (lazily created) gradient."""
 
-    __slots__ = ("data", "grad", "requires_grad", "name", "bn_ctx", "bn_partial")
+    __slots__ = ("data", "grad", "requires_grad", "name", "bn_ctx", "bn_partial", "tail_ctx", "tail_partial",
+                 "pending")
 
     def __init__(self, data, requires_grad=True, name=""):
         self.data = data
@@ -161,6 +162,12 @@ class Act:
         self.name = name
         self.bn_ctx = None        # (y, scale, shift, mean, invstd, relu) of the conv+BN that made it
         self.bn_partial = None    # (partial, T): BN-backward sums already reduced by the dgrad conv
+        # ResNet bottleneck outputs (resnet_layers.bottleneck): (y, mean, invstd of the unit's last conv, own data);
+        # the next unit's LAST gradient contribution (counted down in `pending`) then stores the gradient past
+        # this output's ReLU and leaves the BN-backward sums in tail_partial = (partial, T)
+        self.tail_ctx = None
+        self.tail_partial = None
+        self.pending = None
 
     @property
     def shape(self):

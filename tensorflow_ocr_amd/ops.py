@@ -115,6 +115,17 @@ def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx):
         L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
 
 
+def conv2d_bnred_tail(d, x, w_kc, y, partial, tail_ctx):
+    """Input-gradient conv that completes the gradient of a bottleneck output: stores the gradient past the
+    output ReLU and emits the BN-backward sums of the unit's last conv (include/ocr_hip.h)."""
+    by, mu, istd, out = tail_ctx
+    L.call("ocr_conv2d_bnred_tail_f16", byref(d), ptr(x), ptr(w_kc), ptr(y), ptr(partial), ptr(by), ptr(mu),
+           ptr(istd), ptr(out), _st())
+    if L.RECORDER is not None:
+        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+        L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
+
+
 def bn_relu_bwd_apply(y, scale, shift, save_mean, save_invstd, da_full, relu, partial, T, dgamma, dbeta, dy, ws):
     n, h, w, c = y.shape
     stage = ws.get(bn_reduce_workspace(T, c))

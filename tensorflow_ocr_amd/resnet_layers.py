@@ -16,6 +16,7 @@ from ._lib import CONV_ACCUM_F16, CONV_STATS
 
 
 USE_S2D = __import__("os").environ.get("OCR_RESNET_S2D", "1") == "1"     # measurement switch (A/B against the subsample form)
+FUSE_TAIL = __import__("os").environ.get("OCR_RESNET_FUSE_TAIL", "1") == "1"   # measurement switch (bottleneck tail fusion)
 
 
 class ConvBN:
@@ -134,7 +135,16 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             flags |= CONV_ACCUM_F16
             x.bn_partial = None     # an earlier consumer's fused BN-backward sums no longer cover the full gradient
         dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, flags)
-        if x.bn_ctx is not None and not flags and FUSE_BN_REDUCE:
+        if x.pending is not None:
+            x.pending -= 1
+        if x.pending == 0 and x.tail_ctx is not None and k == 1 and FUSE_TAIL:
+            # x is the previous bottleneck's output and this is the last contribution to its gradient: store
+            # the gradient past its ReLU and emit the BN-backward sums of its last conv (ops.conv2d_bnred_tail)
+            Tm = ops.conv2d_num_mtiles(dg)
+            partial = g.empty((Tm, 2, d.cin), F32)
+            ops.conv2d_bnred_tail(dg, dy, w_dg, x.grad, partial, x.tail_ctx)
+            x.tail_partial = (partial, Tm)
+        elif x.bn_ctx is not None and not flags and FUSE_BN_REDUCE:
             # sole consumer of a conv+BN(+ReLU) output: this input-gradient kernel also emits that
             # layer's BN-backward sums, so its backward skips the reduction pass (layers.py does the same)
             Tm = ops.conv2d_num_mtiles(dg)
@@ -227,38 +237,76 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
     from .layers import max_pool2d
     depth_in = x.shape[-1]
     ws = g.workspace()
+    fuse_in = g.precision != "f32" and x.tail_ctx is not None
+    if fuse_in:
+        # x is the previous unit's output.  This unit reads it twice (conv1 and the shortcut); whatever else
+        # consumes it was built later and so contributes to its gradient EARLIER in the backward pass.  The
+        # 1x1 convolution that makes the last of this unit's two contributions finishes x's gradient
+        # (conv_bn_raw.backward_from): conv1 for an identity / subsampling shortcut (recorded first, runs
+        # last), the projection shortcut otherwise (built before conv1 below).
+        x.pending = 2
+
+    def make_shortcut():
+        if depth == depth_in:
+            if stride == 1:
+                return x
+            return max_pool2d(g, x, 1, stride, scope="shortcut")
+        if stride != 1:
+            raise NotImplementedError("strided projection shortcut")
+        return conv_bn_act(g, x, depth, 1, "shortcut", relu=False, is_training=is_training)
     with g.variable_scope(scope):
         with g.variable_scope("bottleneck_v1"):
-            if depth == depth_in:
-                shortcut = x if stride == 1 else max_pool2d(g, x, 1, stride, scope="shortcut")
-            else:
-                if stride != 1:
-                    raise NotImplementedError("strided projection shortcut")
-                shortcut = conv_bn_act(g, x, depth, 1, "shortcut", relu=False, is_training=is_training)
+            # variables are created in the reference's order (shortcut first) when there is a projection; a
+            # subsampling shortcut has none and is recorded AFTER the residual branch, so that its backward
+            # (zero insertion into x's gradient) runs before conv1's
+            late = depth == depth_in and stride != 1
+            shortcut = None if late else make_shortcut()
             r = conv_bn_act(g, x, depth_bottleneck, 1, "conv1", is_training=is_training)
             r = conv_bn_act(g, r, depth_bottleneck, 3, "conv2", stride=stride, is_training=is_training)
             c3 = conv_bn_raw(g, r, depth, 1, "conv3", is_training=is_training)
+            if late:
+                shortcut = make_shortcut()
+                if fuse_in:
+                    def count():                     # runs right after the subsample's backward
+                        if x.pending is not None:
+                            x.pending -= 1
+                    g.record(count)
+                    # (recorded after the pool: executes BEFORE it; the pool is the first of the two
+                    # contributions either way, so the order of the decrement does not matter)
     if g.precision == "f32":
         from . import layers_f32
         return layers_f32.bn_add_relu(g, c3, shortcut, scope)
     out = Act(g.empty(c3.y.shape), name=scope)
     ops.bn_add_relu(c3.y, c3.scale, c3.shift, shortcut.data, out.data)
+    if is_training and FUSE_TAIL:
+        out.tail_ctx = (c3.y, c3.mean, c3.invstd, out.data)
 
     def backward():
         if out.grad is None:
             return
-        dz = g.empty(out.shape)
-        ops.relu_bwd(out.data, out.grad, dz)
         dy = g.empty(c3.y.shape)
-        ops.bn_relu_bwd(c3.y, c3.scale, c3.shift, c3.mean, c3.invstd, dz, None, False, 0, c3.gamma.grad,
-                        c3.beta.grad, dy, ws)
+        if out.tail_partial is not None:
+            # out.grad is already the gradient past the ReLU and the BN-backward sums are reduced
+            dz = out.grad
+            part_f, T_f = out.tail_partial
+            ops.bn_relu_bwd_apply(c3.y, c3.scale, c3.shift, c3.mean, c3.invstd, dz, False, part_f, T_f,
+                                  c3.gamma.grad, c3.beta.grad, dy, ws)
+            out.tail_partial = None
+        else:
+            dz = g.empty(out.shape)
+            ops.relu_bwd(out.data, out.grad, dz)
+            ops.bn_relu_bwd(c3.y, c3.scale, c3.shift, c3.mean, c3.invstd, dz, None, False, 0, c3.gamma.grad,
+                            c3.beta.grad, dy, ws)
         c3.backward_from(dy)
         if shortcut.requires_grad:
             if shortcut.grad is None:
                 shortcut.grad = dz
             else:
                 ops.add_inplace(shortcut.grad, dz)
+            if shortcut is x and x.pending is not None:
+                x.pending -= 1
         out.grad = None
+        out.pending = None
     g.record(backward, (c3.wv, c3.gamma, c3.beta))
     return out
 

@@ -250,3 +250,47 @@ def test_strided_conv_space_to_depth_equals_subsample_form(device, monkeypatch):
         scale = np.abs(b).max()
         assert np.abs(a - b).max() <= tol * scale, (np.abs(a - b).max(), scale)
     assert np.abs(res[True][3]).max() > 0 and np.abs(res[True][4]).max() > 0
+
+
+def test_bottleneck_tail_fusion_equals_separate_passes(device, monkeypatch):
+    """A chain of four units (projection, identity, subsampling, projection after the stride) with a second
+    consumer on two of the outputs: the gradient-past-ReLU + BN-backward sums emitted by the next unit's last
+    1x1 input-gradient conv (ocr_conv2d_bnred_tail_f16) give the gradients of the separate relu_bwd /
+    reduction passes — same sums, reduced in a different order."""
+    from tensorflow_ocr_amd import resnet_layers as R
+    from tensorflow_ocr_amd.graph import Act, Graph
+    rng = np.random.default_rng(11)
+    n, hw, cin = 2, 16, 64
+    xin = np.abs(rng.standard_normal((n, hw, hw, cin))).astype(np.float32)
+    g_end = (rng.standard_normal((n, hw // 2, hw // 2, 256)) * 0.1).astype(np.float32)
+    g_mid = (rng.standard_normal((n, hw, hw, 128)) * 0.1).astype(np.float32)
+    res = {}
+    fused_launches = {}
+    for mode in (True, False):
+        monkeypatch.setattr(R, "FUSE_TAIL", mode)
+        calls = []
+        real = R.ops.conv2d_bnred_tail
+        monkeypatch.setattr(R.ops, "conv2d_bnred_tail", lambda *a, _r=real, _c=calls: (_c.append(1), _r(*a))[1])
+        g = Graph(device, seed=7, loss_scale=1.0)
+        x = Act(torch.from_numpy(xin).to(device).to(R.ops.F16), name="x")
+        u1 = R.bottleneck(g, x, 128, 32, 1, "u1")        # projection shortcut (x is not a bottleneck output)
+        u2 = R.bottleneck(g, u1, 128, 32, 1, "u2")       # identity: conv1 completes u1's gradient
+        u3 = R.bottleneck(g, u2, 128, 32, 2, "u3")       # subsampling shortcut: conv1 completes u2's gradient
+        u4 = R.bottleneck(g, u3, 256, 64, 1, "u4")       # projection: the shortcut conv completes u3's gradient
+        # second consumers (built later = earlier in backward), as the EAST merge branch has them
+        u2.grad = torch.from_numpy(g_mid).to(device).to(R.ops.F16)
+        u4.grad = torch.from_numpy(g_end).to(device).to(R.ops.F16)
+        g.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(R.ops, "conv2d_bnred_tail", real)
+        fused_launches[mode] = len(calls)
+        out = {"x.grad": x.grad.float().cpu().numpy()}
+        for k, v in g.store.vars.items():
+            if v.trainable:
+                out[k] = v.grad.float().cpu().numpy()
+        res[mode] = out
+    assert fused_launches[True] == 3 and fused_launches[False] == 0
+    for k in res[True]:
+        a, b = res[True][k], res[False][k]
+        assert np.isfinite(a).all()
+        assert _rel2(a, b) < 2e-3 * TOL, (k, _rel2(a, b))
