@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   const int m_tiles = p.n * p.tiles_x * p.tiles_y;
   const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
   const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
-  const BnRed* br = p.br.y ? &p.br : nullptr;
+  const bool has_br = p.br.y != nullptr;         // (fields read by value: a pointer to p.br would pin the kernel arguments in scratch)
 
   // all weight slices of this cout tile -> LDS, once (BN * CPP = 512 chunks per slice: one per thread)
   for (int tap = 0; tap < ntaps; ++tap) {
@@ -445,6 +445,23 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     }
     __syncthreads();                                 // halo (and, the first time, the weights) visible
     if (mt + m_step < m_tiles) halo_load(mt + m_step);   // in flight under this tile's MFMAs
+    // the epilogue's global operands (BN-backward operand, old gradient under ACCUM) of THIS tile: requested
+    // here, ahead of the MFMAs — behind the epilogue's stores each would wait for them and cost a full HBM
+    // latency per pixel group (measured: +0.36 ms on a 0.92 ms launch)
+    half8_t yq[4], oq[4];
+    {
+      const int c = lane & 7, pg = lane >> 3;
+      const int oy = tyi * TILE_H + wave;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ox = txi * TILE_W + k * 8 + pg;
+        if (oy < p.oh && ox < p.ow) {
+          const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8;
+          if (do_stats && has_br) yq[k] = *reinterpret_cast<const half8_t*>(p.br.y + off);
+          if (accum) oq[k] = *reinterpret_cast<const half8_t*>(y + off);
+        }
+      }
+    }
 
     f32x4 acc[AI][AT];
 #pragma unroll
@@ -514,22 +531,20 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
           half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
           const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8;
           if (accum) {
-            const half8_t old = *reinterpret_cast<const half8_t*>(y + off);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
           }
           *reinterpret_cast<half8_t*>(y + off) = v;
           if (do_stats) {
-            if (br != nullptr) {
-              const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
+            if (has_br) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const int cc = co0 + c * 8 + e;
-                const float yf = (float)yv[e];
-                const float z = (float)(half_t)(yf * br->scale[cc] + br->shift[cc]);
-                const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
+                const float yf = (float)yq[k][e];
+                const float z = (float)(half_t)(yf * p.br.scale[cc] + p.br.shift[cc]);
+                const float dz = (!p.br.relu || z > 0.f) ? (float)v[e] : 0.f;
                 s[e] += dz;
-                q2[e] += dz * ((yf - br->mean[cc]) * br->invstd[cc]);
+                q2[e] += dz * ((yf - p.br.mean[cc]) * p.br.invstd[cc]);
               }
             } else {
 #pragma unroll
@@ -937,7 +952,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     char* const stage = smem + wave * 2048;
     const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
     const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
-    const BnRed* br = p.br.y ? &p.br : nullptr;
+    const bool has_br = p.br.y != nullptr;      // (fields read by value: a pointer to p.br would pin the kernel arguments in scratch)
     const int g4 = lane >> 4;                        // accumulator layout: pixel L, couts 4*g4..+3 of a 16x16 tile
     const int c8 = lane & 7, pg = lane >> 3;         // read-back layout: 16-byte chunk of a pixel's 64 couts, pixel
     const int cow = co0 + wco * 128;
@@ -950,20 +965,54 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     // (scale / shift decide the ReLU mask per element; mean / invstd enter linearly and are applied to the
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[2][8], bsh[2][8];
-    if (br != nullptr) {
+    if (has_br) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int cc = cow + hf * 64 + c8 * 8 + e;
-          bsc[hf][e] = br->scale[cc]; bsh[hf][e] = br->shift[cc];
+          bsc[hf][e] = p.br.scale[cc]; bsh[hf][e] = p.br.shift[cc];
         }
+    }
+    // Round it = 2*t + hf (16 rounds).  The global operands of a round — the BN-backward operand `p.br.y`, the old
+    // gradient under ACCUM — are requested FOUR ROUNDS AHEAD: a load placed behind a store waits for it (the
+    // tensors may alias as far as the compiler knows), and with one wave per SIMD a round that waits for its
+    // own loads pays the whole HBM latency (measured: +0.16 ms on a 0.52 ms launch, 16 x 1.5 us per tile).
+    constexpr int PF = 4;
+    half8_t yq[PF][2], oq[2];
+    auto round_off = [&](int it, int k, bool& ok) __attribute__((always_inline)) {
+      const int t = it >> 1, hf = it & 1;
+      const int oy = tyi * TH + wpx * 4 + (t >> 1);
+      const int px = k * 8 + pg;
+      const int ox = txi * TILE_W + (t & 1) * 16 + px;
+      ok = oy < p.oh && ox < p.ow;
+      return (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + cow + hf * 64 + c8 * 8;
+    };
+    auto request = [&](int it) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        bool ok;
+        const size_t off = round_off(it, k, ok);
+        if (ok && do_stats && has_br) yq[it % PF][k] = *reinterpret_cast<const half8_t*>(p.br.y + off);
+      }
+    };
+    if (do_stats && has_br) {
+#pragma unroll
+      for (int it = 0; it < PF; ++it) request(it);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const int oy = tyi * TH + wpx * 4 + (t >> 1);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
+        const int it = t * 2 + hf;
+        if (accum) {                                  // old gradient of this round: in flight under the staging
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            bool ok;
+            const size_t off = round_off(it, k, ok);
+            if (ok) oq[k] = *reinterpret_cast<const half8_t*>(y + off);
+          }
+        }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = hf * 4 + ii;
@@ -986,25 +1035,23 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+          bool ok;
+          const size_t off = round_off(it, k, ok);
           const int px = k * 8 + pg;
-          const int ox = txi * TILE_W + (t & 1) * 16 + px;
-          if (oy < p.oh && ox < p.ow) {
+          if (ok) {
             half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
-            const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + cow + hf * 64 + c8 * 8;
             if (accum) {
-              const half8_t old = *reinterpret_cast<const half8_t*>(y + off);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
             }
             *reinterpret_cast<half8_t*>(y + off) = v;
             if (do_stats) {
-              if (br != nullptr) {
-                const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
+              if (has_br) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  const float yf = (float)yv[e];
+                  const float yf = (float)yq[it % PF][k][e];
                   const float z = (float)(half_t)(yf * bsc[hf][e] + bsh[hf][e]);
-                  const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
+                  const float dz = (!p.br.relu || z > 0.f) ? (float)v[e] : 0.f;
                   s[hf][e] += dz;
                   q2[hf][e] += dz * yf;
                 }
@@ -1019,19 +1066,20 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
             }
           }
         }
+        if (do_stats && has_br && it + PF < 16) request(it + PF);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();          // the next round's writes come after these reads (in-order LDS)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
     if (do_stats) {
-      if (br != nullptr) {
+      if (has_br) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int cc = cow + hf * 64 + c8 * 8 + e;
-            q2[hf][e] = (q2[hf][e] - br->mean[cc] * s[hf][e]) * br->invstd[cc];
+            q2[hf][e] = (q2[hf][e] - p.br.mean[cc] * s[hf][e]) * p.br.invstd[cc];
           }
       }
 #pragma unroll
@@ -1254,7 +1302,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     char* const stage = smem + wave * 2048;
     const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
     const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
-    const BnRed* br = p.br.y ? &p.br : nullptr;
+    const bool has_br = p.br.y != nullptr;
     const int g4 = lane >> 4;
     const int c8 = lane & 7, pg = lane >> 3;
     float s[NW][8], q2[NW][8];
@@ -1265,20 +1313,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     // (scale / shift decide the ReLU mask per element; mean / invstd enter linearly and are applied to the
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[NW][8], bsh[NW][8];
-    if (br != nullptr) {
+    if (has_br) {
 #pragma unroll
       for (int hf = 0; hf < NW; ++hf)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int cc = co0 + hf * 64 + c8 * 8 + e;
-          bsc[hf][e] = br->scale[cc]; bsh[hf][e] = br->shift[cc];
+          bsc[hf][e] = p.br.scale[cc]; bsh[hf][e] = p.br.shift[cc];
         }
+    }
+    // Round it = NW*t + hf; global operands of a round (BN-backward operand, old gradient under ACCUM) are
+    // requested PF rounds ahead, never behind a store (see conv3x3_w4_kernel's epilogue)
+    constexpr int NR = AT * NW, PF = 2;           // two rounds ahead: 128 vector registers here
+    half8_t yq[PF][2], oq[2];
+    auto round_off = [&](int it, int k, bool& ok) __attribute__((always_inline)) {
+      const int t = it / NW, hf = it % NW;
+      const int oy = tyi * TH + wave * 2 + (t >> 1);
+      const int px = k * 8 + pg;
+      const int ox = txi * TILE_W + (t & 1) * 16 + px;
+      ok = oy < p.oh && ox < p.ow;
+      return (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + hf * 64 + c8 * 8;
+    };
+    const bool gops = do_stats && has_br;
+    auto request = [&](int it) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        bool ok;
+        const size_t off = round_off(it, k, ok);
+        if (ok && do_stats && has_br) yq[it % PF][k] = *reinterpret_cast<const half8_t*>(p.br.y + off);
+      }
+    };
+    if (gops) {
+#pragma unroll
+      for (int it = 0; it < PF; ++it) request(it);
     }
 #pragma unroll
     for (int t = 0; t < AT; ++t) {
-      const int oy = tyi * TH + wave * 2 + (t >> 1);
 #pragma unroll
       for (int hf = 0; hf < NW; ++hf) {
+        const int it = t * NW + hf;
+        if (accum) {                                  // old gradient of this round: in flight under the staging
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            bool ok;
+            const size_t off = round_off(it, k, ok);
+            if (ok) oq[k] = *reinterpret_cast<const half8_t*>(y + off);
+          }
+        }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = hf * 4 + ii;
@@ -1301,25 +1382,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+          bool ok;
+          const size_t off = round_off(it, k, ok);
           const int px = k * 8 + pg;
-          const int ox = txi * TILE_W + (t & 1) * 16 + px;
-          if (oy < p.oh && ox < p.ow) {
+          if (ok) {
             half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
-            const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + hf * 64 + c8 * 8;
             if (accum) {
-              const half8_t old = *reinterpret_cast<const half8_t*>(y + off);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)old[e]);
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
             }
             *reinterpret_cast<half8_t*>(y + off) = v;
             if (do_stats) {
-              if (br != nullptr) {
-                const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);
+              if (has_br) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  const float yf = (float)yv[e];
+                  const float yf = (float)yq[it % PF][k][e];
                   const float z = (float)(half_t)(yf * bsc[hf][e] + bsh[hf][e]);
-                  const float dz = (!br->relu || z > 0.f) ? (float)v[e] : 0.f;
+                  const float dz = (!p.br.relu || z > 0.f) ? (float)v[e] : 0.f;
                   s[hf][e] += dz;
                   q2[hf][e] += dz * yf;
                 }
@@ -1334,19 +1413,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
             }
           }
         }
+        if (gops && it + PF < NR) request(it + PF);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
     if (do_stats) {
-      if (br != nullptr) {
+      if (has_br) {
 #pragma unroll
         for (int hf = 0; hf < NW; ++hf)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int cc = co0 + hf * 64 + c8 * 8 + e;
-            q2[hf][e] = (q2[hf][e] - br->mean[cc] * s[hf][e]) * br->invstd[cc];
+            q2[hf][e] = (q2[hf][e] - p.br.mean[cc] * s[hf][e]) * p.br.invstd[cc];
           }
       }
 #pragma unroll
