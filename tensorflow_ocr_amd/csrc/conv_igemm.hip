@@ -432,6 +432,14 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     }
   };
 
+  // batch-norm partials: per lane over ALL tiles of this wave (its 8 couts are fixed), one row per wave of the
+  // grid at the end (ocr_conv2d_num_mtiles: 8 x workgroups per cout tile).  One row per tile cost a block
+  // barrier and a 512-byte store per tile — 0.16 ms of a 0.96 ms launch — and 32,768 rows for the finalize
+  // kernel of conv1_2 to read.
+  float s[8], q2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
+
   if (m_first < m_tiles) halo_load(m_first);
   for (int mt = m_first; mt < m_tiles; mt += m_step) {
     const int txi = mt % p.tiles_x;
@@ -520,9 +528,6 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     {
       const int c = lane & 7, pg = lane >> 3;          // 16-byte chunk of the row, pixel group
       const int oy = tyi * TILE_H + wave;
-      float s[8], q2[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int px = k * 8 + pg;
@@ -557,31 +562,24 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
           }
         }
       }
-      if (do_stats) {
+    }
+  }
+  if (do_stats) {
+    const int c = lane & 7, pg = lane >> 3;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 8; ++e) {
 #pragma unroll
-          for (int o = 8; o < 64; o <<= 1) {
-            s[e] += __shfl_xor(s[e], o, 64);
-            q2[e] += __shfl_xor(q2[e], o, 64);
-          }
-        }
-        // (in-order LDS: this wave's row reads above are complete before these writes land)
-        float* part = reinterpret_cast<float*>(stage);          // [2][64] of this wave
-        if (pg == 0) {
+      for (int o = 8; o < 64; o <<= 1) {
+        s[e] += __shfl_xor(s[e], o, 64);
+        q2[e] += __shfl_xor(q2[e], o, 64);
+      }
+    }
+    if (pg == 0) {
+      float* row = stats + ((size_t)(m_first * 8 + wave) * 2) * p.cout + co0 + c * 8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            part[c * 8 + e] = s[e];
-            part[64 + c * 8 + e] = q2[e];
-          }
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-          float tot = 0.f;
-#pragma unroll
-          for (int wv = 0; wv < 8; ++wv) tot += reinterpret_cast<const float*>(stage_all + wv * (32 * 128))[tid];
-          stats[((size_t)mt * 2 + (tid >> 6)) * p.cout + co0 + (tid & 63)] = tot;
-        }
+      for (int e = 0; e < 8; ++e) {
+        row[e] = s[e];
+        row[p.cout + e] = q2[e];
       }
     }
   }
@@ -1520,26 +1518,37 @@ static bool conv_c64_ok(const ConvP& p) {
          (size_t)p.n * p.h * p.w * p.cin < (1u << 30);   // 32-bit buffer offsets
 }
 
+// workgroups per cout tile of the persistent 64-channel kernel: one workgroup per CU in all
+static int c64_per(const ConvP& p) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
+  int per = cus / p.n_tiles;
+  if (per < 1) per = 1;
+  if (per > m_tiles) per = m_tiles;
+  return per;
+}
+
 static int launch_c64(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
                       hipStream_t st) {
   const size_t area = ((size_t)p.halo_bytes + 15) & ~(size_t)15;
   const size_t lds = area + (size_t)p.kh * p.kw * 64 * conv_wrs(64) + 8 * 32 * 128;   // halo + weights + wave staging
   if (lds > 160 * 1024) return OCR_ERR_UNSUPPORTED;
   auto kern = conv_c64_persist_kernel<64>;
-  static int cus = 0;
-  if (!cus) {
+  static bool configured = false;
+  if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(160 * 1024)) != hipSuccess)
       return OCR_ERR_HIP;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OCR_ERR_HIP;
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    configured = true;
   }
-  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
-  int per = cus / p.n_tiles;                          // workgroups per cout tile: one workgroup per CU
-  if (per < 1) per = 1;
-  if (per > m_tiles) per = m_tiles;
+  const int per = c64_per(p);
+  if (per <= 0) return OCR_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3((unsigned)(per * p.n_tiles)), dim3(512), lds, st, p, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats), (int)area);
@@ -1585,6 +1594,13 @@ static int conv_w4s_bn(const ConvP& p) {
   return p.cout % 128 == 0 ? 128 : p.cout % 64 == 0 ? 64 : 0;
 }
 
+struct TileCfg { int bn, ck, th; };
+
+// the persistent 64-channel kernel runs this shape (its partial rows are per wave of the grid, not per tile)
+static bool uses_c64(const ConvP& p, const TileCfg& c) {
+  return !p.pw && conv_w4s_bn(p) == 0 && c.bn == 64 && c.ck == 64 && c.th == 8 && conv_c64_ok(p);
+}
+
 template <int BN>
 static int launch_w4s(const ConvP& p0, const void* x, const void* w, const void* bias, void* y, void* stats,
                       hipStream_t st) {
@@ -1620,7 +1636,6 @@ int launch(const ConvP& p, const void* x, const void* w, const void* bias, void*
 // LDS stage.  Per-wave register tile is 64 couts x 128 px wherever cout allows (accumulators = 128
 // VGPRs), so narrow layers get taller pixel tiles: that halves the fragment reads per MFMA of the
 // 64-/128-cout layers and amortises each streamed weight slice over more pixels.
-struct TileCfg { int bn, ck, th; };
 
 // 1x1 stride-1 convs whose pixel count is a multiple of 32 go to the pointwise GEMM kernel
 static bool conv_is_pw(const ocr_conv_desc* d) {
@@ -1695,6 +1710,12 @@ OCR_DIAG_READER(ocr_diag_read_conv, ocr_diag_conv)
 extern "C" int ocr_conv2d_num_mtiles(const ocr_conv_desc* d) {
   if (!d) return OCR_ERR_INVALID_ARG;
   if (conv_is_pw(d)) return (int)(((long long)d->n * d->oh * d->ow + 255) / 256);   // flat 256-pixel tiles
+  ConvP p;
+  TileCfg c;
+  if (fill_params(d, &p, &c) == OCR_OK && uses_c64(p, c)) {
+    const int per = c64_per(p);                      // one row per wave of the persistent grid
+    return per > 0 ? 8 * per : OCR_ERR_HIP;
+  }
   return d->n * ocr_cdiv(d->ow, TILE_W) * ocr_cdiv(d->oh, TILE_H);
 }
 
@@ -1746,7 +1767,10 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     case 1286408: return launch<128, 64, 2>(p, x, w_kc, bias, y, stats, st);
     case 1283208: return launch<128, 32, 2>(p, x, w_kc, bias, y, stats, st);
     case 646408:
-      if (!tail && conv_c64_ok(p)) return launch_c64(p, x, w_kc, bias, y, stats, st);
+      if (conv_c64_ok(p)) {
+        if (tail) return OCR_ERR_UNSUPPORTED;      // (ocr_conv2d_num_mtiles sized the partials for launch_c64)
+        return launch_c64(p, x, w_kc, bias, y, stats, st);
+      }
       return launch<64, 64, 2>(p, x, w_kc, bias, y, stats, st);
     case 643208: return launch<64, 32, 2>(p, x, w_kc, bias, y, stats, st);
     case 326408: return launch<32, 64, 1>(p, x, w_kc, bias, y, stats, st);
