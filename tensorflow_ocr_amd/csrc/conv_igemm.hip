@@ -346,244 +346,6 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// 64-channel multi-tap layers at large spatial size (conv1_2 forward / input gradient: cin = 64,
-// cout = 64, 8 x 32 pixel tiles).  There the tap-sweeping kernel above is bound by its per-tile
-// latency chain, not by MFMA, LDS or HBM throughput: one channel chunk means nothing to prefetch
-// under, every 16 MFMAs per wave sit between two barriers + a weight DMA, and the block-wide staged
-// epilogue costs as much as the main loop (measured: main loop alone 0.35 ms, epilogue alone 0.54 ms
-// of 1.15 ms for conv1_2).  This variant is PERSISTENT and WEIGHT-STATIONARY:
-//   * a workgroup stages all kh*kw weight slices of its cout tile in LDS once (73 KB for 3x3x64x64)
-//     and then walks pixel tiles;
-//   * per tile the halo of the NEXT tile is already in flight in registers while the kh*kw*2 k-steps
-//     of MFMAs run without a single barrier;
-//   * wave w owns tile row w (32 pixels) x all 64 couts, so its output rows are whole 128-byte
-//     lines: the epilogue is WAVE-PRIVATE (4 KB of LDS per wave, XOR-swizzled, no block barrier):
-//     a wave that is done computing transposes and drains its row with 16-byte coalesced stores
-//     while slower waves still compute;
-//   * batch-norm partials (of the STORED 16-bit values; with `br` the producing layer's BN-backward
-//     sums): per lane over its 4 pixels, butterfly over the 8 pixel groups of the wave, then the 8
-//     waves through LDS in wave order (deterministic).
-// Same weight/halo fragment layout and MFMA shape as conv_igemm_kernel<64,64,2,true,8>.
-template <int BN>
-__global__ __launch_bounds__(512) void conv_c64_persist_kernel(
-    ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
-    const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats, int halo_area) {
-  constexpr int NT = 512, CK = 64, TH = 8;
-  constexpr int PSTR = conv_pstr(CK, true);
-  constexpr int CPP = CK / 8;
-  constexpr int WRS = conv_wrs(CK);
-  constexpr int AI = 4, AT = 2;                      // 64 couts x 32 pixels per wave
-  constexpr int NH = 6;                              // halo prefetch registers (16 B each) per thread
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* halo = smem;
-  char* wbuf = smem + halo_area;                     // [ntaps][BN][CK] f16, rows XOR-swizzled
-  char* stage_all = wbuf + p.kh * p.kw * (BN * WRS); // [8 waves][32 px][128 B]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  char* stage = stage_all + wave * (32 * 128);
-  const int ntaps = p.kh * p.kw;
-  const int WT = p.WT;
-  const int halo_total = p.HT * WT * CPP;            // <= NH * NT (checked by the launcher)
-  const int nt = blockIdx.x % p.n_tiles;
-  const int co0 = nt * BN;
-  const int m_first = blockIdx.x / p.n_tiles, m_step = gridDim.x / p.n_tiles;
-  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
-  const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
-  const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
-  const bool has_br = p.br.y != nullptr;         // (fields read by value: a pointer to p.br would pin the kernel arguments in scratch)
-
-  // all weight slices of this cout tile -> LDS, once (BN * CPP = 512 chunks per slice: one per thread)
-  for (int tap = 0; tap < ntaps; ++tap) {
-    const int tapw = p.flip ? (ntaps - 1 - tap) : tap;
-    const half_t* src = w + ((size_t)tapw * p.cout + co0) * p.cin;
-    const int rr = tid / CPP, c = tid % CPP;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + (size_t)rr * p.cin + ((c ^ wswz(rr, CK, true)) << 3)),
-        (__attribute__((address_space(3))) void*)(wbuf + tap * (BN * WRS) + (tid & ~63) * 16), 16, 0, 0);
-  }
-
-  const int frow = lane & 15, fkg = lane >> 4;
-  const int a_lane = frow * WRS;
-  const int fx = wswz(frow, CK, true);
-  const int b_lane = (frow * p.stride) * PSTR + fkg * 16;
-  const int b_half = 16 * p.stride * PSTR;
-  const int b_row = p.stride * WT * PSTR;
-
-  // halo loads are BUFFER loads whose range check supplies the zero padding (offset beyond the descriptor ->
-  // zeros): no branch, no per-load wait (see wgrad3_kernel); the launcher keeps tensors under 2 GiB here
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<half_t*>(x), 0, (int)((size_t)p.n * p.h * p.w * p.cin * 2), 0x00020000);
-  u32x4 hreg[NH];
-  auto halo_load = [&](int mt) {
-    const int txi = mt % p.tiles_x;
-    const int tmp = mt / p.tiles_x;
-    const int tyi = tmp % p.tiles_y, img = tmp / p.tiles_y;
-    const int iy0 = tyi * TH * p.stride - p.pt, ix0 = txi * TILE_W * p.stride - p.pl;
-#pragma unroll
-    for (int u = 0; u < NH; ++u) {
-      const int idx = u * NT + tid;
-      const int hp = idx / CPP, c = idx % CPP;
-      const int hy = hp / WT, hx = hp - hy * WT;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      const bool ok = idx < halo_total && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-      const unsigned off = ok ? (unsigned)((((img * p.h + iy) * p.w + ix) * p.cin + c * 8) * 2) : 0xfffffff0u;
-      hreg[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
-    }
-  };
-
-  // batch-norm partials: per lane over ALL tiles of this wave (its 8 couts are fixed), one row per wave of the
-  // grid at the end (ocr_conv2d_num_mtiles: 8 x workgroups per cout tile).  One row per tile cost a block
-  // barrier and a 512-byte store per tile — 0.16 ms of a 0.96 ms launch — and 32,768 rows for the finalize
-  // kernel of conv1_2 to read.
-  float s[8], q2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
-
-  if (m_first < m_tiles) halo_load(m_first);
-  for (int mt = m_first; mt < m_tiles; mt += m_step) {
-    const int txi = mt % p.tiles_x;
-    const int tmp = mt / p.tiles_x;
-    const int tyi = tmp % p.tiles_y, img = tmp / p.tiles_y;
-    __syncthreads();                                 // every wave has finished the previous tile (halo + partials free)
-#pragma unroll
-    for (int u = 0; u < NH; ++u) {
-      const int idx = u * NT + tid;
-      if (idx < halo_total) *reinterpret_cast<u32x4*>(halo + (idx / CPP) * PSTR + (idx % CPP) * 16) = hreg[u];
-    }
-    __syncthreads();                                 // halo (and, the first time, the weights) visible
-    if (mt + m_step < m_tiles) halo_load(mt + m_step);   // in flight under this tile's MFMAs
-    // the epilogue's global operands (BN-backward operand, old gradient under ACCUM) of THIS tile: requested
-    // here, ahead of the MFMAs — behind the epilogue's stores each would wait for them and cost a full HBM
-    // latency per pixel group (measured: +0.36 ms on a 0.92 ms launch)
-    half8_t yq[4], oq[4];
-    {
-      const int c = lane & 7, pg = lane >> 3;
-      const int oy = tyi * TILE_H + wave;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int ox = txi * TILE_W + k * 8 + pg;
-        if (oy < p.oh && ox < p.ow) {
-          const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8;
-          if (do_stats && has_br) yq[k] = *reinterpret_cast<const half8_t*>(p.br.y + off);
-          if (accum) oq[k] = *reinterpret_cast<const half8_t*>(y + off);
-        }
-      }
-    }
-
-    f32x4 acc[AI][AT];
-#pragma unroll
-    for (int i = 0; i < AI; ++i)
-#pragma unroll
-      for (int t = 0; t < AT; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][t][e] = 0.f;
-    for (int tap = 0; tap < ntaps; ++tap) {
-      const int ky = tap / p.kw, kx = tap - ky * p.kw;
-      const char* ab = wbuf + tap * (BN * WRS) + a_lane;
-      const char* bb = halo + b_lane + ((ky * p.dil) * WT + kx * p.dil) * PSTR + wave * b_row;
-#pragma unroll
-      for (int ks = 0; ks < CK / 32; ++ks) {
-        half8_t a[AI], b[AT];
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-          a[i] = *reinterpret_cast<const half8_t*>(ab + i * 16 * WRS + (((ks * 4 + fkg) ^ fx) << 4));
-#pragma unroll
-        for (int t = 0; t < AT; ++t) b[t] = *reinterpret_cast<const half8_t*>(bb + t * b_half + ks * 64);
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-#pragma unroll
-          for (int t = 0; t < AT; ++t) acc[i][t] = OCR_MFMA_16x16x32(a[i], b[t], acc[i][t], 0, 0, 0);
-      }
-    }
-
-    // ---- wave-private epilogue: accumulator quads -> this wave's [32 px][64 co] staging rows
-    // (16-byte chunk index XOR-swizzled by the pixel) -> whole 128-byte output rows
-    {
-      const int r = lane & 15, g4 = lane >> 4;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (has_bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + i * 16 + g4 * 4 + e];
-        }
-#pragma unroll
-        for (int t = 0; t < AT; ++t) {
-          const int px = t * 16 + r;
-          half4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[i][t][e] + bv[e];
-            if (relu) v = v > 0.f ? v : 0.f;
-            o[e] = (half_t)v;
-          }
-          *reinterpret_cast<half4_t*>(stage + px * 128 + (((i * 2 + (g4 >> 1)) ^ (px & 7)) << 4) + (g4 & 1) * 8) = o;
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      const int c = lane & 7, pg = lane >> 3;          // 16-byte chunk of the row, pixel group
-      const int oy = tyi * TILE_H + wave;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int px = k * 8 + pg;
-        const int ox = txi * TILE_W + px;
-        if (oy < p.oh && ox < p.ow) {
-          half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c ^ (px & 7)) << 4));
-          const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8;
-          if (accum) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
-          }
-          *reinterpret_cast<half8_t*>(y + off) = v;
-          if (do_stats) {
-            if (has_br) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const int cc = co0 + c * 8 + e;
-                const float yf = (float)yq[k][e];
-                const float z = (float)(half_t)(yf * p.br.scale[cc] + p.br.shift[cc]);
-                const float dz = (!p.br.relu || z > 0.f) ? (float)v[e] : 0.f;
-                s[e] += dz;
-                q2[e] += dz * ((yf - p.br.mean[cc]) * p.br.invstd[cc]);
-              }
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float f = (float)v[e];
-                s[e] += f;
-                q2[e] += f * f;
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  if (do_stats) {
-    const int c = lane & 7, pg = lane >> 3;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) {
-        s[e] += __shfl_xor(s[e], o, 64);
-        q2[e] += __shfl_xor(q2[e], o, 64);
-      }
-    }
-    if (pg == 0) {
-      float* row = stats + ((size_t)(m_first * 8 + wave) * 2) * p.cout + co0 + c * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        row[e] = s[e];
-        row[p.cout + e] = q2[e];
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Pointwise (1x1, stride 1) convolutions as a plain GEMM:  y[px][co] = sum_ci x[px][ci] * w[co][ci].
@@ -1457,6 +1219,261 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64 input channels, 3x3 / stride 1, on large maps (conv1_2 forward / input gradient: 2.1 GB of activations
+// for 0.62 TFLOP — the floor is the HBM stream, not MFMA; also ResNet's block1 3x3).  The tap-sweeping
+// kernels re-fetch 72 KB of weight slices per 32 KB of output here.  This variant is PERSISTENT and
+// WEIGHT-STATIONARY:
+//   * a workgroup stages all nine [64 couts][64 channels] slices of its cout tile in LDS once (72 KB, rows of
+//     128 B, chunk ^ ((row >> 1) & 7)) and then walks 8 x 32-pixel tiles;
+//   * the 64-channel halo of a tile (10 x 34 pixels x 128 B, chunk ^ (pixel & 7), zero padding by the buffer
+//     range check) goes global -> LDS by LDS-DMA into one of TWO buffers: the halo of tile k+1 is requested
+//     before tile k's MFMAs and has their whole duration to land (the first version of this kernel
+//     carried it through registers: six 16-byte loads per thread with their address arithmetic, six LDS
+//     stores and two block barriers per tile);
+//   * wave w owns tile row w (32 pixels) x all 64 couts: 18 k-steps of 8 MFMAs from LDS alone; its output
+//     rows are whole 128-byte lines, so the epilogue is wave-private — staged through 4 KB of the halo
+//     buffer the tile was just computed from (dead by then);
+//   * the epilogue's global operands (BN-backward operand, old gradient under ACCUM) are requested before
+//     the MFMAs; batch-norm partials are accumulated per lane over ALL tiles of the wave and leave as
+//     one row per wave of the grid (ocr_conv2d_num_mtiles: 8 x workgroups per cout tile).
+// Per tile: DMA(k+1) | MFMAs(k) | wait for DMA(k+1) + barrier (every wave is done reading halo k, halo k+1 is
+// visible) | epilogue(k) | barrier (staging reads done: the buffer may receive DMA(k+2)).  The wait sits BEFORE
+// the epilogue's stores are issued, so it never waits for them.
+constexpr int C64_NH = 6;                                          // halo DMA rounds of 512 slots (2720 slots used)
+constexpr int C64_LDS = 2 * W4_HBYTES + 9 * 64 * 128;              // 163840 = the whole LDS
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv_c64_persist_kernel(
+    ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
+    const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
+  static_assert(BN == 64, "one 64-cout tile per workgroup");
+  constexpr int TH = 8, WT = W4_WT, AI = 4, AT = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wst = smem + 2 * W4_HBYTES;             // [9][64 couts][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = tile row
+  const int L = lane & 15, kg = lane >> 4;
+  const int nt = blockIdx.x % p.n_tiles;
+  const int co0 = nt * BN;
+  const int m_first = blockIdx.x / p.n_tiles, m_step = gridDim.x / p.n_tiles;
+  const int m_tiles = p.n * p.tiles_x * p.tiles_y;
+  const int ntile = m_first < m_tiles ? (m_tiles - m_first + m_step - 1) / m_step : 0;
+  const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
+  const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
+  const bool has_br = p.br.y != nullptr;              // (fields read by value: a pointer to p.br would pin the arguments in scratch)
+
+  // weights -> LDS, once: slot tap*512 + tid -> row tid>>3, stored chunk tid&7 holds logical chunk c ^ swz
+  {
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(w), 0, 9 * p.cout * p.cin * 2, 0x00020000);
+    const int rr = tid >> 3, c = tid & 7;
+    const unsigned wvo = (unsigned)((rr * p.cin + ((c ^ ((rr >> 1) & 7)) << 3)) * 2);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tapw = p.flip ? (8 - tap) : tap;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          wrs, (__attribute__((address_space(3))) void*)(wst + tap * 8192 + wave * 1024), 16, wvo,
+          ((tapw * p.cout + co0) * p.cin) * 2, 0, 0);
+    }
+  }
+
+  auto tile_of = [&](int k, int& img, int& tyi, int& txi) __attribute__((always_inline)) {
+    const int mt = m_first + k * m_step;
+    txi = mt % p.tiles_x;
+    const int tmp = mt / p.tiles_x;
+    tyi = tmp % p.tiles_y;
+    img = tmp / p.tiles_y;
+  };
+  // halo of this workgroup's k-th tile -> buffer hb (6 rounds of 512 slots; slots past the 340 pixels fall
+  // into the buffer's padding, the waves that would leave it sit the last round out)
+  constexpr unsigned OOB = 0x80000000u;
+  auto dma_tile = [&](int k, int hb) __attribute__((always_inline)) {
+    int img, tyi, txi;
+    tile_of(k, img, tyi, txi);
+    const int iy0 = tyi * TH - p.pt, ix0 = txi * TILE_W - p.pl;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(x) + (size_t)img * p.h * p.w * p.cin, 0, p.h * p.w * p.cin * 2, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < C64_NH; ++u) {
+      if (u == C64_NH - 1 && (u * 512 + wave * 64) * 16 >= W4_HBYTES) continue;      // waves 4..7, last round
+      const int idx = u * 512 + tid;
+      const int hp = idx >> 3, sl = idx & 7;
+      const int hy = hp / WT, hx = hp - hy * WT;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const unsigned off = ((hp < W4_HT * WT) & ((unsigned)iy < (unsigned)p.h) & ((unsigned)ix < (unsigned)p.w))
+                               ? (unsigned)(((iy * p.w + ix) * p.cin + ((sl ^ (hp & 7)) << 3)) * 2)
+                               : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          xrs, (__attribute__((address_space(3))) void*)(smem + hb * W4_HBYTES + (u * 512 + wave * 64) * 16), 16, off,
+          0, 0, 0);
+    }
+  };
+
+  // pixel fragment of 16-pixel group t at tap (ky,kx): halo pixel hp = (wave + ky)*34 + t*16 + kx + L, chunk
+  // (ks*4 + kg) ^ (hp & 7); hp & 7 = (L + 2*wave + u) & 7 with u = (2*ky + kx) & 7 static
+  unsigned tb[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      tb[ks][u] = (unsigned)((wave * WT + L) * 128 + (((ks * 4 + kg) ^ ((L + 2 * wave + u) & 7)) << 4));
+  unsigned ab[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    ab[ks] = (unsigned)(2 * W4_HBYTES + L * 128 + (((ks * 4 + kg) ^ ((L >> 1) & 7)) << 4));
+
+  // batch-norm partials: per lane over all tiles of this wave (its 8 couts are fixed)
+  const int c8 = lane & 7, pg = lane >> 3;
+  float s[8], q2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
+
+  if (ntile > 0) dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int k = 0; k < ntile; ++k) {
+    const int hb = k & 1;
+    int img, tyi, txi;
+    tile_of(k, img, tyi, txi);
+#ifndef C64_ABL
+#define C64_ABL 0      // dev ablations: 1 no halo DMA in the loop, 2 no output stores, 4 no MFMAs
+#endif
+    if ((C64_ABL & 1) == 0 && k + 1 < ntile) dma_tile(k + 1, hb ^ 1);        // lands under this tile's MFMAs
+    // the epilogue's global operands of THIS tile, requested ahead of the MFMAs
+    half8_t yq[4], oq[4];
+    const int oy = tyi * TH + wave;
+    {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int ox = txi * TILE_W + kk * 8 + pg;
+        if (oy < p.oh && ox < p.ow) {
+          const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c8 * 8;
+          if (do_stats && has_br) yq[kk] = *reinterpret_cast<const half8_t*>(p.br.y + off);
+          if (accum) oq[kk] = *reinterpret_cast<const half8_t*>(y + off);
+        }
+      }
+    }
+
+    f32x4 acc[AI][AT];
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int t = 0; t < AT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned hoff = (unsigned)(hb * W4_HBYTES);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+      const int u = (2 * ky + kx) & 7;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        half8_t a[AI], b[AT];
+#pragma unroll
+        for (int i = 0; i < AI; ++i) a[i] = *reinterpret_cast<const half8_t*>(smem + (ab[ks] + tap * 8192 + i * 2048));
+#pragma unroll
+        for (int t = 0; t < AT; ++t)
+          b[t] = *reinterpret_cast<const half8_t*>(smem + (hoff + tb[ks][u] + (ky * WT + t * 16 + kx) * 128));
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int t = 0; t < AT; ++t)
+            if ((C64_ABL & 4) == 0) acc[i][t] = OCR_MFMA_16x16x32(a[i], b[t], acc[i][t], 0, 0, 0);
+            else acc[i][t][0] += (float)a[i][0] * (float)b[t][0];
+      }
+    }
+    // halo k+1 (and the operands above) have landed; behind the barrier every wave is done reading halo k
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- wave-private epilogue: accumulator quads -> this wave's [32 px][64 co] staging rows in the dead halo
+    // buffer (16-byte chunk index XOR (pixel & 7)) -> whole 128-byte output rows
+    char* const stage = smem + hb * W4_HBYTES + wave * 4096;
+    {
+      const int g4 = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + i * 16 + g4 * 4 + e];
+        }
+#pragma unroll
+        for (int t = 0; t < AT; ++t) {
+          const int px = t * 16 + L;
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][t][e] + bv[e];
+            if (relu) v = v > 0.f ? v : 0.f;
+            o[e] = (half_t)v;
+          }
+          *reinterpret_cast<half4_t*>(stage + px * 128 + (((i * 2 + (g4 >> 1)) ^ (px & 7)) << 4) + (g4 & 1) * 8) = o;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int px = kk * 8 + pg;
+      const int ox = txi * TILE_W + px;
+      if (oy < p.oh && ox < p.ow) {
+        half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
+        const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c8 * 8;
+        if (accum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[kk][e]);
+        }
+        if ((C64_ABL & 2) == 0 || v[0] == (half_t)12345.f) *reinterpret_cast<half8_t*>(y + off) = v;
+        if (do_stats) {
+          if (has_br) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int cc = co0 + c8 * 8 + e;
+              const float yf = (float)yq[kk][e];
+              const float z = (float)(half_t)(yf * p.br.scale[cc] + p.br.shift[cc]);
+              const float dz = (!p.br.relu || z > 0.f) ? (float)v[e] : 0.f;
+              s[e] += dz;
+              q2[e] += dz * ((yf - p.br.mean[cc]) * p.br.invstd[cc]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = (float)v[e];
+              s[e] += f;
+              q2[e] += f * f;
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own staging reads are done ...
+    __builtin_amdgcn_s_barrier();                         // ... and everyone's: the buffer may receive the halo of tile k+2
+  }
+  if (do_stats) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        s[e] += __shfl_xor(s[e], o, 64);
+        q2[e] += __shfl_xor(q2[e], o, 64);
+      }
+    }
+    if (pg == 0) {
+      float* row = stats + ((size_t)(m_first * 8 + wave) * 2) * p.cout + co0 + c8 * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        row[e] = s[e];
+        row[p.cout + e] = q2[e];
+      }
+    }
+  }
+}
+
 template <int BN, int WCO>
 int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
               hipStream_t st) {
@@ -1512,10 +1529,9 @@ int launch_t(const ConvP& p, const void* x, const void* w, const void* bias, voi
 // persistent weight-stationary variant: cin == 64, 64-cout tiles, 16x16x32 MFMA, 8-row tiles
 static bool conv_c64_ok(const ConvP& p) {
   static const int on = [] { const char* e = getenv("OCR_CONV_PERSIST"); return e ? atoi(e) : 1; }();
-  const int ntaps = p.kh * p.kw;
-  return on && p.m16 && p.cin == 64 && ntaps > 1 && ntaps <= 9 && p.HT * p.WT * 8 <= 6 * 512 &&
-         p.n * p.tiles_x * p.tiles_y >= 128 &&      // enough pixel tiles to amortise the weight staging
-         (size_t)p.n * p.h * p.w * p.cin < (1u << 30);   // 32-bit buffer offsets
+  return on && p.m16 && p.cin == 64 && p.kh == 3 && p.kw == 3 && p.dil == 1 && p.stride == 1 &&
+         p.n * p.tiles_x * ocr_cdiv(p.oh, 8) >= 128 &&   // enough pixel tiles to amortise the weight staging
+         (size_t)p.h * p.w * p.cin * 2 < (1u << 31);      // per-image buffer descriptors
 }
 
 // workgroups per cout tile of the persistent 64-channel kernel: one workgroup per CU in all
@@ -1534,11 +1550,8 @@ static int c64_per(const ConvP& p) {
   return per;
 }
 
-static int launch_c64(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
+static int launch_c64(const ConvP& p0, const void* x, const void* w, const void* bias, void* y, void* stats,
                       hipStream_t st) {
-  const size_t area = ((size_t)p.halo_bytes + 15) & ~(size_t)15;
-  const size_t lds = area + (size_t)p.kh * p.kw * 64 * conv_wrs(64) + 8 * 32 * 128;   // halo + weights + wave staging
-  if (lds > 160 * 1024) return OCR_ERR_UNSUPPORTED;
   auto kern = conv_c64_persist_kernel<64>;
   static bool configured = false;
   if (!configured) {
@@ -1547,11 +1560,13 @@ static int launch_c64(const ConvP& p, const void* x, const void* w, const void* 
       return OCR_ERR_HIP;
     configured = true;
   }
+  ConvP p = p0;
+  p.tiles_y = ocr_cdiv(p.oh, 8);                 // (the tile configuration may have chosen 16-row tiles)
   const int per = c64_per(p);
   if (per <= 0) return OCR_ERR_HIP;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(per * p.n_tiles)), dim3(512), lds, st, p, static_cast<const half_t*>(x),
-                     static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
-                     static_cast<float*>(stats), (int)area);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(per * p.n_tiles)), dim3(512), (size_t)C64_LDS, st, p,
+                     static_cast<const half_t*>(x), static_cast<const half_t*>(w), static_cast<const float*>(bias),
+                     static_cast<half_t*>(y), static_cast<float*>(stats));
   return ocr_launch_status();
 }
 
