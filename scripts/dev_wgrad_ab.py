@@ -3,8 +3,8 @@ import ctypes, os, sys
 import torch
 sys.path.insert(0, '.')
 from tensorflow_ocr_amd import _lib as L
-SH = [(256,64,128),(256,128,128),(128,128,256),(128,256,256),(64,256,512),(64,512,512),(32,512,512)]
-WT = [1,1,1,2,1,2,3]
+SH = [(512,64,64),(256,64,128),(256,128,128),(128,128,256),(128,256,256),(64,256,512),(64,512,512),(32,512,512)]
+WT = [1,1,1,1,2,1,2,3]
 def run(hw,cin,cout,iters=10,B=32):
     dev='cuda'
     x=torch.randn(B,hw,hw,cin,device=dev).half(); dy=(torch.randn(B,hw,hw,cout,device=dev)*0.1).half()

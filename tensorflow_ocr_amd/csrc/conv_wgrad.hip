@@ -438,14 +438,17 @@ __device__ __forceinline__ void static_for4(F&& f) {
   f(WgIC<3>{});
 }
 
-template <int MAXTAPS>
+template <int MAXTAPS, int COB2>
 __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __restrict__ x,
                                                       const half_t* __restrict__ dy,
                                                       float* __restrict__ slab) {
-  constexpr int NT = 256, COB2 = 128;
+  constexpr int NT = 256;
+  static_assert(COB2 == 128 || COB2 == 64, "cout block");
+  constexpr int NJ = COB2 / 32;             // 16-cout blocks per wave: wave tile 32 ci x (COB2 / 2) co
   constexpr int DSTR2 = COB2 * 2 + 32;
   constexpr int DCH = COB2 / 8;
-  constexpr int NDY = 128 * DCH / NT;      // 8
+  constexpr int NDY = 128 * DCH / NT;      // 8 | 4 passes over the 128 dy pixels
+  constexpr int PPP = NT / DCH;            // 16 | 32 pixels per pass
   constexpr int XPP = NT / 8;              // 32 halo pixels per pass
   constexpr int NXMAX = (224 + XPP - 1) / XPP;   // 7
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int ciw = wave >> 1, cow = wave & 1;       // 32-ci half, 64-co half
+  const int ciw = wave >> 1, cow = wave & 1;       // 32-ci half, cout half
   const int li = lane & 15, g = lane >> 4;
   const int q = li >> 2, pp = li & 3;
 
@@ -468,17 +471,17 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
   const int ci0 = cib * CIB, co0 = cob * COB2;
   const int ntaps = p.kh * p.kw;
 
-  f32x4 acc[MAXTAPS][2][4];      // [tap][ci half of 16][co quarter of 16]
+  f32x4 acc[MAXTAPS][2][NJ];     // [tap][ci half of 16][16-cout block]
 #pragma unroll
   for (int t = 0; t < MAXTAPS; ++t)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int a_lane = ((4 * g + q) * p.stride) * X2STR + (ciw * 32 + 4 * pp) * 2;
   const int a_half = 16 * p.stride * X2STR;
-  const int b_lane = (4 * g + q) * DSTR2 + (cow * 64 + 4 * pp) * 2;
+  const int b_lane = (4 * g + q) * DSTR2 + (cow * (COB2 / 2) + 4 * pp) * 2;
   const int b_half = 16 * DSTR2;
 
   const int mt_begin = split * p.tiles_per_split;
@@ -508,10 +511,10 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
     hxv[u] = (hp < HALO_PX && ci0 + xc * 8 < p.cin) ? hx : 0x40000000;
     relx[u] = (unsigned)(((hy * p.w + hx) * p.cin + ci0 + xc * 8) * 2);
   }
-  const int dc = tid % DCH, dprow = tid / DCH;           // dy piece u: pixel u*16 + dprow = row u>>1, column (u&1)*16 + dprow
+  const int dc = tid % DCH, dprow = tid / DCH;           // dy piece u: pixel u*PPP + dprow = row (u*PPP)>>5, column (u*PPP & 31) + dprow
   int colv[2];
 #pragma unroll
-  for (int h2 = 0; h2 < 2; ++h2) colv[h2] = (co0 + dc * 8 < p.cout) ? h2 * 16 + dprow : 0x40000000;
+  for (int h2 = 0; h2 < 2; ++h2) colv[h2] = (co0 + dc * 8 < p.cout) ? (h2 * 16) % 32 + dprow : 0x40000000;
   const unsigned reld = (unsigned)((dprow * p.cout + co0 + dc * 8) * 2);
 
   // the tile whose pieces are being loaded: scalar state
@@ -557,8 +560,8 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
     } else {
       const int u = k - NXMAX;
       if (!(hh & 1)) {
-        const int ox = colv[u & 1] + s_ox0;
-        offp = (unsigned)ox < (unsigned)p.ow ? reld + (unsigned)(s_orgd + ((u >> 1) * p.ow + (u & 1) * 16) * p.cout * 2) : OOB;
+        const int ox = colv[((u * PPP) >> 4) & 1] + s_ox0;
+        offp = (unsigned)ox < (unsigned)p.ow ? reld + (unsigned)(s_orgd + (((u * PPP) >> 5) * p.ow + ((u * PPP) & 31)) * p.cout * 2) : OOB;
       } else {
         dr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, offp, 0, 0));
       }
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
         *reinterpret_cast<u32x4*>(xh + (k * XPP + (tid >> 3)) * X2STR + xc * 16) = xr[k];
     } else if (k < NXMAX + NDY) {
       const int u = k - NXMAX;
-      *reinterpret_cast<u32x4*>(xh + halo_bytes + (u * 16 + dprow) * DSTR2 + dc * 16) = dr[u];
+      *reinterpret_cast<u32x4*>(xh + halo_bytes + (u * PPP + dprow) * DSTR2 + dc * 16) = dr[u];
     }
   };
   auto load_tile = [&]() {
@@ -611,13 +614,13 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
   // 6.4 cycles per read, 19 % of the loop).  x fragment pairs: slot = running tap index & 3 (36 taps per
   // tile), fetched two taps ahead; dy fragments: two sets, the next step's fetched behind taps 4 and 5.
   typedef short short8v __attribute__((ext_vector_type(8)));
-  short4v al[4][2], ah[4][2], bl[2][4], bh[2][4];
+  short4v al[4][2], ah[4][2], bl[2][NJ], bh[2][NJ];
   auto rd = [&](const char* a) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(a)); };
   auto frag = [&](const short4v& lo, const short4v& hi) {
     short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(half8_t, v);
   };
-  // read k (0..7) of the dy fragments of step ty: fragment j = k >> 1, half k & 1
+  // read k (0..2*NJ-1) of the dy fragments of step ty: fragment j = k >> 1, half k & 1
   auto read_b1 = [&](int set, const char* dyt, int ty, int k) {
     if constexpr ((WG3_ABL & 8) != 0) return;
     const char* a = dyt + b_lane + ty * 32 * DSTR2 + (k >> 1) * 32 + ((k & 1) ? b_half : 0);
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
   };
   if (mt_begin < mt_end) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) read_b1(0, smem + halo_bytes, 0, k);
+    for (int k = 0; k < 2 * NJ; ++k) read_b1(0, smem + halo_bytes, 0, k);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       read_a1(0, smem, 0, 0, k);
@@ -664,30 +667,40 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < NJ; ++j) {
             const half8_t fa = frag(al[cur][i], ah[cur][i]), fb = frag(bl[S][j], bh[S][j]);
-            // 288 accumulators: taps 0..7 fill the 256 accumulator-file registers, tap 8 lives in VGPRs
+            // 9 * 2 * NJ accumulator quads: taps 0..7 in the accumulator file, tap 8 in VGPRs
             if (t < 8) mfma16_acc(acc[t][i][j], fa, fb);
-            else if (ty == 3 && i == 1 && j == 3) mfma16_acc_v_drain(acc[t][i][j], fa, fb);   // last MFMA of the loop body
+            else if (ty == 3 && i == 1 && j == NJ - 1) mfma16_acc_v_drain(acc[t][i][j], fa, fb);   // last MFMA of the loop body
             else mfma16_acc_v(acc[t][i][j], fa, fb);
-            const int m = i * 4 + j;                   // one LDS read behind this MFMA
+            const int m = i * NJ + j;                  // gap behind this MFMA: 2 * NJ per tap
+            // (a) the x fragment pair two taps ahead: four reads, one per gap (with NJ = 2 every gap of a tap)
             if (m < 4) {
-              // x fragment pair two taps ahead (next step / next tile past this one's; garbage past the last tile: unused)
               if (t2 < 9) read_a1(nxt, xh, ty, t2, m);
               else if (ty < 3) read_a1(nxt, xh, ty + 1, t2 - 9, m);
-              else read_a1(nxt, xh_n, 0, t2 - 9, m);
-            } else if (t == 4 || t == 5) {
-              const int k = (t - 4) * 4 + (m - 4);
-              if (ty < 3) read_b1(S ^ 1, dyt, ty + 1, k);
-              else read_b1(S ^ 1, xh_n + halo_bytes, 0, k);
-            } else if constexpr (!(WG3_ABL & 1)) {
-              // free gap f (28 per step): step 1 = the 15 stores, then load halves 0..12; step 2 = load halves 13..29
-              const int f = (t < 4 ? t * 4 : (t - 2) * 4) + (m - 4);
-              if constexpr (ty == 1) {
-                if (f < NXMAX + NDY) store_piece(buf ^ 1, f);
-                else load_half(f - (NXMAX + NDY));
+              else read_a1(nxt, xh_n, 0, t2 - 9, m);   // next tile (garbage past the last one: unused)
+            }
+            // (b) the next step's dy fragments (2 * NJ reads) and the staging pieces go into the gaps (a) leaves
+            // free — NJ = 4: gaps 4..7 of every tap; NJ = 2: as a second instruction in all four gaps
+            constexpr int FG = 4;                      // such slots per tap
+            const int fm = NJ == 4 ? m - 4 : m;
+            if (fm >= 0) {
+              constexpr int NBT = 2 * NJ / FG;         // taps whose slots carry the dy reads: 4,5 | 4
+              if (t >= 4 && t < 4 + NBT) {
+                const int k = (t - 4) * FG + fm;
+                if (ty < 3) read_b1(S ^ 1, dyt, ty + 1, k);
+                else read_b1(S ^ 1, xh_n + halo_bytes, 0, k);
+              } else if constexpr (!(WG3_ABL & 1)) {
+                // free slot f of the step ((9 - NBT) * 4 of them): step 1 = the stores, then the first load
+                // halves; step 2 = the remaining load halves
+                constexpr int NPC = NXMAX + NDY, NSL = (9 - NBT) * FG;
+                const int f = (t < 4 ? t : t - NBT) * FG + fm;
+                if constexpr (ty == 1) {
+                  if (f < NPC) store_piece(buf ^ 1, f);
+                  else load_half(f - NPC);
+                }
+                if constexpr (ty == 2) load_half(f + NSL - NPC);
               }
-              if constexpr (ty == 2) load_half(f + 28 - (NXMAX + NDY));
             }
           }
       }
@@ -700,12 +713,12 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(Wg2P p, const half_t* __res
   for (int t = 0; t < MAXTAPS; ++t) {
     if (t < ntaps) {
       float* dst = slab + (((size_t)split * ntaps + t) * p.cin + ci0 + ciw * 32 + 4 * g) * p.cout +
-                   co0 + cow * 64 + li;
-      if (ci0 + ciw * 32 < p.cin && co0 + cow * 64 < p.cout) {
+                   co0 + cow * (COB2 / 2) + li;
+      if (ci0 + ciw * 32 < p.cin && co0 + cow * (COB2 / 2) < p.cout) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) dst[(size_t)(i * 16 + e) * p.cout + j * 16] = acc[t][i][j][e];
       }
@@ -810,16 +823,18 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
     if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
     rc = ocr_detail::wgrad_pw_launch(d, x, dy, workspace, st);
   } else if (fill2(d, &p2, &cob) == OCR_OK) {
-    splits = p2.splits * (cob == 64 ? 2 : 1);
+    static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();
+    const bool small = (size_t)d->n * d->h * d->w * d->cin < (1u << 30) && (size_t)d->n * d->oh * d->ow * d->cout < (1u << 30);   // < 2 GiB each
+    const bool use3 = ntaps == 9 && v3 && small && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1;
+    splits = p2.splits * (cob == 64 && !use3 ? 2 : 1);       // (wgrad2<64> splits K once more inside the workgroup)
     if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
     const size_t lds = 2 * ((size_t)p2.HT * p2.WT * X2STR + 128 * (cob * 2 + 32));
     const unsigned grid = (unsigned)(p2.splits * p2.nci * p2.nco);
     static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 2; }();
     p2.xcd_swizzle = (swz & 2) && grid % 8 == 0;
-    static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();
-    const bool small = (size_t)d->n * d->h * d->w * d->cin < (1u << 30) && (size_t)d->n * d->oh * d->ow * d->cout < (1u << 30);   // < 2 GiB each
-    if (cob == 128 && ntaps == 9 && v3 && small && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1)
-      rc = launch_wg(wgrad3_kernel<9>, p2, grid, lds, x, dy, workspace, st, 256);
+    if (use3)
+      rc = cob == 128 ? launch_wg(wgrad3_kernel<9, 128>, p2, grid, lds, x, dy, workspace, st, 256)
+                      : launch_wg(wgrad3_kernel<9, 64>, p2, grid, lds, x, dy, workspace, st, 256);
     else if (cob == 128)
       rc = ntaps == 1 ? launch_wg(wgrad2_kernel<128, 1>, p2, grid, lds, x, dy, workspace, st, 512)
                       : launch_wg(wgrad2_kernel<128, 9>, p2, grid, lds, x, dy, workspace, st, 512);
