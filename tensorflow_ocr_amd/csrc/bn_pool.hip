@@ -75,11 +75,18 @@ __device__ __forceinline__ void bn_fin_apply<BnBwdFin>(const BnBwdFin& f, int c,
   f.dgamma[c] = (float)q;
 }
 
-// Partial rows per block: small blocks cost ~0.1 us each in dispatch alone (measured: launch time ~
-// 12 us + 0.1 us x blocks), long blocks serialise their loads; aim at <= 128 row blocks per channel group.
+// Partial rows per block.  The launch is a latency chain: first phase (rows / 64 batches of 8 loads per thread),
+// tickets, then the last arriver of a channel group sums the R = T / rows stage rows (R / 16 batches of
+// agent-scope loads) — and every block costs ~0.1 us of dispatch.  Measured (MI355X, us per launch, rows =
+// 64 | 256 | 512): T x C = 6400 x 256: 38.6 | 14.7 | 13.1; 8192 x 128: 28.6 | 11.9 | 11.4; 2048 x 256: 14.9 | 10.1 |
+// 10.7; 400 x 1024: 13.9 | 9.9 | 9.0 (one block per channel group: 8.7).  So: up to 1024 rows one block per channel
+// group finalises directly; beyond that T / 16 rows per block, at least 256.
 static inline int red_rows(int T) {
-  int rows = ((T + 127) / 128 + 31) / 32 * 32;
-  if (rows < 64) rows = 64;
+  static const int forced = [] { const char* e = getenv("OCR_BN_ROWS"); return e ? atoi(e) : 0; }();   // dev sweep
+  if (forced > 0) return forced;
+  if (T <= 1024) return (T + 63) / 64 * 64;
+  int rows = ((T + 15) / 16 + 31) / 32 * 32;
+  if (rows < 256) rows = 256;
   if (rows > 2048) rows = 2048;
   return rows;
 }
