@@ -98,10 +98,13 @@ int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc
  * past the ReLU, i.e. of the shortcut and of bn(bn_y) alike — and `partial` [ocr_conv2d_num_mtiles][2][cout]
  * receives (sum dz, sum dz*xhat(bn_y)) for ocr_bn_relu_bwd_apply_f16 (relu = 0).  Replaces one masking pass
  * and the reduction pass over the bottleneck's widest tensors.  1x1 and generic 3x3 tile kernels only:
- * OCR_ERR_UNSUPPORTED never occurs for 1x1 convolutions. */
+ * OCR_ERR_UNSUPPORTED never occurs for 1x1 convolutions.
+ * sub_grad (may be NULL): the gradient of subsample(out, 2) = out[:, ::2, ::2]
+ * (nets/resnet_utils.py:59-75, the stride-2 identity shortcut), [n][ceil(oh/2)][ceil(ow/2)][cout] f16, added at
+ * the even positions before the mask — instead of a zero-inserted full-size tensor under OCR_CONV_ACCUM_F16. */
 int ocr_conv2d_bnred_tail_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y, void* partial,
                               const void* bn_y, const void* bn_mean, const void* bn_invstd,
-                              const void* tail_out, void* stream);
+                              const void* tail_out, const void* sub_grad, void* stream);
 
 /* First-layer convolution (cin = 3, images [n,h,w,4] f16 with channel 3 zero,
  * produced by ocr_prep_images): 3x3 stride 1, pad 1.

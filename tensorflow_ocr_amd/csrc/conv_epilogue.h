@@ -21,6 +21,14 @@ struct BnRed {
   // mask pass — and the sums are (sum dz, sum dz * xhat(y)).  Only kernels that end in conv_epilogue_store
   // implement it (ocr_conv2d_bnred_tail_f16 routes accordingly).
   const half_t* mask;
+  // tail mode, optional: gradient of a SUBSAMPLED view of this tensor (ResNet's stride-2 identity shortcut,
+  // subsample(x, 2) = x[:, ::2, ::2]), [n][ceil(sub_h/2)][ceil(sub_w/2)][cout]: added at the even positions
+  // instead of being zero-inserted into a full-size tensor first.  sub_h x sub_w = this tensor's spatial size;
+  // the flat pixel index is split by multiply-shift (m, l: q = (P * m) >> (31 + l), exact below 2^31).
+  const half_t* sub;
+  int sub_h, sub_w;
+  unsigned long long sub_m_hw, sub_m_w;
+  int sub_l_hw, sub_l_w;
 };
 
 // LDS needed by the epilogue for a BN-wide tile.
@@ -67,38 +75,56 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
     constexpr int UB = PPT < 4 ? PPT : 4;
     static_assert(PPT % UB == 0, "pixels per thread");
     for (int k0 = 0; k0 < PPT; k0 += UB) {
-      half8_t v[UB], old[UB], mk[UB], yv[UB];
+      half8_t v[UB], old[UB], mk[UB], yv[UB], sv[UB];
       size_t off[UB];
-      bool ok[UB];
-  #pragma unroll
+      bool ok[UB], has_sub[UB];
+#pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int px = rg + (k0 + u) * RG;
         const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
         ok[u] = oy < oh && ox < ow;
         off[u] = (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
         v[u] = *reinterpret_cast<const half8_t*>(otile + px * OSTR + c * 16);
+        has_sub[u] = false;
         if (ok[u]) {
           if (accum) old[u] = *reinterpret_cast<const half8_t*>(y + off[u]);
           if (tail) mk[u] = *reinterpret_cast<const half8_t*>(br->mask + off[u]);
           if (do_stats && br != nullptr) yv[u] = *reinterpret_cast<const half8_t*>(br->y + off[u]);
+          if (tail && br->sub != nullptr) {
+            const unsigned P = (unsigned)(((size_t)img * oh + oy) * ow + ox);      // flat pixel index
+            const unsigned im = (unsigned)(((unsigned long long)P * br->sub_m_hw) >> (31 + br->sub_l_hw));
+            const unsigned rem = P - im * (unsigned)(br->sub_h * br->sub_w);
+            const unsigned yy = (unsigned)(((unsigned long long)rem * br->sub_m_w) >> (31 + br->sub_l_w));
+            const unsigned xx = rem - yy * (unsigned)br->sub_w;
+            if (((yy | xx) & 1u) == 0u) {
+              const int sh = (br->sub_h + 1) >> 1, sw = (br->sub_w + 1) >> 1;
+              has_sub[u] = true;
+              sv[u] = *reinterpret_cast<const half8_t*>(
+                  br->sub + (((size_t)im * sh + (yy >> 1)) * sw + (xx >> 1)) * cout + co0 + c * 8);
+            }
+          }
         }
       }
-  #pragma unroll
+#pragma unroll
       for (int u = 0; u < UB; ++u) {
         if (!ok[u]) continue;
         half8_t w = v[u];
         if (accum) {
-  #pragma unroll
+#pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)old[u][e]);
         }
+        if (has_sub[u]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)sv[u][e]);
+        }
         if (tail) {
-  #pragma unroll
+#pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = (float)mk[u][e] > 0.f ? w[e] : (half_t)0.f;
         }
         *reinterpret_cast<half8_t*>(y + off[u]) = w;
         if (do_stats) {
           if (br != nullptr) {
-  #pragma unroll
+#pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float yf = (float)yv[u][e];
               bool pass = true;                      // tail mode: w is dz already
@@ -108,7 +134,7 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
               q2[e] += dz * yf;
             }
           } else {
-  #pragma unroll
+#pragma unroll
             for (int e = 0; e < 8; ++e) {
               float f = (float)w[e];
               s[e] += f;
@@ -130,6 +156,20 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
           const half8_t old = *reinterpret_cast<const half8_t*>(y + off);
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)old[e]);
+        }
+        if (tail && br->sub != nullptr) {
+          const unsigned P = (unsigned)(((size_t)img * oh + oy) * ow + ox);      // flat pixel index
+          const unsigned im = (unsigned)(((unsigned long long)P * br->sub_m_hw) >> (31 + br->sub_l_hw));
+          const unsigned rem = P - im * (unsigned)(br->sub_h * br->sub_w);
+          const unsigned yy = (unsigned)(((unsigned long long)rem * br->sub_m_w) >> (31 + br->sub_l_w));
+          const unsigned xx = rem - yy * (unsigned)br->sub_w;
+          if (((yy | xx) & 1u) == 0u) {
+            const int sh = (br->sub_h + 1) >> 1, sw = (br->sub_w + 1) >> 1;
+            const half8_t sv = *reinterpret_cast<const half8_t*>(
+                br->sub + (((size_t)im * sh + (yy >> 1)) * sw + (xx >> 1)) * cout + co0 + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)sv[e]);
+          }
         }
         if (tail) {
           const half8_t mk = *reinterpret_cast<const half8_t*>(br->mask + off);

@@ -1823,9 +1823,18 @@ extern "C" int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const
   return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }
 
+// q = (P * m) >> (31 + l) == P / d for every P < 2^31 (round-up method: m = ceil(2^(31+l) / d), l = ceil(log2 d))
+static void magic31(unsigned d, unsigned long long* m, int* l) {
+  int k = 0;
+  while ((1ull << k) < d) ++k;
+  *l = k;
+  *m = ((1ull << (31 + k)) + d - 1) / d;
+}
+
 extern "C" int ocr_conv2d_bnred_tail_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y,
                                          void* partial, const void* bn_y, const void* bn_mean,
-                                         const void* bn_invstd, const void* tail_out, void* stream) {
+                                         const void* bn_invstd, const void* tail_out, const void* sub_grad,
+                                         void* stream) {
   ConvP p;
   TileCfg cfg;
   int rc = fill_params(d, &p, &cfg);
@@ -1835,5 +1844,13 @@ extern "C" int ocr_conv2d_bnred_tail_f16(const ocr_conv_desc* d, const void* x, 
   p.flags |= OCR_CONV_STATS;
   p.br = BnRed{static_cast<const half_t*>(bn_y), nullptr, nullptr, static_cast<const float*>(bn_mean),
                static_cast<const float*>(bn_invstd), 0, static_cast<const half_t*>(tail_out)};
+  if (sub_grad != nullptr) {
+    OCR_CHECK_SHAPE((long long)d->n * d->oh * d->ow < (1ll << 31));
+    p.br.sub = static_cast<const half_t*>(sub_grad);
+    p.br.sub_h = d->oh;
+    p.br.sub_w = d->ow;
+    magic31((unsigned)(d->oh * d->ow), &p.br.sub_m_hw, &p.br.sub_l_hw);
+    magic31((unsigned)d->ow, &p.br.sub_m_w, &p.br.sub_l_w);
+  }
   return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }

@@ -153,7 +153,7 @@ class Act:
     """Activation handle: device tensor + (lazily created) gradient."""
 
     __slots__ = ("data", "grad", "requires_grad", "name", "bn_ctx", "bn_partial", "tail_ctx", "tail_partial",
-                 "pending")
+                 "pending", "sub_grad")
 
     def __init__(self, data, requires_grad=True, name=""):
         self.data = data
@@ -168,6 +168,7 @@ class Act:
         self.tail_ctx = None
         self.tail_partial = None
         self.pending = None
+        self.sub_grad = None      # gradient of this output's stride-2 subsample, waiting for the fused tail conv
 
     @property
     def shape(self):

@@ -115,12 +115,13 @@ def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx):
         L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
 
 
-def conv2d_bnred_tail(d, x, w_kc, y, partial, tail_ctx):
+def conv2d_bnred_tail(d, x, w_kc, y, partial, tail_ctx, sub_grad=None):
     """Input-gradient conv that completes the gradient of a bottleneck output: stores the gradient past the
-    output ReLU and emits the BN-backward sums of the unit's last conv (include/ocr_hip.h)."""
+    output ReLU and emits the BN-backward sums of the unit's last conv; `sub_grad`: gradient of the output's
+    stride-2 subsample, added at the even positions (include/ocr_hip.h)."""
     by, mu, istd, out = tail_ctx
     L.call("ocr_conv2d_bnred_tail_f16", byref(d), ptr(x), ptr(w_kc), ptr(y), ptr(partial), ptr(by), ptr(mu),
-           ptr(istd), ptr(out), _st())
+           ptr(istd), ptr(out), ptr(sub_grad), _st())
     if L.RECORDER is not None:
         flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
         L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))

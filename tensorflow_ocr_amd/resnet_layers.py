@@ -17,6 +17,7 @@ from ._lib import CONV_ACCUM_F16, CONV_STATS
 
 USE_S2D = __import__("os").environ.get("OCR_RESNET_S2D", "1") == "1"     # measurement switch (A/B against the subsample form)
 FUSE_TAIL = __import__("os").environ.get("OCR_RESNET_FUSE_TAIL", "1") == "1"   # measurement switch (bottleneck tail fusion)
+FUSE_SUB = __import__("os").environ.get("OCR_RESNET_FUSE_SUB", "1") == "1"     # ... subsampled shortcut gradient in that conv's epilogue
 
 
 class ConvBN:
@@ -142,7 +143,8 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             # the gradient past its ReLU and emit the BN-backward sums of its last conv (ops.conv2d_bnred_tail)
             Tm = ops.conv2d_num_mtiles(dg)
             partial = g.empty((Tm, 2, d.cin), F32)
-            ops.conv2d_bnred_tail(dg, dy, w_dg, x.grad, partial, x.tail_ctx)
+            ops.conv2d_bnred_tail(dg, dy, w_dg, x.grad, partial, x.tail_ctx, x.sub_grad)
+            x.sub_grad = None
             x.tail_partial = (partial, Tm)
         elif x.bn_ctx is not None and not flags and FUSE_BN_REDUCE:
             # sole consumer of a conv+BN(+ReLU) output: this input-gradient kernel also emits that
@@ -264,15 +266,30 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
             r = conv_bn_act(g, x, depth_bottleneck, 1, "conv1", is_training=is_training)
             r = conv_bn_act(g, r, depth_bottleneck, 3, "conv2", stride=stride, is_training=is_training)
             c3 = conv_bn_raw(g, r, depth, 1, "conv3", is_training=is_training)
-            if late:
+            if late and fuse_in and FUSE_TAIL and FUSE_SUB and is_training:
+                # the subsample's gradient is not zero-inserted into a full-size tensor: it waits in
+                # x.sub_grad for conv1's input-gradient conv (the last contribution), whose epilogue adds it at
+                # the even positions (ocr_conv2d_bnred_tail_f16)
+                n_, h_, w_, c_ = x.shape
+                ys = g.empty((n_, -(-h_ // stride), -(-w_ // stride), c_))
+                ops.maxpool(x.data, 1, stride, (0, 0), ys, None)
+                shortcut = Act(ys, name="shortcut")
+
+                def sub_back():
+                    if shortcut.grad is None:
+                        return
+                    if x.grad is None and x.pending == 2 and stride == 2:
+                        x.sub_grad = shortcut.grad
+                    else:                            # someone else contributed already: materialise
+                        acc = x.grad is not None
+                        if not acc:
+                            x.grad = g.empty(x.shape)
+                        ops.maxpool_bwd(x.data, shortcut.grad, 1, stride, (0, 0), x.grad, acc, in_shape=x.shape)
+                    x.pending -= 1
+                    shortcut.grad = None
+                g.record(sub_back)
+            elif late:
                 shortcut = make_shortcut()
-                if fuse_in:
-                    def count():                     # runs right after the subsample's backward
-                        if x.pending is not None:
-                            x.pending -= 1
-                    g.record(count)
-                    # (recorded after the pool: executes BEFORE it; the pool is the first of the two
-                    # contributions either way, so the order of the decrement does not matter)
     if g.precision == "f32":
         from . import layers_f32
         return layers_f32.bn_add_relu(g, c3, shortcut, scope)

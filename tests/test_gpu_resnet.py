@@ -253,16 +253,18 @@ def test_strided_conv_space_to_depth_equals_subsample_form(device, monkeypatch):
 
 
 def test_bottleneck_tail_fusion_equals_separate_passes(device, monkeypatch):
-    """A chain of four units (projection, identity, subsampling, projection after the stride) with a second
-    consumer on two of the outputs: the gradient-past-ReLU + BN-backward sums emitted by the next unit's last
-    1x1 input-gradient conv (ocr_conv2d_bnred_tail_f16) give the gradients of the separate relu_bwd /
-    reduction passes — same sums, reduced in a different order."""
+    """A chain of five units (projection, identity, subsampling, projection after the stride, subsampling) with a
+    second consumer on one of the outputs: the gradient-past-ReLU + BN-backward sums emitted by the next unit's
+    last 1x1 input-gradient conv (ocr_conv2d_bnred_tail_f16) give the gradients of the separate relu_bwd /
+    reduction passes — same sums, reduced in a different order.  u3's input already carries a gradient when its
+    subsampling shortcut runs backward (zero insertion + accumulate); u5's does not, so the shortcut gradient
+    rides into conv1's epilogue as `sub_grad` (odd spatial size: ceil(h/2))."""
     from tensorflow_ocr_amd import resnet_layers as R
     from tensorflow_ocr_amd.graph import Act, Graph
     rng = np.random.default_rng(11)
-    n, hw, cin = 2, 16, 64
+    n, hw, cin = 2, 18, 64
     xin = np.abs(rng.standard_normal((n, hw, hw, cin))).astype(np.float32)
-    g_end = (rng.standard_normal((n, hw // 2, hw // 2, 256)) * 0.1).astype(np.float32)
+    g_end = (rng.standard_normal((n, 5, 5, 256)) * 0.1).astype(np.float32)       # 18 -> 9 -> 5
     g_mid = (rng.standard_normal((n, hw, hw, 128)) * 0.1).astype(np.float32)
     res = {}
     fused_launches = {}
@@ -277,9 +279,10 @@ def test_bottleneck_tail_fusion_equals_separate_passes(device, monkeypatch):
         u2 = R.bottleneck(g, u1, 128, 32, 1, "u2")       # identity: conv1 completes u1's gradient
         u3 = R.bottleneck(g, u2, 128, 32, 2, "u3")       # subsampling shortcut: conv1 completes u2's gradient
         u4 = R.bottleneck(g, u3, 256, 64, 1, "u4")       # projection: the shortcut conv completes u3's gradient
-        # second consumers (built later = earlier in backward), as the EAST merge branch has them
+        u5 = R.bottleneck(g, u4, 256, 64, 2, "u5")       # subsampling, 9 -> 5: conv1 completes u4's gradient (+ sub_grad)
+        # a second consumer (built later = earlier in backward), as the EAST merge branch has them
         u2.grad = torch.from_numpy(g_mid).to(device).to(R.ops.F16)
-        u4.grad = torch.from_numpy(g_end).to(device).to(R.ops.F16)
+        u5.grad = torch.from_numpy(g_end).to(device).to(R.ops.F16)
         g.backward()
         torch.cuda.synchronize()
         monkeypatch.setattr(R.ops, "conv2d_bnred_tail", real)
@@ -289,7 +292,7 @@ def test_bottleneck_tail_fusion_equals_separate_passes(device, monkeypatch):
             if v.trainable:
                 out[k] = v.grad.float().cpu().numpy()
         res[mode] = out
-    assert fused_launches[True] == 3 and fused_launches[False] == 0
+    assert fused_launches[True] == 4 and fused_launches[False] == 0
     for k in res[True]:
         a, b = res[True][k], res[False][k]
         assert np.isfinite(a).all()
