@@ -46,7 +46,9 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
   constexpr int OSTR = BN * 2 + 16;
   const int tid = threadIdx.x;
   char* otile = smem;
-  float* red = reinterpret_cast<float*>(smem + 256 * OSTR);
+  // BATCH: `red` ALIASES the output tile (a barrier separates the tile's last read from its first write), so
+  // that a 256-cout tile fits the LDS in one piece: 256 x (512 + 16) = 132 KB
+  float* red = reinterpret_cast<float*>(BATCH ? smem : smem + 256 * OSTR);
   __syncthreads();
   constexpr int NC = BN / 8;    // 16-byte chunks per output row
   constexpr int RG = NT / NC;   // row groups
@@ -72,56 +74,59 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
     for (int e = 0; e < 8; ++e) { bsc[e] = br->scale[co0 + c * 8 + e]; bsh[e] = br->shift[co0 + c * 8 + e]; }
   }
   if constexpr (BATCH) {
-    constexpr int UB = PPT < 4 ? PPT : 4;
+    // ALL of the thread's pixels in one batch (up to 8 x 3 operands of 16 bytes in flight per thread): one workgroup
+    // is resident per CU and each batch exposes one HBM latency — with batches of four the expanding 1x1
+    // input-gradient convolutions of ResNet (64 -> 256 at 160^2) ran at 3 TB/s in tail mode, 1.8 with the
+    // BN-backward operand alone
+    constexpr int UB = PPT < 8 ? PPT : 8;
     static_assert(PPT % UB == 0, "pixels per thread");
     for (int k0 = 0; k0 < PPT; k0 += UB) {
-      half8_t v[UB], old[UB], mk[UB], yv[UB], sv[UB];
-      size_t off[UB];
-      bool ok[UB], has_sub[UB];
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
+      half8_t old[UB], mk[UB], yv[UB];
+      auto pixel = [&](int u, bool& ok) __attribute__((always_inline)) {     // (recomputed, not carried: registers)
         const int px = rg + (k0 + u) * RG;
         const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
-        ok[u] = oy < oh && ox < ow;
-        off[u] = (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
-        v[u] = *reinterpret_cast<const half8_t*>(otile + px * OSTR + c * 16);
-        has_sub[u] = false;
-        if (ok[u]) {
-          if (accum) old[u] = *reinterpret_cast<const half8_t*>(y + off[u]);
-          if (tail) mk[u] = *reinterpret_cast<const half8_t*>(br->mask + off[u]);
-          if (do_stats && br != nullptr) yv[u] = *reinterpret_cast<const half8_t*>(br->y + off[u]);
-          if (tail && br->sub != nullptr) {
-            const unsigned P = (unsigned)(((size_t)img * oh + oy) * ow + ox);      // flat pixel index
-            const unsigned im = (unsigned)(((unsigned long long)P * br->sub_m_hw) >> (31 + br->sub_l_hw));
-            const unsigned rem = P - im * (unsigned)(br->sub_h * br->sub_w);
-            const unsigned yy = (unsigned)(((unsigned long long)rem * br->sub_m_w) >> (31 + br->sub_l_w));
-            const unsigned xx = rem - yy * (unsigned)br->sub_w;
-            if (((yy | xx) & 1u) == 0u) {
-              const int sh = (br->sub_h + 1) >> 1, sw = (br->sub_w + 1) >> 1;
-              has_sub[u] = true;
-              sv[u] = *reinterpret_cast<const half8_t*>(
-                  br->sub + (((size_t)im * sh + (yy >> 1)) * sw + (xx >> 1)) * cout + co0 + c * 8);
-            }
-          }
+        ok = oy < oh && ox < ow;
+        return (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
+      };
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        bool ok;
+        const size_t off = pixel(u, ok);
+        if (ok) {
+          if (accum) old[u] = *reinterpret_cast<const half8_t*>(y + off);
+          if (tail) mk[u] = *reinterpret_cast<const half8_t*>(br->mask + off);
+          if (do_stats && br != nullptr) yv[u] = *reinterpret_cast<const half8_t*>(br->y + off);
         }
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        if (!ok[u]) continue;
-        half8_t w = v[u];
+        bool ok;
+        const size_t off = pixel(u, ok);
+        if (!ok) continue;
+        half8_t w = *reinterpret_cast<const half8_t*>(otile + (rg + (k0 + u) * RG) * OSTR + c * 16);
         if (accum) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)old[u][e]);
         }
-        if (has_sub[u]) {
+        if (tail && br->sub != nullptr) {            // (three launches per ResNet-50 step: loaded in place)
+          const unsigned P = (unsigned)(off / (size_t)cout);                    // flat pixel index
+          const unsigned im = (unsigned)(((unsigned long long)P * br->sub_m_hw) >> (31 + br->sub_l_hw));
+          const unsigned rem = P - im * (unsigned)(br->sub_h * br->sub_w);
+          const unsigned yy = (unsigned)(((unsigned long long)rem * br->sub_m_w) >> (31 + br->sub_l_w));
+          const unsigned xx = rem - yy * (unsigned)br->sub_w;
+          if (((yy | xx) & 1u) == 0u) {
+            const int sh = (br->sub_h + 1) >> 1, sw = (br->sub_w + 1) >> 1;
+            const half8_t sv = *reinterpret_cast<const half8_t*>(
+                br->sub + (((size_t)im * sh + (yy >> 1)) * sw + (xx >> 1)) * cout + co0 + c * 8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)sv[u][e]);
+            for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)sv[e]);
+          }
         }
         if (tail) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = (float)mk[u][e] > 0.f ? w[e] : (half_t)0.f;
         }
-        *reinterpret_cast<half8_t*>(y + off[u]) = w;
+        *reinterpret_cast<half8_t*>(y + off) = w;
         if (do_stats) {
           if (br != nullptr) {
 #pragma unroll
@@ -207,6 +212,7 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
       for (int e = 0; e < 8; ++e)
         q2[e] = (q2[e] - br->mean[co0 + c * 8 + e] * s[e]) * br->invstd[co0 + c * 8 + e];
     }
+    if constexpr (BATCH) __syncthreads();            // every thread is done reading the output tile `red` aliases
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       red[(rg * NC + c) * 16 + e] = s[e];

@@ -459,15 +459,20 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
   }
 
   // epilogue on the flat tile: "row" r of the 8x32 layout = pixels px0 + 32r .. +31
-  constexpr int EBN = BN > 128 ? 128 : BN;
-  constexpr int EWCO = BN > 128 ? 2 : WCO;
+  // The store-only epilogue takes a 256-cout tile in two 128-cout halves (the staging tile and its reduction
+  // scratch share the LDS with nothing else then).  The epilogue WITH global operands stages all 256 couts at once:
+  // in halves the second half's 64 accumulator registers stay live under the first half's operand batch and the
+  // kernel spilled 120 registers — scratch reloads wait on the same counter as the operand loads and serialise
+  // them (ResNet's 64 -> 256 input-gradient convolutions ran at 1.8-3 TB/s).
+  constexpr int EBN = EPI_LOADS ? BN : (BN > 128 ? 128 : BN);
+  constexpr int EWCO = EBN < BN ? 2 : WCO;
   const int rows = (int)(p.npix / 32);
 #pragma unroll
   for (int h = 0; h < BN / EBN; ++h) {
     __syncthreads();
-    const bool active = BN <= 128 || (wco >> 1) == h;
+    const bool active = EBN == BN || (wco >> 1) == h;
     conv_epilogue16<EBN, TCO, TPX, EWCO, NT, EPI_LOADS>(acc, smem, p.flags, bias, y, stats, 0, mt, 0, mt, co0 + h * EBN,
-                                             rows, 32, p.cout, BN > 128 ? (wco & 1) : wco, wpx, active,
+                                             rows, 32, p.cout, EBN < BN ? (wco & 1) : wco, wpx, active,
                                              p.br.y ? &p.br : nullptr);
   }
 }
@@ -1478,8 +1483,11 @@ template <int BN, int WCO>
 int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
               hipStream_t st) {
   const size_t main_bytes = 2 * ((size_t)BN * 128 + 256 * 128);
+  // (the epilogue with global operands stages the whole tile and aliases its reduction scratch: 256 x (2 BN + 16))
   const size_t epi_bytes = conv_epilogue_lds(BN > 128 ? 128 : BN, 512);
-  const size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  const size_t epi_loads_bytes = (size_t)256 * (BN * 2 + 16) > (size_t)512 * 16 * 4 ? (size_t)256 * (BN * 2 + 16) : (size_t)512 * 16 * 4;
+  size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  if (epi_loads_bytes > lds) lds = epi_loads_bytes;
   // two instantiations: the epilogue with global operands (ACCUM / BN-backward / tail) batches its loads
   // ahead of its stores (conv_epilogue.h) and needs ~40 more registers than the store-only one
   const bool epi_loads = (p.flags & OCR_CONV_ACCUM_F16) != 0 || p.br.y != nullptr;
