@@ -32,7 +32,9 @@ struct BnRed {
 };
 
 // LDS needed by the epilogue for a BN-wide tile.
-constexpr size_t conv_epilogue_lds(int bn, int nt = 256) { return 256 * (bn * 2 + 16) + nt * 16 * sizeof(float); }
+constexpr size_t conv_epilogue_lds(int bn, int nt = 256) {
+  return 256 * (bn * 2 + 16) > nt * 16 * sizeof(float) ? 256 * (bn * 2 + 16) : nt * 16 * sizeof(float);   // staging tile | reduction scratch (aliased)
+}
 
 // Second half of the epilogue, shared by both accumulator layouts: LDS [256 px][BN] f16 -> HBM rows.
 // BATCH: the variant for kernels launched WITH global operands in the epilogue (ACCUM / BN-backward / tail):
@@ -46,9 +48,9 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
   constexpr int OSTR = BN * 2 + 16;
   const int tid = threadIdx.x;
   char* otile = smem;
-  // BATCH: `red` ALIASES the output tile (a barrier separates the tile's last read from its first write), so
-  // that a 256-cout tile fits the LDS in one piece: 256 x (512 + 16) = 132 KB
-  float* red = reinterpret_cast<float*>(BATCH ? smem : smem + 256 * OSTR);
+  // `red` ALIASES the output tile (a barrier separates the tile's last read from its first write): a 256-cout
+  // tile fits the LDS in one piece (256 x (512 + 16) = 132 KB), a 128-cout one leaves room for a second workgroup
+  float* red = reinterpret_cast<float*>(smem);
   __syncthreads();
   constexpr int NC = BN / 8;    // 16-byte chunks per output row
   constexpr int RG = NT / NC;   // row groups
@@ -212,7 +214,7 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
       for (int e = 0; e < 8; ++e)
         q2[e] = (q2[e] - br->mean[co0 + c * 8 + e] * s[e]) * br->invstd[co0 + c * 8 + e];
     }
-    if constexpr (BATCH) __syncthreads();            // every thread is done reading the output tile `red` aliases
+    __syncthreads();                                 // every thread is done reading the output tile `red` aliases
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       red[(rg * NC + c) * 16 + e] = s[e];

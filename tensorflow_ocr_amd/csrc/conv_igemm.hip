@@ -1482,15 +1482,14 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
 template <int BN, int WCO>
 int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
               hipStream_t st) {
-  const size_t main_bytes = 2 * ((size_t)BN * 128 + 256 * 128);
-  // (the epilogue with global operands stages the whole tile and aliases its reduction scratch: 256 x (2 BN + 16))
-  const size_t epi_bytes = conv_epilogue_lds(BN > 128 ? 128 : BN, 512);
-  const size_t epi_loads_bytes = (size_t)256 * (BN * 2 + 16) > (size_t)512 * 16 * 4 ? (size_t)256 * (BN * 2 + 16) : (size_t)512 * 16 * 4;
-  size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
-  if (epi_loads_bytes > lds) lds = epi_loads_bytes;
+  // one K stage (cin = 64): nothing to double-buffer
+  const size_t main_bytes = (p.cin == 64 ? 1 : 2) * ((size_t)BN * 128 + 256 * 128);
+  const bool epi_loads = (p.flags & OCR_CONV_ACCUM_F16) != 0 || p.br.y != nullptr;
+  // the store-only epilogue takes a 256-cout tile in two halves, the one with global operands in one piece
+  const size_t epi_bytes = conv_epilogue_lds(epi_loads ? BN : (BN > 128 ? 128 : BN), 512);
+  const size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   // two instantiations: the epilogue with global operands (ACCUM / BN-backward / tail) batches its loads
   // ahead of its stores (conv_epilogue.h) and needs ~40 more registers than the store-only one
-  const bool epi_loads = (p.flags & OCR_CONV_ACCUM_F16) != 0 || p.br.y != nullptr;
   auto kern = epi_loads ? conv_pw_kernel<BN, WCO, true> : conv_pw_kernel<BN, WCO, false>;
   static bool configured[2] = {false, false};
   if (!configured[epi_loads]) {
@@ -1772,6 +1771,15 @@ extern "C" int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap)
 static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const void* bias, void* y,
                     void* stats, hipStream_t st) {
   if (p.pw) {
+    // cin = 64 (one K stage, nothing to prefetch under) without global operands in the epilogue: 128-cout tiles
+    // need 70 KB of LDS and 118 registers — two workgroups per CU, whose phases overlap (ResNet's 64 -> 256
+    // forward convolutions: one 256-cout workgroup per CU exposes its fetch latency on every tile)
+    static const int split = [] { const char* e = getenv("OCR_PW_SPLIT64"); return e ? atoi(e) : 1; }();
+    const bool epi_loads = (p.flags & OCR_CONV_ACCUM_F16) != 0 || p.br.y != nullptr;
+    if (split && c.bn == 256 && p.cin == 64 && !epi_loads) {
+      p.n_tiles = p.cout / 128;
+      return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
+    }
     if (c.bn == 256) return launch_pw<256, 4>(p, x, w_kc, bias, y, stats, st);
     if (c.bn == 128) return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
     return launch_pw<64, 1>(p, x, w_kc, bias, y, stats, st);
