@@ -90,32 +90,38 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(PwP p, const half_t* __re
   int mt_end = mt_begin + p.tiles_per_split;
   if (mt_end > p.m_tiles) mt_end = p.m_tiles;
 
+  // Stage loads are BUFFER loads with the range check doing the zero padding (an offset beyond the descriptor reads
+  // as zero): with ordinary loads under `if (inside)` hipcc branches around every one of the eight loads and waits
+  // for each before the next (conv_wgrad.hip: wgrad3_kernel).  Both tensors are < 2 GiB (checked by pw_plan).
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(x), 0, (int)((size_t)p.n * p.h * p.w * p.cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(dy), 0, (int)((size_t)p.n * p.oh * p.ow * p.cout * 2), 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
   u32x4 xr[NX], dr[ND];
   auto load_tile = [&](int mt) {
     const int txi = mt % p.tiles_x;
     const int tmp = mt / p.tiles_x;
     const int tyi = tmp % p.tiles_y;
     const int img = tmp / p.tiles_y;
-    const half_t* xb = x + (size_t)img * p.h * p.w * p.cin + ci0;
-    const half_t* db = dy + (size_t)img * p.oh * p.ow * p.cout + co0;
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
       const int idx = u * NT + tid;
       const int px = idx / XCH, c = idx % XCH;
       const int oy = tyi * PW_ROWS + (px >> 5), ox = txi * 32 + (px & 31);
       const int iy = oy * p.stride - pt, ix = ox * p.stride - pl;
-      xr[u] = u32x4{0u, 0u, 0u, 0u};
-      if (oy < p.oh && ox < p.ow && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
-        xr[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin + c * 8);
+      const bool ok = (oy < p.oh) & (ox < p.ow) & ((unsigned)iy < (unsigned)p.h) & ((unsigned)ix < (unsigned)p.w);
+      const unsigned off = ok ? (unsigned)((((img * p.h + iy) * p.w + ix) * p.cin + ci0 + c * 8) * 2) : OOB;
+      xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
     }
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
       const int idx = u * NT + tid;
       const int px = idx / DCH, c = idx % DCH;
       const int oy = tyi * PW_ROWS + (px >> 5), ox = txi * 32 + (px & 31);
-      dr[u] = u32x4{0u, 0u, 0u, 0u};
-      if (oy < p.oh && ox < p.ow)
-        dr[u] = *reinterpret_cast<const u32x4*>(db + ((size_t)oy * p.ow + ox) * p.cout + c * 8);
+      const bool ok = (oy < p.oh) & (ox < p.ow);
+      const unsigned off = ok ? (unsigned)((((img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8) * 2) : OOB;
+      dr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0));
     }
   };
   auto store_tile = [&](int buf) {
@@ -176,6 +182,8 @@ struct PwCfg { int cib, cob; };
 
 bool pw_plan(const ocr_conv_desc* d, PwP* p, PwCfg* c) {
   if (d->cin % 64 || d->cout % 64) return false;
+  if ((size_t)d->n * d->h * d->w * d->cin >= (1u << 30) || (size_t)d->n * d->oh * d->ow * d->cout >= (1u << 30))
+    return false;                                   // 32-bit buffer offsets (the tap-sweeping kernels take these)
   // 1x1 convs, and dilated k x k convs (taps far apart: no halo reuse worth a tap-sweeping tile)
   if (!(d->kh * d->kw == 1 || (d->dilation > 1 && d->kh * d->kw <= 9))) return false;
   c->cib = d->cin % 256 == 0 ? 256 : d->cin % 128 == 0 ? 128 : 64;
