@@ -145,19 +145,20 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
   const int halo_total = halo_px * CPP;
   const bool prefetch = NH > 1 && halo_total <= NH * NT && nchunks > 1;
   u32x4 hreg[NH];
+  // BUFFER loads with the range check doing the zero padding (per-image descriptor, an offset beyond it reads as
+  // zero): under `if (inside)` hipcc branches around every load and waits for each before the next
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(x) + (size_t)img * p.h * p.w * p.cin, 0, p.h * p.w * p.cin * 2, 0x00020000);
   auto halo_load = [&](int cc) {
-    const half_t* xb = x + (size_t)img * p.h * p.w * p.cin + cc * CK;
 #pragma unroll
     for (int u = 0; u < NH; ++u) {
       const int idx = u * NT + tid;
-      hreg[u] = u32x4{0u, 0u, 0u, 0u};
-      if (idx < halo_total) {
-        const int hp = idx / CPP, c = idx % CPP;
-        const int hy = hp / WT, hx = hp - hy * WT;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
-          hreg[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.w + ix) * p.cin + c * 8);
-      }
+      const int hp = idx / CPP, c = idx % CPP;
+      const int hy = hp / WT, hx = hp - hy * WT;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = (idx < halo_total) & ((unsigned)iy < (unsigned)p.h) & ((unsigned)ix < (unsigned)p.w);
+      const unsigned off = ok ? (unsigned)(((iy * p.w + ix) * p.cin + cc * CK + c * 8) * 2) : 0x80000000u;
+      hreg[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
     }
   };
   auto halo_store = [&]() {
