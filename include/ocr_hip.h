@@ -148,6 +148,16 @@ int ocr_conv2d_stem_wgrad_f16(int n, int h, int w, int cout, const void* x4, con
 int ocr_pack_weights_f16(const void* w_hwio_f32, int taps, int cin, int cout, void* w_kc,
                          void* w_ck, void* stream);
 int ocr_pack_weights_first_f16(const void* w_hwio_f32, int cout, void* w_first, void* stream);
+/* ocr_pack_weights_f16 for n layers in ONE launch (the re-pack that follows every optimiser step).
+ * ocr_pack_weights_batch_table fills a HOST table of ocr_pack_weights_batch_table_bytes(n) bytes from n
+ * (weights, taps, cin, cout, w_kc, w_ck) tuples of DEVICE pointers (w_kc[i] or w_ck[i] may be NULL) and returns the
+ * launch grid; the caller copies the table to device memory once (the pointers are static) and passes the
+ * device copy to ocr_pack_weights_batch_f16 every step. */
+size_t ocr_pack_weights_batch_table_bytes(int n);
+int ocr_pack_weights_batch_table(int n, const void* const* w_hwio_f32, const int* taps, const int* cin,
+                                 const int* cout, void* const* w_kc, void* const* w_ck, void* table_host,
+                                 int* grid_out);
+int ocr_pack_weights_batch_f16(const void* table_dev, int n, int grid, void* stream);
 /* head weights f32 [cin][cout<=32] -> w_kc32 f16 [32][cin] and w_ck32 f16 [cin][32], zero padded */
 int ocr_pack_weights_small_f16(const void* w_f32, int cin, int cout, void* w_kc32, void* w_ck32,
                                void* stream);

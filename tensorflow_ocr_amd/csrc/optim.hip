@@ -83,6 +83,48 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int taps, int c
   }
 }
 
+// The same re-pack for MANY layers in one launch (after the optimiser step: 14 launches of ~7 us per VGG step, 62 per
+// ResNet-50 step otherwise).  items[i] = one layer; block_first[i] = first block of layer i (block_first[n] = grid):
+// a block finds its layer by bisection, then its (tap, ci tile, co tile) inside it.
+struct PackItem {
+  const float* w;
+  half_t* w_kc;
+  half_t* w_ck;
+  int taps, cin, cout, tiles_ci, tiles_co;
+};
+
+__global__ void pack_weights_batch_kernel(const PackItem* __restrict__ items, const int* __restrict__ block_first, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n;                              // block_first[lo] <= blockIdx.x < block_first[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= block_first[mid]) lo = mid;
+    else hi = mid;
+  }
+  const PackItem it = items[lo];
+  int b = (int)blockIdx.x - block_first[lo];
+  const int cot = b % it.tiles_co;
+  b /= it.tiles_co;
+  const int cit = b % it.tiles_ci;
+  const int tap = b / it.tiles_ci;
+  const int ci0 = cit * 32, co0 = cot * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* wt = it.w + (size_t)tap * it.cin * it.cout;
+  for (int k = ty; k < 32; k += 8) {
+    const int ci = ci0 + k, co = co0 + tx;
+    const float v = (ci < it.cin && co < it.cout) ? wt[(size_t)ci * it.cout + co] : 0.f;
+    tile[k][tx] = v;
+    if (it.w_ck && ci < it.cin && co < it.cout) it.w_ck[((size_t)tap * it.cin + ci) * it.cout + co] = (half_t)v;
+  }
+  __syncthreads();
+  if (it.w_kc) {
+    for (int k = ty; k < 32; k += 8) {
+      const int co = co0 + k, ci = ci0 + tx;
+      if (ci < it.cin && co < it.cout) it.w_kc[((size_t)tap * it.cout + co) * it.cin + ci] = (half_t)tile[tx][k];
+    }
+  }
+}
+
 // head weights f32 [cin][cout<=32] -> w_kc32 f16 [32][cin], w_ck32 f16 [cin][32] (zero padded)
 __global__ void pack_small_kernel(const float* __restrict__ w, int cin, int cout,
                                   half_t* __restrict__ w_kc32, half_t* __restrict__ w_ck32) {
@@ -186,6 +228,35 @@ extern "C" int ocr_pack_weights_f16(const void* w_hwio_f32, int taps, int cin, i
                      dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float*>(w_hwio_f32), taps, cin, cout,
                      static_cast<half_t*>(w_kc), static_cast<half_t*>(w_ck));
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_pack_weights_batch_table_bytes(int n) { return (size_t)n * sizeof(PackItem) + (size_t)(n + 1) * sizeof(int); }
+
+extern "C" int ocr_pack_weights_batch_table(int n, const void* const* w_hwio_f32, const int* taps, const int* cin,
+                                            const int* cout, void* const* w_kc, void* const* w_ck, void* table_host,
+                                            int* grid_out) {
+  OCR_CHECK_ARG(n > 0 && w_hwio_f32 && taps && cin && cout && w_kc && w_ck && table_host && grid_out);
+  PackItem* items = static_cast<PackItem*>(table_host);
+  int* first = reinterpret_cast<int*>(items + n);
+  int g = 0;
+  for (int i = 0; i < n; ++i) {
+    OCR_CHECK_ARG(w_hwio_f32[i] && (w_kc[i] || w_ck[i]) && taps[i] > 0 && cin[i] > 0 && cout[i] > 0);
+    items[i] = PackItem{static_cast<const float*>(w_hwio_f32[i]), static_cast<half_t*>(w_kc[i]),
+                        static_cast<half_t*>(w_ck[i]), taps[i], cin[i], cout[i], ocr_cdiv(cin[i], 32), ocr_cdiv(cout[i], 32)};
+    first[i] = g;
+    g += taps[i] * items[i].tiles_ci * items[i].tiles_co;
+  }
+  first[n] = g;
+  *grid_out = g;
+  return OCR_OK;
+}
+
+extern "C" int ocr_pack_weights_batch_f16(const void* table_dev, int n, int grid, void* stream) {
+  OCR_CHECK_ARG(table_dev && n > 0 && grid > 0);
+  const PackItem* items = static_cast<const PackItem*>(table_dev);
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     items, reinterpret_cast<const int*>(items + n), n);
   return ocr_launch_status();
 }
 

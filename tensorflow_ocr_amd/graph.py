@@ -255,6 +255,22 @@ class Graph:
             return t
         return ent[1]
 
+    def repack_all(self):
+        """Refresh every [tap][cout][cin] / [tap][cin][cout] operand pack in ONE launch (after the optimiser step;
+        the packs' own lazy refresh in `packed` then finds them current).  Other pack kinds stay lazy."""
+        from . import ops
+        ents = [(v, v.packed["kc_ck"]) for v in self.store.vars.values() if "kc_ck" in getattr(v, "packed", {})]
+        if not ents:
+            return
+        key = tuple(id(e[1][1]) for e in ents)
+        pb = getattr(self, "_pack_batch", None)
+        if pb is None or pb[0] != key:
+            pb = (key, ops.PackBatch([(v.data, e[1][0], e[1][1]) for v, e in ents], self.device))
+            self._pack_batch = pb
+        pb[1].run()
+        for v, e in ents:
+            v.packed["kc_ck"] = (self.store.version, e[1])
+
     # --- tape ---
     def record(self, fn, produces=()):
         """`produces`: the variables whose gradients are complete once `fn` has run."""

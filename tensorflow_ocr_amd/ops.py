@@ -218,6 +218,33 @@ def pack_weights(w_hwio, w_kc=None, w_ck=None):
            ptr(w_ck), _st())
 
 
+class PackBatch:
+    """Device table for ocr_pack_weights_batch_f16: built once for a list of (w_hwio f32, w_kc, w_ck) tensors."""
+
+    def __init__(self, entries, device):
+        import ctypes
+        n = len(entries)
+        vp = ctypes.c_void_p * n
+        ci = ctypes.c_int * n
+        ws = vp(*[w.data_ptr() for w, _, _ in entries])
+        kc = vp(*[(a.data_ptr() if a is not None else None) for _, a, _ in entries])
+        ck = vp(*[(b.data_ptr() if b is not None else None) for _, _, b in entries])
+        taps = ci(*[w.shape[0] * w.shape[1] for w, _, _ in entries])
+        cin = ci(*[w.shape[2] for w, _, _ in entries])
+        cout = ci(*[w.shape[3] for w, _, _ in entries])
+        nbytes = L.call_size("ocr_pack_weights_batch_table_bytes", c_int(n))
+        host = torch.empty(nbytes, dtype=torch.uint8)
+        grid = ctypes.c_int(0)
+        L.call("ocr_pack_weights_batch_table", c_int(n), ws, taps, cin, cout, kc, ck, ctypes.c_void_p(host.data_ptr()),
+               ctypes.byref(grid))
+        self.table = host.to(device)
+        self.n, self.grid = n, grid.value
+        self.keep = entries                      # the tensors the table points at
+
+    def run(self):
+        L.call("ocr_pack_weights_batch_f16", ptr(self.table), c_int(self.n), c_int(self.grid), _st())
+
+
 def pack_weights_small(w, w_kc32, w_ck32):
     cin, cout = w.shape
     L.call("ocr_pack_weights_small_f16", ptr(w), c_int(cin), c_int(cout), ptr(w_kc32), ptr(w_ck32), _st())

@@ -279,9 +279,11 @@ class TrainStep:
             _lib.RECORDER = None
         self.reducer.finish()
         self.opt.apply_gradients(self.reducer.grad_scale)
+        g.repack_all()                      # the conv operand packs of the new weights, one launch
         if record:
             rec.py(self.reducer.finish)
             rec.py(lambda: self.opt.apply_gradients(self.reducer.grad_scale))
+            rec.py(g.repack_all)
             self.plan = rec.entries
             self.static_batch = list(batch)
             self.keepalive, g.keepalive = g.keepalive, None
