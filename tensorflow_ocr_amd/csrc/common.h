@@ -16,6 +16,11 @@ typedef __bf16 half8_t __attribute__((ext_vector_type(8)));
 #define OCR_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #define OCR_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define OCR_STORAGE_NAME "bf16"
+// a float z rounds (to nearest even) to a POSITIVE 16-bit value iff z > OCR_RELU_TIE: half the smallest subnormal
+// (the kernels run with denormals preserved).  The fused BN-backward reductions test the ReLU mask of the STORED
+// activation this way instead of converting to 16 bits and back (two conversions per element in epilogues that
+// are bound by instruction issue).
+#define OCR_RELU_TIE 0x1p-134f
 #else
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -24,6 +29,7 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 #define OCR_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
 #define OCR_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define OCR_STORAGE_NAME "f16"
+#define OCR_RELU_TIE 0x1p-25f
 #endif
 // ---- in-kernel clock stamps: DIAGNOSTIC BUILD ONLY (libocr_hip_diag.so, -DOCR_DIAG_CLOCK) --------------
 // MI355X_MICROARCH.md "DVFS give-back" item 6: the clock a kernel really runs at is

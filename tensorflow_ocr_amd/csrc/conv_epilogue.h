@@ -135,7 +135,7 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
             for (int e = 0; e < 8; ++e) {
               const float yf = (float)yv[u][e];
               bool pass = true;                      // tail mode: w is dz already
-              if (remask) pass = (float)(half_t)(yf * bsc[e] + bsh[e]) > 0.f;
+              if (remask) pass = yf * bsc[e] + bsh[e] > OCR_RELU_TIE;   // mask of the stored activation
               const float dz = pass ? (float)w[e] : 0.f;
               s[e] += dz;
               q2[e] += dz * yf;
@@ -191,7 +191,7 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
             for (int e = 0; e < 8; ++e) {
               const float yf = (float)yv[e];
               bool pass = true;                    // tail mode: w is dz already
-              if (remask) pass = (float)(half_t)(yf * bsc[e] + bsh[e]) > 0.f;
+              if (remask) pass = yf * bsc[e] + bsh[e] > OCR_RELU_TIE;   // mask of the stored activation
               const float dz = pass ? (float)w[e] : 0.f;
               s[e] += dz;
               q2[e] += dz * yf;

@@ -731,6 +731,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     // (scale / shift decide the ReLU mask per element; mean / invstd enter linearly and are applied to the
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[2][8], bsh[2][8];
+    const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;   // no ReLU: every element passes
     if (has_br) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
@@ -816,8 +817,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   const float yf = (float)yq[it % PF][k][e];
-                  const float z = (float)(half_t)(yf * bsc[hf][e] + bsh[hf][e]);
-                  const float dz = (!p.br.relu || z > 0.f) ? (float)v[e] : 0.f;
+                  const float dz = yf * bsc[hf][e] + bsh[hf][e] > relu_thr ? (float)v[e] : 0.f;   // mask of the stored activation
                   s[hf][e] += dz;
                   q2[hf][e] += dz * yf;
                 }
@@ -1079,6 +1079,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     // (scale / shift decide the ReLU mask per element; mean / invstd enter linearly and are applied to the
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[NW][8], bsh[NW][8];
+    const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;   // no ReLU: every element passes
     if (has_br) {
 #pragma unroll
       for (int hf = 0; hf < NW; ++hf)
@@ -1163,8 +1164,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   const float yf = (float)yq[it % PF][k][e];
-                  const float z = (float)(half_t)(yf * bsc[hf][e] + bsh[hf][e]);
-                  const float dz = (!p.br.relu || z > 0.f) ? (float)v[e] : 0.f;
+                  const float dz = yf * bsc[hf][e] + bsh[hf][e] > relu_thr ? (float)v[e] : 0.f;   // mask of the stored activation
                   s[hf][e] += dz;
                   q2[hf][e] += dz * yf;
                 }
@@ -1331,11 +1331,19 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   for (int ks = 0; ks < 2; ++ks)
     ab[ks] = (unsigned)(2 * W4_HBYTES + L * 128 + (((ks * 4 + kg) ^ ((L >> 1) & 7)) << 4));
 
-  // batch-norm partials: per lane over all tiles of this wave (its 8 couts are fixed)
+  // batch-norm partials: per lane over all tiles of this wave (its 8 couts are fixed; so are the producing layer's
+  // BN coefficients of the fused BN-backward reduction: scale / shift decide the ReLU mask per element, mean /
+  // invstd enter linearly and are applied to the sums at the end)
   const int c8 = lane & 7, pg = lane >> 3;
-  float s[8], q2[8];
+  float s[8], q2[8], bsc[8], bsh[8];
+  const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q2[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) {
+    s[e] = 0.f;
+    q2[e] = 0.f;
+    bsc[e] = has_br ? p.br.scale[co0 + c8 * 8 + e] : 0.f;
+    bsh[e] = has_br ? p.br.shift[co0 + c8 * 8 + e] : 0.f;
+  }
 
   if (ntile > 0) dma_tile(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1439,12 +1447,10 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
           if (has_br) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const int cc = co0 + c8 * 8 + e;
               const float yf = (float)yq[kk][e];
-              const float z = (float)(half_t)(yf * p.br.scale[cc] + p.br.shift[cc]);
-              const float dz = (!p.br.relu || z > 0.f) ? (float)v[e] : 0.f;
+              const float dz = yf * bsc[e] + bsh[e] > relu_thr ? (float)v[e] : 0.f;   // mask of the stored activation
               s[e] += dz;
-              q2[e] += dz * ((yf - p.br.mean[cc]) * p.br.invstd[cc]);
+              q2[e] += dz * yf;
             }
           } else {
 #pragma unroll
@@ -1461,6 +1467,11 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     __builtin_amdgcn_s_barrier();                         // ... and everyone's: the buffer may receive the halo of tile k+2
   }
   if (do_stats) {
+    if (has_br) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        q2[e] = (q2[e] - p.br.mean[co0 + c8 * 8 + e] * s[e]) * p.br.invstd[co0 + c8 * 8 + e];
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
 #pragma unroll
