@@ -1345,6 +1345,13 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     bsh[e] = has_br ? p.br.shift[co0 + c8 * 8 + e] : 0.f;
   }
 
+  // this lane's 16 bias values (its accumulator quads' couts are fixed over the tiles)
+  float bvv[AI][4];
+#pragma unroll
+  for (int i = 0; i < AI; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bvv[i][e] = has_bias ? bias[co0 + i * 16 + (lane >> 4) * 4 + e] : 0.f;
+
   if (ntile > 0) dma_tile(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1409,18 +1416,13 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
       const int g4 = lane >> 4;
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (has_bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + i * 16 + g4 * 4 + e];
-        }
 #pragma unroll
         for (int t = 0; t < AT; ++t) {
           const int px = t * 16 + L;
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float v = acc[i][t][e] + bv[e];
+            float v = acc[i][t][e] + bvv[i][e];
             if (relu) v = v > 0.f ? v : 0.f;
             o[e] = (half_t)v;
           }
