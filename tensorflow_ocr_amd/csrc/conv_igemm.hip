@@ -747,13 +747,15 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     // own loads pays the whole HBM latency (measured: +0.16 ms on a 0.52 ms launch, 16 x 1.5 us per tile).
     constexpr int PF = 4;
     half8_t yq[PF][2], oq[2];
+    // element offset of (round, k): a per-lane base computed once + a wave-uniform delta; bounds as "rows / columns
+    // left" (the epilogue is bound by instruction issue: a dozen 64-bit address and compare instructions per
+    // store were a tenth of it)
+    const size_t pbase = (((size_t)img * p.oh + tyi * TH + wpx * 4) * p.ow + txi * TILE_W + pg) * p.cout + cow + c8 * 8;
+    const int rows_left = p.oh - (tyi * TH + wpx * 4), cols_left = p.ow - (txi * TILE_W + pg);
     auto round_off = [&](int it, int k, bool& ok) __attribute__((always_inline)) {
       const int t = it >> 1, hf = it & 1;
-      const int oy = tyi * TH + wpx * 4 + (t >> 1);
-      const int px = k * 8 + pg;
-      const int ox = txi * TILE_W + (t & 1) * 16 + px;
-      ok = oy < p.oh && ox < p.ow;
-      return (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + cow + hf * 64 + c8 * 8;
+      ok = ((t >> 1) < rows_left) & ((t & 1) * 16 + k * 8 < cols_left);
+      return pbase + (size_t)(((t >> 1) * p.ow + (t & 1) * 16 + k * 8) * p.cout + hf * 64);
     };
     auto request = [&](int it) __attribute__((always_inline)) {
 #pragma unroll
@@ -1093,13 +1095,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     // requested PF rounds ahead, never behind a store (see conv3x3_w4_kernel's epilogue)
     constexpr int NR = AT * NW, PF = 2;           // two rounds ahead: 128 vector registers here
     half8_t yq[PF][2], oq[2];
+    // element offset of (round, k): per-lane base + wave-uniform delta; bounds as rows / columns left (see conv3x3_w4)
+    const size_t pbase = (((size_t)img * p.oh + tyi * TH + wave * 2) * p.ow + txi * TILE_W + pg) * p.cout + co0 + c8 * 8;
+    const int rows_left = p.oh - (tyi * TH + wave * 2), cols_left = p.ow - (txi * TILE_W + pg);
     auto round_off = [&](int it, int k, bool& ok) __attribute__((always_inline)) {
       const int t = it / NW, hf = it % NW;
-      const int oy = tyi * TH + wave * 2 + (t >> 1);
-      const int px = k * 8 + pg;
-      const int ox = txi * TILE_W + (t & 1) * 16 + px;
-      ok = oy < p.oh && ox < p.ow;
-      return (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + hf * 64 + c8 * 8;
+      ok = ((t >> 1) < rows_left) & ((t & 1) * 16 + k * 8 < cols_left);
+      return pbase + (size_t)(((t >> 1) * p.ow + (t & 1) * 16 + k * 8) * p.cout + hf * 64);
     };
     const bool gops = do_stats && has_br;
     auto request = [&](int it) __attribute__((always_inline)) {
