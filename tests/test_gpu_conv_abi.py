@@ -148,3 +148,29 @@ def test_special_kernels_are_selected_and_emit_stats(device, n, h, w, c, variant
     got2 = part2.cpu().numpy().astype(np.float64).sum(0)
     assert np.allclose(got2[0], dz.sum((0, 1, 2)), rtol=1e-3, atol=5e-2)
     assert np.allclose(got2[1], (dz * xh).sum((0, 1, 2)), rtol=1e-3, atol=5e-2)
+
+
+def test_batched_weight_repack_equals_per_layer(device):
+    """ocr_pack_weights_batch_f16 (every conv layer's two operand layouts in one launch, after the optimiser step)
+    writes exactly what ocr_pack_weights_f16 writes layer by layer — including ragged 32-tiles and a NULL layout."""
+    from tensorflow_ocr_amd import ops
+    rng = np.random.default_rng(7)
+    shapes = [(3, 3, 64, 64), (1, 1, 96, 160), (3, 3, 40, 24), (2, 2, 256, 64), (1, 1, 1024, 512)]
+    ws = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(device) for s in shapes]
+    ref, ents = [], []
+    for i, w in enumerate(ws):
+        kh, kw, cin, cout = w.shape
+        a = torch.empty((kh * kw, cout, cin), dtype=O.STORAGE, device=device)
+        b = torch.empty((kh * kw, cin, cout), dtype=O.STORAGE, device=device)
+        ops.pack_weights(w, a, b)
+        ref.append((a, b))
+        a2 = torch.zeros_like(a)
+        b2 = None if i == 2 else torch.zeros_like(b)          # one layer without the [tap][cin][cout] layout
+        ents.append((w, a2, b2))
+    pb = ops.PackBatch(ents, torch.device(device))
+    pb.run()
+    torch.cuda.synchronize()
+    for (a, b), (_, a2, b2) in zip(ref, ents):
+        assert torch.equal(a, a2)
+        if b2 is not None:
+            assert torch.equal(b, b2)
