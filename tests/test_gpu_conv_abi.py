@@ -174,3 +174,53 @@ def test_batched_weight_repack_equals_per_layer(device):
         assert torch.equal(a, a2)
         if b2 is not None:
             assert torch.equal(b, b2)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,with_sub", [(2, 12, 16, 64, 128, False), (2, 12, 16, 64, 256, True),
+                                                     (1, 9, 9, 64, 64, True), (3, 10, 32, 128, 512, False)])
+def test_bottleneck_tail_conv_vs_numpy(device, n, h, w, cin, cout, with_sub):
+    """ocr_conv2d_bnred_tail_f16 (1x1 input-gradient conv completing a bottleneck output's gradient): stored value =
+    [tail_out > 0] * (conv + what was there [+ gradient of the stride-2 subsample at the even positions]), partial
+    rows summing to (sum dz, sum dz * xhat(bn_y)) — against a float64 restatement on the same 16-bit operands.  Flat
+    256-pixel tiles (pixel count a multiple of 32: the batched epilogue) and the generic tile kernel (9 x 9)."""
+    from tensorflow_ocr_amd import ops
+    rng = np.random.default_rng(n * 100 + cout)
+    x = _h(rng.standard_normal((n, h, w, cin)) * 0.5)
+    wt = _h(rng.standard_normal((1, 1, cin, cout)) * np.sqrt(2.0 / cin))
+    old = _h(rng.standard_normal((n, h, w, cout)) * 0.3)
+    out = _h(rng.standard_normal((n, h, w, cout)))                    # the bottleneck output (mask = out > 0)
+    by = _h(rng.standard_normal((n, h, w, cout)))
+    mean = rng.normal(0, 0.2, cout).astype(np.float32)
+    invstd = rng.uniform(0.7, 1.3, cout).astype(np.float32)
+    sh, sw = (h + 1) // 2, (w + 1) // 2
+    sub = _h(rng.standard_normal((n, sh, sw, cout)) * 0.3)
+    dev = lambda a: torch.from_numpy(a).to(O.STORAGE).to(device)
+    wm = torch.from_numpy(wt).to(device)
+    w_kc = torch.empty((1, cout, cin), dtype=O.STORAGE, device=device)
+    w_ck = torch.empty((1, cin, cout), dtype=O.STORAGE, device=device)
+    ops.pack_weights(wm, w_kc, w_ck)
+    d = ops.conv_desc((n, h, w, cin), cout, 1, 1, 1, 1)
+    d.flags = ops.CONV_ACCUM_F16
+    T = ops.conv2d_num_mtiles(d)
+    y = dev(old).clone()
+    part = torch.zeros((T, 2, cout), dtype=torch.float32, device=device)
+    ctx = (dev(by), torch.from_numpy(mean).to(device), torch.from_numpy(invstd).to(device), dev(out))
+    ops.conv2d_bnred_tail(d, dev(x), w_kc, y, part, ctx, dev(sub) if with_sub else None)
+    torch.cuda.synchronize()
+    # restatement: 16-bit roundings where the kernel rounds (conv result, + old, + sub)
+    conv = _h(x.reshape(-1, cin).astype(np.float64) @ wt.reshape(cin, cout).astype(np.float64)).reshape(n, h, w, cout)
+    tot = _h(conv + old)
+    if with_sub:
+        z = np.zeros_like(tot)
+        z[:, ::2, ::2, :] = sub
+        tot = _h(tot + z)
+    dz = np.where(out > 0, tot, 0.0).astype(np.float32)
+    got = y.float().cpu().numpy()
+    tol = 8e-3 if O.STORAGE == torch.bfloat16 else 1.5e-3
+    assert np.abs(got - dz).max() <= tol * max(1.0, np.abs(dz).max())
+    assert ((got == 0) == (dz == 0))[out <= 0].all()                  # the mask is exact
+    xh = (by.astype(np.float64) - mean) * invstd
+    sums = part.cpu().numpy().astype(np.float64).sum(0)
+    gd = got.astype(np.float64)                                        # sums are of the STORED values
+    assert np.allclose(sums[0], gd.sum((0, 1, 2)), rtol=1e-4, atol=2e-2)
+    assert np.allclose(sums[1], (gd * xh).sum((0, 1, 2)), rtol=1e-3, atol=5e-2)
