@@ -224,3 +224,38 @@ def test_bottleneck_tail_conv_vs_numpy(device, n, h, w, cin, cout, with_sub):
     gd = got.astype(np.float64)                                        # sums are of the STORED values
     assert np.allclose(sums[0], gd.sum((0, 1, 2)), rtol=1e-4, atol=2e-2)
     assert np.allclose(sums[1], (gd * xh).sum((0, 1, 2)), rtol=1e-3, atol=5e-2)
+
+
+@pytest.mark.parametrize("n,h,w,c,k", [(2, 16, 40, 128, 3), (2, 100, 130, 64, 3), (2, 37, 70, 256, 3), (2, 12, 16, 128, 1)])
+def test_fused_reduction_relu_mask_at_the_rounding_boundary(device, n, h, w, c, k):
+    """The fused BN-backward reductions decide the ReLU mask of the STORED activation by `z > half the smallest
+    subnormal` instead of rounding z to 16 bits (common.h: OCR_RELU_TIE).  With bn_y = 0, scale = 1 the pre-activation
+    is the shift itself: channels whose shift is tie/2 or exactly the tie round to 0 (masked), a hair above the tie
+    or twice it round to the smallest subnormal (pass) — on every kernel family that carries the reduction."""
+    from tensorflow_ocr_amd import ops
+    tie = 2.0 ** -134 if O.STORAGE == torch.bfloat16 else 2.0 ** -25
+    rng = np.random.default_rng(3)
+    x = _h(rng.standard_normal((n, h, w, c)))
+    wt = _h(rng.standard_normal((k, k, c, c)) * np.sqrt(2.0 / (k * k * c)))
+    xd = torch.from_numpy(x).to(O.STORAGE).to(device)
+    w_kc = torch.empty((k * k, c, c), dtype=O.STORAGE, device=device)
+    w_ck = torch.empty((k * k, c, c), dtype=O.STORAGE, device=device)
+    ops.pack_weights(torch.from_numpy(wt).to(device), w_kc, w_ck)
+    d = ops.conv_desc((n, h, w, c), c, k, k, 1, 1)
+    d.flags = 0
+    T = ops.conv2d_num_mtiles(d)
+    y = torch.empty((n, h, w, c), dtype=O.STORAGE, device=device)
+    part = torch.zeros((T, 2, c), dtype=torch.float32, device=device)
+    shift = np.array([tie / 2, tie, tie * (1 + 2.0 ** -10), 2 * tie] * (c // 4), np.float32)
+    expect_pass = np.array([False, False, True, True] * (c // 4))
+    # the 16-bit conversion this build performs agrees with the rule
+    conv16 = torch.from_numpy(shift).to(device).to(O.STORAGE).float().cpu().numpy() > 0
+    assert (conv16 == expect_pass).all()
+    ctx = (torch.zeros((n, h, w, c), dtype=O.STORAGE, device=device), torch.ones(c, device=device),
+           torch.from_numpy(shift).to(device), torch.zeros(c, device=device), torch.ones(c, device=device), True)
+    ops.conv2d_bnred(d, xd, w_kc, y, part, ctx)
+    torch.cuda.synchronize()
+    s0 = part.cpu().numpy().astype(np.float64).sum(0)[0]
+    full = y.float().cpu().numpy().astype(np.float64).sum((0, 1, 2))
+    assert np.allclose(s0[expect_pass], full[expect_pass], rtol=1e-4, atol=2e-2)
+    assert (s0[~expect_pass] == 0).all()
