@@ -722,6 +722,12 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     const int g4 = lane >> 4;                        // accumulator layout: pixel L, couts 4*g4..+3 of a 16x16 tile
     const int c8 = lane & 7, pg = lane >> 3;         // read-back layout: 16-byte chunk of a pixel's 64 couts, pixel
     const int cow = co0 + wco * 128;
+    // the tile's 256 bias values through LDS (PixelLink's VGG has biases, no BN): a round would fetch 16 of them
+    float* const lbias = reinterpret_cast<float*>(smem + 4 * 2048 + 4096);
+    if (has_bias) {
+      lbias[tid] = bias[co0 + tid];
+      __syncthreads();
+    }
     float s[2][8], q2[2][8];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
@@ -785,11 +791,8 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = hf * 4 + ii;
-          float bv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (has_bias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = bias[cow + i * 16 + g4 * 4 + e];
-          }
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (has_bias) bv = *reinterpret_cast<const f32x4*>(lbias + (wco * 128 + i * 16 + g4 * 4));   // one LDS read, not four loads
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -1073,6 +1076,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     const bool has_br = p.br.y != nullptr;
     const int g4 = lane >> 4;
     const int c8 = lane & 7, pg = lane >> 3;
+    // the tile's BN bias values through LDS (see conv3x3_w4_kernel)
+    float* const lbias = reinterpret_cast<float*>(smem + 4 * 2048 + 4096);
+    if (has_bias) {
+      if (tid < BN) lbias[tid] = bias[co0 + tid];
+      __syncthreads();
+    }
     float s[NW][8], q2[NW][8];
 #pragma unroll
     for (int hf = 0; hf < NW; ++hf)
@@ -1132,11 +1141,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = hf * 4 + ii;
-          float bv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (has_bias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + i * 16 + g4 * 4 + e];
-          }
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (has_bias) bv = *reinterpret_cast<const f32x4*>(lbias + (i * 16 + g4 * 4));   // one LDS read, not four loads
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
