@@ -26,26 +26,113 @@ MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH
 TRAIN_GFLOP_PER_IMG = 516.5       # BASELINE.md §2, VGG-16 + PixelLink heads at 512x512
 
 
-def cpu_baseline(size, threads):
-    """The oracle's (CPU restatement, f32) full train step on a bounded sample: ONE image of the
-    benchmark's size (1/32 of a step's batch), forward + loss + backward, best of 3 after a warm-up."""
+def cpu_baseline(size, threads, batch=2, runs=5):
+    """The oracle's (CPU restatement, f32) full train step on a bounded sample: a batch of `batch` images of the
+    benchmark's size (SURVEY 8d asks for batch 32; one image costs ~2.4 s of host time, so 32 x 7 runs would
+    not fit the few-minutes budget of the default run), forward + loss + backward, MEDIAN of `runs` after one
+    warm-up."""
     from oracle import ocr_oracle as O
-    threads = min(threads, 64)            # batch-1 convs stop scaling long before 256 threads
+    threads = min(threads, 64)            # small-batch convs stop scaling long before 256 threads
     torch.set_num_threads(threads)
     rng = np.random.default_rng(0)
     p = O.init_model_vgg_params(rng)
-    images, pixel, link, mask = O.synthetic_batch(rng, 1, size)
+    images, pixel, link, mask = O.synthetic_batch(rng, batch, size)
     times = []
-    for it in range(4):
+    for it in range(runs + 1):
         t0 = time.time()
         tp = O.to_torch_params(p)
         px, lk, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=False)
         L = O.dice_loss(torch.from_numpy(pixel), px, torch.from_numpy(link), lk, torch.from_numpy(mask))
         L.backward()
         times.append(time.time() - t0)
-    return {"value": round(1.0 / min(times[1:]), 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "one %dx%d image (1/32 of the step's batch), forward+loss+backward, best of 3 after a warm-up, "
-                      "torch-CPU f32 oracle (%.1f s of CPU work in all)" % (size, size, sum(times))}
+    med = float(np.median(times[1:]))
+    return {"value": round(batch / med, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "batch of %d %dx%d images (1/%d of the step's batch), forward+loss+backward, median of %d after a "
+                      "warm-up, torch-CPU f32 oracle (%.1f s of CPU work in all)" % (batch, size, size, 32 // batch, runs,
+                                                                                    sum(times))}
+
+
+CONFIG_LEGS = (
+    # (key, scripts/bench_configs.py --which, environment of the child, BASELINE.json configs index)
+    ("pixellink_vgg16_512_b32_train_decode", "pixellink", {}, 2),
+    ("east_resnet50_640_b64_bf16_one_gpu_share", "resnet", {"OCR_STORAGE": "bf16"}, 3),
+    ("pixellink_infer_1024_b16_decode_lanms", "decode", {}, 4),
+)
+
+
+def config_legs(steps=5, warmup=2, timeout=240):
+    """Short legs of the OTHER BASELINE.json configs, after the timed region, N = 1 only.
+    Each leg is a FRESH child process (`subprocess.run`, never exec; the bf16 leg needs its own interpreter
+    because the storage type is process wide) running scripts/bench_configs.py; its one JSON line is
+    condensed here.  A leg that fails or times out is reported as {"error": ...} — it never fails the bench."""
+    import subprocess
+    out = {}
+    for key, which, extra_env, idx in CONFIG_LEGS:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
+                                                                  "OCR_STORAGE", "OCR_HIP_LIB")}
+        env.update(extra_env)
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", "bench_configs.py"), "--which", which,
+               "--steps", str(steps), "--warmup", str(warmup)]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[key] = {"baseline_config": idx, "error": (r.stderr.decode()[-300:] or "no output")}
+                continue
+            j = json.loads(lines[-1])
+            leg = {"baseline_config": idx, "workload": j.get("config"), "dtype": j.get("dtype", "f16"),
+                   "steps": j.get("steps"), "ms_per_step": j.get("ms_per_step"), "img_s": j.get("images_per_sec"),
+                   "tflops": j.get("tflops"), "frac_of_peak": j.get("frac_of_peak"),
+                   "dominant_kernel": j.get("dominant_kernel"), "leg_wall_s": round(time.time() - t0, 1)}
+            for k in ("loss", "decode_ms_per_batch", "net_forward_ms", "lanms_ms_per_batch", "lanms_boxes_per_sec",
+                      "decode_algorithmic_GBps", "components", "peak_hbm_gib"):
+                if k in j:
+                    leg[k] = j[k]
+            out[key] = leg
+        except Exception as e:                                        # timeout, bad JSON: report, do not fail
+            out[key] = {"baseline_config": idx, "error": repr(e)[:300]}
+    return out
+
+
+def counters_from_profiles(dom):
+    """`roofline.traffic / mfma_busy / clock_ghz` come from separate rocprofv3 --pmc passes and the diagnostic
+    build (they cannot be collected inside an un-profiled run): committed summaries under profiles/.  Each file
+    carries the fingerprint of the kernel sources it was measured on (`_provenance.csrc_sha16`,
+    _lib.csrc_fingerprint); a field whose file is absent or was measured on other sources is null, and
+    `counters_from` says which file, which fingerprint and when."""
+    from tensorflow_ocr_amd import _lib
+    now = _lib.csrc_fingerprint()
+
+    def load(fname):
+        try:
+            with open(os.path.join(ROOT, "profiles", fname)) as f:
+                return json.load(f)
+        except Exception:
+            return None
+    src = {"csrc_sha16_now": now, "files": {}}
+    vals = {"traffic": None, "mfma_busy": None, "clock_ghz": None}
+    for field, fname in (("traffic", PROFILE_ROUND + "_pmc_traffic.json"), ("mfma_busy", PROFILE_ROUND + "_pmc_mfma.json"),
+                         ("clock_ghz", PROFILE_ROUND + "_clock_diag.json")):
+        j = load(fname)
+        prov = (j or {}).get("_provenance") or {}
+        fresh = j is not None and prov.get("csrc_sha16") == now
+        src["files"][field] = {"file": "profiles/" + fname if j is not None else None,
+                               "csrc_sha16": prov.get("csrc_sha16"), "date": prov.get("date"), "current": bool(fresh)}
+        if not fresh:
+            continue
+        if field == "traffic":
+            vals[field] = (j.get(dom) or {}).get("hbm_bytes_per_launch")
+        elif field == "mfma_busy":
+            vals[field] = (j.get(dom) or {}).get("mfma_busy_frac")
+        else:
+            ck = [v["clock_ghz_median"] for k, v in j.items() if k != "_provenance" and v.get("kernel") == dom
+                  and v.get("operands") == "random"]
+            vals[field] = round(sum(ck) / len(ck), 3) if ck else None
+    return vals, src
+
+
+PROFILE_ROUND = "r03"
 
 
 def main():
@@ -56,6 +143,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (reference: batch_size_per_gpu)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs of BASELINE configs[2..4]")
+    ap.add_argument("--no-pg", action="store_true", help="N=1: do not run the bucketed exchange through a "
+                    "one-rank RCCL communicator (by default it runs, so the line records that RCCL loaded)")
     ap.add_argument("--loss-scale", type=float, default=1024.0)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "gloo lets several ranks share one GPU for a functional check")
@@ -85,6 +175,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
+    # N = 1: the gradient buckets still go through a ONE-rank RCCL communicator (C ABI: ocr_allreduce_bucket on a
+    # comm stream, event-ordered against the compute stream), so the single-GPU line exercises and reports the
+    # same exchange path the N > 1 runs use.  Falls back to no exchange if RCCL cannot be initialised here.
+    force_reduce = args.force_pg
+    exchange_error = None
+    if world == 1 and not args.no_pg and not args.force_pg:
+        try:
+            if dist.exchange_mode(1, True, force=True) == "abi":
+                dist.AbiComm(0, 1).destroy()          # probe: RCCL present and a one-rank communicator comes up
+                force_reduce = True
+        except Exception as e:
+            exchange_error = repr(e)[:200]
 
     g = Graph(device, loss_scale=args.loss_scale, seed=1)           # same init on every rank
     rng = np.random.default_rng(100 + rank)                          # different data per rank
@@ -96,7 +198,7 @@ def main():
         return M.loss(px, f_score, lk, f_geometry, mk, graph=gr)
 
     step = TrainStep(g, forward_loss, lambda gr: AdamOptimizer(gr, learning_rate=1e-4), world_size=world,
-                     force_reduce=args.force_pg)
+                     force_reduce=force_reduce)
 
     def barrier():
         if td.is_initialized():
@@ -131,10 +233,16 @@ def main():
     # is the communication the backward pass did NOT hide.  (The towers' weights drift apart in (2);
     # nothing is measured after it.)
     comm = None
-    if td.is_available() and td.is_initialized():
-        ones = torch.ones(1, dtype=torch.float32, device=device)
-        td.all_reduce(ones)
-        red = step.reducer
+    red = step.reducer
+    if red is not None and red.active:
+        if red.mode == "abi":
+            ones = torch.ones(1, dtype=torch.float32, device=device)
+            red.comm.all_reduce_(ones)                     # through ocr_allreduce_bucket, on the compute stream
+            backend = "rccl (C ABI: ocr_allreduce_bucket)"
+        else:
+            ones = torch.ones(1, dtype=torch.float32, device=device)
+            td.all_reduce(ones)
+            backend = td.get_backend()
         red.enabled = False
         for _ in range(2):
             step(*batch)
@@ -145,10 +253,12 @@ def main():
         barrier()
         dt_off = max_over_ranks(time.perf_counter() - t1)
         red.enabled = True
-        comm = {"backend": td.get_backend(), "rccl_ranks": int(round(ones.item())),
+        comm = {"backend": backend, "mode": red.mode, "rccl_ranks": int(round(ones.item())),
                 "bucket_bytes": red.bucket_nbytes(), "grad_bytes": int(g.store.flat_grad.numel() * 4),
                 "ms_per_step_no_exchange": round(dt_off / args.steps * 1e3, 3),
                 "comm_exposed_ms": round((dt - dt_off) / args.steps * 1e3, 3)}
+    elif exchange_error is not None:
+        comm = {"backend": None, "error": exchange_error}
 
     # dominant kernel: the conv_igemm instantiation with the most accumulated time
     per, fwd = {}, {}
@@ -167,27 +277,8 @@ def main():
     if dom:
         fl, sec, cnt = per[dom]
         ach = fl / sec / 1e12
-        # HBM bytes per launch of this kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE on this same command, summarised by scripts/pmc_traffic.py with the gfx950 FETCH_SIZE x2
-        # correction of MI355X_MICROARCH.md §HBM); MFMA-pipe occupancy from the SQ counter pass
-        # (scripts/pmc_mfma.py) and the in-kernel clock on random operands from the diagnostic build's
-        # s_memtime / s_memrealtime stamps (scripts/clock_diag.py).  null when the file is absent.
-        def committed(fname, *keys):
-            try:
-                with open(os.path.join(ROOT, "profiles", fname)) as f:
-                    v = json.load(f)
-                for k in keys:
-                    v = v[k]
-                return v
-            except Exception:
-                return None
-        traffic = committed("r02_pmc_traffic.json", dom, "hbm_bytes_per_launch")
-        mfma_busy = committed("r02_pmc_mfma.json", dom, "mfma_busy_frac")
-        clock = None
-        cd = committed("r02_clock_diag.json") or {}
-        ck = [v["clock_ghz_median"] for v in cd.values() if v.get("kernel") == dom and v.get("operands") == "random"]
-        if ck:
-            clock = round(sum(ck) / len(ck), 3)
+        vals, counters_from = counters_from_profiles(dom)
+        traffic, mfma_busy, clock = vals["traffic"], vals["mfma_busy"], vals["clock_ghz"]
         # `achieved` averages EVERY launch of the kernel in the timed region (forward and input-gradient
         # launches), as rocprofv3 --stats does; `achieved_alone` = the forward launches only (the
         # input-gradient ones also carry the fused BN-backward sums in their epilogue).
@@ -197,7 +288,7 @@ def main():
                 "launches_per_step": cnt // args.steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
                 "share_of_step": round(sec / dt, 3), "achieved_alone": alone,
                 "frac_alone": round(alone / MFMA_F16_PEAK_TFLOPS, 4) if alone else None,
-                "clock_ghz": clock, "mfma_busy": mfma_busy}
+                "clock_ghz": clock, "mfma_busy": mfma_busy, "counters_from": counters_from}
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
@@ -216,6 +307,12 @@ def main():
         }
         if comm is not None:
             out["exchange"] = comm
+        if world == 1 and not args.no_config_legs:
+            # free this process's activations first: the legs are children that need the HBM
+            del step, batch
+            g.tape.clear()
+            torch.cuda.empty_cache()
+            out["configs"] = config_legs()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)

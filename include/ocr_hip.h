@@ -29,7 +29,8 @@ enum {
   OCR_ERR_INVALID_ARG = -1,
   OCR_ERR_UNSUPPORTED = -2,
   OCR_ERR_HIP = -3,
-  OCR_ERR_WORKSPACE = -4
+  OCR_ERR_WORKSPACE = -4,
+  OCR_ERR_RCCL = -5            /* ocr_comm_last_error() has the RCCL message */
 };
 
 int ocr_abi_version(void);
@@ -502,6 +503,39 @@ int ocr_sum_squares_f32(const void* x, int64_t n, float scale, void* out_f32, vo
                         size_t ws_bytes, void* stream);
 int ocr_scale_f32(void* x, int64_t n, float s, void* stream);
 int ocr_fill_f32(void* x, int64_t n, float value, void* stream);   /* n 4-byte words */
+
+/* ------------------------------------------------------------------------- *
+ * Data-parallel exchange.  Replaces `average_gradients`
+ * (multigpu_train.py:70-85: concat + reduce_mean of the per-tower gradients, called
+ * from the tower loop :118-133) and `sum_gradients` (train_pixellink.py:179-194):
+ * ONE in-place all-reduce(SUM) per contiguous bucket of the tower's flat f32 gradient
+ * buffer; the mean's 1/world factor is folded into the optimiser's `inv_loss_scale`.
+ *
+ * The RCCL communicator is created and owned by the host layer (one process per GPU):
+ * rank 0 calls ocr_comm_unique_id and hands the OCR_COMM_ID_BYTES bytes to every rank
+ * through its own rendezvous (torch.distributed's store in this build); each rank then
+ * calls ocr_comm_init_rank ON ITS DEVICE and keeps the opaque handle.  RCCL is bound at
+ * first use (dlsym of the librccl already in the process, else dlopen): ocr_comm_available()
+ * = 0 and every call below returns OCR_ERR_RCCL when there is none.
+ * ocr_allreduce_bucket is asynchronous on `stream` like every other entry point; ordering
+ * against the compute stream is the caller's, with ocr_event_record / ocr_stream_wait_event
+ * (hipEventRecord / hipStreamWaitEvent on caller-visible handles), so a recorded step is a
+ * flat list of C-ABI calls, exchange included.
+ * ------------------------------------------------------------------------- */
+#define OCR_COMM_ID_BYTES 128
+enum { OCR_DT_F32 = 0, OCR_DT_F16 = 1, OCR_DT_BF16 = 2, OCR_DT_I32 = 3 };
+enum { OCR_RED_SUM = 0, OCR_RED_MAX = 1 };
+int ocr_comm_available(void);
+const char* ocr_comm_last_error(void);
+int ocr_comm_unique_id(void* id_out /* OCR_COMM_ID_BYTES host bytes */);
+int ocr_comm_init_rank(void** comm_out, int nranks, const void* id, int rank);
+int ocr_comm_size(void* comm);            /* number of ranks (>= 1), negative = error */
+int ocr_comm_destroy(void* comm);
+int ocr_allreduce_bucket(void* comm, void* buf, size_t count, int dtype, int op, void* stream);
+int ocr_event_create(void** event_out);   /* timing disabled */
+int ocr_event_destroy(void* event);
+int ocr_event_record(void* event, void* stream);
+int ocr_stream_wait_event(void* stream, void* event);
 
 #ifdef __cplusplus
 }

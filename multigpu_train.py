@@ -129,8 +129,10 @@ def _train_loop(FLAGS, g, step, feeder, rng, rank, world, device, start):
             raise FileNotFoundError('no checkpoint at %s' % src)
         if FLAGS.restore:
             checkpoint.restore_training_state(src, g, opt)
+            if opt.restored_variables == 0:
+                raise ValueError('no variable of this graph found in %s' % src)
             if rank == 0:
-                print('continue training from previous checkpoint')
+                print('continue training from previous checkpoint (%d variables)' % opt.restored_variables)
         else:
             sd, _ = checkpoint.load_tf_checkpoint(src)        # variables only (slim.assign_from_checkpoint_fn)
             g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, sd), strict=False)
@@ -138,9 +140,10 @@ def _train_loop(FLAGS, g, step, feeder, rng, rank, world, device, start):
                 opt.ema.copy_(g.store.flat)
             if rank == 0:
                 print('loaded ' + src)
-    first = opt.global_step
-    for it in range(first, FLAGS.max_steps):
-        if it > first:
+    # `for step in range(FLAGS.max_steps)` (multigpu_train.py:168): the loop counter is separate from the restored
+    # `global_step` (which the optimiser continues from), so a resumed run takes max_steps MORE steps
+    for it in range(FLAGS.max_steps):
+        if it > 0:
             batch = _next_batch(FLAGS, feeder, rng, device)
         loss = step(*batch)
         if it % 10 == 0:
@@ -159,7 +162,7 @@ def _train_loop(FLAGS, g, step, feeder, rng, rank, world, device, start):
                 tl = ml + opt.regularization_loss().item()
                 print('Step {:06d}, model loss {:.4f}, total loss {:.4f}, {:.2f} seconds/step, {:.2f} examples/second'.format(
                     it, ml, tl, avg_time_per_step, avg_examples_per_second), flush=True)
-        if rank == 0 and it % FLAGS.save_checkpoint_steps == 0 and it > first:
+        if rank == 0 and it % FLAGS.save_checkpoint_steps == 0:     # step 0 included (multigpu_train.py:185-186)
             # saver.save(sess, FLAGS.checkpoint_path + 'model.ckpt', global_step=global_step) (:186-187):
             # a TensorFlow V2 bundle of Saver(tf.global_variables()) — variables, EMA shadows, Adam slots
             checkpoint.save_training_state(FLAGS.checkpoint_path, g, opt)

@@ -38,8 +38,27 @@ def timed(fn, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def train_config(name, forward_loss, opt_factory, batch, size, steps, warmup, extra=None, prep=None):
-    from tensorflow_ocr_amd import synthetic
+MFMA_PEAK_TFLOPS = 2500.0          # dense f16 / bf16 MFMA, MI355X_MICROARCH.md (same constant as bench.py)
+
+
+def dominant_kernel(timing):
+    """(name, TFLOP/s, launches) of the conv instantiation with the most accumulated HIP-event time."""
+    per = {}
+    for variant, flops, phase, e0, e1 in timing:
+        a = per.setdefault(variant, [0.0, 0.0, 0])
+        a[0] += flops
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    if not per:
+        return None
+    k = max(per, key=lambda n: per[n][1])
+    fl, sec, cnt = per[k]
+    return {"kernel": k, "achieved_tflops": round(fl / sec / 1e12, 1), "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "launches": cnt, "avg_launch_ms": round(sec / cnt * 1e3, 4)}
+
+
+def train_config(name, forward_loss, opt_factory, batch, size, steps, warmup, extra=None, prep=None, gflop_per_img=None):
+    from tensorflow_ocr_amd import _lib, ops, synthetic
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.train import TrainStep
     dev = torch.device("cuda", 0)
@@ -52,10 +71,25 @@ def train_config(name, forward_loss, opt_factory, batch, size, steps, warmup, ex
     loss = None
     for _ in range(3):
         loss = step(*data)
-    dt = timed(lambda: step(*data), warmup, steps)
-    out = {"config": name, "batch": batch, "size": size, "ms_per_step": round(dt * 1e3, 3),
+    for _ in range(warmup):
+        step(*data)
+    torch.cuda.synchronize()
+    ops.KERNEL_TIMING = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(*data)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
+    out = {"config": name, "batch": batch, "size": size, "steps": steps, "dtype": _lib.STORAGE,
+           "ms_per_step": round(dt * 1e3, 3),
            "images_per_sec": round(batch / dt, 1), "loss": round(float(step(*data).item()), 5),
            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    if gflop_per_img:
+        tf = batch * gflop_per_img / 1e3 / dt
+        out["tflops"] = round(tf, 1)
+        out["frac_of_peak"] = round(tf / MFMA_PEAK_TFLOPS, 4)
+    out["dominant_kernel"] = dominant_kernel(timing)
     if extra:
         out.update(extra(g, data))
     print(json.dumps(out), flush=True)
@@ -98,7 +132,7 @@ def main():
             return {"decode_ms_per_batch": round(dt * 1e3, 3), "decode_images_per_sec": round(n / dt, 1)}
         train_config("PixelLink VGG-16 512x512 b32: softmax/OHNM + link loss, Momentum", fl,
                      lambda gr: MomentumOptimizer(gr), 32, 512, args.steps, args.warmup, extra=decode,
-                     prep=lambda d: [(d[0] - 120.0) / 60.0] + d[1:])
+                     prep=lambda d: [(d[0] - 120.0) / 60.0] + d[1:], gflop_per_img=516.5)
 
     if "resnet" in which:
         from tensorflow_ocr_amd.nets import model_vgg_16 as MV
@@ -108,7 +142,8 @@ def main():
             return MV.loss(sm, a, gm, b, tm, graph=g)
         train_config("EAST ResNet-v1-50 %d^2 b%d: dice, Adam+EMA (per-GPU share of configs[3])" % (
             args.resnet_size, args.resnet_batch), fr, lambda gr: AdamOptimizer(gr, learning_rate=1e-4),
-            args.resnet_batch, args.resnet_size, args.steps, args.warmup)
+            args.resnet_batch, args.resnet_size, args.steps, args.warmup,
+            gflop_per_img=180.9 * (args.resnet_size / 640.0) ** 2)      # 60.3 GFLOP/img forward x 3
 
     if "decode" in which:
         from tensorflow_ocr_amd.graph import Graph
@@ -127,7 +162,12 @@ def main():
             g.reset_tape()
             holder["net"] = net
         fwd()
-        dt_net = timed(fwd, 1, 3)
+        from tensorflow_ocr_amd import ops as _ops
+        fwd()
+        torch.cuda.synchronize()
+        _ops.KERNEL_TIMING = []
+        dt_net = timed(fwd, 0, 3)
+        timing, _ops.KERNEL_TIMING = _ops.KERNEL_TIMING, None
         net = holder["net"]
         rng2 = np.random.default_rng(4)
         pix = torch.from_numpy(rng2.normal(0, 2, (n, S // 4, S // 4, 2)).astype(np.float32)).to(dev)
@@ -153,7 +193,12 @@ def main():
         ct = torch.full((n,), K, dtype=torch.int32, device=dev)
         dt_nms = timed(lambda: lanms.lanms_batch(bt, ct, 0.2, graph=g), 2, 10)
         px = n * (S // 4) ** 2
-        print(json.dumps({"config": "PixelLink inference 1024^2 b16 + decode + LANMS",
+        fwd_tf = n * 2 * 344.9 / 1e3 / dt_net              # 344.9 GMAC per 1024^2 image
+        print(json.dumps({"config": "PixelLink inference 1024^2 b16 + decode + LANMS", "batch": n, "size": S, "steps": 3,
+                          "ms_per_step": round((dt_net + dt_dec + dt_nms) * 1e3, 3),
+                          "images_per_sec": round(n / (dt_net + dt_dec + dt_nms), 1),
+                          "tflops": round(fwd_tf, 1), "frac_of_peak": round(fwd_tf / MFMA_PEAK_TFLOPS, 4),
+                          "dominant_kernel": dominant_kernel(timing),
                           "net_forward_ms": round(dt_net * 1e3, 2), "net_images_per_sec": round(n / dt_net, 1),
                           "decode_ms_per_batch": round(dt_dec * 1e3, 3), "decode_images_per_sec": round(n / dt_dec, 1),
                           "decode_algorithmic_GBps": round(px * 76 / dt_dec / 1e9, 1), "components": ncomp,

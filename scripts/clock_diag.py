@@ -96,7 +96,11 @@ def main():
                 r = run_case(kind, hw, cin, cout, zero)
                 out["%s | %s | %s" % (label, kind, r["operands"])] = r
                 print(label, kind, r, file=sys.stderr, flush=True)
-    print(json.dumps(out, indent=1))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from pmc_mfma import provenance
+    res = {"_provenance": provenance("python3 scripts/clock_diag.py (libocr_hip_diag.so)")}
+    res.update(out)
+    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":

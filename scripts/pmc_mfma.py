@@ -29,6 +29,16 @@ import sys
 SIMDS = 1024.0
 
 
+def provenance(command):
+    """Which kernel sources the counters were measured on (bench.py nulls them when the sources changed)."""
+    import datetime
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tensorflow_ocr_amd import _lib
+    return {"csrc_sha16": _lib.csrc_fingerprint(), "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+            "command": command}
+
+
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     m = re.match(r"(?:void )?([A-Za-z0-9_]+)(<[^>]*>)?", name)
@@ -78,7 +88,10 @@ def main(d):
             e["clock_ghz"] = round(cyc / (sum(ds) / len(ds)), 3)
         out[k] = e
     keep = {k: v for k, v in out.items() if v["mfma_busy_cycles_per_simd"] > 0}
-    print(json.dumps(dict(sorted(keep.items(), key=lambda kv: -kv[1]["kernel_cycles"] * kv[1]["launches"])), indent=1))
+    res = {"_provenance": provenance("rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES "
+                                     "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python3 bench.py")}
+    res.update(dict(sorted(keep.items(), key=lambda kv: -kv[1]["kernel_cycles"] * kv[1]["launches"])))
+    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":

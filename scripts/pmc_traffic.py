@@ -13,7 +13,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from pmc_mfma import short  # noqa: E402
+from pmc_mfma import provenance, short  # noqa: E402
 
 out = {}
 for name, d in (("FETCH_SIZE", sys.argv[1]), ("WRITE_SIZE", sys.argv[2])):
@@ -32,4 +32,6 @@ for k, v in out.items():
         continue                                                        # tiny kernels: not worth a row
     res[k] = {"hbm_read_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
               "hbm_bytes_per_launch": round(fetch + write), "launches_profiled": v.get("FETCH_SIZE", {}).get("launches")}
-print(json.dumps(dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * (kv[1]["launches_profiled"] or 1))), indent=1))
+final = {"_provenance": provenance("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- python3 bench.py")}
+final.update(dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * (kv[1]["launches_profiled"] or 1))))
+print(json.dumps(final, indent=1))

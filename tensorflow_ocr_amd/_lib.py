@@ -179,3 +179,23 @@ def call_int(name, *args):
     if v < 0:
         check(v, name)
     return v
+
+
+def csrc_fingerprint():
+    """sha256 (first 16 hex digits) over the kernel sources — csrc/*.hip, *.h, *.cpp, the Makefile and
+    include/ocr_hip.h, in name order.  The counter summaries under profiles/ carry the fingerprint of the
+    sources they were measured on (scripts/pmc_*.py, clock_diag.py); bench.py reports them as measurements
+    only while it still matches, so a changed kernel cannot travel with stale counters.  (A content hash,
+    not `git log`: the GPU box's copy of the repo has no .git.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) +
+                   glob.glob(os.path.join(src, "*.cpp")) + [os.path.join(src, "Makefile")])
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "ocr_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

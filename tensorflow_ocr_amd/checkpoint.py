@@ -147,7 +147,9 @@ def restore_training_state(path, graph, opt, strict=False):
                 break
         else:
             plain[k] = v
-    graph.store.load_state_dict(tf_to_internal(names, plain), strict=strict)
+    internal = tf_to_internal(names, plain)
+    graph.store.load_state_dict(internal, strict=strict)
+    opt.restored_variables = sum(1 for k in internal if k in graph.store.vars)
     opt.load_state(global_step=step, slots={k: tf_to_internal(names, v) for k, v in slots.items() if v},
                    ema=tf_to_internal(names, ema) if ema else None)
     return step

@@ -12,6 +12,7 @@ extern "C" const char* ocr_status_string(int status) {
     case OCR_ERR_UNSUPPORTED: return "unsupported shape for this kernel";
     case OCR_ERR_HIP: return "HIP runtime error";
     case OCR_ERR_WORKSPACE: return "workspace too small";
+    case OCR_ERR_RCCL: return "RCCL error or RCCL not available (ocr_comm_last_error)";
     default: return "unknown status";
   }
 }

@@ -1,0 +1,168 @@
+// Gradient exchange behind the C ABI (include/ocr_hip.h "Data-parallel exchange"): the all-reduce that
+// replaces `average_gradients` (multigpu_train.py:70-85) / `sum_gradients` (train_pixellink.py:179-194),
+// issued on a caller-supplied stream through a caller-owned RCCL communicator, plus the two stream-ordering
+// primitives the step needs around it (event record / stream wait).  With these the whole training step —
+// exchange included — is a flat list of C-ABI calls.
+//
+// RCCL is bound at first use with dlsym/dlopen, not at link time: a process that imported PyTorch-ROCm already
+// holds ONE librccl (torch's); binding to that copy keeps a single RCCL runtime in the process, and the
+// library still loads (and every non-exchange entry point works) on a box without RCCL.
+#include <dlfcn.h>
+#include <string.h>
+#include <mutex>
+#include "common.h"
+
+namespace {
+
+// the subset of rccl.h this file needs (ABI-stable NCCL 2.x definitions; /opt/rocm/include/rccl/rccl.h:40-43,
+// 187,220,260,339,448-468,611)
+struct NcclUniqueId { char internal[OCR_COMM_ID_BYTES]; };
+typedef void* NcclComm;
+typedef int (*GetUniqueIdFn)(NcclUniqueId*);
+typedef int (*CommInitRankFn)(NcclComm*, int, NcclUniqueId, int);
+typedef int (*CommDestroyFn)(NcclComm);
+typedef int (*CommCountFn)(NcclComm, int*);
+typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, NcclComm, hipStream_t);
+typedef const char* (*ErrStrFn)(int);
+
+struct Rccl {
+  GetUniqueIdFn get_unique_id = nullptr;
+  CommInitRankFn comm_init_rank = nullptr;
+  CommDestroyFn comm_destroy = nullptr;
+  CommCountFn comm_count = nullptr;
+  AllReduceFn all_reduce = nullptr;
+  ErrStrFn err_str = nullptr;
+  bool ok = false;
+};
+
+Rccl g_rccl;
+std::once_flag g_once;
+char g_last_error[256] = "";
+
+void* find(void* handle, const char* name) {
+  void* p = dlsym(RTLD_DEFAULT, name);          // the copy already in the process (torch's librccl)
+  if (!p && handle) p = dlsym(handle, name);
+  return p;
+}
+
+void bind() {
+  void* h = nullptr;
+  if (!dlsym(RTLD_DEFAULT, "ncclAllReduce")) {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) {
+      snprintf(g_last_error, sizeof(g_last_error), "librccl not found: %s", dlerror());
+      return;
+    }
+  }
+  g_rccl.get_unique_id = (GetUniqueIdFn)find(h, "ncclGetUniqueId");
+  g_rccl.comm_init_rank = (CommInitRankFn)find(h, "ncclCommInitRank");
+  g_rccl.comm_destroy = (CommDestroyFn)find(h, "ncclCommDestroy");
+  g_rccl.comm_count = (CommCountFn)find(h, "ncclCommCount");
+  g_rccl.all_reduce = (AllReduceFn)find(h, "ncclAllReduce");
+  g_rccl.err_str = (ErrStrFn)find(h, "ncclGetErrorString");
+  g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.all_reduce;
+  if (!g_rccl.ok) snprintf(g_last_error, sizeof(g_last_error), "librccl lacks a required symbol");
+}
+
+bool rccl() {
+  std::call_once(g_once, bind);
+  return g_rccl.ok;
+}
+
+int fail(int rc, const char* what) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", what,
+           g_rccl.err_str ? g_rccl.err_str(rc) : "rccl error", rc);
+  return OCR_ERR_RCCL;
+}
+
+}  // namespace
+
+extern "C" const char* ocr_comm_last_error(void) { return g_last_error; }
+
+extern "C" int ocr_comm_available(void) { return rccl() ? 1 : 0; }
+
+extern "C" int ocr_comm_unique_id(void* id_out) {
+  if (!id_out) return OCR_ERR_INVALID_ARG;
+  if (!rccl()) return OCR_ERR_RCCL;
+  NcclUniqueId id;
+  int rc = g_rccl.get_unique_id(&id);
+  if (rc != 0) return fail(rc, "ncclGetUniqueId");
+  memcpy(id_out, &id, sizeof(id));
+  return OCR_OK;
+}
+
+extern "C" int ocr_comm_init_rank(void** comm_out, int nranks, const void* id, int rank) {
+  if (!comm_out || !id || nranks < 1 || rank < 0 || rank >= nranks) return OCR_ERR_INVALID_ARG;
+  if (!rccl()) return OCR_ERR_RCCL;
+  NcclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  NcclComm c = nullptr;
+  int rc = g_rccl.comm_init_rank(&c, nranks, uid, rank);
+  if (rc != 0) return fail(rc, "ncclCommInitRank");
+  *comm_out = c;
+  return OCR_OK;
+}
+
+extern "C" int ocr_comm_size(void* comm) {
+  if (!comm || !rccl() || !g_rccl.comm_count) return OCR_ERR_INVALID_ARG;
+  int n = 0;
+  int rc = g_rccl.comm_count((NcclComm)comm, &n);
+  if (rc != 0) return fail(rc, "ncclCommCount");
+  return n;
+}
+
+extern "C" int ocr_comm_destroy(void* comm) {
+  if (!comm) return OCR_OK;
+  if (!rccl()) return OCR_ERR_RCCL;
+  int rc = g_rccl.comm_destroy((NcclComm)comm);
+  return rc == 0 ? OCR_OK : fail(rc, "ncclCommDestroy");
+}
+
+extern "C" int ocr_allreduce_bucket(void* comm, void* buf, size_t count, int dtype, int op, void* stream) {
+  if (!comm || (!buf && count)) return OCR_ERR_INVALID_ARG;
+  int nt, no;
+  switch (dtype) {
+    case OCR_DT_F32: nt = 7; break;       // ncclFloat32
+    case OCR_DT_F16: nt = 6; break;       // ncclFloat16
+    case OCR_DT_BF16: nt = 9; break;      // ncclBfloat16
+    case OCR_DT_I32: nt = 2; break;       // ncclInt32
+    default: return OCR_ERR_INVALID_ARG;
+  }
+  switch (op) {
+    case OCR_RED_SUM: no = 0; break;      // ncclSum
+    case OCR_RED_MAX: no = 2; break;      // ncclMax
+    default: return OCR_ERR_INVALID_ARG;
+  }
+  if (count == 0) return OCR_OK;
+  if (!rccl()) return OCR_ERR_RCCL;
+  int rc = g_rccl.all_reduce(buf, buf, count, nt, no, (NcclComm)comm, (hipStream_t)stream);
+  return rc == 0 ? OCR_OK : fail(rc, "ncclAllReduce");
+}
+
+// --- stream ordering --------------------------------------------------------------------------------------
+extern "C" int ocr_event_create(void** event_out) {
+  if (!event_out) return OCR_ERR_INVALID_ARG;
+  hipEvent_t e;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return OCR_ERR_HIP;
+  *event_out = e;
+  return OCR_OK;
+}
+
+extern "C" int ocr_event_destroy(void* event) {
+  if (!event) return OCR_OK;
+  return hipEventDestroy((hipEvent_t)event) == hipSuccess ? OCR_OK : OCR_ERR_HIP;
+}
+
+extern "C" int ocr_event_record(void* event, void* stream) {
+  if (!event) return OCR_ERR_INVALID_ARG;
+  return hipEventRecord((hipEvent_t)event, (hipStream_t)stream) == hipSuccess ? OCR_OK : OCR_ERR_HIP;
+}
+
+extern "C" int ocr_stream_wait_event(void* stream, void* event) {
+  if (!event) return OCR_ERR_INVALID_ARG;
+  return hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) == hipSuccess ? OCR_OK : OCR_ERR_HIP;
+}

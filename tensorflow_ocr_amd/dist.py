@@ -76,14 +76,100 @@ def plan_buckets(var_ranges, total, bucket_elems):
     return buckets
 
 
+class AbiComm:
+    """An RCCL communicator created and used through the C ABI (include/ocr_hip.h: ocr_comm_*,
+    ocr_allreduce_bucket).  The 128-byte unique id travels from rank 0 to the others through
+    torch.distributed's key-value store (the rendezvous the launcher already set up); at world 1 no
+    rendezvous is needed at all.  Must be created with the rank's device current."""
+
+    _serial = 0
+
+    def __init__(self, rank=0, world=1, store=None):
+        import ctypes
+        from . import _lib as L
+        if not L.call_int("ocr_comm_available"):
+            raise L.OcrHipError("RCCL is not available: %s" % _last_comm_error())
+        ident = ctypes.create_string_buffer(128)
+        key = "ocr_comm_id_%d" % AbiComm._serial
+        AbiComm._serial += 1
+        if world > 1:
+            if store is None:
+                store = td.distributed_c10d._get_default_store()
+            if rank == 0:
+                self._check(L._fn("ocr_comm_unique_id", ctypes.c_int)(ident), "ocr_comm_unique_id")
+                store.set(key, ident.raw)
+            else:
+                ident = ctypes.create_string_buffer(bytes(store.get(key)), 128)
+        else:
+            self._check(L._fn("ocr_comm_unique_id", ctypes.c_int)(ident), "ocr_comm_unique_id")
+        self.handle = ctypes.c_void_p()
+        self._check(L._fn("ocr_comm_init_rank", ctypes.c_int)(ctypes.byref(self.handle), ctypes.c_int(world),
+                                                               ident, ctypes.c_int(rank)), "ocr_comm_init_rank")
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            from . import _lib as L
+            raise L.OcrHipError("%s failed: %s (%s)" % (what, L.load().ocr_status_string(rc).decode(),
+                                                        _last_comm_error()))
+
+    def size(self):
+        from . import _lib as L
+        return L.call_int("ocr_comm_size", self.handle)
+
+    def all_reduce_(self, t, op="sum", stream=None):
+        """In-place all-reduce of a contiguous f32 / 16-bit / int32 device tensor on `stream` (default: current)."""
+        import ctypes
+        from . import _lib as L
+        dt = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.int32: 3}[t.dtype]
+        st = L.stream_ptr() if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        L.call("ocr_allreduce_bucket", self.handle, L.ptr(t), ctypes.c_size_t(t.numel()), ctypes.c_int(dt),
+               ctypes.c_int({"sum": 0, "max": 1}[op]), st)
+
+    def destroy(self):
+        import ctypes
+        from . import _lib as L
+        if self.handle is not None and self.handle.value:
+            L._fn("ocr_comm_destroy", ctypes.c_int)(self.handle)
+            self.handle = None
+
+
+def _last_comm_error():
+    import ctypes
+    from . import _lib as L
+    fn = L._fn("ocr_comm_last_error", ctypes.c_char_p)
+    return (fn() or b"").decode()
+
+
+def exchange_mode(world, cuda, force=False):
+    """"abi": buckets go through ocr_allreduce_bucket on this process's own RCCL communicator (every entry of
+    the recorded step is then a C-ABI call); "torch": through torch.distributed (gloo on CPU / shared-GPU
+    functional runs, or OCR_EXCHANGE=torch)."""
+    import os
+    want = os.environ.get("OCR_EXCHANGE", "")
+    if want in ("abi", "torch"):
+        return want
+    if not cuda or (world == 1 and not force):
+        return "torch"
+    if td.is_available() and td.is_initialized() and td.get_backend() != "nccl":
+        return "torch"
+    return "abi"
+
+
 class GradientAllReduce:
     def __init__(self, store, world_size, bucket_bytes=32 << 20, op="mean", group=None, fold_mean=False,
-                 force=False):
+                 force=False, mode=None, comm=None):
         """op: "mean" = `average_gradients` (multigpu_train.py:70-85); "sum" = `sum_gradients`
         (train_pixellink.py:179-194: the caller has already divided its loss by num_clones).
         fold_mean: leave the SUM in the buffer and let the optimiser apply `grad_scale` (= 1/world)
         inside its own pass instead of one more sweep over the gradients.
-        force: run the bucket / comm-stream / wait path at world 1 too (a one-rank group must exist).
+        force: run the bucket / comm-stream / wait path at world 1 too (torch mode: a one-rank group must
+        exist; abi mode: a one-rank communicator is created here).
+        mode: "abi" | "torch" (default: `exchange_mode`).  In abi mode every bucket is
+        event-record(compute) -> stream-wait(comm) -> ocr_allreduce_bucket(comm) -> event-record(comm), and
+        `finish` is one stream-wait(compute) per bucket: C-ABI calls only, recorded into the step plan like
+        any kernel launch.  In torch mode the hooks are host callbacks (`Recorder.py`).
         `enabled = False` turns every hook into a no-op (bench.py's comm-exposed A/B: the step without
         its exchange)."""
         self.store = store
@@ -113,6 +199,22 @@ class GradientAllReduce:
         self.cuda = store.flat.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
         self.extra_streams = []       # streams that also produce gradients (side-stream wgrad)
+        self.mode = (mode or exchange_mode(world_size, self.cuda, force)) if self.active else "torch"
+        self.comm = comm
+        self.ev_ready = self.ev_done = None
+        self._replaying = False
+        if self.active and self.mode == "abi":
+            import ctypes
+            from . import _lib as L
+            if self.comm is None:
+                rank = td.get_rank() if (td.is_available() and td.is_initialized()) else 0
+                self.comm = AbiComm(rank, world_size)
+            self.ev_ready, self.ev_done = [], []
+            for _ in self.buckets:
+                for lst in (self.ev_ready, self.ev_done):
+                    h = ctypes.c_void_p()
+                    L.check(L._fn("ocr_event_create", ctypes.c_int)(ctypes.byref(h)), "ocr_event_create")
+                    lst.append(h)
         self.reset()
 
     def reset(self):
@@ -124,7 +226,16 @@ class GradientAllReduce:
         return [(e - s) * 4 for s, e in self.buckets]
 
     def on_grads_ready(self, variables):
-        if not self.active or not self.enabled:
+        """Graph.backward's hook.  While a step is being recorded: in torch mode the hook itself becomes a
+        host callback of the plan; in abi mode the C-ABI calls `_fire` makes are recorded (tagged "xchg")
+        and replayed like any launch — the countdown below is record-time logic only."""
+        if not self.active:
+            return
+        from . import _lib
+        rec = _lib.RECORDER
+        if rec is not None and self.mode == "torch" and not self._replaying:
+            rec.py(lambda vs=tuple(variables): self._replayed(self.on_grads_ready, vs))
+        if not self.enabled:
             return
         for v in variables:
             bi = self.bucket_of.get(v.name)
@@ -134,10 +245,31 @@ class GradientAllReduce:
             if self.left[bi] == 0 and not self.fired[bi]:
                 self._fire(bi)
 
+    def _replayed(self, fn, *args):
+        self._replaying = True
+        try:
+            fn(*args)
+        finally:
+            self._replaying = False
+
     def _fire(self, bi):
         self.fired[bi] = True
         s, e = self.buckets[bi]
         buf = self.store.flat_grad[s:e]
+        if self.mode == "abi":
+            import ctypes
+            from . import _lib as L
+            cur = L.stream_ptr()
+            cs = ctypes.c_void_p(self.comm_stream.cuda_stream)
+            for es in self.extra_streams:                  # side-stream weight gradients (off by default)
+                self.comm_stream.wait_stream(es)
+            self._xcall("ocr_event_record", self.ev_ready[bi], cur)
+            self._xcall("ocr_stream_wait_event", cs, self.ev_ready[bi])
+            self._xcall("ocr_allreduce_bucket", self.comm.handle, L.ptr(buf), ctypes.c_size_t(e - s),
+                        ctypes.c_int(0), ctypes.c_int(0), cs)
+            self._xcall("ocr_event_record", self.ev_done[bi], cs)
+            self.handles.append((bi, buf))
+            return
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -150,17 +282,34 @@ class GradientAllReduce:
             h = td.all_reduce(buf, op=td.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append((h, buf))
 
+    @staticmethod
+    def _xcall(name, *args):
+        from . import _lib as L
+        L.call(name, *args)
+        if L.RECORDER is not None:
+            L.RECORDER.tag_last(("xchg",))
+
     def finish(self):
         """Fire whatever has not been fired (variables without a gradient this step), wait for all
-        buckets, and turn the sum into the tower mean (multigpu_train.py:80-81)."""
+        buckets, and turn the sum into the tower mean (multigpu_train.py:80-81).  Recorded like
+        `on_grads_ready`: a host callback in torch mode, C-ABI stream waits in abi mode."""
+        from . import _lib
+        rec = _lib.RECORDER
+        if rec is not None and not self._replaying and (self.mode == "torch" or not self.active):
+            rec.py(lambda: self._replayed(self.finish))
         if not self.active or not self.enabled:
             self.reset()
             return
         for bi in range(len(self.buckets)):
             if not self.fired[bi]:
                 self._fire(bi)
-        for h, buf in self.handles:
-            h.wait()          # cuda: makes the current stream wait for the collective
+        if self.mode == "abi":
+            cur = _lib.stream_ptr()
+            for bi, _ in self.handles:
+                self._xcall("ocr_stream_wait_event", cur, self.ev_done[bi])
+        else:
+            for h, buf in self.handles:
+                h.wait()          # cuda: makes the current stream wait for the collective
         if self.op == "mean" and not self.fold_mean:
             if self.cuda:
                 from . import ops

@@ -280,15 +280,12 @@ class Graph:
         """Run the tape in reverse (the loss op seeds its own gradient).  `on_grads_ready(vars)` is
         called as soon as a closure has finished a set of parameter gradients — the hook the
         data-parallel all-reduce uses to overlap communication with the rest of backward."""
-        from . import _lib
         if self.precision != "f16":
             raise NotImplementedError("the f32 verification precision is forward-only")
         for fn, produces in reversed(self.tape):
             fn()
             if on_grads_ready is not None and produces:
-                on_grads_ready(produces)
-                if _lib.RECORDER is not None:
-                    _lib.RECORDER.py(lambda pr=produces: on_grads_ready(pr))
+                on_grads_ready(produces)      # while a step is recorded the hook records itself (dist.py)
         self.tape.clear()
 
     def reset_tape(self):

@@ -22,6 +22,7 @@ import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 
@@ -40,9 +41,11 @@ def child_env(rank, world, port, visible=None, base=None):
     if visible is not None:
         # the reference's os.environ['CUDA_VISIBLE_DEVICES'] = FLAGS.gpu_list (multigpu_train.py:90):
         # LOCAL_RANK then indexes into the list
+        # HIP_VISIBLE_DEVICES indexes INSIDE whatever ROCR_VISIBLE_DEVICES the scheduler / container set: that
+        # restriction is kept.  CUDA_VISIBLE_DEVICES is the same HIP-level filter under another name, so the
+        # list replaces it.
         env["HIP_VISIBLE_DEVICES"] = visible
         env.pop("CUDA_VISIBLE_DEVICES", None)
-        env.pop("ROCR_VISIBLE_DEVICES", None)
     return env
 
 
@@ -66,6 +69,17 @@ def self_launch(nproc, argv=None, visible=None, poll=0.05):
     argv = list(sys.argv if argv is None else argv)
     port = free_port()
     procs = []
+
+    # a cancelled job (SIGTERM / SIGHUP to the launcher) must not leave N ranks waiting in a collective
+    class _Cancelled(BaseException):
+        pass
+
+    def on_signal(signum, frame):
+        raise _Cancelled(signum)
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        for sg in (signal.SIGTERM, signal.SIGHUP):
+            old_handlers[sg] = signal.signal(sg, on_signal)
     try:
         for r in range(nproc):
             procs.append(subprocess.Popen([sys.executable] + argv, env=child_env(r, nproc, port, visible),
@@ -86,6 +100,13 @@ def self_launch(nproc, argv=None, visible=None, poll=0.05):
                     break
             time.sleep(poll)
         return rc
+    except _Cancelled as c:
+        sys.stderr.write("launcher: signal %d; stopping %d ranks\n" % (c.args[0], len(procs)))
+        _reap(procs, grace=5.0)
+        return 128 + int(c.args[0])
     except BaseException:
         _reap(procs, grace=2.0)
         raise
+    finally:
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)

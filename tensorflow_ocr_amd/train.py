@@ -229,6 +229,7 @@ class TrainStep:
         self.loss = None
         self.side_stream = None
         self.side_ptr = None
+        self._packed_version = None
         # weight gradients on a second stream: measured neutral-to-negative once the wgrad kernels
         # reached the conv kernels' efficiency (both saturate the VGPR file, so they time-slice rather
         # than overlap, and every overlapped launch is stretched); off by default, kept as a switch
@@ -244,12 +245,18 @@ class TrainStep:
         from .dist import GradientAllReduce
         g = self.g
         g.reset_tape()
+        # the dry-run forward updates the BN moving statistics: put back what was there BEFORE it (variables that
+        # exist already may hold loaded statistics; the ones the dry run creates start from their initial value)
+        before = {n: g.store.vars[n].data.clone() for n in g.store.order if not g.store.vars[n].trainable}
         self.forward_loss(g, *batch)
         g.reset_tape()
         self.opt = self.optimizer_factory(g)
         g.store.reset_non_trainable()
+        for n, t in before.items():
+            g.store.vars[n].data.copy_(t)
         self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, op=self.grad_op,
-                                         fold_mean=True, force=self.force_reduce)
+                                         fold_mean=True, force=self.force_reduce,
+                                         mode="torch" if self.use_side_stream else None)
         return self
 
     # -- eager / recording path --------------------------------------------------------------
@@ -273,17 +280,18 @@ class TrainStep:
                 from .dist import GradientAllReduce
                 self.opt = self.optimizer_factory(g)           # materialises the flat buffers
                 self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, op=self.grad_op,
-                                                 fold_mean=True, force=self.force_reduce)
+                                                 fold_mean=True, force=self.force_reduce,
+                                                 mode="torch" if self.use_side_stream else None)
             g.backward(self.reducer.on_grads_ready if self.reducer.active else None)
+            self.reducer.finish()           # records itself: host callback (torch mode) or C-ABI stream waits (abi mode)
         finally:
             _lib.RECORDER = None
-        self.reducer.finish()
         self.opt.apply_gradients(self.reducer.grad_scale)
-        g.repack_all()                      # the conv operand packs of the new weights, one launch
+        self._repack()                      # the conv operand packs of the new weights, one launch
         if record:
-            rec.py(self.reducer.finish)
             rec.py(lambda: self.opt.apply_gradients(self.reducer.grad_scale))
-            rec.py(g.repack_all)
+            rec.entries[-1].append("opt")
+            rec.py(self._repack)
             self.plan = rec.entries
             self.static_batch = list(batch)
             self.keepalive, g.keepalive = g.keepalive, None
@@ -291,9 +299,19 @@ class TrainStep:
         self.loss = loss
         return loss
 
+    def _repack(self):
+        """Batched re-pack of the [tap][cout][cin] / [tap][cin][cout] operand copies from the f32 masters, stamped
+        with the store version it saw: a replayed plan holds no lazy refresh of these packs, so `_replay` compares
+        the stamp and re-packs first when the masters changed outside the step (load_state_dict, a restored
+        checkpoint, an EMA swap)."""
+        self.g.repack_all()
+        self._packed_version = self.g.store.version
+
     def _replay(self, batch):
         import ctypes
         from . import _lib, ops
+        if self.g.store.version != self._packed_version:
+            self._repack()
         for dst, src in zip(self.static_batch, batch):
             if src is not dst:
                 dst.copy_(src, non_blocking=True)
@@ -308,6 +326,13 @@ class TrainStep:
         for e in self.plan:
             if e[0] == "c":
                 tag = e[4]
+                if tag is not None and tag[0] == "xchg":
+                    # the gradient exchange as C-ABI calls (dist.GradientAllReduce, abi mode)
+                    if self.reducer.enabled:
+                        rc = e[1](*e[2])
+                        if rc != 0:
+                            _lib.check(rc, e[3])
+                    continue
                 if tag is not None and tag[0] == "side" and self.use_side_stream:
                     # weight gradient: only the optimiser (and the all-reduce) consumes it
                     side.wait_stream(main)
@@ -324,7 +349,7 @@ class TrainStep:
                 if rc != 0:
                     _lib.check(rc, e[3])
             else:
-                if side_used and (not self.reducer.active or e[1] == self.reducer.finish):
+                if side_used and len(e) > 2 and e[2] == "opt":
                     main.wait_stream(side)       # optimiser / end of step: weight gradients done
                     side_used = False
                 e[1]()

@@ -66,12 +66,15 @@ def test_multigpu_train_on_icdar_directory(device, tmp_path, capsys):
     tot = [float(l.split("total loss ")[1].split(",")[0]) for l in lines]
     assert all(t > m for t, m in zip(tot, losses))            # + sum(REGULARIZATION_LOSSES), > 0
     out = _run("multigpu_train", ["--gpu_list", "0", "--batch_size_per_gpu", "2", "--input_size", "128",
-                                  "--max_steps", "21", "--net", "model_vgg", "--num_readers", "0", "--restore",
+                                  "--max_steps", "11", "--net", "model_vgg", "--num_readers", "0", "--restore",
+                                  "--save_checkpoint_steps", "5",
                                   "--training_data_path", os.path.join(d, "none"), "--checkpoint_path", ck], capsys)
     assert "continue training from previous checkpoint" in out
-    # the resumed run continues at the restored global step (11): its only log line is Step 000020
+    # `for step in range(FLAGS.max_steps)` after saver.restore (multigpu_train.py:153-168): the loop counter restarts
+    # at 0 and max_steps MORE updates run, while the restored global_step (11) goes on numbering the checkpoints
     lines = [l for l in out.splitlines() if l.startswith("Step ")]
-    assert len(lines) == 1 and lines[0].startswith("Step 000020"), lines
+    assert len(lines) == 2 and lines[0].startswith("Step 000000") and lines[1].startswith("Step 000010"), lines
+    assert tf_bundle.get_checkpoint_state(ck).endswith("model.ckpt-22")
 
 
 def test_train_pixellink_on_icdar_directory(device, tmp_path, capsys):

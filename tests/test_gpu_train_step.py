@@ -316,6 +316,10 @@ def _bench(args, timeout=540):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    if "--with-config-legs" in args:
+        args = [a for a in args if a != "--with-config-legs"]
+    else:
+        args = args + ["--no-config-legs"]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=timeout)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
@@ -340,5 +344,25 @@ def test_bench_one_rank_rccl_exchange(device):
     out = _bench(["--gpus", "1", "--force-pg", "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "64",
                   "--no-cpu-baseline"])
     ex = out["exchange"]
-    assert ex["backend"] == "nccl" and ex["rccl_ranks"] == 1 and len(ex["bucket_bytes"]) >= 2
+    # the one-rank `nccl` group exists (--force-pg) and the buckets travel through the C ABI on a communicator of
+    # the library's own (dist.AbiComm: ocr_comm_init_rank / ocr_allreduce_bucket)
+    assert ex["backend"].startswith("rccl") and ex["mode"] == "abi" and ex["rccl_ranks"] == 1 and len(ex["bucket_bytes"]) >= 2
     assert out["n_gpus"] == 1 and np.isfinite(out["loss"])
+
+
+def test_bench_default_single_gpu_line_reports_the_exchange(device):
+    """the N = 1 line carries `exchange` (one-rank RCCL communicator through
+    ocr_allreduce_bucket, no torch.distributed group at all) so the driver's record shows RCCL loaded; and
+    OCR_EXCHANGE=torch keeps the torch.distributed path selectable."""
+    out = _bench(["--steps", "2", "--warmup", "1", "--batch", "2", "--size", "64", "--no-cpu-baseline"])
+    ex = out["exchange"]
+    assert ex["mode"] == "abi" and ex["rccl_ranks"] == 1 and sum(ex["bucket_bytes"]) == ex["grad_bytes"]
+    assert "comm_exposed_ms" in ex and "ms_per_step_no_exchange" in ex
+    rf = out["roofline"]
+    assert set(rf["counters_from"]["files"]) == {"traffic", "mfma_busy", "clock_ghz"}
+    for f, v in rf["counters_from"]["files"].items():      # a counter is reported only with current provenance
+        key = {"traffic": "traffic", "mfma_busy": "mfma_busy", "clock_ghz": "clock_ghz"}[f]
+        assert v["current"] or rf[key] is None
+    out2 = _bench(["--steps", "2", "--warmup", "1", "--batch", "2", "--size", "64", "--no-cpu-baseline", "--no-pg"])
+    assert "exchange" not in out2
+    assert abs(out2["loss"] - out["loss"]) < 1e-6            # a one-rank exchange changes nothing

@@ -336,3 +336,102 @@ def test_recorder_only_records_its_owner_thread():
     assert seen == [False] and rec.entries == []
     rec.py(lambda: None)
     assert len(rec.entries) == 1
+
+
+# ------------------------------------------------------------------ world 8 (the node the SCALE run uses)
+def test_self_launch_world8_and_rank_failure_teardown(tmp_path):
+    """The launcher at the driver's scale, on CPU: 8 children rendezvous over gloo, rank 0's single JSON
+    line says ranks == 8; with one rank dying before the collective the other 7 are reaped and the
+    launcher exits with that rank's code (no rank is left waiting in an all-reduce)."""
+    import json
+    r = _run_launcher(tmp_path, 8, "ok", timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip() and not l.startswith("[Gloo]")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"ranks": 8, "stop": True, "none": False}, lines
+    for k in range(1, 8):
+        assert ("noise from rank %d" % k).encode() in r.stderr
+    r = _run_launcher(tmp_path, 8, "fail", timeout=120)
+    assert r.returncode == 7 and b"rank 1 exited with code 7" in r.stderr and b"{" not in r.stdout
+
+
+_HANG_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+from tensorflow_ocr_amd import launch
+rc = launch.self_launch(3)
+if rc is not None:
+    sys.exit(rc)
+open(os.path.join(%r, "pid_%%s" %% os.environ["RANK"]), "w").write(str(os.getpid()))
+time.sleep(600)                 # a rank stuck in a collective
+"""
+
+
+def test_launcher_sigterm_reaps_its_ranks(tmp_path):
+    """a cancelled job (SIGTERM to the launcher) must not orphan the ranks."""
+    import signal
+    import time
+    script = tmp_path / "hang.py"
+    script.write_text(_HANG_SCRIPT % (ROOT, str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.Popen([sys.executable, str(script)], env=env, stderr=subprocess.PIPE)
+    t0 = time.time()
+    while len([f for f in os.listdir(tmp_path) if f.startswith("pid_")]) < 3 and time.time() - t0 < 60:
+        time.sleep(0.1)
+    pids = [int(open(os.path.join(tmp_path, f)).read()) for f in os.listdir(tmp_path) if f.startswith("pid_")]
+    assert len(pids) == 3
+    p.send_signal(signal.SIGTERM)
+    err = p.communicate(timeout=60)[1]
+    assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err.decode()[-1000:])
+    assert b"stopping 3 ranks" in err
+    time.sleep(0.2)
+    for pid in pids:
+        alive = True
+        try:
+            os.kill(pid, 0)
+            # a zombie of another parent cannot exist here: the launcher waited for its children
+        except ProcessLookupError:
+            alive = False
+        assert not alive, pid
+
+
+def test_child_env_keeps_the_scheduler_restriction():
+    """--gpu_list narrows HIP_VISIBLE_DEVICES inside ROCR_VISIBLE_DEVICES, it never lifts it."""
+    from tensorflow_ocr_amd import launch
+    env = launch.child_env(1, 2, 999, visible="0,1", base={"ROCR_VISIBLE_DEVICES": "4,5", "CUDA_VISIBLE_DEVICES": "3"})
+    assert env["ROCR_VISIBLE_DEVICES"] == "4,5" and env["HIP_VISIBLE_DEVICES"] == "0,1" and "CUDA_VISIBLE_DEVICES" not in env
+
+
+def test_exchange_abi_argument_checks_without_a_gpu():
+    """ocr_allreduce_bucket / ocr_comm_* / ocr_event_* reject bad arguments before touching RCCL or HIP."""
+    from tensorflow_ocr_amd import _lib
+    lib = _lib.load()
+    for n in ("ocr_allreduce_bucket", "ocr_comm_init_rank", "ocr_comm_unique_id", "ocr_event_record",
+              "ocr_stream_wait_event", "ocr_comm_destroy", "ocr_event_destroy"):
+        getattr(lib, n).restype = ctypes.c_int
+    assert lib.ocr_allreduce_bucket(None, None, ctypes.c_size_t(4), 0, 0, None) == -1          # NULL communicator
+    fake = ctypes.c_void_p(1)
+    assert lib.ocr_allreduce_bucket(fake, None, ctypes.c_size_t(4), 0, 0, None) == -1          # NULL buffer
+    buf = ctypes.c_void_p(4096)
+    assert lib.ocr_allreduce_bucket(fake, buf, ctypes.c_size_t(4), 99, 0, None) == -1          # unknown dtype
+    assert lib.ocr_allreduce_bucket(fake, buf, ctypes.c_size_t(4), 0, 99, None) == -1          # unknown op
+    assert lib.ocr_allreduce_bucket(fake, buf, ctypes.c_size_t(0), 0, 0, None) == 0            # empty bucket
+    h = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(128)
+    assert lib.ocr_comm_init_rank(ctypes.byref(h), 0, ident, 0) == -1                           # nranks < 1
+    assert lib.ocr_comm_init_rank(ctypes.byref(h), 2, ident, 2) == -1                           # rank out of range
+    assert lib.ocr_comm_unique_id(None) == -1
+    assert lib.ocr_event_record(None, None) == -1 and lib.ocr_stream_wait_event(None, None) == -1
+    assert lib.ocr_comm_destroy(None) == 0 and lib.ocr_event_destroy(None) == 0
+    lib.ocr_status_string.restype = ctypes.c_char_p
+    assert b"RCCL" in lib.ocr_status_string(-5)
+
+
+def test_exchange_mode_selection(monkeypatch):
+    from tensorflow_ocr_amd import dist
+    monkeypatch.delenv("OCR_EXCHANGE", raising=False)
+    assert dist.exchange_mode(8, cuda=False) == "torch"           # gloo / CPU towers
+    assert dist.exchange_mode(1, cuda=True) == "torch"            # a single tower exchanges nothing
+    assert dist.exchange_mode(1, cuda=True, force=True) == "abi"  # one-rank RCCL communicator through the C ABI
+    assert dist.exchange_mode(8, cuda=True) == "abi"
+    monkeypatch.setenv("OCR_EXCHANGE", "torch")
+    assert dist.exchange_mode(8, cuda=True) == "torch"
