@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (reference: batch_size_per_gpu)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loss-trace", action="store_true", help="also report the loss of EVERY step taken (the three "
+                    "engine-build steps, the warm-up and the timed steps are all real optimiser steps on the same batch): "
+                    "one host sync per step, so for checking (tests/test_gpu_batch_parity.py), not for timing")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs of BASELINE configs[2..4]")
     ap.add_argument("--no-pg", action="store_true", help="N=1: do not run the bucketed exchange through a "
                     "one-rank RCCL communicator (by default it runs, so the line records that RCCL loaded)")
@@ -206,15 +209,21 @@ def main():
         torch.cuda.synchronize()
 
     loss = None
+    trace = [] if args.loss_trace else None
+
+    def take(l):
+        if trace is not None:
+            trace.append(round(float(l.item()), 6))
+        return l
     for _ in range(3):          # engine build: variables, flat buffers, recorded step plan (untimed)
-        loss = step(*batch)
+        loss = take(step(*batch))
     for _ in range(args.warmup):
-        loss = step(*batch)
+        loss = take(step(*batch))
     barrier()
     ops.KERNEL_TIMING = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step(*batch)
+        loss = take(step(*batch))
     barrier()
     dt = time.perf_counter() - t0
     timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
@@ -305,6 +314,8 @@ def main():
             "train_tflops": round(value * TRAIN_GFLOP_PER_IMG / 1e3 * (args.size / 512.0) ** 2, 1),
             "roofline": roof,
         }
+        if trace is not None:
+            out["loss_trace"] = trace
         if comm is not None:
             out["exchange"] = comm
         if world == 1 and not args.no_config_legs:

@@ -368,6 +368,19 @@ int ocr_link_cc(const void* pixel_score, const void* link_score, int link_elem_s
                 int link_elem_offset, int n, int h, int w, float pixel_thresh, float link_thresh,
                 int min_size, void* labels_i32, void* ncomp_i32, void* comps_i32, int max_comps,
                 void* workspace, size_t ws_bytes, void* stream);
+/* The reference's own grouping rule, exactly (test_pixellink_fast.py:153-178; Python-2 dict order restated as
+ * ascending pixel index): DIRECTED reachability from the smallest unassigned key through unassigned pixels,
+ * a set gets a gid only if it has more than min_size members, sets that fail stay 0 and can be collected
+ * again.  Refines ocr_link_cc's weakly-connected components (directed sets never leave one):
+ * union_labels / union_ncomp are ocr_link_cc's outputs for the SAME maps and thresholds; labels (a different
+ * buffer), ncomp, comps [n][max_comps][2] = (seed pixel, size) as for ocr_link_cc, gids in ascending seed
+ * order.  Bit-exact against oracle.ocr_oracle.link_cc_reference_dfs. */
+size_t ocr_link_cc_directed_workspace(int n, int h, int w);
+int ocr_link_cc_directed(const void* pixel_score, const void* link_score, int link_elem_stride,
+                         int link_elem_offset, int n, int h, int w, float pixel_thresh, float link_thresh,
+                         int min_size, const void* union_labels_i32, const void* union_ncomp_i32,
+                         void* labels_i32, void* ncomp_i32, void* comps_i32, int max_comps,
+                         void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Locality-aware NMS (EAST, Zhou et al. CVPR 2017, Algorithm 1).  ABSENT from the reference tree

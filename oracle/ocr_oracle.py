@@ -589,6 +589,54 @@ def link_cc_reference_dfs(pixel_score, link_scores, pixel_thresh=0.8, link_thres
     return group.reshape(h, w)
 
 
+def link_cc_directed_rounds(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, min_size=10):
+    """The schedule `ocr_link_cc_directed` runs (csrc/decode.hip: cc_directed_kernel), restated on the CPU so that
+    its equivalence with the literal script (`link_cc_reference_dfs`) is checked without a GPU: inside every
+    weakly-connected component, rounds of (seed = smallest key that is unassigned and not known to fail;
+    R = forward-reachable set through unassigned pixels; |R| > min_size ? assign : all of R known to fail),
+    gids in ascending seed order.  Returns int32 labels [h,w]."""
+    h, w = pixel_score.shape
+    seg = pixel_score > pixel_thresh
+    ulab, _ = link_cc_union(pixel_score, link_scores, pixel_thresh, link_thresh, min_size)
+    ulab = ulab.ravel()
+    edges = {}
+    for y in range(1, h - 1):
+        for x in range(1, w - 1):
+            if seg[y, x] and ulab[y * w + x] > 0:
+                edges[y * w + x] = [(y + dy) * w + x + dx for d, (dx, dy) in enumerate(LINK_OFFSETS)
+                                    if link_scores[d][y, x] > link_thresh and seg[y + dy, x + dx]]
+    state = np.where(ulab > 0, 1, 0)
+    dead = np.zeros(h * w, bool)
+    group = np.zeros(h * w, np.int64)
+    while True:
+        seeds = {}
+        for k in sorted(edges):
+            if state[k] == 1 and not dead[k] and ulab[k] not in seeds:
+                seeds[ulab[k]] = k
+        if not seeds:
+            break
+        for c, s0 in seeds.items():
+            R, frontier = {s0}, [s0]
+            while frontier:
+                nxt = []
+                for v in frontier:
+                    for q in edges.get(v, []):
+                        if state[q] == 1 and q not in R:
+                            R.add(q)
+                            nxt.append(q)
+                frontier = nxt
+            R = np.fromiter(R, np.int64)
+            if len(R) > min_size:
+                group[R] = s0 + 1
+                state[R] = 2
+            else:
+                dead[R] = True
+    seeds_ok = np.nonzero(group == np.arange(h * w) + 1)[0]
+    ids = np.zeros(h * w + 1, np.int32)
+    ids[seeds_ok + 1] = np.arange(1, len(seeds_ok) + 1)
+    return ids[group].reshape(h, w).astype(np.int32)
+
+
 def link_cc_union(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, min_size=10):
     """Weakly-connected components of the same graph (every directed edge joins its two pixels),
     dense ids in ascending order of each component's smallest pixel index — what the HIP kernel
@@ -694,9 +742,10 @@ def init_pixellink_params(rng, width_div=1):
     return p
 
 
-def pixellink_net(inputs, p, mixed=False):
-    """nets/pixellink.py:40-86.  inputs: preprocessed NHWC image.  Returns (pixel_cls, link_cls, end_points)."""
-    _, ep = vgg_basenet(inputs, p, "vgg/", None, mixed)
+def pixellink_net(inputs, p, mixed=False, taps=None):
+    """nets/pixellink.py:40-86.  inputs: preprocessed NHWC image.  Returns (pixel_cls, link_cls, end_points).
+    taps: as in `vgg_basenet` (per trunk conv: input, output, pooled output, gradients retained)."""
+    _, ep = vgg_basenet(inputs, p, "vgg/", None, mixed, taps=taps)
     outs = []
     for kind, c in (("pixel", 2), ("link", 16)):
         def conv(key, st):
@@ -770,8 +819,10 @@ def bottleneck(x, p, u, depth, stride, is_training, mixed, updates):
     return q(torch.relu(shortcut + r), mixed)
 
 
-def resnet_v1_50(x, p, is_training=True, scope="resnet_v1_50", mixed=False, updates=None, blocks=None):
-    """nets/resnet_v1.py:114-259 (root 7x7/2 + 3x3/2 max-pool, blocks, end points pool2..pool5)."""
+def resnet_v1_50(x, p, is_training=True, scope="resnet_v1_50", mixed=False, updates=None, blocks=None, taps=None):
+    """nets/resnet_v1.py:114-259 (root 7x7/2 + 3x3/2 max-pool, blocks, end points pool2..pool5).
+    taps (dict, optional): per bottleneck unit `<scope>/<block>/unit_<i>/bottleneck_v1 -> {"x": input, "out": output}`
+    with gradients retained (unit-by-unit checks of the device path, tests/test_gpu_batch_parity.py)."""
     updates = {} if updates is None else updates
     blocks = blocks or RESNET50_BLOCKS
     ep = {}
@@ -780,8 +831,15 @@ def resnet_v1_50(x, p, is_training=True, scope="resnet_v1_50", mixed=False, upda
     ep["pool2"] = net
     for bname, units in blocks:
         for i, (depth, db, stride) in enumerate(units):
-            net = bottleneck(net, p, "%s/%s/unit_%d/bottleneck_v1" % (scope, bname, i + 1), depth, stride,
-                             is_training, mixed, updates)
+            uname = "%s/%s/unit_%d/bottleneck_v1" % (scope, bname, i + 1)
+            xin = net
+            if taps is not None and xin.requires_grad:
+                xin.retain_grad()
+            net = bottleneck(xin, p, uname, depth, stride, is_training, mixed, updates)
+            if taps is not None:
+                if net.requires_grad:
+                    net.retain_grad()
+                taps[uname] = {"x": xin, "out": net, "depth": depth, "depth_bottleneck": db, "stride": stride}
         ep[scope + "/" + bname] = net
     ep["pool3"], ep["pool4"], ep["pool5"] = ep[scope + "/block1"], ep[scope + "/block2"], net
     return net, ep
@@ -853,11 +911,12 @@ def init_model_east_params(rng, blocks=None):
     return p
 
 
-def model_east(images, p, is_training=True, mixed=False, updates=None, blocks=None):
-    """nets/model_vgg_16.py:85-136 -> (F_score [N,H/4,W/4,1], geo_map [N,H/4,W/4,8], end_points)."""
+def model_east(images, p, is_training=True, mixed=False, updates=None, blocks=None, taps=None):
+    """nets/model_vgg_16.py:85-136 -> (F_score [N,H/4,W/4,1], geo_map [N,H/4,W/4,8], end_points).
+    taps: per bottleneck unit, see `resnet_v1_50`."""
     updates = {} if updates is None else updates
     x = mean_image_subtraction(images)
-    _, ep = resnet_v1_50(x, p, is_training, "resnet_v1_50", mixed, updates, blocks)
+    _, ep = resnet_v1_50(x, p, is_training, "resnet_v1_50", mixed, updates, blocks, taps=taps)
     f = [ep["pool5"], ep["pool4"], ep["pool3"], ep["pool2"]]
     idx = [0]
 

@@ -322,6 +322,142 @@ __global__ void zero_pixels_kernel(unsigned char* __restrict__ mask, const int* 
   if ((int)threadIdx.x < count) mask[idx[threadIdx.x]] = 0;
 }
 
+// ---- the reference's DIRECTED grouping (test_pixellink_fast.py:153-178) ------------------------------------
+// The script walks its neighbour graph with a depth-first search along DIRECTED edges: for every key (interior
+// segment pixel; Python-2 dict order restated as ascending pixel index) whose group is still 0 it
+// collects everything reachable from the key through pixels whose group is 0, and gives the set a new gid
+// only if it has more than min_size members — otherwise the members stay 0 and later keys may collect them
+// again.  Result per weakly-connected component C (ocr_link_cc's label; sets never leave C):
+//     repeat: seed = smallest key of C that is unassigned and not yet known to fail;
+//             R = pixels reachable from seed along edges through unassigned pixels;
+//             |R| > min_size ? assign R to the seed's group : every key of R is known to fail
+//             (a later search from k in R runs on a subset of the unassigned pixels and stays inside R).
+// Components are independent, so ONE round serves one seed of every component at once; a round is a frontier
+// expansion to its fixed point.  gid order = ascending seed index (the order the script meets its seeds).
+// One workgroup per image: the sequential depth is the number of rounds, not the image size.
+__global__ __launch_bounds__(1024) void cc_directed_kernel(CcP p, const float* __restrict__ score,
+                                                           const float* __restrict__ link,
+                                                           const int* __restrict__ ulabel_all,
+                                                           const int* __restrict__ uncomp, unsigned char* __restrict__ ws8,
+                                                           int* __restrict__ ws32, int* __restrict__ labels_all,
+                                                           int* __restrict__ ncomp_out, int* __restrict__ comps_out,
+                                                           int max_comps) {
+  __shared__ int s_scan[16];
+  __shared__ int s_base;
+  const int img = blockIdx.x, hw = p.h * p.w, tid = threadIdx.x;
+  const int* ulabel = ulabel_all + (size_t)img * hw;
+  unsigned char* edges = ws8 + (size_t)img * hw * 4;
+  unsigned char* state = edges + hw;      // 0 outside every kept component, 1 unassigned, 2 assigned
+  unsigned char* reach = state + hw;      // 0, 1 = reached, not expanded yet, 2 = expanded
+  unsigned char* dead = reach + hw;       // key that cannot seed a group any more
+  int* group = ws32 + (size_t)img * hw * 4;   // seed index + 1 of the pixel's group (0: none)
+  int* seed = group + hw;                 // per union label: this round's seed; later: dense ids per pixel
+  int* cnt = seed + hw;                   // per union label: |R| of this round
+  int* gsize = cnt + hw;                  // per seed pixel: size of its group
+  int* labels = labels_all + (size_t)img * hw;
+  const float* sc = score + (size_t)img * hw;
+  const int K = min(uncomp[img], hw - 1);
+  for (int i = tid; i < hw; i += 1024) {
+    const int L = ulabel[i];
+    const int x = i % p.w, y = i / p.w;
+    unsigned e = 0;
+    if (L > 0 && x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const int q = (y + kDy[d]) * p.w + x + kDx[d];
+        if (link[(((size_t)d * p.n + img) * hw + i) * p.ls + p.lo] > p.tl && sc[q] > p.tp) e |= 1u << d;
+      }
+    }
+    edges[i] = (unsigned char)e;
+    state[i] = L > 0 ? 1 : 0;
+    reach[i] = 0;
+    dead[i] = 0;
+    group[i] = 0;
+    gsize[i] = 0;
+  }
+  for (int c = tid; c <= K; c += 1024) { seed[c] = 0x7fffffff; cnt[c] = 0; }
+  __syncthreads();
+  for (int round = 0; round < hw; ++round) {
+    for (int i = tid; i < hw; i += 1024) {
+      if (state[i] == 1 && !dead[i]) {
+        const int x = i % p.w, y = i / p.w;
+        if (x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2 && i < seed[ulabel[i]]) atomicMin(seed + ulabel[i], i);
+      }
+    }
+    __syncthreads();
+    int any = 0;
+    for (int c = 1 + tid; c <= K; c += 1024)
+      if (seed[c] != 0x7fffffff) { reach[seed[c]] = 1; any = 1; }
+    if (!__syncthreads_or(any)) break;
+    for (int sweep = 0; sweep < hw; ++sweep) {
+      int changed = 0;
+      for (int i = tid; i < hw; i += 1024) {
+        if (reach[i] != 1) continue;
+        reach[i] = 2;
+        const unsigned e = edges[i];
+        const int x = i % p.w, y = i / p.w;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          if (!(e >> d & 1)) continue;
+          const int q = (y + kDy[d]) * p.w + x + kDx[d];
+          if (state[q] == 1 && reach[q] == 0) { reach[q] = 1; changed = 1; }
+        }
+      }
+      if (!__syncthreads_or(changed)) break;
+    }
+    for (int i = tid; i < hw; i += 1024)
+      if (reach[i]) atomicAdd(cnt + ulabel[i], 1);
+    __syncthreads();
+    for (int i = tid; i < hw; i += 1024) {
+      if (!reach[i]) continue;
+      const int c = ulabel[i];
+      if (cnt[c] > p.min_size) {
+        group[i] = seed[c] + 1;
+        state[i] = 2;
+        if (i == seed[c]) gsize[i] = cnt[c];
+      } else {
+        dead[i] = 1;
+      }
+      reach[i] = 0;
+    }
+    __syncthreads();
+    for (int c = 1 + tid; c <= K; c += 1024) { seed[c] = 0x7fffffff; cnt[c] = 0; }
+    __syncthreads();
+  }
+  __syncthreads();
+  // dense ids in ascending seed order: a pixel is a successful seed iff group[i] == i + 1
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  int* ids = seed;                          // the per-label slots are dead now
+  for (int i0 = 0; i0 < hw; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool flag = i < hw && group[i] == i + 1;
+    const unsigned long long vote = __ballot(flag);
+    if ((tid & 63) == 0) s_scan[tid >> 6] = __popcll(vote);
+    __syncthreads();
+    int off = s_base;
+    for (int k = 0; k < (tid >> 6); ++k) off += s_scan[k];
+    if (flag) {
+      const int id = off + __popcll(vote & ((1ull << (tid & 63)) - 1ull)) + 1;
+      ids[i] = id;
+      if (id <= max_comps) {
+        comps_out[((size_t)img * max_comps + id - 1) * 2 + 0] = i;
+        comps_out[((size_t)img * max_comps + id - 1) * 2 + 1] = gsize[i];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += s_scan[k];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < hw; i += 1024) labels[i] = group[i] ? ids[group[i] - 1] : 0;
+  if (tid == 0) ncomp_out[img] = s_base;
+}
+
 unsigned dgrid(size_t items) {
   size_t b = (items + 255) / 256;
   if (b > 4096) b = 4096;
@@ -399,6 +535,31 @@ extern "C" int ocr_link_cc(const void* pixel_score, const void* link_score, int 
   hipLaunchKernelGGL(cc_root_kernel, dim3(dgrid(total)), dim3(256), 0, st, p, parent, root, size, ids);
   cc_number(p, root, size, ids, blkcnt, static_cast<int*>(labels_i32), static_cast<int*>(ncomp_i32),
             static_cast<int*>(comps_i32), max_comps, st);
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_link_cc_directed_workspace(int n, int h, int w) {
+  return (size_t)n * h * w * (4 + 4 * sizeof(int));
+}
+
+extern "C" int ocr_link_cc_directed(const void* pixel_score, const void* link_score, int link_elem_stride,
+                                    int link_elem_offset, int n, int h, int w, float pixel_thresh, float link_thresh,
+                                    int min_size, const void* union_labels_i32, const void* union_ncomp_i32,
+                                    void* labels_i32, void* ncomp_i32, void* comps_i32, int max_comps,
+                                    void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(pixel_score && link_score && union_labels_i32 && union_ncomp_i32 && labels_i32 && ncomp_i32 && comps_i32 &&
+                workspace);
+  OCR_CHECK_ARG(n > 0 && h > 2 && w > 2 && max_comps > 0 && labels_i32 != union_labels_i32);
+  OCR_CHECK_ARG(link_elem_stride >= 1 && link_elem_offset >= 0 && link_elem_offset < link_elem_stride);
+  if (ws_bytes < ocr_link_cc_directed_workspace(n, h, w)) return OCR_ERR_WORKSPACE;
+  CcP p{n, h, w, min_size, pixel_thresh, link_thresh, link_elem_stride, link_elem_offset};
+  const size_t total = (size_t)n * h * w;
+  int* ws32 = static_cast<int*>(workspace);                                  // 16-byte aligned part first
+  unsigned char* ws8 = reinterpret_cast<unsigned char*>(ws32 + total * 4);
+  hipLaunchKernelGGL(cc_directed_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), p,
+                     static_cast<const float*>(pixel_score), static_cast<const float*>(link_score),
+                     static_cast<const int*>(union_labels_i32), static_cast<const int*>(union_ncomp_i32), ws8, ws32,
+                     static_cast<int*>(labels_i32), static_cast<int*>(ncomp_i32), static_cast<int*>(comps_i32), max_comps);
   return ocr_launch_status();
 }
 

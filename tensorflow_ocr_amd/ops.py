@@ -529,6 +529,16 @@ def link_cc(pixel_score, link_score, stride, offset, n, h, w, pixel_thresh, link
            ptr(comps), c_int(comps.shape[1]), ptr(buf), c_size_t(nbytes), _st())
 
 
+def link_cc_directed(pixel_score, link_score, stride, offset, n, h, w, pixel_thresh, link_thresh, min_size,
+                     union_labels, union_ncomp, labels, ncomp, comps, ws):
+    """The reference's directed-DFS grouping, refining ocr_link_cc's components (include/ocr_hip.h)."""
+    nbytes = L.call_size("ocr_link_cc_directed_workspace", c_int(n), c_int(h), c_int(w))
+    buf = ws.get(nbytes)
+    L.call("ocr_link_cc_directed", ptr(pixel_score), ptr(link_score), c_int(stride), c_int(offset), c_int(n),
+           c_int(h), c_int(w), c_float(pixel_thresh), c_float(link_thresh), c_int(min_size), ptr(union_labels),
+           ptr(union_ncomp), ptr(labels), ptr(ncomp), ptr(comps), c_int(comps.shape[1]), ptr(buf), c_size_t(nbytes), _st())
+
+
 def lanms(boxes, counts, iou_thresh, merged, n_merged, keep_idx, n_keep, ws):
     n_images, max_k, _ = boxes.shape
     nbytes = L.call_size("ocr_lanms_workspace", c_int(n_images), c_int(max_k))

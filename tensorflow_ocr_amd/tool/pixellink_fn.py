@@ -55,10 +55,17 @@ def tf_pixel_detect(score_map, geo_map, score_map_thresh, link_thresh, graph=Non
 
 
 def link_cc_decode(pixel_score, link_score, pixel_conf_threshold=0.8, link_conf_threshold=0.9,
-                   min_size=10, max_comps=4096, graph=None):
+                   min_size=10, max_comps=4096, graph=None, mode="union"):
     """test_pixellink_fast.py:110-178 for a whole batch.  pixel_score [N,h,w] = softmax(pixel_cls)
     [...,1]; link_score [8,N,h,w,2] (stacked softmaxes) or [8,N,h,w].  Returns (labels int32
-    [N,h,w], ncomp int32 [N], comps int32 [N,max_comps,2] = (smallest pixel index, size))."""
+    [N,h,w], ncomp int32 [N], comps int32 [N,max_comps,2] = (smallest pixel index, size)).
+
+    mode="union" (default): weakly-connected components of the link graph (order independent; equals the
+    script's result whenever the link predictions are symmetric).  mode="reference_dfs": the script's own
+    rule, exactly — directed reachability from each unassigned key in ascending pixel order, groups of more
+    than min_size pixels only (:153-178); comps = (seed pixel, size)."""
+    if mode not in ("union", "reference_dfs"):
+        raise ValueError("mode must be 'union' or 'reference_dfs'")
     g = graph or get_default_graph()
     ps = _dev(g, pixel_score)
     lk = _dev(g, link_score)
@@ -69,7 +76,14 @@ def link_cc_decode(pixel_score, link_score, pixel_conf_threshold=0.8, link_conf_
     comps = torch.zeros((n, max_comps, 2), dtype=torch.int32, device=g.device)
     ops.link_cc(ps, lk, stride, off, n, h, w, float(pixel_conf_threshold), float(link_conf_threshold),
                 int(min_size), labels, ncomp, comps, g.workspace())
-    return labels, ncomp, comps
+    if mode == "union":
+        return labels, ncomp, comps
+    labels_d = torch.empty_like(labels)
+    ncomp_d = torch.empty_like(ncomp)
+    comps_d = torch.zeros_like(comps)
+    ops.link_cc_directed(ps, lk, stride, off, n, h, w, float(pixel_conf_threshold), float(link_conf_threshold),
+                         int(min_size), labels, ncomp, labels_d, ncomp_d, comps_d, g.workspace())
+    return labels_d, ncomp_d, comps_d
 
 
 def resize_scores_cubic(pixel_score, link_score, out_h=720, out_w=1280, graph=None):

@@ -1,0 +1,91 @@
+"""GPU: `link_cc_decode(mode="reference_dfs")` — the reference's own directed-DFS grouping
+(test_pixellink_fast.py:153-178) — bit-exact against the literal script restatement
+`O.link_cc_reference_dfs`, on the maps where it differs from the default union labelling."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ocr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _sm(l):
+    e = np.exp(l - l.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+def _maps(seed, n, q4, strength):
+    rng = np.random.default_rng(seed)
+    pl, ll = O.synthetic_decode_maps(rng, n, q4, strength)
+    ps = _sm(pl)[..., 1].astype(np.float32)                                                 # [n,q,q]
+    ls = np.stack([_sm(ll[..., 2 * d:2 * d + 2])[..., 1] for d in range(8)]).astype(np.float32)   # [8,n,q,q]
+    return ps, ls
+
+
+def _decode(g, ps, ls, pt, lt, ms, mode, max_comps=4096):
+    from tensorflow_ocr_amd.tool import pixellink_fn as PF
+    lab, nc, comps = PF.link_cc_decode(torch.from_numpy(ps), torch.from_numpy(ls), pt, lt, min_size=ms,
+                                       max_comps=max_comps, graph=g, mode=mode)
+    return lab.cpu().numpy(), nc.cpu().numpy(), comps.cpu().numpy()
+
+
+@pytest.mark.parametrize("seed,n,q4,strength,pt,lt,ms", [
+    (0, 2, 64, 3.0, 0.8, 0.9, 10),      # the survey's decode maps: directed == union here
+    (1, 2, 64, 1.5, 0.8, 0.9, 10),      # weak links: single boundary pixels reachable one way only
+    (2, 3, 48, 0.8, 0.6, 0.7, 3),       # near noise, small size filter: many failing seeds, re-collected later
+    (3, 2, 40, 0.4, 0.5, 0.6, 2),
+    (4, 1, 96, 2.0, 0.8, 0.9, 10),
+    (5, 2, 33, 1.0, 0.7, 0.8, 5),       # odd size: tiles of the union pass are ragged
+])
+def test_reference_dfs_mode_bit_exact(device, seed, n, q4, strength, pt, lt, ms):
+    from tensorflow_ocr_amd.graph import Graph
+    g = Graph(device)
+    ps, ls = _maps(seed, n, q4, strength)
+    lab, nc, comps = _decode(g, ps, ls, pt, lt, ms, "reference_dfs")
+    for b in range(n):
+        ref = O.link_cc_reference_dfs(ps[b], [ls[d, b] for d in range(8)], pt, lt, ms)
+        assert np.array_equal(lab[b], ref), (b, int((lab[b] != ref).sum()))
+        k = int(ref.max())
+        assert nc[b] == k
+        for gid in range(1, min(k, comps.shape[1]) + 1):        # comps = (seed = smallest key of the group's search, size)
+            members = np.nonzero(ref.ravel() == gid)[0]
+            assert comps[b, gid - 1, 1] == len(members) and comps[b, gid - 1, 0] in members
+
+
+def test_reference_dfs_differs_from_union_only_where_the_oracles_do(device):
+    """Same maps through both modes: the device's two labellings differ exactly where the two oracles differ
+    (the a15 deviation of the default mode, now selectable away)."""
+    from tensorflow_ocr_amd.graph import Graph
+    g = Graph(device)
+    ps, ls = _maps(1, 4, 64, 1.5)
+    d_lab, _, _ = _decode(g, ps, ls, 0.8, 0.9, 10, "reference_dfs")
+    u_lab, _, _ = _decode(g, ps, ls, 0.8, 0.9, 10, "union")
+    n_diff = 0
+    for b in range(4):
+        A = O.link_cc_reference_dfs(ps[b], [ls[d, b] for d in range(8)], 0.8, 0.9, 10)
+        U, _ = O.link_cc_union(ps[b], [ls[d, b] for d in range(8)], 0.8, 0.9, 10)
+        assert np.array_equal(d_lab[b], A) and np.array_equal(u_lab[b], U)
+        n_diff += int(((A > 0) != (U > 0)).sum())
+    assert n_diff > 0
+
+
+def test_reference_dfs_mode_edge_cases(device):
+    from tensorflow_ocr_amd.graph import Graph
+    g = Graph(device)
+    q = 24
+    ps = np.zeros((4, q, q), np.float32)
+    ls = np.zeros((8, 4, q, q), np.float32)
+    ps[1] = 0.95; ls[:, 1] = 0.99                      # everything linked both ways: one group incl. the frame pixels
+    ps[2] = 0.95                                       # no links at all: nothing survives a size filter
+    # image 3: a one-way chain along a row — only "right" links (direction 3): from the leftmost key everything to its
+    # right is reachable; from any other key only its suffix
+    ps[3, 5, 2:20] = 0.9; ls[3, 3, 5, 2:20] = 0.95
+    for ms in (0, 4, 30):
+        lab, nc, _ = _decode(g, ps, ls, 0.8, 0.9, ms, "reference_dfs")
+        for b in range(4):
+            ref = O.link_cc_reference_dfs(ps[b], [ls[d, b] for d in range(8)], 0.8, 0.9, ms)
+            assert np.array_equal(lab[b], ref), (b, ms)
+            assert nc[b] == ref.max()
+    with pytest.raises(ValueError):
+        _decode(g, ps, ls, 0.8, 0.9, 0, "dfs")

@@ -287,13 +287,30 @@ assert not s0.reducer.active
 assert torch.equal(g0.store.flat, g1.store.flat), (g0.store.flat - g1.store.flat).abs().max().item()
 assert torch.equal(s0.opt.m, s1.opt.m) and torch.isfinite(g1.store.flat).all()
 n_py = sum(1 for e in s1.plan if e[0] == "py")
-assert n_py >= len(red.buckets) + 2, n_py            # bucket hooks + finish + optimiser are in the replayed plan
+n_x = sum(1 for e in s1.plan if e[0] == "c" and e[4] is not None and e[4][0] == "xchg")
+names = [e[3] for e in s1.plan if e[0] == "c" and e[4] is not None and e[4][0] == "xchg"]
+if os.environ.get("OCR_EXCHANGE") == "torch":
+    assert red.mode == "torch" and n_x == 0
+    assert n_py >= len(red.buckets) + 2, n_py        # bucket hooks + finish + optimiser are host callbacks of the plan
+else:
+    # the exchange is C-ABI calls of the plan: per bucket event-record, stream-wait, ocr_allreduce_bucket,
+    # event-record, and one stream-wait per bucket before the optimiser; only optimiser + re-pack stay host callbacks
+    assert red.mode == "abi" and red.comm.size() == 1
+    nb = len(red.buckets)
+    assert n_x == 5 * nb and names.count("ocr_allreduce_bucket") == nb and n_py == 2, (n_x, n_py, names)
+    # bench.py's A/B switch: with the exchange disabled the replay skips those entries and still trains
+    red.enabled = False
+    s1(*b1); s0(*b0)
+    red.enabled = True
+    torch.cuda.synchronize()
+    assert torch.equal(g0.store.flat, g1.store.flat)
 td.barrier(); td.destroy_process_group()
-print("rccl-1 ok buckets", red.bucket_nbytes())
+print("rccl-1 ok buckets", red.bucket_nbytes(), red.mode)
 """
 
 
-def test_rccl_one_rank_group_through_trainstep(device, tmp_path):
+@pytest.mark.parametrize("exchange", ["abi", "torch"])
+def test_rccl_one_rank_group_through_trainstep(device, tmp_path, exchange):
     """The `nccl` (= RCCL) path of dist.GradientAllReduce — comm stream, event from the compute
     stream, async all_reduce handles, `h.wait()` before the replayed optimiser launch — executed on
     hardware with the one GPU this box has: a ONE-rank communicator (multigpu_train.py:70-85,118-133)."""
@@ -305,8 +322,9 @@ def test_rccl_one_rank_group_through_trainstep(device, tmp_path):
     script.write_text(_RCCL1_WORKER % root)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OCR_EXCHANGE"] = exchange
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=540)
-    assert r.returncode == 0 and b"rccl-1 ok" in r.stdout, r.stdout.decode()[-3000:]
+    assert r.returncode == 0 and b"rccl-1 ok" in r.stdout and exchange.encode() in r.stdout, r.stdout.decode()[-3000:]
 
 
 def _bench(args, timeout=540):

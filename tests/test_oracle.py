@@ -150,6 +150,30 @@ def test_link_cc_union_vs_reference_dfs_on_asymmetric_links():
         assert differs <= bound * tot, (strength, differs, tot)
 
 
+def test_directed_rounds_schedule_equals_the_literal_dfs():
+    """The kernel's schedule for the reference's directed grouping (rounds of smallest-seed reachability per
+    weakly-connected component, `O.link_cc_directed_rounds`) against the literal script restatement
+    (`O.link_cc_reference_dfs`) — on the survey's decode maps, on weak / asymmetric predictions where the two
+    differ from the union labelling, and on near-noise maps with a small size filter where many seeds fail and
+    are collected again by later ones."""
+    def sm(l):
+        e = np.exp(l - l.max(-1, keepdims=True))
+        return e / e.sum(-1, keepdims=True)
+    differs_from_union = 0
+    for seed, q4, strength, pt, lt, ms in ((0, 48, 3.0, 0.8, 0.9, 10), (1, 48, 1.5, 0.8, 0.9, 10), (2, 40, 0.8, 0.6, 0.7, 3),
+                                           (3, 40, 0.4, 0.5, 0.6, 2), (4, 32, 0.2, 0.5, 0.55, 4)):
+        rng = np.random.default_rng(seed)
+        pl, ll = O.synthetic_decode_maps(rng, 1, q4, strength)
+        ps = sm(pl[0])[..., 1]
+        ls = [sm(ll[0][..., 2 * d:2 * d + 2])[..., 1] for d in range(8)]
+        A = O.link_cc_reference_dfs(ps, ls, pt, lt, ms)
+        B = O.link_cc_directed_rounds(ps, ls, pt, lt, ms)
+        assert np.array_equal(A, B), (seed, int((A != B).sum()))
+        U, _ = O.link_cc_union(ps, ls, pt, lt, ms)
+        differs_from_union += int(((A > 0) != (U > 0)).sum())
+    assert differs_from_union > 0          # the cases do exercise the directed / union difference
+
+
 def test_link_cc_union_fast_equals_the_loop_version():
     def sm(l):
         e = np.exp(l - l.max(-1, keepdims=True))
