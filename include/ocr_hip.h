@@ -102,10 +102,34 @@ int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc
  * OCR_ERR_UNSUPPORTED never occurs for 1x1 convolutions.
  * sub_grad (may be NULL): the gradient of subsample(out, 2) = out[:, ::2, ::2]
  * (nets/resnet_utils.py:59-75, the stride-2 identity shortcut), [n][ceil(oh/2)][ceil(ow/2)][cout] f16, added at
- * the even positions before the mask — instead of a zero-inserted full-size tensor under OCR_CONV_ACCUM_F16. */
+ * the even positions before the mask — instead of a zero-inserted full-size tensor under OCR_CONV_ACCUM_F16.
+ * tail_mask_bits (may be NULL): the ReLU mask of tail_out as bits, one byte per 8 channels (written by
+ * ocr_bn_add_relu_f16 / ocr_conv2d_pw_bnaddrelu_f16); when given it is read INSTEAD of tail_out (1/16 of the bytes). */
 int ocr_conv2d_bnred_tail_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y, void* partial,
                               const void* bn_y, const void* bn_mean, const void* bn_invstd,
-                              const void* tail_out, const void* sub_grad, void* stream);
+                              const void* tail_out, const void* tail_mask_bits, const void* sub_grad, void* stream);
+
+/* 1x1 convolutions of a ResNet bottleneck with the element-wise pass in front of them APPLIED WHILE THE PIXEL
+ * OPERAND IS LOADED (conv_pwx_kernel; 1x1, stride 1, cin >= 128, cin % 64 == 0, pixel count % 32 == 0, else
+ * OCR_ERR_UNSUPPORTED), training mode:
+ *  - ocr_conv2d_pw_bnaddrelu_f16: the input is the previous unit's output
+ *      x = relu(bn(prev_y) + shortcut)        (nets/resnet_v1.py:107; sc_scale/sc_shift: projection shortcut's BN)
+ *    computed on load and written to x_out [n,h,w,cin] (+ mask_bits, optional) for the other consumers;
+ *    y = conv1x1(x) with BN partial sums under OCR_CONV_STATS — replaces ocr_bn_add_relu_f16 + ocr_conv2d_f16 and one
+ *    full read of x;
+ *  - ocr_conv2d_pw_bnbwd_bnred_f16 (d = the input-gradient form): the operand is the batch-norm backward apply
+ *      dy = A*dz + B*y_above + C              (ocr_bn_bwd_coefficients)
+ *    computed on load and written to dy_out (the weight gradient reads it next); dx = conv1x1^T(dy) with the fused
+ *    BN-backward reduction of the layer below as in ocr_conv2d_bnred_f16 — replaces the apply half of
+ *    ocr_bn_relu_bwd_apply_f16 and one full read of dy. */
+int ocr_conv2d_pw_bnaddrelu_f16(const ocr_conv_desc* d, const void* prev_y, const void* prev_scale,
+                                const void* prev_shift, const void* shortcut, const void* sc_scale,
+                                const void* sc_shift, void* x_out, void* mask_bits, const void* w_kc, void* y,
+                                void* stats, void* stream);
+int ocr_conv2d_pw_bnbwd_bnred_f16(const ocr_conv_desc* d, const void* dz, const void* y_above, const void* coef_a,
+                                  const void* coef_b, const void* coef_c, void* dy_out, const void* w_kc, void* dx,
+                                  void* partial, const void* bn_y, const void* bn_scale, const void* bn_shift,
+                                  const void* bn_mean, const void* bn_invstd, int bn_relu, void* stream);
 
 /* First-layer convolution (cin = 3, images [n,h,w,4] f16 with channel 3 zero,
  * produced by ocr_prep_images): 3x3 stride 1, pad 1.
@@ -211,8 +235,17 @@ int ocr_channel_stats_num_partials(int64_t npix, int c);
 int ocr_channel_stats_f16(const void* x, int64_t npix, int c, void* partial, void* stream);
 /* ResNet bottleneck tail (nets/resnet_v1.py:107): out = relu(bn(y) + shortcut); its ReLU
  * backward dz = dout * [out > 0]; a += b on f16 gradients. */
+/* sc_scale / sc_shift (both or neither): the shortcut is a PROJECTION whose own batch norm is applied here
+ * (its normalised copy is never stored); mask_bits (optional): one byte per 8 channels, bit e = out[..+e] > 0. */
 int ocr_bn_add_relu_f16(const void* y, const void* scale, const void* shift, const void* shortcut,
-                        int64_t npix, int c, void* out, void* stream);
+                        const void* sc_scale, const void* sc_shift, int64_t npix, int c, void* out,
+                        void* mask_bits, void* stream);
+/* BN-backward sums [T][2][c] (sum dz, sum dz*xhat) -> dgamma, dbeta and the coefficients of the apply step as an
+ * affine map dy = A*dz + B*y + C, for ocr_conv2d_pw_bnbwd_bnred_f16.  count = elements per channel. */
+int ocr_bn_bwd_coefficients(const void* partial, int T, int c, double count, const void* scale,
+                            const void* save_mean, const void* save_invstd, void* dgamma, void* dbeta,
+                            void* coef_a, void* coef_b, void* coef_c, void* workspace, size_t ws_bytes,
+                            void* stream);
 int ocr_relu_bwd_f16(const void* out, const void* dout, int64_t n, void* dz, void* stream);
 int ocr_add_inplace_f16(void* a, const void* b, int64_t n, void* stream);
 

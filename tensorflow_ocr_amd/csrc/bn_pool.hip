@@ -38,6 +38,12 @@ struct BnFin {            // MODE 0: batch-norm forward statistics -> scale/shif
 struct BnBwdFin {         // MODE 1: batch-norm backward sums -> dbeta, dgamma
   float *dgamma, *dbeta;
 };
+struct BnBwdFinC {        // MODE 2: ... and the coefficients of dy = A*dz + B*y + C (the apply step as an affine map of
+  float *dgamma, *dbeta;  //         (dz, y), for a consumer that applies it while loading: conv_pwx_kernel)
+  const float *scale, *mean, *invstd;
+  float inv_count;
+  float *A, *B, *C;
+};
 
 // Arrival counters, zero at load, self-resetting.  Two levels: blocks take a ticket of their group of 32
 // row blocks, the last of a group takes a ticket of the channel group — R same-address atomics in a
@@ -73,6 +79,18 @@ template <>
 __device__ __forceinline__ void bn_fin_apply<BnBwdFin>(const BnBwdFin& f, int c, double s, double q) {
   f.dbeta[c] = (float)s;
   f.dgamma[c] = (float)q;
+}
+
+template <>
+__device__ __forceinline__ void bn_fin_apply<BnBwdFinC>(const BnBwdFinC& f, int c, double s, double q) {
+  f.dbeta[c] = (float)s;
+  f.dgamma[c] = (float)q;
+  // bn_relu_bwd_kernel<1>: dy = sc * (dz - k_dz - (y - mu) * is * k_dzx),  k_dz = dbeta / N, k_dzx = dgamma / N
+  const float sc = f.scale[c], mu = f.mean[c], is = f.invstd[c];
+  const float k_dz = (float)s * f.inv_count, k_dzx = (float)q * f.inv_count;
+  f.A[c] = sc;
+  f.B[c] = -sc * is * k_dzx;
+  f.C[c] = sc * (mu * is * k_dzx - k_dz);
 }
 
 // Partial rows per block.  The launch is a latency chain: first phase (rows / 64 batches of 8 loads per thread),
@@ -615,24 +633,48 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const half_t* __rest
 }
 
 // ResNet bottleneck tail: out = relu(y*scale + shift + shortcut)   (nets/resnet_v1.py:107)
-__global__ void bn_add_relu_kernel(const half_t* __restrict__ y, const float* __restrict__ scale,
-                                   const float* __restrict__ shift, const half_t* __restrict__ sc,
-                                   size_t npix, int c, half_t* __restrict__ out) {
+// sc_scale != nullptr: the shortcut is a projection whose batch norm is applied here too
+// (shortcut = sc*sc_scale + sc_shift, rounded to 16 bits as the separate pass stored it): its normalised copy is
+// never written.  bits != nullptr: also one byte per 8 channels, bit e = out[.. + e] > 0 — the ReLU mask the
+// backward tail (ocr_conv2d_bnred_tail_f16) reads instead of `out` itself.
+template <bool PROJ, bool BITS>
+__global__ __launch_bounds__(256) void bn_add_relu_kernel(const half_t* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const half_t* __restrict__ sc,
+                                                          const float* __restrict__ sc_scale,
+                                                          const float* __restrict__ sc_shift, size_t npix, int c,
+                                                          half_t* __restrict__ out, unsigned char* __restrict__ bits) {
   const int chunks = c >> 3;
   const size_t total = npix * chunks;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ch = (int)(i % chunks);
-    half8_t v = *reinterpret_cast<const half8_t*>(y + i * 8);
-    half8_t r = *reinterpret_cast<const half8_t*>(sc + i * 8);
+    const int ch = (int)(i % chunks) * 8;
+    const half8_t v = *reinterpret_cast<const half8_t*>(y + i * 8);
+    const half8_t r = *reinterpret_cast<const half8_t*>(sc + i * 8);
+    float a[8], b[8], pa[8], pb[8];
+    *reinterpret_cast<f32x4*>(a) = *reinterpret_cast<const f32x4*>(scale + ch);
+    *reinterpret_cast<f32x4*>(a + 4) = *reinterpret_cast<const f32x4*>(scale + ch + 4);
+    *reinterpret_cast<f32x4*>(b) = *reinterpret_cast<const f32x4*>(shift + ch);
+    *reinterpret_cast<f32x4*>(b + 4) = *reinterpret_cast<const f32x4*>(shift + ch + 4);
+    if (PROJ) {
+      *reinterpret_cast<f32x4*>(pa) = *reinterpret_cast<const f32x4*>(sc_scale + ch);
+      *reinterpret_cast<f32x4*>(pa + 4) = *reinterpret_cast<const f32x4*>(sc_scale + ch + 4);
+      *reinterpret_cast<f32x4*>(pb) = *reinterpret_cast<const f32x4*>(sc_shift + ch);
+      *reinterpret_cast<f32x4*>(pb + 4) = *reinterpret_cast<const f32x4*>(sc_shift + ch + 4);
+    }
     half8_t o;
+    unsigned m = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      // the normalised residual is rounded to f16 first (it is what BN backward differentiates)
-      const float z = (float)(half_t)((float)v[e] * scale[ch * 8 + e] + shift[ch * 8 + e]);
-      const float f = z + (float)r[e];
+      // the normalised residual is rounded to 16 bits first (it is what BN backward differentiates); explicit
+      // fused multiply-adds: conv_pwx_kernel evaluates the same expression and must round identically
+      const float z = (float)(half_t)__builtin_fmaf((float)v[e], a[e], b[e]);
+      float rv = (float)r[e];
+      if (PROJ) rv = (float)(half_t)__builtin_fmaf(rv, pa[e], pb[e]);
+      const float f = z + rv;
       o[e] = (half_t)(f > 0.f ? f : 0.f);
+      if (BITS) m |= (f > 0.f && (float)o[e] > 0.f ? 1u : 0u) << e;
     }
     *reinterpret_cast<half8_t*>(out + i * 8) = o;
+    if (BITS) bits[i] = (unsigned char)m;
   }
 }
 
@@ -1095,13 +1137,50 @@ extern "C" int ocr_channel_stats_f16(const void* x, int64_t npix, int c, void* p
 }
 
 extern "C" int ocr_bn_add_relu_f16(const void* y, const void* scale, const void* shift,
-                                   const void* shortcut, int64_t npix, int c, void* out, void* stream) {
+                                   const void* shortcut, const void* sc_scale, const void* sc_shift, int64_t npix,
+                                   int c, void* out, void* mask_bits, void* stream) {
   OCR_CHECK_ARG(y && scale && shift && shortcut && out && npix > 0);
+  OCR_CHECK_ARG((sc_scale == nullptr) == (sc_shift == nullptr));
   OCR_CHECK_SHAPE(c % 8 == 0);
-  hipLaunchKernelGGL(bn_add_relu_kernel, dim3(stream_grid((size_t)npix * (c / 8))), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(y),
-                     static_cast<const float*>(scale), static_cast<const float*>(shift),
-                     static_cast<const half_t*>(shortcut), (size_t)npix, c, static_cast<half_t*>(out));
+  const dim3 grid(stream_grid((size_t)npix * (c / 8)));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const half_t* yp = static_cast<const half_t*>(y);
+  const half_t* sp = static_cast<const half_t*>(shortcut);
+  const float *a = static_cast<const float*>(scale), *b = static_cast<const float*>(shift);
+  const float *pa = static_cast<const float*>(sc_scale), *pb = static_cast<const float*>(sc_shift);
+  half_t* op = static_cast<half_t*>(out);
+  unsigned char* bp = static_cast<unsigned char*>(mask_bits);
+  const size_t np = (size_t)npix;
+  if (pa) {
+    if (bp) hipLaunchKernelGGL((bn_add_relu_kernel<true, true>), grid, dim3(256), 0, st, yp, a, b, sp, pa, pb, np, c, op, bp);
+    else hipLaunchKernelGGL((bn_add_relu_kernel<true, false>), grid, dim3(256), 0, st, yp, a, b, sp, pa, pb, np, c, op, bp);
+  } else {
+    if (bp) hipLaunchKernelGGL((bn_add_relu_kernel<false, true>), grid, dim3(256), 0, st, yp, a, b, sp, pa, pb, np, c, op, bp);
+    else hipLaunchKernelGGL((bn_add_relu_kernel<false, false>), grid, dim3(256), 0, st, yp, a, b, sp, pa, pb, np, c, op, bp);
+  }
+  return ocr_launch_status();
+}
+
+// BN-backward sums -> dgamma, dbeta and the per-channel coefficients of the apply step as an affine map,
+// dy = A*dz + B*y + C (conv_pwx_kernel applies it while staging the pixel operand of the input-gradient GEMM, so
+// the separate apply pass over the widest tensors of a ResNet unit disappears).  Same reduction launch as
+// ocr_bn_relu_bwd_apply_f16's first half.
+extern "C" int ocr_bn_bwd_coefficients(const void* partial, int T, int c, double count, const void* scale,
+                                       const void* save_mean, const void* save_invstd, void* dgamma, void* dbeta,
+                                       void* coef_a, void* coef_b, void* coef_c, void* workspace, size_t ws_bytes,
+                                       void* stream) {
+  OCR_CHECK_ARG(partial && scale && save_mean && save_invstd && dgamma && dbeta && coef_a && coef_b && coef_c);
+  OCR_CHECK_ARG(workspace && T > 0 && c > 0 && count > 0);
+  if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
+  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
+  hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFinC>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(partial),
+                     static_cast<double*>(workspace), T, c, bn_ticket_slot(), rows,
+                     BnBwdFinC{static_cast<float*>(dgamma), static_cast<float*>(dbeta), static_cast<const float*>(scale),
+                               static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                               (float)(1.0 / count), static_cast<float*>(coef_a), static_cast<float*>(coef_b),
+                               static_cast<float*>(coef_c)});
   return ocr_launch_status();
 }
 

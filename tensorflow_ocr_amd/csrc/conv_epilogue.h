@@ -29,6 +29,9 @@ struct BnRed {
   int sub_h, sub_w;
   unsigned long long sub_m_hw, sub_m_w;
   int sub_l_hw, sub_l_w;
+  // tail mode, instead of `mask`: the ReLU mask as BITS, one byte per 8 channels (bit e = out[.. + e] > 0), written
+  // by the kernel that produced the output (bn_add_relu_kernel / conv_pwx_kernel): 1/16 of the bytes of `out`
+  const unsigned char* mask_bits;
 };
 
 // LDS needed by the epilogue for a BN-wide tile.
@@ -66,7 +69,8 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
   // tensors as far as the compiler knows, and a load placed behind one waits for it (measured on the
   // 1x1 input-gradient kernels of ResNet-50: three dependent loads per pixel made the fused tail 2x slower
   // than the separate element-wise passes it replaces).
-  const bool tail = br != nullptr && br->mask != nullptr;
+  const bool tail = br != nullptr && (br->mask != nullptr || br->mask_bits != nullptr);
+  const bool tbits = tail && br->mask_bits != nullptr;
   // this thread's 8 couts are fixed: the ReLU-mask coefficients once, up front; mean / invstd enter the sums
   // linearly and are applied at the end (sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
   float bsc[8], bsh[8];
@@ -84,6 +88,7 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
     static_assert(PPT % UB == 0, "pixels per thread");
     for (int k0 = 0; k0 < PPT; k0 += UB) {
       half8_t old[UB], mk[UB], yv[UB];
+      unsigned mb[UB];
       auto pixel = [&](int u, bool& ok) __attribute__((always_inline)) {     // (recomputed, not carried: registers)
         const int px = rg + (k0 + u) * RG;
         const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
@@ -96,7 +101,8 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
         const size_t off = pixel(u, ok);
         if (ok) {
           if (accum) old[u] = *reinterpret_cast<const half8_t*>(y + off);
-          if (tail) mk[u] = *reinterpret_cast<const half8_t*>(br->mask + off);
+          if (tbits) mb[u] = br->mask_bits[off >> 3];
+          else if (tail) mk[u] = *reinterpret_cast<const half8_t*>(br->mask + off);
           if (do_stats && br != nullptr) yv[u] = *reinterpret_cast<const half8_t*>(br->y + off);
         }
       }
@@ -124,7 +130,10 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
             for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)sv[e]);
           }
         }
-        if (tail) {
+        if (tbits) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = (mb[u] >> e & 1u) ? w[e] : (half_t)0.f;
+        } else if (tail) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = (float)mk[u][e] > 0.f ? w[e] : (half_t)0.f;
         }
@@ -178,7 +187,11 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
             for (int e = 0; e < 8; ++e) w[e] = (half_t)((float)w[e] + (float)sv[e]);
           }
         }
-        if (tail) {
+        if (tbits) {
+          const unsigned mb = br->mask_bits[off >> 3];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = (mb >> e & 1u) ? w[e] : (half_t)0.f;
+        } else if (tail) {
           const half8_t mk = *reinterpret_cast<const half8_t*>(br->mask + off);
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = (float)mk[e] > 0.f ? w[e] : (half_t)0.f;

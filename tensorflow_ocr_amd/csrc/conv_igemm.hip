@@ -479,6 +479,205 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv_pw_kernel with the PIXEL OPERAND TRANSFORMED WHILE IT IS STAGED (ResNet bottlenecks, training).
+// The element-wise passes around a 1x1 convolution read and write the widest tensors of a unit only to hand
+// them to that convolution; here the convolution's own loader applies them and WRITES the transformed operand
+// back once (other consumers still need it), so one full read of that tensor disappears per pass:
+//   MODE 1 (forward):  v = relu(half(s0*f0 + f2) + r),  r = f1 ? half(s1*f1 + f3) : s1
+//                      = the unit output relu(bn(conv3) + shortcut) of the PREVIOUS unit (nets/resnet_v1.py:107;
+//                      f1/f3: the projection shortcut's own batch norm), consumed as conv1 / shortcut input;
+//                      `out` receives v, `bits` its ReLU mask (one byte per 8 channels)
+//   MODE 2 (backward): v = half(f0*s0 + f1*s1 + f2) = the batch-norm backward apply dy = A*dz + B*y + C
+//                      (ocr_bn_bwd_coefficients), consumed as the input-gradient GEMM's operand; `out` receives dy
+//                      for the weight gradient that follows.
+// Weights still arrive by LDS-DMA; the pixel rows go global -> registers (requested under the previous stage's
+// MFMAs) -> transform -> ds_write into the same swizzled slots the DMA form fills, so the MFMA loop and the
+// epilogues are conv_pw_kernel's.  The VALU work (60-75 operations per 16-byte chunk) equals what the separate
+// pass spent and stays under the kernel's HBM time (memory-bound launches: MFMA pipe ~0.2 busy).  Only the first
+// cout tile writes `out` / `bits`.
+struct PwX {
+  const half_t *s0, *s1;
+  const float *f0, *f1, *f2, *f3;
+  half_t* out;
+  unsigned char* bits;
+};
+
+// LDS-only barrier: the waves' own ds_writes are complete, nothing is said about vector memory.  __syncthreads()
+// waits vmcnt(0) — in this kernel that would be the operand loads of the NEXT stage and the side-write stores of
+// this one, i.e. one full HBM round trip per K stage (measured: 7.9 us per stage with it).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int BN, int WCO, bool EPI_LOADS, int MODE, bool PROJ>
+__global__ __launch_bounds__(512) void conv_pwx_kernel(
+    ConvP p, PwX t, const half_t* __restrict__ w, half_t* __restrict__ y, float* __restrict__ stats) {
+  constexpr int NT = 512;
+  constexpr int WPX = 8 / WCO;
+  constexpr int TCO = BN / WCO / 32;
+  constexpr int TPX = 8 / WPX;
+  constexpr int AI = TCO * 2, AT = TPX * 2;
+  constexpr int RS = 128;
+  constexpr int ABYTES = BN * RS, BBYTES = 256 * RS, STAGE = ABYTES + BBYTES;
+  constexpr int NA = BN * 8 / NT, NB = 256 * 8 / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* coef = reinterpret_cast<float*>(smem + 2 * STAGE);     // [4][cin]: f0, f1, f2, f3 (absent arrays: zeros)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wco = wave % WCO, wpx = wave / WCO;
+  const int frow = lane & 15, fkg = lane >> 4;
+
+  const int bid = blockIdx.x;
+  const int nt = bid % p.n_tiles;
+  const int mt = bid / p.n_tiles;
+  const int co0 = nt * BN;
+  const long long px0 = (long long)mt * 256;
+  const int nk = p.cin / 64;
+  const bool writer = nt == 0;
+  constexpr bool proj = MODE == 1 && PROJ;
+
+  f32x4 acc[AI][AT];
+#pragma unroll
+  for (int i = 0; i < AI; ++i)
+#pragma unroll
+    for (int tt = 0; tt < AT; ++tt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][tt][e] = 0.f;
+
+  const int a_lane = (wco * TCO * 32 + frow) * RS;
+  const int b_lane = (wpx * TPX * 32 + frow) * RS;
+  const int fxa = (frow >> 1) & 7, fxb = frow & 7;
+
+  // this thread's slot in a staged row: position (tid & 7) of row (tid >> 3) + 64 u; the slot holds logical
+  // 16-byte chunk position ^ swizzle(row) — weights (row >> 1) & 7, pixels row & 7 (the layout conv_pw_kernel's
+  // LDS-DMA produces, so the fragment reads below are its own)
+  const int prl = tid >> 3;
+  const int cs = (tid & 7) ^ (prl & 7);
+  const int csa = (tid & 7) ^ ((prl >> 1) & 7);         // weight rows prl + 64 u: ((prl + 64 u) >> 1) & 7 == (prl >> 1) & 7
+  half8_t ra[NA], r0[NB], r1[NB];
+  // everything travels through registers: no vmcnt is waited at a barrier
+  auto request = [&](int kc) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u)
+      ra[u] = *reinterpret_cast<const half8_t*>(w + (size_t)(co0 + prl + 64 * u) * p.cin + kc * 64 + csa * 8);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const long long gp = px0 + prl + 64 * u;
+      if (gp < p.npix) {
+        const size_t off = (size_t)gp * p.cin + kc * 64 + cs * 8;
+        r0[u] = *reinterpret_cast<const half8_t*>(t.s0 + off);
+        r1[u] = *reinterpret_cast<const half8_t*>(t.s1 + off);
+      }
+    }
+  };
+  auto stash = [&](int kc, int buf) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + ABYTES;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) *reinterpret_cast<half8_t*>(As + (u * NT + tid) * 16) = ra[u];
+    const int ch = kc * 64 + cs * 8;
+    float c0[8], c1[8], c2[8], c3[8];
+    *reinterpret_cast<f32x4*>(c0) = *reinterpret_cast<const f32x4*>(coef + ch);
+    *reinterpret_cast<f32x4*>(c0 + 4) = *reinterpret_cast<const f32x4*>(coef + ch + 4);
+    *reinterpret_cast<f32x4*>(c2) = *reinterpret_cast<const f32x4*>(coef + 2 * p.cin + ch);
+    *reinterpret_cast<f32x4*>(c2 + 4) = *reinterpret_cast<const f32x4*>(coef + 2 * p.cin + ch + 4);
+    if (MODE == 2 || proj) {
+      *reinterpret_cast<f32x4*>(c1) = *reinterpret_cast<const f32x4*>(coef + p.cin + ch);
+      *reinterpret_cast<f32x4*>(c1 + 4) = *reinterpret_cast<const f32x4*>(coef + p.cin + ch + 4);
+    }
+    if (proj) {
+      *reinterpret_cast<f32x4*>(c3) = *reinterpret_cast<const f32x4*>(coef + 3 * p.cin + ch);
+      *reinterpret_cast<f32x4*>(c3 + 4) = *reinterpret_cast<const f32x4*>(coef + 3 * p.cin + ch + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const long long gp = px0 + prl + 64 * u;
+      half8_t v;
+      if (gp < p.npix) {
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (MODE == 1) {                    // bn_add_relu_kernel's expression, operation for operation
+            const float z = (float)(half_t)__builtin_fmaf((float)r0[u][e], c0[e], c2[e]);
+            float rv = (float)r1[u][e];
+            if (proj) rv = (float)(half_t)__builtin_fmaf(rv, c1[e], c3[e]);
+            const float f = z + rv;
+            v[e] = (half_t)(f > 0.f ? f : 0.f);
+            m |= (f > 0.f && (float)v[e] > 0.f ? 1u : 0u) << e;
+          } else {
+            v[e] = (half_t)__builtin_fmaf(c0[e], (float)r0[u][e], __builtin_fmaf(c1[e], (float)r1[u][e], c2[e]));
+          }
+        }
+        if (writer) {
+          const size_t off = (size_t)gp * p.cin + ch;
+          *reinterpret_cast<half8_t*>(t.out + off) = v;
+          if (MODE == 1 && t.bits != nullptr) t.bits[off >> 3] = (unsigned char)m;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
+      }
+      *reinterpret_cast<half8_t*>(Bs + (u * NT + tid) * 16) = v;
+    }
+  };
+
+  request(0);
+  for (int i = tid; i < 4 * p.cin; i += NT) {
+    const int arr = i / p.cin, chn = i - arr * p.cin;
+    const float* src = arr == 0 ? t.f0 : arr == 1 ? t.f1 : arr == 2 ? t.f2 : t.f3;
+    coef[i] = src != nullptr ? src[chn] : 0.f;
+  }
+  lds_barrier();
+  stash(0, 0);
+  if (nk > 1) request(1);
+  int buf = 0;
+  for (int kc = 0; kc < nk; ++kc) {
+    // after this barrier stage kc is complete in `buf` (every wave's ds_writes precede its arrival) and the readers
+    // of the other buffer (stage kc-1's MFMAs) are done.  The operands of stage kc+1 were requested one iteration
+    // ago and are turned into LDS rows now; stage kc+2 is requested behind them, under this stage's MFMAs.
+    lds_barrier();
+    if (kc + 1 < nk) {
+      stash(kc + 1, buf ^ 1);
+      if (kc + 2 < nk) request(kc + 2);
+    }
+    const char* ab = smem + buf * STAGE + a_lane;
+    const char* bb = smem + buf * STAGE + ABYTES + b_lane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8_t a[AI];
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        a[i] = *reinterpret_cast<const half8_t*>(ab + i * 16 * RS + (((ks * 4 + fkg) ^ fxa) << 4));
+      constexpr int TG = AT > 4 ? 4 : AT;
+#pragma unroll
+      for (int t0 = 0; t0 < AT; t0 += TG) {
+        half8_t b[TG];
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt)
+          b[tt] = *reinterpret_cast<const half8_t*>(bb + (t0 + tt) * 16 * RS + (((ks * 4 + fkg) ^ fxb) << 4));
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+          for (int tt = 0; tt < TG; ++tt)
+            acc[i][t0 + tt] = OCR_MFMA_16x16x32(a[i], b[tt], acc[i][t0 + tt], 0, 0, 0);
+      }
+    }
+    buf ^= 1;
+  }
+
+  constexpr int EBN = EPI_LOADS ? BN : (BN > 128 ? 128 : BN);
+  constexpr int EWCO = EBN < BN ? 2 : WCO;
+  const int rows = (int)(p.npix / 32);
+#pragma unroll
+  for (int h = 0; h < BN / EBN; ++h) {
+    __syncthreads();
+    const bool active = EBN == BN || (wco >> 1) == h;
+    conv_epilogue16<EBN, TCO, TPX, EWCO, NT, EPI_LOADS>(acc, smem, p.flags, nullptr, y, stats, 0, mt, 0, mt, co0 + h * EBN,
+                                             rows, 32, p.cout, EBN < BN ? (wco & 1) : wco, wpx, active,
+                                             p.br.y ? &p.br : nullptr);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / dilation 1 layers with cin % 64 == 0: FOUR waves per workgroup, ONE per SIMD, each
 // with the whole 512-entry register file (wave tile 128 couts x 128 pixels = 256 accumulator registers,
 // fragments of the next k-step double-buffered in the remaining VGPRs).
@@ -1543,6 +1742,42 @@ int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, vo
   return ocr_launch_status();
 }
 
+struct TileCfg { int bn, ck, th; };
+
+template <int BN, int WCO, int MODE, bool PROJ>
+int launch_pwx(const ConvP& p, const PwX& t, const void* w, void* y, void* stats, hipStream_t st) {
+  const size_t main_bytes = 2 * ((size_t)BN * 128 + 256 * 128) + (size_t)p.cin * 16;     // two stages + coefficients
+  if (main_bytes > 160 * 1024) return OCR_ERR_UNSUPPORTED;
+  constexpr bool epi_loads = MODE == 2;          // the backward form carries the fused BN-backward reduction
+  const size_t epi_bytes = conv_epilogue_lds(epi_loads ? BN : (BN > 128 ? 128 : BN), 512);
+  const size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  auto kern = conv_pwx_kernel<BN, WCO, epi_loads, MODE, PROJ>;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(160 * 1024)) != hipSuccess)
+      return OCR_ERR_HIP;
+    configured = true;
+  }
+  const unsigned m_tiles = (unsigned)((p.npix + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(m_tiles * p.n_tiles), dim3(512), lds, st, p, t, static_cast<const half_t*>(w),
+                     static_cast<half_t*>(y), static_cast<float*>(stats));
+  return ocr_launch_status();
+}
+
+template <int MODE>
+int dispatch_pwx(ConvP& p, const TileCfg& c, const PwX& t, const void* w, void* y, void* stats, hipStream_t st) {
+  if (!p.pw || p.cin < 128) return OCR_ERR_UNSUPPORTED;      // (cin = 64: one stage, nothing to overlap the loads with)
+  if (MODE == 1 && t.f1 != nullptr) {            // the shortcut is a projection: its batch norm is applied too
+    if (c.bn == 256) return launch_pwx<256, 4, MODE, MODE == 1>(p, t, w, y, stats, st);
+    if (c.bn == 128) return launch_pwx<128, 2, MODE, MODE == 1>(p, t, w, y, stats, st);
+    return launch_pwx<64, 1, MODE, MODE == 1>(p, t, w, y, stats, st);
+  }
+  if (c.bn == 256) return launch_pwx<256, 4, MODE, false>(p, t, w, y, stats, st);
+  if (c.bn == 128) return launch_pwx<128, 2, MODE, false>(p, t, w, y, stats, st);
+  return launch_pwx<64, 1, MODE, false>(p, t, w, y, stats, st);
+}
+
 template <int BN, int CK, int WCO, bool M16, int TH>
 int launch_t(const ConvP& p, const void* x, const void* w, const void* bias, void* y,
              void* stats, hipStream_t st) {
@@ -1654,7 +1889,6 @@ static int conv_w4s_bn(const ConvP& p) {
   return p.cout % 128 == 0 ? 128 : p.cout % 64 == 0 ? 64 : 0;
 }
 
-struct TileCfg { int bn, ck, th; };
 
 // the persistent 64-channel kernel runs this shape (its partial rows are per wave of the grid, not per tile)
 static bool uses_c64(const ConvP& p, const TileCfg& c) {
@@ -1822,7 +2056,7 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     if (c.bn == 128) return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
     return launch_pw<64, 1>(p, x, w_kc, bias, y, stats, st);
   }
-  const bool tail = p.br.mask != nullptr;          // only the kernels ending in conv_epilogue_store implement it
+  const bool tail = p.br.mask != nullptr || p.br.mask_bits != nullptr;   // only the kernels ending in conv_epilogue_store implement it
   if (const int bn = tail ? 0 : conv_w4s_bn(p))
     return bn == 128 ? launch_w4s<128>(p, x, w_kc, bias, y, stats, st) : launch_w4s<64>(p, x, w_kc, bias, y, stats, st);
   const int key = c.bn * 10000 + c.ck * 100 + c.th;
@@ -1877,6 +2111,53 @@ extern "C" int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const
   return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }
 
+// 1x1 convolution whose input is the previous bottleneck's output relu(bn(conv3) + shortcut), computed while the
+// operand is loaded; x_out (and mask_bits) receive that output.  y = conv(x_out) with the usual BN partial sums
+// (OCR_CONV_STATS) of the convolution itself.  nets/resnet_v1.py:96-107.
+extern "C" int ocr_conv2d_pw_bnaddrelu_f16(const ocr_conv_desc* d, const void* prev_y, const void* prev_scale,
+                                           const void* prev_shift, const void* shortcut, const void* sc_scale,
+                                           const void* sc_shift, void* x_out, void* mask_bits, const void* w_kc,
+                                           void* y, void* stats, void* stream) {
+  ConvP p;
+  TileCfg cfg;
+  int rc = fill_params(d, &p, &cfg);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(prev_y && prev_scale && prev_shift && shortcut && x_out && w_kc && y);
+  OCR_CHECK_ARG((sc_scale == nullptr) == (sc_shift == nullptr));
+  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_BIAS | OCR_CONV_RELU | OCR_CONV_ACCUM_F16)));
+  OCR_CHECK_ARG(!(d->flags & OCR_CONV_STATS) || stats);
+  PwX t{static_cast<const half_t*>(prev_y), static_cast<const half_t*>(shortcut), static_cast<const float*>(prev_scale),
+        static_cast<const float*>(sc_scale), static_cast<const float*>(prev_shift), static_cast<const float*>(sc_shift),
+        static_cast<half_t*>(x_out), static_cast<unsigned char*>(mask_bits)};
+  return dispatch_pwx<1>(p, cfg, t, w_kc, y, stats, static_cast<hipStream_t>(stream));
+}
+
+// Input-gradient 1x1 convolution whose operand is the batch-norm backward apply dy = A*dz + B*bn_y_in + C of the
+// layer above (coefficients: ocr_bn_bwd_coefficients), computed while loading; dy_out receives it (the weight
+// gradient reads it next).  The epilogue carries the fused BN-backward reduction of the layer BELOW as
+// ocr_conv2d_bnred_f16 does (bn_* arguments: that layer).
+extern "C" int ocr_conv2d_pw_bnbwd_bnred_f16(const ocr_conv_desc* d, const void* dz, const void* y_above,
+                                             const void* coef_a, const void* coef_b, const void* coef_c, void* dy_out,
+                                             const void* w_kc, void* dx, void* partial, const void* bn_y,
+                                             const void* bn_scale, const void* bn_shift, const void* bn_mean,
+                                             const void* bn_invstd, int bn_relu, void* stream) {
+  ConvP p;
+  TileCfg cfg;
+  int rc = fill_params(d, &p, &cfg);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(dz && y_above && coef_a && coef_b && coef_c && dy_out && w_kc && dx);
+  OCR_CHECK_ARG(partial && bn_y && bn_scale && bn_shift && bn_mean && bn_invstd);
+  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_BIAS | OCR_CONV_RELU | OCR_CONV_ACCUM_F16)));
+  p.flags |= OCR_CONV_STATS;
+  p.br = BnRed{static_cast<const half_t*>(bn_y), static_cast<const float*>(bn_scale),
+               static_cast<const float*>(bn_shift), static_cast<const float*>(bn_mean),
+               static_cast<const float*>(bn_invstd), bn_relu};
+  PwX t{static_cast<const half_t*>(dz), static_cast<const half_t*>(y_above), static_cast<const float*>(coef_a),
+        static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), nullptr, static_cast<half_t*>(dy_out),
+        nullptr};
+  return dispatch_pwx<2>(p, cfg, t, w_kc, dx, partial, static_cast<hipStream_t>(stream));
+}
+
 // q = (P * m) >> (31 + l) == P / d for every P < 2^31 (round-up method: m = ceil(2^(31+l) / d), l = ceil(log2 d))
 static void magic31(unsigned d, unsigned long long* m, int* l) {
   int k = 0;
@@ -1887,17 +2168,18 @@ static void magic31(unsigned d, unsigned long long* m, int* l) {
 
 extern "C" int ocr_conv2d_bnred_tail_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y,
                                          void* partial, const void* bn_y, const void* bn_mean,
-                                         const void* bn_invstd, const void* tail_out, const void* sub_grad,
-                                         void* stream) {
+                                         const void* bn_invstd, const void* tail_out, const void* tail_mask_bits,
+                                         const void* sub_grad, void* stream) {
   ConvP p;
   TileCfg cfg;
   int rc = fill_params(d, &p, &cfg);
   if (rc != OCR_OK) return rc;
-  OCR_CHECK_ARG(x && w_kc && y && partial && bn_y && bn_mean && bn_invstd && tail_out);
+  OCR_CHECK_ARG(x && w_kc && y && partial && bn_y && bn_mean && bn_invstd && (tail_out || tail_mask_bits));
   OCR_CHECK_ARG(!(d->flags & (OCR_CONV_BIAS | OCR_CONV_RELU)));
   p.flags |= OCR_CONV_STATS;
   p.br = BnRed{static_cast<const half_t*>(bn_y), nullptr, nullptr, static_cast<const float*>(bn_mean),
-               static_cast<const float*>(bn_invstd), 0, static_cast<const half_t*>(tail_out)};
+               static_cast<const float*>(bn_invstd), 0, static_cast<const half_t*>(tail_mask_bits ? nullptr : tail_out)};
+  p.br.mask_bits = static_cast<const unsigned char*>(tail_mask_bits);
   if (sub_grad != nullptr) {
     OCR_CHECK_SHAPE((long long)d->n * d->oh * d->ow < (1ll << 31));
     p.br.sub = static_cast<const half_t*>(sub_grad);

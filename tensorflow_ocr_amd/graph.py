@@ -150,29 +150,50 @@ class VariableStore:
 
 
 class Act:
-    """Activation handle: device tensor + (lazily created) gradient."""
+    """Activation handle: device tensor + (lazily created) gradient.
 
-    __slots__ = ("data", "grad", "requires_grad", "name", "bn_ctx", "bn_partial", "tail_ctx", "tail_partial",
-                 "pending", "sub_grad")
+    `data` may be DEFERRED: a ResNet bottleneck's output relu(bn(conv3) + shortcut) is not computed when the unit is
+    built — the next 1x1 convolution that consumes it computes it while loading its operand and writes it back
+    (resnet_layers.conv_bn_raw, ocr_conv2d_pw_bnaddrelu_f16).  Any other access to `.data` runs the plain
+    element-wise pass first, so consumers that know nothing about this stay correct."""
+
+    __slots__ = ("_data", "grad", "requires_grad", "name", "bn_ctx", "bn_partial", "tail_ctx", "tail_partial",
+                 "pending", "sub_grad", "deferred", "tail_fwd", "pending_owner", "consumed")
 
     def __init__(self, data, requires_grad=True, name=""):
-        self.data = data
+        self._data = data
         self.grad = None
         self.requires_grad = requires_grad
         self.name = name
         self.bn_ctx = None        # (y, scale, shift, mean, invstd, relu) of the conv+BN that made it
         self.bn_partial = None    # (partial, T): BN-backward sums already reduced by the dgrad conv
-        # ResNet bottleneck outputs (resnet_layers.bottleneck): (y, mean, invstd of the unit's last conv, own data);
-        # the next unit's LAST gradient contribution (counted down in `pending`) then stores the gradient past
-        # this output's ReLU and leaves the BN-backward sums in tail_partial = (partial, T)
+        # ResNet bottleneck outputs (resnet_layers.bottleneck): (y, mean, invstd of the unit's last conv, own data, mask
+        # bits); the next unit's LAST gradient contribution (counted down in `pending`, by the consumers that carry
+        # `pending_owner`) then stores the gradient past this output's ReLU and leaves the BN-backward sums in
+        # tail_partial = (partial, T)
         self.tail_ctx = None
         self.tail_partial = None
         self.pending = None
+        self.pending_owner = None
+        self.consumed = False     # a convolution has read it already (tail fusion must then stay off: build order)
         self.sub_grad = None      # gradient of this output's stride-2 subsample, waiting for the fused tail conv
+        self.deferred = None      # callable that fills _data (the plain pass), while nobody has computed it yet
+        self.tail_fwd = None      # (y3, scale, shift, shortcut tensor, sc_scale, sc_shift, bits): what a fusing consumer needs
+
+    @property
+    def data(self):
+        if self.deferred is not None:
+            fill, self.deferred = self.deferred, None
+            fill()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
 
     @property
     def shape(self):
-        return tuple(self.data.shape)
+        return tuple(self._data.shape)
 
 
 class Graph:

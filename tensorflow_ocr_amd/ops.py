@@ -118,13 +118,43 @@ def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx):
 def conv2d_bnred_tail(d, x, w_kc, y, partial, tail_ctx, sub_grad=None):
     """Input-gradient conv that completes the gradient of a bottleneck output: stores the gradient past the
     output ReLU and emits the BN-backward sums of the unit's last conv; `sub_grad`: gradient of the output's
-    stride-2 subsample, added at the even positions (include/ocr_hip.h)."""
-    by, mu, istd, out = tail_ctx
+    stride-2 subsample, added at the even positions (include/ocr_hip.h).  tail_ctx = (y, mean, invstd, out[, bits]):
+    with `bits` (the output's ReLU mask, one byte per 8 channels) the kernel reads them instead of `out`."""
+    by, mu, istd, out = tail_ctx[:4]
+    bits = tail_ctx[4] if len(tail_ctx) > 4 else None
     L.call("ocr_conv2d_bnred_tail_f16", byref(d), ptr(x), ptr(w_kc), ptr(y), ptr(partial), ptr(by), ptr(mu),
-           ptr(istd), ptr(out), ptr(sub_grad), _st())
+           ptr(istd), ptr(out), ptr(bits), ptr(sub_grad), _st())
     if L.RECORDER is not None:
         flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
         L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
+
+
+def conv2d_pw_bnaddrelu(d, prev_y, prev_scale, prev_shift, shortcut, sc_scale, sc_shift, x_out, bits, w_kc, y, stats):
+    """1x1 conv whose input x = relu(bn(prev_y) + shortcut) is computed while it is loaded and written to x_out (+ bits)."""
+    L.call("ocr_conv2d_pw_bnaddrelu_f16", byref(d), ptr(prev_y), ptr(prev_scale), ptr(prev_shift), ptr(shortcut),
+           ptr(sc_scale), ptr(sc_shift), ptr(x_out), ptr(bits), ptr(w_kc), ptr(y), ptr(stats), _st())
+    if L.RECORDER is not None:
+        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin
+        L.RECORDER.tag_last((conv2d_variant(d).replace("conv_pw_kernel", "conv_pwx_kernel"), flops, "fwd"))
+
+
+def conv2d_pw_bnbwd_bnred(d, dz, y_above, coef, dy_out, w_kc, dx, partial, bn_ctx):
+    """1x1 input-gradient conv whose operand dy = A*dz + B*y_above + C is computed while it is loaded and written to
+    dy_out; fused BN-backward reduction of the layer below as in conv2d_bnred."""
+    by, sc, sh, mu, istd, relu = bn_ctx
+    a, b, c = coef
+    L.call("ocr_conv2d_pw_bnbwd_bnred_f16", byref(d), ptr(dz), ptr(y_above), ptr(a), ptr(b), ptr(c), ptr(dy_out),
+           ptr(w_kc), ptr(dx), ptr(partial), ptr(by), ptr(sc), ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), _st())
+    if L.RECORDER is not None:
+        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin
+        L.RECORDER.tag_last((conv2d_variant(d).replace("conv_pw_kernel", "conv_pwx_kernel"), flops, "dgrad"))
+
+
+def bn_bwd_coefficients(partial, T, c, count, scale, save_mean, save_invstd, dgamma, dbeta, coef, ws):
+    stage = ws.get(bn_reduce_workspace(T, c))
+    a, b, cc = coef
+    L.call("ocr_bn_bwd_coefficients", ptr(partial), c_int(T), c_int(c), c_double(count), ptr(scale), ptr(save_mean),
+           ptr(save_invstd), ptr(dgamma), ptr(dbeta), ptr(a), ptr(b), ptr(cc), ptr(stage), c_size_t(stage.numel()), _st())
 
 
 def bn_relu_bwd_apply(y, scale, shift, save_mean, save_invstd, da_full, relu, partial, T, dgamma, dbeta, dy, ws):
@@ -331,10 +361,12 @@ def channel_stats(x, partial):
     L.call("ocr_channel_stats_f16", ptr(x), c_int64(x.numel() // c), c_int(c), ptr(partial), _st())
 
 
-def bn_add_relu(y, scale, shift, shortcut, out):
+def bn_add_relu(y, scale, shift, shortcut, out, sc_scale=None, sc_shift=None, bits=None):
+    """out = relu(bn(y) + shortcut); sc_scale/sc_shift: the shortcut's own (projection) batch norm applied on the fly;
+    bits: optional ReLU-mask bytes (one per 8 channels)."""
     c = y.shape[-1]
-    L.call("ocr_bn_add_relu_f16", ptr(y), ptr(scale), ptr(shift), ptr(shortcut), c_int64(y.numel() // c),
-           c_int(c), ptr(out), _st())
+    L.call("ocr_bn_add_relu_f16", ptr(y), ptr(scale), ptr(shift), ptr(shortcut), ptr(sc_scale), ptr(sc_shift),
+           c_int64(y.numel() // c), c_int(c), ptr(out), ptr(bits), _st())
 
 
 def relu_bwd(out, dout, dz):

@@ -18,14 +18,23 @@ from ._lib import CONV_ACCUM_F16, CONV_STATS
 USE_S2D = __import__("os").environ.get("OCR_RESNET_S2D", "1") == "1"     # measurement switch (A/B against the subsample form)
 FUSE_TAIL = __import__("os").environ.get("OCR_RESNET_FUSE_TAIL", "1") == "1"   # measurement switch (bottleneck tail fusion)
 FUSE_SUB = __import__("os").environ.get("OCR_RESNET_FUSE_SUB", "1") == "1"     # ... subsampled shortcut gradient in that conv's epilogue
+# round 3: the element-wise passes around the 1x1 convolutions applied while those convolutions load their operand
+FUSE_FWD = __import__("os").environ.get("OCR_RESNET_FUSE_FWD", "1") == "1"     # relu(bn(conv3) + shortcut) inside the NEXT 1x1 conv
+FUSE_BWD = __import__("os").environ.get("OCR_RESNET_FUSE_BWD", "1") == "1"     # conv3's BN-backward apply inside its input-gradient conv
+MASK_BITS = __import__("os").environ.get("OCR_RESNET_MASK_BITS", "0") == "1"   # tail mask as bits instead of the output tensor: measured SLOWER (byte stores +8 % on the writers, byte loads no faster in the latency-bound tail epilogue), off
 
 
 class ConvBN:
     """Raw conv output + the batch-norm coefficients of one conv layer."""
-    __slots__ = ("y", "scale", "shift", "mean", "invstd", "gamma", "beta", "wv", "backward_from")
+    __slots__ = ("y", "scale", "shift", "mean", "invstd", "gamma", "beta", "wv", "backward_from", "can_fuse_bwd")
 
 
-def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, weight_decay=True):
+def _pw_fusable(d):
+    """The pointwise GEMM kernel (and so conv_pwx_kernel) takes this 1x1 convolution."""
+    return d.kh == 1 and d.cin >= 128 and ops.conv2d_variant(d).startswith("conv_pw_kernel")
+
+
+def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, weight_decay=True, owner=None):
     """slim.conv2d(normalizer_fn=slim.batch_norm) up to (not including) the normalise step.
     x: Act f16 [n,h,w,cin].  Returns ConvBN; `backward_from(dy)` propagates the gradient of the
     conv output into the weights and into x."""
@@ -41,6 +50,8 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
     strided = stride != 1
     if strided and k == 1:
         raise NotImplementedError("strided 1x1 conv (the slim variant in the reference has none)")
+    if owner is None or owner is not x.pending_owner:
+        x.consumed = True
     s2d = strided and stride == 2 and k == 3 and rate == 1 and h % 2 == 0 and w % 2 == 0 and cin % 16 == 0 and USE_S2D
     if s2d:
         def mk22(old):
@@ -69,7 +80,7 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
     else:
         w_fwd, w_dg = _packs(g, wv, False)
         d = ops.conv_desc((n, h, w, cin), cout, k, k, 1, rate)          # stride-1 SAME
-        x_in = x.data
+        x_in = x._data            # (the buffer: a deferred x is filled by the convolution below or by x.data)
         y_full = g.empty((n, d.oh, d.ow, cout))
         mt = ops.conv2d_num_mtiles(d)
     if s2d:
@@ -90,7 +101,15 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
         T = mt
         part, stage = g.ws_small.two(T * 2 * cout * 4, ops.bn_reduce_workspace(T, cout))
         d.flags = CONV_STATS if is_training else 0
-        ops.conv2d(d, x.data, w_fwd, y, None, part if is_training else None)
+        if (x.deferred is not None and x.tail_fwd is not None and is_training and FUSE_FWD and cout <= 512
+                and _pw_fusable(d)):
+            # x is the previous unit's output and nobody has computed it yet: this convolution does, while loading
+            # its pixel operand, and writes it (and its ReLU-mask bits) for the consumers that follow
+            x.deferred = None
+            py, psc, psh, short, ssc, ssh, bits = x.tail_fwd
+            ops.conv2d_pw_bnaddrelu(d, py, psc, psh, short, ssc, ssh, x._data, bits, w_fwd, y, part)
+        else:
+            ops.conv2d(d, x.data, w_fwd, y, None, part if is_training else None)
     c = ConvBN()
     c.y, c.gamma, c.beta, c.wv = y, gamma, beta, wv
     c.scale, c.shift = g.empty((cout,), F32), g.empty((cout,), F32)
@@ -101,7 +120,21 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
     else:
         ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, c.scale, c.shift)
 
-    def backward_from(dy):
+    def backward_from(dy, fused=None):
+        """dy: gradient of the conv output.  fused = (dz, y_bn, (A, B, C)): dy is still EMPTY — it is the batch-norm
+        backward apply A*dz + B*y_bn + C, which the input-gradient convolution computes while loading its operand and
+        writes into `dy` for the weight gradient (see `can_fuse_bwd`)."""
+        if fused is not None:
+            dz_f, ybn_f, coef_f = fused
+            dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, 1, 1, 1, 1, 0, 0, 1, 0)
+            x.grad = g.empty(x.shape)
+            Tm = ops.conv2d_num_mtiles(dg)
+            partial = g.empty((Tm, 2, d.cin), F32)
+            ops.conv2d_pw_bnbwd_bnred(dg, dz_f, ybn_f, coef_f, dy, w_dg, x.grad, partial, x.bn_ctx)
+            x.bn_partial = (partial, Tm)
+            dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, 1, 1, 1, 1, 0, 0, 0, 0)
+            ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad)
+            return
         if strided and not s2d:
             dy_full = g.empty(y_full.shape)
             ops.maxpool_bwd(y_full, dy, 1, stride, (0, 0), dy_full, False)   # zero insertion
@@ -136,9 +169,14 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             flags |= CONV_ACCUM_F16
             x.bn_partial = None     # an earlier consumer's fused BN-backward sums no longer cover the full gradient
         dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, flags)
-        if x.pending is not None:
+        last = False
+        if x.pending is not None and owner is not None and owner is x.pending_owner:
+            # only the owning unit's two contributions are counted (any other consumer of x was built
+            # later, runs earlier in the backward pass and has already added its share)
             x.pending -= 1
-        if x.pending == 0 and x.tail_ctx is not None and k == 1 and FUSE_TAIL:
+            assert x.pending >= 0, "more gradient contributions than the owning unit has consumers"
+            last = x.pending == 0
+        if last and x.tail_ctx is not None and k == 1 and FUSE_TAIL:
             # x is the previous bottleneck's output and this is the last contribution to its gradient: store
             # the gradient past its ReLU and emit the BN-backward sums of its last conv (ops.conv2d_bnred_tail)
             Tm = ops.conv2d_num_mtiles(dg)
@@ -155,17 +193,26 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             x.bn_partial = (partial, Tm)
         else:
             ops.conv2d(dg, dy, w_dg, x.grad, None, None)
+    def can_fuse_bwd():
+        """The fused form of `backward_from`: this is a stride-1 1x1 convolution the pointwise kernel takes, its input is
+        a conv+BN(+ReLU) output nobody else has contributed a gradient to (so the epilogue's fused reduction applies)."""
+        if not (FUSE_BWD and FUSE_BN_REDUCE and k == 1 and not strided and x.requires_grad and x.grad is None
+                and x.bn_ctx is not None and x.pending is None and cout >= 128):
+            return False
+        dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, 1, 1, 1, 1, 0, 0, 1, 0)
+        return _pw_fusable(dg)
     c.backward_from = backward_from
+    c.can_fuse_bwd = can_fuse_bwd
     return c
 
 
-def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_training=True):
+def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_training=True, owner=None):
     """conv + batch_norm + (ReLU | identity) -> Act."""
     if g.precision == "f32":
         from . import layers_f32
         return layers_f32.conv_bn_act(g, x, cout, k, scope, stride=stride, rate=rate, relu=relu,
                                       is_training=is_training)
-    c = conv_bn_raw(g, x, cout, k, scope, stride=stride, rate=rate, is_training=is_training)
+    c = conv_bn_raw(g, x, cout, k, scope, stride=stride, rate=rate, is_training=is_training, owner=owner)
     a = Act(g.empty(c.y.shape), name=scope)
     ops.bn_relu(c.y, c.scale, c.shift, relu, 0, a.data, None)
     ws = g.workspace()
@@ -235,11 +282,19 @@ def root_block(g, x4, scope="conv1", cout=64, is_training=True):
 def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
     """nets/resnet_v1.py:68-111: shortcut = subsample(x, stride) if depth == depth_in else
     1x1 conv(stride) + BN;  residual = 1x1 -> 3x3(stride) -> 1x1 with BN (ReLU, ReLU, none);
-    output = relu(shortcut + residual)."""
+    output = relu(shortcut + residual).
+
+    Training mode keeps the element-wise passes of the unit's widest tensors out of HBM where a 1x1 convolution can
+    carry them: the output is DEFERRED to the next unit's first 1x1 convolution (FUSE_FWD), a projection
+    shortcut's batch norm is applied inside that same expression and never stored, the output's ReLU mask travels to
+    the backward pass as bits, and conv3's batch-norm backward apply runs inside conv3's input-gradient convolution
+    (FUSE_BWD)."""
     from .layers import max_pool2d
+    import torch
     depth_in = x.shape[-1]
     ws = g.workspace()
-    fuse_in = g.precision != "f32" and x.tail_ctx is not None
+    owner = object()                       # identifies this unit's own consumers of x (conv1, shortcut)
+    fuse_in = g.precision != "f32" and x.tail_ctx is not None and not x.consumed
     if fuse_in:
         # x is the previous unit's output.  This unit reads it twice (conv1 and the shortcut); whatever else
         # consumes it was built later and so contributes to its gradient EARLIER in the backward pass.  The
@@ -247,15 +302,36 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
         # (conv_bn_raw.backward_from): conv1 for an identity / subsampling shortcut (recorded first, runs
         # last), the projection shortcut otherwise (built before conv1 below).
         x.pending = 2
+        x.pending_owner = owner
+    projection = depth != depth_in
+    sc_hold = {"dz": None}
+    sc = None
 
     def make_shortcut():
-        if depth == depth_in:
+        nonlocal sc
+        if not projection:
             if stride == 1:
                 return x
             return max_pool2d(g, x, 1, stride, scope="shortcut")
         if stride != 1:
             raise NotImplementedError("strided projection shortcut")
-        return conv_bn_act(g, x, depth, 1, "shortcut", relu=False, is_training=is_training)
+        if g.precision == "f32":
+            return conv_bn_act(g, x, depth, 1, "shortcut", relu=False, is_training=is_training)
+        # the projection's batch norm is applied where the shortcut is added (never stored on its own): keep the raw
+        # conv output and its coefficients; its backward runs where the reference's shortcut closure ran (last)
+        sc = conv_bn_raw(g, x, depth, 1, "shortcut", is_training=is_training, owner=owner)
+
+        def sc_backward():
+            dz = sc_hold["dz"]
+            if dz is None:
+                return
+            dy = g.empty(sc.y.shape)
+            ops.bn_relu_bwd(sc.y, sc.scale, sc.shift, sc.mean, sc.invstd, dz, None, False, 0, sc.gamma.grad,
+                            sc.beta.grad, dy, ws)
+            sc.backward_from(dy)
+            sc_hold["dz"] = None
+        g.record(sc_backward, (sc.wv, sc.gamma, sc.beta))
+        return Act(sc.y, name="shortcut_raw")
     with g.variable_scope(scope):
         with g.variable_scope("bottleneck_v1"):
             # variables are created in the reference's order (shortcut first) when there is a projection; a
@@ -263,7 +339,7 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
             # (zero insertion into x's gradient) runs before conv1's
             late = depth == depth_in and stride != 1
             shortcut = None if late else make_shortcut()
-            r = conv_bn_act(g, x, depth_bottleneck, 1, "conv1", is_training=is_training)
+            r = conv_bn_act(g, x, depth_bottleneck, 1, "conv1", is_training=is_training, owner=owner)
             r = conv_bn_act(g, r, depth_bottleneck, 3, "conv2", stride=stride, is_training=is_training)
             c3 = conv_bn_raw(g, r, depth, 1, "conv3", is_training=is_training)
             if late and fuse_in and FUSE_TAIL and FUSE_SUB and is_training:
@@ -294,9 +370,21 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
         from . import layers_f32
         return layers_f32.bn_add_relu(g, c3, shortcut, scope)
     out = Act(g.empty(c3.y.shape), name=scope)
-    ops.bn_add_relu(c3.y, c3.scale, c3.shift, shortcut.data, out.data)
+    bits = None
+    if is_training and FUSE_TAIL and MASK_BITS:
+        bits = g.empty((out._data.numel() // 8,), torch.uint8)
+    sc_scale, sc_shift = (sc.scale, sc.shift) if sc is not None else (None, None)
+    short_t = shortcut.data                       # (an identity shortcut is x itself: computed by conv1 above)
+
+    def fill():
+        ops.bn_add_relu(c3.y, c3.scale, c3.shift, short_t, out._data, sc_scale, sc_shift, bits)
+    if is_training and FUSE_FWD:
+        out.deferred = fill
+        out.tail_fwd = (c3.y, c3.scale, c3.shift, short_t, sc_scale, sc_shift, bits)
+    else:
+        fill()
     if is_training and FUSE_TAIL:
-        out.tail_ctx = (c3.y, c3.mean, c3.invstd, out.data)
+        out.tail_ctx = (c3.y, c3.mean, c3.invstd, out._data, bits)
 
     def backward():
         if out.grad is None:
@@ -306,16 +394,26 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
             # out.grad is already the gradient past the ReLU and the BN-backward sums are reduced
             dz = out.grad
             part_f, T_f = out.tail_partial
-            ops.bn_relu_bwd_apply(c3.y, c3.scale, c3.shift, c3.mean, c3.invstd, dz, False, part_f, T_f,
-                                  c3.gamma.grad, c3.beta.grad, dy, ws)
+            if c3.can_fuse_bwd():
+                n_, h_, w_, c_ = c3.y.shape
+                coef = (g.empty((c_,), F32), g.empty((c_,), F32), g.empty((c_,), F32))
+                ops.bn_bwd_coefficients(part_f, T_f, c_, float(n_) * h_ * w_, c3.scale, c3.mean, c3.invstd,
+                                        c3.gamma.grad, c3.beta.grad, coef, ws)
+                c3.backward_from(dy, fused=(dz, c3.y, coef))
+            else:
+                ops.bn_relu_bwd_apply(c3.y, c3.scale, c3.shift, c3.mean, c3.invstd, dz, False, part_f, T_f,
+                                      c3.gamma.grad, c3.beta.grad, dy, ws)
+                c3.backward_from(dy)
             out.tail_partial = None
         else:
             dz = g.empty(out.shape)
             ops.relu_bwd(out.data, out.grad, dz)
             ops.bn_relu_bwd(c3.y, c3.scale, c3.shift, c3.mean, c3.invstd, dz, None, False, 0, c3.gamma.grad,
                             c3.beta.grad, dy, ws)
-        c3.backward_from(dy)
-        if shortcut.requires_grad:
+            c3.backward_from(dy)
+        if sc is not None:
+            sc_hold["dz"] = dz                       # the projection's backward closure runs later (recorded first)
+        elif shortcut.requires_grad:
             if shortcut.grad is None:
                 shortcut.grad = dz
             else:

@@ -259,3 +259,134 @@ def test_fused_reduction_relu_mask_at_the_rounding_boundary(device, n, h, w, c, 
     full = y.float().cpu().numpy().astype(np.float64).sum((0, 1, 2))
     assert np.allclose(s0[expect_pass], full[expect_pass], rtol=1e-4, atol=2e-2)
     assert (s0[~expect_pass] == 0).all()
+
+
+# ------------------------------------------------------------------ round 3: operand transforms inside the 1x1 kernels
+@pytest.mark.parametrize("n,h,w,cin,cout,proj", [
+    (2, 16, 24, 256, 64, False),      # conv1 of a stage-1 unit: 64-cout tile, four K stages, three flat tiles
+    (1, 20, 32, 512, 128, True),      # 128-cout tile, projection shortcut's BN folded in
+    (2, 8, 20, 1024, 256, False),     # 256-cout tile, 1.25 flat tiles (ragged last tile)
+    (1, 8, 8, 2048, 512, False),      # two cout tiles: only the first writes x_out / bits
+    (3, 5, 32, 128, 64, True),        # two K stages
+])
+def test_pw_bnaddrelu_equals_the_two_pass_form(device, n, h, w, cin, cout, proj):
+    """ocr_conv2d_pw_bnaddrelu_f16 (the previous unit's relu(bn(y3) + shortcut) computed while the 1x1 convolution
+    loads its operand) against ocr_bn_add_relu_f16 followed by ocr_conv2d_f16: the written-back operand and its mask
+    bits equal the element-wise kernel's bit for bit (same f32 expression, same roundings), and so do the convolution
+    output and its BN partial sums (same MFMA order on the same operand); the element-wise kernel itself against numpy."""
+    from tensorflow_ocr_amd import ops
+    rng = np.random.default_rng(cin + cout)
+    y3 = _h(rng.standard_normal((n, h, w, cin)))
+    short = _h(rng.standard_normal((n, h, w, cin)))
+    scale = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    shift = rng.normal(0, 0.3, cin).astype(np.float32)
+    ssc = rng.uniform(0.5, 1.5, cin).astype(np.float32) if proj else None
+    ssh = rng.normal(0, 0.3, cin).astype(np.float32) if proj else None
+    wt = _h(rng.standard_normal((1, 1, cin, cout)) * np.sqrt(2.0 / cin))
+    dev = lambda a: torch.from_numpy(a).to(O.STORAGE).to(device)
+    f32 = lambda a: None if a is None else torch.from_numpy(a).to(device)
+    w_kc = torch.empty((1, cout, cin), dtype=O.STORAGE, device=device)
+    w_ck = torch.empty((1, cin, cout), dtype=O.STORAGE, device=device)
+    ops.pack_weights(torch.from_numpy(wt).to(device), w_kc, w_ck)
+    d = ops.conv_desc((n, h, w, cin), cout, 1, 1, 1, 1)
+    d.flags = ops.CONV_STATS
+    T = ops.conv2d_num_mtiles(d)
+    # two passes
+    x_ref = torch.empty((n, h, w, cin), dtype=O.STORAGE, device=device)
+    bits_ref = torch.zeros((n * h * w * cin // 8,), dtype=torch.uint8, device=device)
+    ops.bn_add_relu(dev(y3), f32(scale), f32(shift), dev(short), x_ref, f32(ssc), f32(ssh), bits_ref)
+    y_ref = torch.empty((n, h, w, cout), dtype=O.STORAGE, device=device)
+    part_ref = torch.zeros((T, 2, cout), dtype=torch.float32, device=device)
+    ops.conv2d(d, x_ref, w_kc, y_ref, None, part_ref)
+    # one
+    x_out = torch.full((n, h, w, cin), float("nan"), dtype=O.STORAGE, device=device)
+    bits = torch.full((n * h * w * cin // 8,), 0xAA, dtype=torch.uint8, device=device)
+    y = torch.empty((n, h, w, cout), dtype=O.STORAGE, device=device)
+    part = torch.zeros((T, 2, cout), dtype=torch.float32, device=device)
+    ops.conv2d_pw_bnaddrelu(d, dev(y3), f32(scale), f32(shift), dev(short), f32(ssc), f32(ssh), x_out, bits, w_kc, y, part)
+    torch.cuda.synchronize()
+    dxo = (x_out.float() - x_ref.float())
+    assert torch.equal(x_out, x_ref), ("x_out", int(torch.isnan(x_out.float()).sum()), int((dxo != 0).sum()), float(dxo.abs().nan_to_num().max()),
+                                        (dxo != 0).nonzero()[:6].tolist())
+    assert torch.equal(bits, bits_ref), ("bits", int((bits != bits_ref).sum()))
+    assert torch.equal(y, y_ref), ("y", float((y.float() - y_ref.float()).abs().max()))
+    assert torch.equal(part, part_ref)
+    # the element-wise definition (nets/resnet_v1.py:107), roundings where the kernels round
+    z = _h(y3 * scale + shift)
+    r = _h(short * ssc + ssh) if proj else short
+    want = _h(np.maximum(z + r, 0.0))
+    got = x_ref.float().cpu().numpy()
+    tol = 8e-3 if O.STORAGE == torch.bfloat16 else 1e-3
+    assert np.abs(got - want).max() <= tol * np.abs(want).max()
+    b = np.unpackbits(bits_ref.cpu().numpy(), bitorder="little").reshape(got.shape)
+    assert ((got > 0) == (b == 1)).all()
+
+
+@pytest.mark.parametrize("n,h,w,c4,c", [(2, 16, 24, 256, 64), (1, 20, 32, 512, 128), (2, 8, 20, 1024, 256), (1, 8, 8, 2048, 512)])
+def test_pw_bnbwd_bnred_equals_the_two_pass_form(device, n, h, w, c4, c):
+    """ocr_bn_bwd_coefficients + ocr_conv2d_pw_bnbwd_bnred_f16 (conv3's batch-norm backward apply computed while its
+    input-gradient convolution loads dy) against ocr_bn_relu_bwd_apply_f16 + ocr_conv2d_bnred_f16 and against float64:
+    dgamma / dbeta identical (same reduction), dy within one 16-bit rounding (the affine form A*dz + B*y + C groups the
+    f32 operations differently), dx and the fused reduction's partial sums accordingly."""
+    from tensorflow_ocr_amd import ops
+    from tensorflow_ocr_amd.ops import Workspace
+    rng = np.random.default_rng(c4 + c)
+    npix = n * h * w
+    dz = _h(rng.standard_normal((n, h, w, c4)) * 0.3)
+    y3 = _h(rng.standard_normal((n, h, w, c4)))
+    gamma = rng.uniform(0.5, 1.5, c4).astype(np.float32)
+    mean = rng.normal(0, 0.2, c4).astype(np.float32)
+    invstd = rng.uniform(0.7, 1.3, c4).astype(np.float32)
+    scale = (gamma * invstd).astype(np.float32)
+    shift = rng.normal(0, 0.3, c4).astype(np.float32)
+    xh = (y3.astype(np.float64) - mean) * invstd
+    s1 = dz.astype(np.float64).sum((0, 1, 2))
+    s2 = (dz.astype(np.float64) * xh).sum((0, 1, 2))
+    partial = torch.from_numpy(np.stack([s1, s2]).astype(np.float32)[None]).to(device)       # T = 1
+    wt = _h(rng.standard_normal((1, 1, c, c4)) * np.sqrt(2.0 / c))                             # conv3: c -> c4
+    y2 = _h(rng.standard_normal((n, h, w, c)))                                                  # conv2's raw output (below)
+    bsc = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    bsh = rng.normal(0, 0.3, c).astype(np.float32)
+    bmu = rng.normal(0, 0.2, c).astype(np.float32)
+    bis = rng.uniform(0.7, 1.3, c).astype(np.float32)
+    dev = lambda a: torch.from_numpy(a).to(O.STORAGE).to(device)
+    f32 = lambda a: torch.from_numpy(a).to(device)
+    w_kc = torch.empty((1, c4, c), dtype=O.STORAGE, device=device)
+    w_ck = torch.empty((1, c, c4), dtype=O.STORAGE, device=device)
+    ops.pack_weights(torch.from_numpy(wt).to(device), w_kc, w_ck)
+    ws = Workspace(device, 64 << 20)
+    dg = ops.ConvDesc(n, h, w, c4, h, w, c, 1, 1, 1, 1, 0, 0, 1, 0)
+    Tm = ops.conv2d_num_mtiles(dg)
+    ctx = (dev(y2), f32(bsc), f32(bsh), f32(bmu), f32(bis), True)
+    # two passes
+    dgam_r, dbet_r = torch.zeros(c4, device=device), torch.zeros(c4, device=device)
+    dy_r = torch.empty((n, h, w, c4), dtype=O.STORAGE, device=device)
+    ops.bn_relu_bwd_apply(dev(y3), f32(scale), f32(shift), f32(mean), f32(invstd), dev(dz), False, partial, 1, dgam_r, dbet_r, dy_r, ws)
+    dx_r = torch.empty((n, h, w, c), dtype=O.STORAGE, device=device)
+    part_r = torch.zeros((Tm, 2, c), dtype=torch.float32, device=device)
+    ops.conv2d_bnred(dg, dy_r, w_ck, dx_r, part_r, ctx)
+    # one
+    dgam, dbet = torch.zeros(c4, device=device), torch.zeros(c4, device=device)
+    coef = tuple(torch.empty(c4, device=device) for _ in range(3))
+    ops.bn_bwd_coefficients(partial, 1, c4, float(npix), f32(scale), f32(mean), f32(invstd), dgam, dbet, coef, ws)
+    dy = torch.full((n, h, w, c4), float("nan"), dtype=O.STORAGE, device=device)
+    dx = torch.empty((n, h, w, c), dtype=O.STORAGE, device=device)
+    part = torch.zeros((Tm, 2, c), dtype=torch.float32, device=device)
+    ops.conv2d_pw_bnbwd_bnred(dg, dev(dz), dev(y3), coef, dy, w_ck, dx, part, ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(dgam, dgam_r) and torch.equal(dbet, dbet_r)
+    # float64 definition of the apply step
+    want = scale * (dz - s1 / npix - xh * (s2 / npix))
+    tol = 8e-3 if O.STORAGE == torch.bfloat16 else 1e-3
+    m = np.abs(want).max()
+    got, got_r = dy.float().cpu().numpy(), dy_r.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= tol * m and np.abs(got_r - want).max() <= tol * m
+    # the convolution of the SAME operand is the same convolution: run the plain kernel on the fused kernel's dy
+    dx_c = torch.empty_like(dx)
+    part_c = torch.zeros_like(part)
+    ops.conv2d_bnred(dg, dy, w_ck, dx_c, part_c, ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_c) and torch.equal(part, part_c)
+    dxf, dxr = dx.float().cpu().numpy(), dx_r.float().cpu().numpy()
+    assert np.abs(dxf - dxr).max() <= 2 * tol * np.abs(dxr).max()

@@ -297,3 +297,59 @@ def test_bottleneck_tail_fusion_equals_separate_passes(device, monkeypatch):
         a, b = res[True][k], res[False][k]
         assert np.isfinite(a).all()
         assert _rel2(a, b) < 2e-3 * TOL, (k, _rel2(a, b))
+
+
+def test_block_output_with_a_foreign_consumer(device):
+    """a bottleneck output consumed by the next (projection-shortcut) unit AND by a convolution built
+    later.  That consumer adds its gradient first in the backward pass; only the owning unit's two contributions may
+    count toward the fused tail (mask + BN-backward sums), or the mask is applied one contribution early and the
+    projection's gradient lands unmasked on top.  Gradients of everything upstream against the oracle."""
+    from tensorflow_ocr_amd import resnet_layers
+    from tensorflow_ocr_amd.graph import Act, Graph
+    rng = np.random.default_rng(7)
+    n, hw = 2, 16
+    x = _h(np.abs(rng.standard_normal((n, hw, hw, 128))))
+    p = {}
+
+    def unit(u, cin, depth, db):
+        for name, k, ci, co in (("shortcut", 1, cin, depth), ("conv1", 1, cin, db), ("conv2", 3, db, db), ("conv3", 1, db, depth)):
+            if name == "shortcut" and cin == depth:
+                continue
+            p["%s/bottleneck_v1/%s/weights" % (u, name)] = _h(rng.standard_normal((k, k, ci, co)) * np.sqrt(2.0 / (k * k * ci)))
+            O._bn_init(p, "%s/bottleneck_v1/%s" % (u, name), co)
+            p["%s/bottleneck_v1/%s/BatchNorm/gamma" % (u, name)] = (1 + 0.1 * rng.standard_normal(co)).astype(np.float32)
+            p["%s/bottleneck_v1/%s/BatchNorm/beta" % (u, name)] = (0.1 * rng.standard_normal(co)).astype(np.float32)
+    unit("a", 128, 128, 64)
+    unit("b", 128, 256, 64)
+    p["extra/weights"] = _h(rng.standard_normal((1, 1, 128, 64)) * np.sqrt(2.0 / 128))
+    O._bn_init(p, "extra", 64)
+    g_b = _h(rng.standard_normal((n, hw, hw, 256)) * 0.1)
+    g_e = _h(rng.standard_normal((n, hw, hw, 64)) * 0.1)
+
+    def build(g, xa):
+        oa = resnet_layers.bottleneck(g, xa, 128, 64, 1, "a")
+        ob = resnet_layers.bottleneck(g, oa, 256, 64, 1, "b")
+        ex = resnet_layers.conv_bn_act(g, oa, 64, 1, "extra")
+        return oa, ob, ex
+    g = Graph(device, loss_scale=1.0)
+    xa = Act(torch.from_numpy(x).to(O.STORAGE).to(device))
+    build(g, xa)
+    g.reset_tape()
+    g.store.load_state_dict(p)
+    oa, ob, ex = build(g, xa)
+    ob.grad = torch.from_numpy(g_b).to(O.STORAGE).to(device)
+    ex.grad = torch.from_numpy(g_e).to(O.STORAGE).to(device)
+    g.backward()
+    torch.cuda.synchronize()
+    tp = O.to_torch_params(p)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    o_a = O.bottleneck(xt, tp, "a/bottleneck_v1", 128, 1, True, True, {})
+    o_b = O.bottleneck(o_a, tp, "b/bottleneck_v1", 256, 1, True, True, {})
+    o_e = O.q(O._conv_bn(O.qg(o_a, True), tp, "extra", 1, True, True, True, {}), True)
+    ((o_b * torch.from_numpy(g_b)).sum() + (o_e * torch.from_numpy(g_e)).sum()).backward()
+    assert np.abs(ob.data.float().cpu().numpy() - o_b.detach().numpy()).max() < 2e-2 * TOL
+    assert _rel2(xa.grad.float().cpu().numpy(), xt.grad.numpy()) < 4e-2 * TOL
+    for k in p:
+        if k.startswith("a/") and k.endswith(("weights", "gamma", "beta")):
+            r = _rel2(g.store.vars[k].grad.cpu().numpy(), tp[k].grad.numpy())
+            assert r < 4e-2 * TOL, (k, r)
