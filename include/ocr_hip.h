@@ -153,6 +153,13 @@ size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d);
 int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const void* x4,
                                const void* dy, void* dw_hwio_f32,
                                void* workspace, size_t ws_bytes, void* stream);
+/* The same weight gradient with conv1_1's batch-norm backward APPLY computed while the tile is staged: `da` is the
+ * gradient of the layer's activation relu(bn(bn_y)); dy = A*dz + B*bn_y + C, dz = da * [bn_y*A + bn_shift rounds to a
+ * positive 16-bit value] (relu) — coefficients from ocr_bn_bwd_coefficients (A = the layer's scale).  conv1_1 has no
+ * input gradient, so nothing else reads dy: the apply pass and its 1 GiB output disappear (nets/vgg.py:14). */
+int ocr_conv2d_first_wgrad_bn_f16(int n, int h, int w, int cout, const void* x4, const void* da, const void* bn_y,
+                                  const void* bn_shift, const void* coef_a, const void* coef_b, const void* coef_c,
+                                  int relu, void* dw, void* workspace, size_t ws_bytes, void* stream);
 size_t ocr_conv2d_first_wgrad_workspace(int n, int h, int w, int cout);
 
 /* ResNet root convolution: 7x7 stride 2, cin = 3 (image [n,h,w,4] f16), explicit (3,3) padding of

@@ -107,8 +107,20 @@ __device__ __forceinline__ half8_t tr_pair_f(const char* base, int second_off) {
 constexpr int PSTRF = 64;        // bytes per im2col row (32 f16): 16 dwords -> tr reads conflict-free
 constexpr int DSTRF = 64 * 2 + 64;  // bytes per dy row
 
+// BNAPPLY: `dy` is the gradient of the layer's ACTIVATION a = relu(bn(y)) and the batch-norm backward apply
+//   dy = A*dz + B*y + C,  dz = da * [relu(bn(y)) > 0]     (coefficients: ocr_bn_bwd_coefficients)
+// is computed while the tile is staged — conv1_1 has no input gradient, so the weight gradient is the ONLY reader
+// of dy and the separate apply pass (read y, read da, write dy: 3 GiB at 32 x 512^2) plus this kernel's read of dy
+// become one read of y and da.
+struct FirstBn {
+  const half_t* y;
+  const float *A, *B, *C, *shift;
+  int relu;
+};
+
+template <bool BNAPPLY>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const half_t* __restrict__ x4,
-                                                               const half_t* __restrict__ dy,
+                                                               const half_t* __restrict__ dy, FirstBn bn,
                                                                float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) char halo[10 * HW * 8];
   __shared__ __attribute__((aligned(16))) char patch[256 * PSTRF];
@@ -127,6 +139,15 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
   // the dy tile (32 KB, the stream that bounds this kernel) of tile t+1 is fetched into registers
   // while tile t's patch rows are built and multiplied
   u32x4 dreg[8];
+  u32x4 yreg[BNAPPLY ? 8 : 1];
+  float cA[8], cB[8], cC[8], cS[8];
+  if (BNAPPLY) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cc = co0 + (tid & 7) * 8 + e;         // this thread's 16-byte chunk of every staged row
+      cA[e] = bn.A[cc]; cB[e] = bn.B[cc]; cC[e] = bn.C[cc]; cS[e] = bn.shift[cc];
+    }
+  }
   auto load_dy = [&](int mt) {
     const int txi = mt % p.tiles_x;
     const int tmp = mt / p.tiles_x;
@@ -138,9 +159,29 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
       const int px = idx >> 3, c = idx & 7;
       const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
       dreg[u] = u32x4{0u, 0u, 0u, 0u};
-      if (oy < p.h && ox < p.w)
-        dreg[u] = *reinterpret_cast<const u32x4*>(dy + (((size_t)img * p.h + oy) * p.w + ox) * p.cout + co0 + c * 8);
+      if (BNAPPLY) yreg[u] = u32x4{0u, 0u, 0u, 0u};
+      if (oy < p.h && ox < p.w) {
+        const size_t off = (((size_t)img * p.h + oy) * p.w + ox) * p.cout + co0 + c * 8;
+        dreg[u] = *reinterpret_cast<const u32x4*>(dy + off);
+        if (BNAPPLY) yreg[u] = *reinterpret_cast<const u32x4*>(bn.y + off);
+      }
     }
+  };
+  // (tiles are whole multiples of the image here or zero padded: a pixel outside the image stages dy = 0)
+  auto staged = [&](int u, bool inside) -> u32x4 {
+    if (!BNAPPLY) return dreg[u];
+    if (!inside) return u32x4{0u, 0u, 0u, 0u};
+    const half8_t g8 = __builtin_bit_cast(half8_t, dreg[u]);
+    const half8_t y8 = __builtin_bit_cast(half8_t, yreg[u]);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float yf = (float)y8[e];
+      const bool pass = !bn.relu || __builtin_fmaf(yf, cA[e], cS[e]) > OCR_RELU_TIE;   // the stored activation is positive
+      const float dz = pass ? (float)g8[e] : 0.f;
+      o[e] = (half_t)__builtin_fmaf(cA[e], dz, __builtin_fmaf(cB[e], yf, cC[e]));
+    }
+    return __builtin_bit_cast(u32x4, o);
   };
   if ((int)blockIdx.x < p.m_tiles) load_dy(blockIdx.x);
   for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
@@ -153,7 +194,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int idx = u * 256 + tid;
-      *reinterpret_cast<u32x4*>(dyt + (idx >> 3) * DSTRF + (idx & 7) * 16) = dreg[u];
+      const int px = idx >> 3;
+      const bool inside = tyi * TILE_H + (px >> 5) < p.h && txi * TILE_W + (px & 31) < p.w;
+      *reinterpret_cast<u32x4*>(dyt + px * DSTRF + (idx & 7) * 16) = staged(u, inside);
     }
     if (mt + (int)gridDim.x < p.m_tiles) load_dy(mt + gridDim.x);
     __syncthreads();
@@ -277,8 +320,30 @@ extern "C" int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const v
   if (ws_bytes < ocr_conv2d_first_wgrad_workspace(n, h, w, cout)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int blocks = wgrad_blocks(p.m_tiles);
-  hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks, cout / 64), dim3(256), 0, st, p,
-                     static_cast<const half_t*>(x4), static_cast<const half_t*>(dy),
+  hipLaunchKernelGGL(conv_first_wgrad_kernel<false>, dim3(blocks, cout / 64), dim3(256), 0, st, p,
+                     static_cast<const half_t*>(x4), static_cast<const half_t*>(dy), FirstBn{},
+                     static_cast<float*>(workspace));
+  const int elems = 27 * cout;
+  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(elems)), dim3(256), 0, st,
+                     static_cast<const float*>(workspace), static_cast<float*>(dw), elems, blocks * 2, 1.f);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_conv2d_first_wgrad_bn_f16(int n, int h, int w, int cout, const void* x4, const void* da,
+                                             const void* bn_y, const void* bn_shift, const void* coef_a,
+                                             const void* coef_b, const void* coef_c, int relu, void* dw,
+                                             void* workspace, size_t ws_bytes, void* stream) {
+  FirstP p;
+  int rc = fill(&p, n, h, w, cout, 0);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x4 && da && bn_y && bn_shift && coef_a && coef_b && coef_c && dw && workspace);
+  if (ws_bytes < ocr_conv2d_first_wgrad_workspace(n, h, w, cout)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int blocks = wgrad_blocks(p.m_tiles);
+  FirstBn bn{static_cast<const half_t*>(bn_y), static_cast<const float*>(coef_a), static_cast<const float*>(coef_b),
+             static_cast<const float*>(coef_c), static_cast<const float*>(bn_shift), relu};
+  hipLaunchKernelGGL(conv_first_wgrad_kernel<true>, dim3(blocks, cout / 64), dim3(256), 0, st, p,
+                     static_cast<const half_t*>(x4), static_cast<const half_t*>(da), bn,
                      static_cast<float*>(workspace));
   const int elems = 27 * cout;
   hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(elems)), dim3(256), 0, st,

@@ -43,6 +43,9 @@ def _packs(g, w, first):
     return g.packed(w, "kc_ck", mk)
 
 
+FUSE_FIRST_WGRAD = __import__("os").environ.get("OCR_FUSE_FIRST_WGRAD", "1") == "1"    # measurement switch
+
+
 def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True, pool=0,
            keep_full=True, is_training=True, bn_training=None, first=False, weight_decay=True,
            initializer=None):
@@ -131,6 +134,17 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 da_pool = g.empty(a_pool.data.shape)
                 ops.fill_(da_pool, 0.0)
             if not pool and da_full is None:
+                return
+            if first and not pool and a_full.bn_partial is not None and FUSE_FIRST_WGRAD:
+                # conv1_1: no input gradient, so the weight gradient is the only reader of dy — it applies the BN
+                # backward while staging its tiles and dy is never written (ocr_conv2d_first_wgrad_bn_f16)
+                part_f, T_f = a_full.bn_partial
+                coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
+                ops.bn_bwd_coefficients(part_f, T_f, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
+                                        beta.grad, coef, ws)
+                ops.conv2d_first_wgrad_bn(x.data, da_full, y, shift, coef, relu, wv.grad, ws)
+                a_full.bn_partial = None
+                a_full.grad = None
                 return
             dy = g.empty(y.shape)
             if not pool and a_full.bn_partial is not None:

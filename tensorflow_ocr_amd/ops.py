@@ -215,6 +215,17 @@ def conv2d_first_wgrad(x4, dy, dw, ws):
            ptr(dw), ptr(buf), c_size_t(nbytes), _st())
 
 
+def conv2d_first_wgrad_bn(x4, da, y, shift, coef, relu, dw, ws):
+    """conv1_1's weight gradient with its BN-backward apply computed on load (coef: bn_bwd_coefficients)."""
+    n, h, w, _ = x4.shape
+    cout = da.shape[-1]
+    nbytes = L.call_size("ocr_conv2d_first_wgrad_workspace", c_int(n), c_int(h), c_int(w), c_int(cout))
+    buf = ws.get(nbytes)
+    a, b, c = coef
+    L.call("ocr_conv2d_first_wgrad_bn_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(da), ptr(y),
+           ptr(shift), ptr(a), ptr(b), ptr(c), c_int(int(relu)), ptr(dw), ptr(buf), c_size_t(nbytes), _st())
+
+
 def conv2d_stem_num_mtiles(n, h, w):
     return L.call_int("ocr_conv2d_stem_num_mtiles", c_int(n), c_int(h), c_int(w))
 

@@ -262,3 +262,55 @@ def test_pooled_bn_backward_with_stored_argmax_equals_recomputing_path(device, n
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][2], outs[1][2])
     assert float(outs[0][0].abs().sum()) > 0
+
+
+def test_first_conv_weight_gradient_with_bn_backward_applied_on_load(device):
+    """conv1_1 -> conv1_2 (both conv + BN + ReLU): conv1_2's input-gradient kernel leaves conv1_1's BN-backward sums,
+    and conv1_1 — which has no input gradient — computes dy = A*dz + B*y + C inside its weight-gradient kernel
+    (ocr_conv2d_first_wgrad_bn_f16) instead of in a separate apply pass.  Against the oracle, and against the
+    unfused device path (same numbers up to the grouping of the f32 operations)."""
+    from tensorflow_ocr_amd import layers
+    from tensorflow_ocr_amd.graph import Graph
+    rng = np.random.default_rng(12)
+    n, h, w, cout = 2, 40, 72, 64
+    img = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    p = {"a/weights": _h(rng.standard_normal((3, 3, 3, cout)) * 0.05),
+         "b/weights": _h(rng.standard_normal((3, 3, cout, cout)) * np.sqrt(2.0 / (9 * cout)))}
+    for nm in ("a", "b"):
+        O._bn_init(p, nm, cout)
+        p[nm + "/BatchNorm/gamma"] = (1 + 0.1 * rng.standard_normal(cout)).astype(np.float32)
+        p[nm + "/BatchNorm/beta"] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    gout = _h(rng.standard_normal((n, h, w, cout)) * 0.1)
+
+    def run(fused):
+        old = layers.FUSE_FIRST_WGRAD
+        layers.FUSE_FIRST_WGRAD = fused
+        try:
+            g = Graph(device, loss_scale=1.0)
+            x4 = layers.prep_images(g, torch.from_numpy(img).to(device))
+
+            def net():
+                a, _ = layers.conv2d(g, x4, cout, 3, "a", first=True)
+                b, _ = layers.conv2d(g, a, cout, 3, "b")
+                return a, b
+            net()
+            g.reset_tape()
+            g.store.load_state_dict(p)
+            a, b = net()
+            b.grad = torch.from_numpy(gout).to(O.STORAGE).to(device)
+            g.backward()
+            torch.cuda.synchronize()
+            return {k: v.grad.cpu().numpy().copy() for k, v in g.store.vars.items() if v.trainable}
+        finally:
+            layers.FUSE_FIRST_WGRAD = old
+    gf, gu = run(True), run(False)
+    tp = O.to_torch_params(p)
+    xm = O.q(O.mean_image_subtraction(torch.from_numpy(img)), True)
+    a = O._conv_block(xm, tp, "a", 1, "bn", True, {})
+    b = O._conv_block(O.qg(a, True), tp, "b", 1, "bn", True, {})
+    (b * torch.from_numpy(gout)).sum().backward()
+    for k in ("a/weights", "a/BatchNorm/gamma", "a/BatchNorm/beta"):
+        ref = tp[k].grad.numpy()
+        assert _rel(gf[k], gu[k]) < 2e-3 * TOL, (k, _rel(gf[k], gu[k]))           # fused vs unfused device paths
+        assert _rel(gf[k], ref) < 1e-2 * TOL, (k, _rel(gf[k], ref))               # vs the oracle (bars of test_first_conv)
+    assert np.array_equal(gf["a/BatchNorm/gamma"], gu["a/BatchNorm/gamma"])       # same reduction either way
