@@ -237,6 +237,20 @@ def main():
     dt = max_over_ranks(dt)
     loss_val = loss.item()
 
+    # data-parallel invariants, checked before the A/B below lets the towers drift: every rank trained on its OWN shard
+    # (checksums of the input images all differ) and every rank holds the SAME parameters (identical initialisation, the
+    # same averaged gradient every step — multigpu_train.py:70-85)
+    replicas = None
+    if world > 1:
+        mine = torch.tensor([float(g.store.flat.double().sum().item()), float(batch[0].double().sum().item())],
+                            dtype=torch.float64, device=device)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(allv, mine)
+        par = [float(v[0].item()) for v in allv]
+        dat = [float(v[1].item()) for v in allv]
+        replicas = {"parameters_identical": len(set(par)) == 1, "data_shards_distinct": len(set(dat)) == world,
+                    "ranks": world}
+
     # the exchange itself, outside the timed region: (1) a collective that proves every rank is in the
     # RCCL communicator, (2) the same K steps with the gradient exchange switched off — the difference
     # is the communication the backward pass did NOT hide.  (The towers' weights drift apart in (2);
@@ -316,6 +330,8 @@ def main():
         }
         if trace is not None:
             out["loss_trace"] = trace
+        if replicas is not None:
+            out["replicas"] = replicas
         if comm is not None:
             out["exchange"] = comm
         if world == 1 and not args.no_config_legs:
