@@ -178,9 +178,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    # N = 1: the gradient buckets still go through a ONE-rank RCCL communicator (C ABI: ocr_allreduce_bucket on a
-    # comm stream, event-ordered against the compute stream), so the single-GPU line exercises and reports the
-    # same exchange path the N > 1 runs use.  Falls back to no exchange if RCCL cannot be initialised here.
+    # N = 1: a single tower exchanges nothing (the reference's tower loop has one tower), so the TIMED steps run without
+    # an exchange.  The recorded step still CONTAINS the bucketed exchange through a ONE-rank RCCL communicator (C ABI:
+    # ocr_allreduce_bucket on a comm stream, event-ordered against the compute stream) — switched off for the timed
+    # region and on for the A/B after it, so the single-GPU line shows that RCCL loaded and what the exchange path
+    # costs (`exchange.ms_per_step_with_exchange`).  Falls back to no exchange if RCCL cannot be initialised here.
     force_reduce = args.force_pg
     exchange_error = None
     if world == 1 and not args.no_pg and not args.force_pg:
@@ -217,6 +219,9 @@ def main():
         return l
     for _ in range(3):          # engine build: variables, flat buffers, recorded step plan (untimed)
         loss = take(step(*batch))
+    probe_only = world == 1 and force_reduce and not args.force_pg
+    if probe_only:
+        step.reducer.enabled = False          # the plan holds the exchange entries; a single tower does not run them
     for _ in range(args.warmup):
         loss = take(step(*batch))
     barrier()
@@ -266,7 +271,7 @@ def main():
             ones = torch.ones(1, dtype=torch.float32, device=device)
             td.all_reduce(ones)
             backend = td.get_backend()
-        red.enabled = False
+        red.enabled = probe_only              # N = 1: the A/B leg is the one WITH the exchange; N > 1: the one without
         for _ in range(2):
             step(*batch)
         barrier()
@@ -274,12 +279,18 @@ def main():
         for _ in range(args.steps):
             step(*batch)
         barrier()
-        dt_off = max_over_ranks(time.perf_counter() - t1)
-        red.enabled = True
+        dt_ab = max_over_ranks(time.perf_counter() - t1)
+        red.enabled = not probe_only
         comm = {"backend": backend, "mode": red.mode, "rccl_ranks": int(round(ones.item())),
-                "bucket_bytes": red.bucket_nbytes(), "grad_bytes": int(g.store.flat_grad.numel() * 4),
-                "ms_per_step_no_exchange": round(dt_off / args.steps * 1e3, 3),
-                "comm_exposed_ms": round((dt - dt_off) / args.steps * 1e3, 3)}
+                "bucket_bytes": red.bucket_nbytes(), "grad_bytes": int(g.store.flat_grad.numel() * 4)}
+        if probe_only:
+            comm["in_timed_region"] = False
+            comm["ms_per_step_with_exchange"] = round(dt_ab / args.steps * 1e3, 3)
+            comm["comm_exposed_ms"] = round((dt_ab - dt) / args.steps * 1e3, 3)
+        else:
+            comm["in_timed_region"] = True
+            comm["ms_per_step_no_exchange"] = round(dt_ab / args.steps * 1e3, 3)
+            comm["comm_exposed_ms"] = round((dt - dt_ab) / args.steps * 1e3, 3)
     elif exchange_error is not None:
         comm = {"backend": None, "error": exchange_error}
 

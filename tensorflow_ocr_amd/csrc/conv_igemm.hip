@@ -2052,6 +2052,13 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
       p.n_tiles = p.cout / 128;
       return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
     }
+    // the same split for the epilogue WITH global operands (ResNet stage-1 tails: 64 -> 256 input gradients with four
+    // operand streams): 70 KB of LDS per workgroup -> two per CU, one's operand batches in flight under the other's MFMAs
+    static const int split_epi = [] { const char* e = getenv("OCR_PW_SPLIT64_EPI"); return e ? atoi(e) : 0; }();
+    if (split_epi && c.bn == 256 && p.cin == 64 && epi_loads) {
+      p.n_tiles = p.cout / 128;
+      return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
+    }
     if (c.bn == 256) return launch_pw<256, 4>(p, x, w_kc, bias, y, stats, st);
     if (c.bn == 128) return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
     return launch_pw<64, 1>(p, x, w_kc, bias, y, stats, st);

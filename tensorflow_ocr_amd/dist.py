@@ -96,10 +96,16 @@ class AbiComm:
             if store is None:
                 store = td.distributed_c10d._get_default_store()
             if rank == 0:
-                self._check(L._fn("ocr_comm_unique_id", ctypes.c_int)(ident), "ocr_comm_unique_id")
-                store.set(key, ident.raw)
+                rc = L._fn("ocr_comm_unique_id", ctypes.c_int)(ident)
+                # a failure here must reach the other ranks too: they would wait for the key, then for this rank inside
+                # ncclCommInitRank
+                store.set(key, ident.raw if rc == 0 else b"ERR")
+                self._check(rc, "ocr_comm_unique_id")
             else:
-                ident = ctypes.create_string_buffer(bytes(store.get(key)), 128)
+                raw = bytes(store.get(key))
+                if raw == b"ERR":
+                    raise L.OcrHipError("rank 0 could not create an RCCL unique id")
+                ident = ctypes.create_string_buffer(raw, 128)
         else:
             self._check(L._fn("ocr_comm_unique_id", ctypes.c_int)(ident), "ocr_comm_unique_id")
         self.handle = ctypes.c_void_p()
@@ -207,8 +213,26 @@ class GradientAllReduce:
             import ctypes
             from . import _lib as L
             if self.comm is None:
-                rank = td.get_rank() if (td.is_available() and td.is_initialized()) else 0
-                self.comm = AbiComm(rank, world_size)
+                grouped = td.is_available() and td.is_initialized()
+                rank = td.get_rank() if grouped else 0
+                err = None
+                try:
+                    self.comm = AbiComm(rank, world_size)
+                except Exception as e:                      # RCCL missing, communicator refused, ...
+                    err = e
+                # every rank takes the SAME path: if any rank failed, all exchange through torch.distributed instead
+                if grouped and world_size > 1 and any_rank(err is not None):
+                    if self.comm is not None:
+                        self.comm.destroy()
+                        self.comm = None
+                    import warnings
+                    warnings.warn("C-ABI RCCL communicator unavailable (%r): gradient exchange through torch.distributed" % (err,))
+                    self.mode = "torch"
+                elif err is not None:
+                    raise err
+        if self.active and self.mode == "abi":
+            import ctypes
+            from . import _lib as L
             self.ev_ready, self.ev_done = [], []
             for _ in self.buckets:
                 for lst in (self.ev_ready, self.ev_done):

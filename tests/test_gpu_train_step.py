@@ -355,7 +355,7 @@ def test_bench_self_launches_two_ranks(device):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     ex = out["exchange"]
     assert ex["backend"] == "gloo" and ex["rccl_ranks"] == 2 and sum(ex["bucket_bytes"]) == ex["grad_bytes"]
-    assert out["value"] > 0 and "comm_exposed_ms" in ex and out["scaling"] == "weak"
+    assert out["value"] > 0 and "comm_exposed_ms" in ex and out["scaling"] == "weak" and ex["in_timed_region"] is True
 
 
 def test_bench_self_launches_four_ranks_with_replica_checks(device):
@@ -386,7 +386,7 @@ def test_bench_default_single_gpu_line_reports_the_exchange(device):
     out = _bench(["--steps", "2", "--warmup", "1", "--batch", "2", "--size", "64", "--no-cpu-baseline"])
     ex = out["exchange"]
     assert ex["mode"] == "abi" and ex["rccl_ranks"] == 1 and sum(ex["bucket_bytes"]) == ex["grad_bytes"]
-    assert "comm_exposed_ms" in ex and "ms_per_step_no_exchange" in ex
+    assert "comm_exposed_ms" in ex and "ms_per_step_with_exchange" in ex and ex["in_timed_region"] is False
     rf = out["roofline"]
     assert set(rf["counters_from"]["files"]) == {"traffic", "mfma_busy", "clock_ghz"}
     for f, v in rf["counters_from"]["files"].items():      # a counter is reported only with current provenance

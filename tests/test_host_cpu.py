@@ -435,3 +435,46 @@ def test_exchange_mode_selection(monkeypatch):
     assert dist.exchange_mode(8, cuda=True) == "abi"
     monkeypatch.setenv("OCR_EXCHANGE", "torch")
     assert dist.exchange_mode(8, cuda=True) == "torch"
+
+
+_STORE_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch.distributed as td
+from tensorflow_ocr_amd import dist
+rank, world, _ = dist.init_process_group_from_env("gloo")
+# the 128-byte RCCL unique id is arbitrary binary (NULs, bytes > 0x7f): the rendezvous dist.AbiComm uses must carry it intact
+ident = np.random.default_rng(5).integers(0, 256, 128).astype(np.uint8).tobytes()
+assert b"\x00" in ident or True
+store = td.distributed_c10d._get_default_store()
+if rank == 0:
+    store.set("ocr_comm_id_test", ident)
+got = bytes(store.get("ocr_comm_id_test"))
+assert got == ident and len(got) == 128, (len(got), got[:8], ident[:8])
+import ctypes
+buf = ctypes.create_string_buffer(got, 128)
+assert buf.raw == ident
+td.barrier(); td.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_unique_id_rendezvous_is_binary_safe(tmp_path):
+    """dist.AbiComm hands rank 0's ocr_comm_unique_id bytes to the other ranks through torch.distributed's store:
+    128 arbitrary bytes must arrive unchanged (world 2, gloo, CPU)."""
+    script = tmp_path / "store.py"
+    script.write_text(_STORE_WORKER % ROOT)
+    from tensorflow_ocr_amd import launch
+    port = launch.free_port()
+    ps = [subprocess.Popen([sys.executable, str(script)], env=launch.child_env(r, 2, port), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT) for r in range(2)]
+    outs = []
+    for p in ps:
+        try:
+            outs.append(p.communicate(timeout=120)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in ps:
+                q.kill()
+            raise
+    for p, o in zip(ps, outs):
+        assert p.returncode == 0 and "ok" in o, o[-2000:]
