@@ -172,6 +172,12 @@ int ocr_conv2d_stem_f16(int n, int h, int w, int cout, const void* x4, const voi
 size_t ocr_conv2d_stem_wgrad_workspace(int n, int h, int w, int cout);
 int ocr_conv2d_stem_wgrad_f16(int n, int h, int w, int cout, const void* x4, const void* dy,
                               void* dw_hwio_f32, void* workspace, size_t ws_bytes, void* stream);
+/* ... and with the root convolution's batch-norm backward apply computed while the dy tile is staged (as
+ * ocr_conv2d_first_wgrad_bn_f16; nets/resnet_v1.py:193): da = gradient of relu(bn(bn_y)), coefficients from
+ * ocr_bn_relu_bwd_reduce_f16. */
+int ocr_conv2d_stem_wgrad_bn_f16(int n, int h, int w, int cout, const void* x4, const void* da, const void* bn_y,
+                                 const void* bn_shift, const void* coef_a, const void* coef_b, const void* coef_c,
+                                 int relu, void* dw, void* workspace, size_t ws_bytes, void* stream);
 
 /* f32 HWIO master weights -> the f16 operand layouts of the MFMA kernels (done once per optimiser
  * step).  w_kc [taps][cout][cin] feeds ocr_conv2d_f16 forward; w_ck [taps][cin][cout] (a plain
@@ -253,6 +259,13 @@ int ocr_bn_bwd_coefficients(const void* partial, int T, int c, double count, con
                             const void* save_mean, const void* save_invstd, void* dgamma, void* dbeta,
                             void* coef_a, void* coef_b, void* coef_c, void* workspace, size_t ws_bytes,
                             void* stream);
+/* The reduction pass of ocr_bn_relu_bwd_f16 (sum dz, sum dz*xhat over y and da_full) + the same finalize: dgamma, dbeta
+ * and (A, B, C), no apply pass — for layers whose dy has a single reader that applies it on load.  partial:
+ * [ocr_bn_bwd_num_partials(n,h,w,c,0)][2][c] f32 scratch. */
+int ocr_bn_relu_bwd_reduce_f16(const void* y, const void* scale, const void* shift, const void* save_mean,
+                               const void* save_invstd, const void* da_full, int n, int h, int w, int c, int relu,
+                               void* dgamma, void* dbeta, void* coef_a, void* coef_b, void* coef_c, void* partial,
+                               void* workspace, size_t ws_bytes, void* stream);
 int ocr_relu_bwd_f16(const void* out, const void* dout, int64_t n, void* dz, void* stream);
 int ocr_add_inplace_f16(void* a, const void* b, int64_t n, void* stream);
 

@@ -70,6 +70,9 @@ def main(d):
             dur[short(r["Kernel_Name"])][r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     out = {}
     for k, disp in per.items():
+        # the first dispatch of a kernel pays the lazy code-object load (29.9 ms for conv3x3_w4_kernel): left out of the means
+        first = min(disp, key=lambda i: int(i)) if len(disp) > 3 else None
+        disp = {i: c for i, c in disp.items() if i != first}
         rows = [c for c in disp.values() if "GRBM_GUI_ACTIVE" in c and "SQ_WAVE_CYCLES" in c]
         if not rows:
             continue

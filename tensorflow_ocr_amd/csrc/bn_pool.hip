@@ -1069,6 +1069,35 @@ extern "C" int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void*
   return ocr_launch_status();
 }
 
+// The reduction half of ocr_bn_relu_bwd_f16 with the apply step handed to a consumer as coefficients
+// (dy = A*dz + B*y + C): for layers whose dy has a single reader that can apply it on load — the first / root
+// convolutions' weight gradients (ocr_conv2d_first_wgrad_bn_f16, ocr_conv2d_stem_wgrad_bn_f16).
+extern "C" int ocr_bn_relu_bwd_reduce_f16(const void* y, const void* scale, const void* shift, const void* save_mean,
+                                          const void* save_invstd, const void* da_full, int n, int h, int w, int c,
+                                          int relu, void* dgamma, void* dbeta, void* coef_a, void* coef_b, void* coef_c,
+                                          void* partial, void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(y && scale && shift && save_mean && save_invstd && da_full && dgamma && dbeta);
+  OCR_CHECK_ARG(coef_a && coef_b && coef_c && partial && workspace);
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int T = bwd_blocks(n, h, w, c, 0);
+  if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
+  BnBwdP p{n, h, w, c, relu, 0, (float)(1.0 / ((double)n * h * w))};
+  hipLaunchKernelGGL(bn_relu_bwd_kernel<0>, dim3(T), dim3(256), 0, st, p, static_cast<const half_t*>(y),
+                     static_cast<const float*>(scale), static_cast<const float*>(shift),
+                     static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                     (const float*)nullptr, (const float*)nullptr, static_cast<const half_t*>(da_full),
+                     (const half_t*)nullptr, static_cast<float*>(partial), (half_t*)nullptr);
+  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
+  hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFinC>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(), rows,
+                     BnBwdFinC{static_cast<float*>(dgamma), static_cast<float*>(dbeta), static_cast<const float*>(scale),
+                               static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd), p.inv_count,
+                               static_cast<float*>(coef_a), static_cast<float*>(coef_b), static_cast<float*>(coef_c)});
+  return ocr_launch_status();
+}
+
 extern "C" int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k, int stride,
                                int pad_top, int pad_left, int oh, int ow, void* y, void* argmax,
                                void* stream) {

@@ -101,8 +101,18 @@ __device__ __forceinline__ half8_t tr_pair_s(const char* base, int second_off) {
 constexpr int PSTRS = 64;             // bytes per im2col row (32 f16)
 constexpr int DSTRS = 64 * 2 + 64;    // bytes per dy row
 
+// BNAPPLY: as conv_first_wgrad_kernel<true> (conv_first.hip) — the root convolution has no input gradient, its weight
+// gradient is the only reader of dy, so the BN-backward apply dy = A*dz + B*y + C, dz = da * [relu(bn(y)) > 0], is
+// computed while the dy tile is staged and the apply pass (3 x 839 MB at 64 x 640^2) and the dy tensor disappear.
+struct StemBn {
+  const half_t* y;
+  const float *A, *B, *C, *shift;
+  int relu;
+};
+
+template <bool BNAPPLY>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemP p, const half_t* __restrict__ x4,
-                                                              const half_t* __restrict__ dy,
+                                                              const half_t* __restrict__ dy, StemBn bn,
                                                               float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) char halo[SHH * SHW * 8];
   __shared__ __attribute__((aligned(16))) char patch[256 * PSTRS];
@@ -119,6 +129,14 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemP p, const hal
     for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
   const int a_lane = (8 * hh + q) * PSTRS + (16 * gc + 4 * pp) * 2;
   const int b_lane = (8 * hh + q) * DSTRS + (cow * 32 + 16 * gc + 4 * pp) * 2;
+  float cA[8], cB[8], cC[8], cS[8];
+  if (BNAPPLY) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cc = co0 + (tid & 7) * 8 + e;         // this thread's 16-byte chunk of every staged row
+      cA[e] = bn.A[cc]; cB[e] = bn.B[cc]; cC[e] = bn.C[cc]; cS[e] = bn.shift[cc];
+    }
+  }
 
   for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
     const int txi = mt % p.tiles_x;
@@ -133,8 +151,23 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemP p, const hal
       const int px = idx >> 3, c = idx & 7;
       const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (oy < p.oh && ox < p.ow)
-        v = *reinterpret_cast<const u32x4*>(dy + (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8);
+      if (oy < p.oh && ox < p.ow) {
+        const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8;
+        v = *reinterpret_cast<const u32x4*>(dy + off);
+        if (BNAPPLY) {
+          const half8_t g8 = __builtin_bit_cast(half8_t, v);
+          const half8_t y8 = *reinterpret_cast<const half8_t*>(bn.y + off);
+          half8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float yf = (float)y8[e];
+            const bool pass = !bn.relu || __builtin_fmaf(yf, cA[e], cS[e]) > OCR_RELU_TIE;
+            const float dz = pass ? (float)g8[e] : 0.f;
+            o[e] = (half_t)__builtin_fmaf(cA[e], dz, __builtin_fmaf(cB[e], yf, cC[e]));
+          }
+          v = __builtin_bit_cast(u32x4, o);
+        }
+      }
       *reinterpret_cast<u32x4*>(dyt + px * DSTRS + c * 16) = v;
     }
 #pragma unroll
@@ -241,9 +274,30 @@ extern "C" int ocr_conv2d_stem_wgrad_f16(int n, int h, int w, int cout, const vo
   if (ws_bytes < ocr_conv2d_stem_wgrad_workspace(n, h, w, cout)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int blocks = stem_blocks(p.m_tiles);
-  hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(blocks, cout / 64), dim3(256), 0, st, p,
-                     static_cast<const half_t*>(x4), static_cast<const half_t*>(dy),
+  hipLaunchKernelGGL(conv_stem_wgrad_kernel<false>, dim3(blocks, cout / 64), dim3(256), 0, st, p,
+                     static_cast<const half_t*>(x4), static_cast<const half_t*>(dy), StemBn{},
                      static_cast<float*>(workspace));
+  const int elems = 147 * cout;
+  hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(elems)), dim3(256), 0, st,
+                     static_cast<const float*>(workspace), static_cast<float*>(dw), elems, blocks * 2, 1.f);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_conv2d_stem_wgrad_bn_f16(int n, int h, int w, int cout, const void* x4, const void* da,
+                                            const void* bn_y, const void* bn_shift, const void* coef_a,
+                                            const void* coef_b, const void* coef_c, int relu, void* dw,
+                                            void* workspace, size_t ws_bytes, void* stream) {
+  StemP p;
+  int rc = fill(&p, n, h, w, cout, 0);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x4 && da && bn_y && bn_shift && coef_a && coef_b && coef_c && dw && workspace);
+  if (ws_bytes < ocr_conv2d_stem_wgrad_workspace(n, h, w, cout)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int blocks = stem_blocks(p.m_tiles);
+  StemBn bn{static_cast<const half_t*>(bn_y), static_cast<const float*>(coef_a), static_cast<const float*>(coef_b),
+            static_cast<const float*>(coef_c), static_cast<const float*>(bn_shift), relu};
+  hipLaunchKernelGGL(conv_stem_wgrad_kernel<true>, dim3(blocks, cout / 64), dim3(256), 0, st, p,
+                     static_cast<const half_t*>(x4), static_cast<const half_t*>(da), bn, static_cast<float*>(workspace));
   const int elems = 147 * cout;
   hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(elems)), dim3(256), 0, st,
                      static_cast<const float*>(workspace), static_cast<float*>(dw), elems, blocks * 2, 1.f);

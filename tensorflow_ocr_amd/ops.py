@@ -245,6 +245,28 @@ def conv2d_stem_wgrad(x4, dy, dw, ws):
            ptr(buf), c_size_t(nbytes), _st())
 
 
+def conv2d_stem_wgrad_bn(x4, da, y, shift, coef, relu, dw, ws):
+    """The root convolution's weight gradient with its BN-backward apply computed on load (coef: bn_relu_bwd_reduce)."""
+    n, h, w, _ = x4.shape
+    cout = da.shape[-1]
+    nbytes = L.call_size("ocr_conv2d_stem_wgrad_workspace", c_int(n), c_int(h), c_int(w), c_int(cout))
+    buf = ws.get(nbytes)
+    a, b, c = coef
+    L.call("ocr_conv2d_stem_wgrad_bn_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(da), ptr(y),
+           ptr(shift), ptr(a), ptr(b), ptr(c), c_int(int(relu)), ptr(dw), ptr(buf), c_size_t(nbytes), _st())
+
+
+def bn_relu_bwd_reduce(y, scale, shift, save_mean, save_invstd, da_full, relu, dgamma, dbeta, coef, ws):
+    """Reduction + finalize of the BN backward, the apply step returned as coefficients (dy = A*dz + B*y + C)."""
+    n, h, w, c = y.shape
+    T = bn_bwd_num_partials(y.shape, 0)
+    part, stage = ws.two(T * 2 * c * 4, bn_reduce_workspace(T, c))
+    a, b, cc = coef
+    L.call("ocr_bn_relu_bwd_reduce_f16", ptr(y), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(da_full),
+           c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(dgamma), ptr(dbeta), ptr(a), ptr(b), ptr(cc),
+           ptr(part), ptr(stage), c_size_t(stage.numel()), _st())
+
+
 def pack_weights_stem(w_hwio, w_stem):
     L.call("ocr_pack_weights_stem_f16", ptr(w_hwio), c_int(w_hwio.shape[-1]), ptr(w_stem), _st())
 

@@ -21,6 +21,7 @@ FUSE_SUB = __import__("os").environ.get("OCR_RESNET_FUSE_SUB", "1") == "1"     #
 # round 3: the element-wise passes around the 1x1 convolutions applied while those convolutions load their operand
 FUSE_FWD = __import__("os").environ.get("OCR_RESNET_FUSE_FWD", "1") == "1"     # relu(bn(conv3) + shortcut) inside the NEXT 1x1 conv
 FUSE_BWD = __import__("os").environ.get("OCR_RESNET_FUSE_BWD", "1") == "1"     # conv3's BN-backward apply inside its input-gradient conv
+FUSE_ROOT_WGRAD = __import__("os").environ.get("OCR_RESNET_FUSE_ROOT_WGRAD", "1") == "1"   # root conv: BN-backward apply inside its weight gradient
 MASK_BITS = __import__("os").environ.get("OCR_RESNET_MASK_BITS", "0") == "1"   # tail mask as bits instead of the output tensor: measured SLOWER (byte stores +8 % on the writers, byte loads no faster in the latency-bound tail epilogue), off
 
 
@@ -271,9 +272,15 @@ def root_block(g, x4, scope="conv1", cout=64, is_training=True):
     def backward():
         if a.grad is None:
             return
-        dy = g.empty(y.shape)
-        ops.bn_relu_bwd(y, scale, shift, mean, invstd, a.grad, None, True, 0, gamma.grad, beta.grad, dy, ws)
-        ops.conv2d_stem_wgrad(x4.data, dy, wv.grad, ws)
+        if FUSE_ROOT_WGRAD:
+            # no input gradient: the weight gradient is the only reader of dy and applies the BN backward on load
+            coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
+            ops.bn_relu_bwd_reduce(y, scale, shift, mean, invstd, a.grad, True, gamma.grad, beta.grad, coef, ws)
+            ops.conv2d_stem_wgrad_bn(x4.data, a.grad, y, shift, coef, True, wv.grad, ws)
+        else:
+            dy = g.empty(y.shape)
+            ops.bn_relu_bwd(y, scale, shift, mean, invstd, a.grad, None, True, 0, gamma.grad, beta.grad, dy, ws)
+            ops.conv2d_stem_wgrad(x4.data, dy, wv.grad, ws)
         a.grad = None
     g.record(backward, (wv, gamma, beta))
     return a

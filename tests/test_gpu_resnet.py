@@ -53,6 +53,25 @@ def test_root_block(device):
     assert np.abs(a.data.float().cpu().numpy() - o.detach().numpy()).max() < 4e-3 * TOL
     assert _rel(g.store.vars["conv1/weights"].grad.cpu().numpy(), tp["conv1/weights"].grad.numpy()) < 1e-2 * TOL
     assert _rel(g.store.vars["conv1/BatchNorm/gamma"].grad.cpu().numpy(), tp["conv1/BatchNorm/gamma"].grad.numpy()) < 5e-3 * TOL
+    # round 3: the weight gradient applied the BN backward while staging dy (ocr_conv2d_stem_wgrad_bn_f16); the two-pass
+    # form gives the same numbers up to the grouping of the f32 operations, and the same dgamma / dbeta bit for bit
+    assert resnet_layers.FUSE_ROOT_WGRAD
+    fused = {k: v.grad.cpu().numpy().copy() for k, v in g.store.vars.items() if v.trainable}
+    resnet_layers.FUSE_ROOT_WGRAD = False
+    try:
+        g2 = Graph(device, loss_scale=1.0)
+        x42 = layers.prep_images(g2, torch.from_numpy(img).to(device))
+        resnet_layers.root_block(g2, x42)
+        g2.reset_tape()
+        g2.store.load_state_dict(p)
+        a2 = resnet_layers.root_block(g2, x42)
+        a2.grad = torch.from_numpy(gout).to(O.STORAGE).to(device)
+        g2.backward()
+        torch.cuda.synchronize()
+    finally:
+        resnet_layers.FUSE_ROOT_WGRAD = True
+    assert _rel(fused["conv1/weights"], g2.store.vars["conv1/weights"].grad.cpu().numpy()) < 2e-3 * TOL
+    assert np.array_equal(fused["conv1/BatchNorm/gamma"], g2.store.vars["conv1/BatchNorm/gamma"].grad.cpu().numpy())
 
 
 @pytest.mark.parametrize("cin,depth,db,stride,hw", [
