@@ -304,6 +304,12 @@ int ocr_bn_relu_pool_bwd_idx_f16(const void* y, const void* scale, const void* s
  * routing); the backward pass takes either it (no re-scan of x) or x itself. */
 int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k, int stride, int pad_top,
                     int pad_left, int oh, int ow, void* y, void* argmax, void* stream);
+/* The same pool over relu(bn_y*scale + shift) (each element rounded to 16 bits as ocr_bn_relu_f16 stores it), read
+ * from the RAW conv output: the activation is never written when the pool is its only reader (ResNet root,
+ * nets/resnet_v1.py:193-194). */
+int ocr_bn_relu_maxpool_f16(const void* bn_y, const void* scale, const void* shift, int relu, int n, int h, int w,
+                            int c, int k, int stride, int pad_top, int pad_left, int oh, int ow, void* y,
+                            void* argmax, void* stream);
 int ocr_maxpool_bwd_f16(const void* x, const void* argmax, const void* dy, int n, int h, int w, int c,
                         int k, int stride, int pad_top, int pad_left, int oh, int ow, void* dx,
                         int accumulate, void* stream);

@@ -782,7 +782,12 @@ struct PoolP {
   int n, h, w, c, oh, ow, k, stride, pt, pl;
 };
 
-__global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, half_t* __restrict__ y,
+// BN: x is a RAW conv output and every window element is relu(x*scale + shift) rounded to 16 bits first — what
+// bn_relu_kernel would have stored (same expression, bn_act8) — so that activation is never written when the pool is its
+// only reader (ResNet root: conv1 -> BN -> ReLU -> 3x3/2 max-pool, nets/resnet_v1.py:193-194).
+template <bool BN>
+__global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, int relu, half_t* __restrict__ y,
                                    unsigned char* __restrict__ argmax) {
   const int chunks = p.c >> 3;
   const size_t total = (size_t)p.n * p.oh * p.ow * chunks;
@@ -793,6 +798,11 @@ __global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, half_t
     u /= p.ow;
     const int oy = (int)(u % p.oh);
     const int img = (int)(u / p.oh);
+    float sc[8], sh[8];
+    if (BN) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = scale[ch * 8 + e]; sh[e] = shift[ch * 8 + e]; }
+    }
     float m[8];
     unsigned long long am = 0xffffffffffffffffull;   // byte e = window position of the FIRST maximum
 #pragma unroll
@@ -803,6 +813,13 @@ __global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, half_t
         if (iy < 0 || iy >= p.h || ix < 0 || ix >= p.w) continue;
         half8_t v = *reinterpret_cast<const half8_t*>(
             x + (((size_t)img * p.h + iy) * p.w + ix) * p.c + ch * 8);
+        if (BN) {
+          float f[8];
+          if (relu) bn_act8<true>(v, sc, sh, f);
+          else bn_act8<false>(v, sc, sh, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)f[e];
+        }
         const unsigned long long pos = (unsigned long long)(ky * p.k + kx);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -1105,8 +1122,22 @@ extern "C" int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k,
   OCR_CHECK_SHAPE(c % 8 == 0);
   PoolP p{n, h, w, c, oh, ow, k, stride, pad_top, pad_left};
   const size_t total = (size_t)n * oh * ow * (c / 8);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x),
+  hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(stream_grid(total)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x), (const float*)nullptr,
+                     (const float*)nullptr, 0, static_cast<half_t*>(y), static_cast<unsigned char*>(argmax));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_relu_maxpool_f16(const void* bn_y, const void* scale, const void* shift, int relu, int n, int h,
+                                       int w, int c, int k, int stride, int pad_top, int pad_left, int oh, int ow,
+                                       void* y, void* argmax, void* stream) {
+  OCR_CHECK_ARG(bn_y && scale && shift && y && n > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0 && k * k <= 255);
+  OCR_CHECK_SHAPE(c % 8 == 0);
+  PoolP p{n, h, w, c, oh, ow, k, stride, pad_top, pad_left};
+  const size_t total = (size_t)n * oh * ow * (c / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(stream_grid(total)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(bn_y),
+                     static_cast<const float*>(scale), static_cast<const float*>(shift), relu,
                      static_cast<half_t*>(y), static_cast<unsigned char*>(argmax));
   return ocr_launch_status();
 }

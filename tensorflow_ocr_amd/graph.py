@@ -158,7 +158,7 @@ class Act:
     element-wise pass first, so consumers that know nothing about this stay correct."""
 
     __slots__ = ("_data", "grad", "requires_grad", "name", "bn_ctx", "bn_partial", "tail_ctx", "tail_partial",
-                 "pending", "sub_grad", "deferred", "tail_fwd", "pending_owner", "consumed")
+                 "pending", "sub_grad", "deferred", "tail_fwd", "pending_owner", "consumed", "bn_fwd")
 
     def __init__(self, data, requires_grad=True, name=""):
         self._data = data
@@ -178,6 +178,7 @@ class Act:
         self.consumed = False     # a convolution has read it already (tail fusion must then stay off: build order)
         self.sub_grad = None      # gradient of this output's stride-2 subsample, waiting for the fused tail conv
         self.deferred = None      # callable that fills _data (the plain pass), while nobody has computed it yet
+        self.bn_fwd = None        # (y, scale, shift, relu): a deferred relu(bn(y)) a fusing consumer (max-pool) can evaluate itself
         self.tail_fwd = None      # (y3, scale, shift, shortcut tensor, sc_scale, sc_shift, bits): what a fusing consumer needs
 
     @property

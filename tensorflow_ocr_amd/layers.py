@@ -231,7 +231,14 @@ def max_pool2d(g, x, k, stride, scope="pool"):
     y = g.empty((n, oh, ow, c))
     # index of the first maximum per window (TF gradient routing), kept for the backward pass
     argmax = g.empty((n, oh, ow, c), torch.uint8) if x.requires_grad else None
-    ops.maxpool(x.data, k, stride, (pt, pl), y, argmax)
+    fwd = getattr(x, "bn_fwd", None)
+    if x.deferred is not None and fwd is not None:
+        # x = relu(bn(y)) that nobody has computed yet (resnet_layers.root_block): the pool evaluates it per window
+        # element from the raw conv output and x stays unwritten unless somebody else asks for x.data
+        by, bsc, bsh, brelu = fwd
+        ops.bn_relu_maxpool(by, bsc, bsh, brelu, k, stride, (pt, pl), y, argmax)
+    else:
+        ops.maxpool(x.data, k, stride, (pt, pl), y, argmax)
     out = Act(y, name=scope)
 
     def backward():
@@ -240,7 +247,9 @@ def max_pool2d(g, x, k, stride, scope="pool"):
         acc = x.grad is not None
         if not acc:
             x.grad = g.empty(x.shape)
-        ops.maxpool_bwd(x.data, out.grad, k, stride, (pt, pl), x.grad, acc, argmax=argmax, in_shape=x.shape)
+        # (with the forward's index tensor the backward never reads x: do not force a deferred x into existence)
+        ops.maxpool_bwd(x._data if argmax is not None else x.data, out.grad, k, stride, (pt, pl), x.grad, acc,
+                        argmax=argmax, in_shape=x.shape)
         out.grad = None
     g.record(backward)
     return out

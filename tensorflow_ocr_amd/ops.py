@@ -452,6 +452,14 @@ def maxpool(x, k, stride, pad, y, argmax=None):
            c_int(pad[0]), c_int(pad[1]), c_int(oh), c_int(ow), ptr(y), ptr(argmax), _st())
 
 
+def bn_relu_maxpool(bn_y, scale, shift, relu, k, stride, pad, y, argmax=None):
+    """max-pool over relu(bn(bn_y)) computed on the fly from the raw conv output."""
+    n, h, w, c = bn_y.shape
+    _, oh, ow, _ = y.shape
+    L.call("ocr_bn_relu_maxpool_f16", ptr(bn_y), ptr(scale), ptr(shift), c_int(int(relu)), c_int(n), c_int(h), c_int(w),
+           c_int(c), c_int(k), c_int(stride), c_int(pad[0]), c_int(pad[1]), c_int(oh), c_int(ow), ptr(y), ptr(argmax), _st())
+
+
 def maxpool_bwd(x, dy, k, stride, pad, dx, accumulate, argmax=None, in_shape=None):
     """Either `x` (arg-max re-derived) or the forward pass's `argmax` index tensor."""
     n, h, w, c = in_shape if in_shape is not None else x.shape

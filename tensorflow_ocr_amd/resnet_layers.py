@@ -21,6 +21,7 @@ FUSE_SUB = __import__("os").environ.get("OCR_RESNET_FUSE_SUB", "1") == "1"     #
 # round 3: the element-wise passes around the 1x1 convolutions applied while those convolutions load their operand
 FUSE_FWD = __import__("os").environ.get("OCR_RESNET_FUSE_FWD", "1") == "1"     # relu(bn(conv3) + shortcut) inside the NEXT 1x1 conv
 FUSE_BWD = __import__("os").environ.get("OCR_RESNET_FUSE_BWD", "1") == "1"     # conv3's BN-backward apply inside its input-gradient conv
+FUSE_ROOT_POOL = __import__("os").environ.get("OCR_RESNET_FUSE_ROOT_POOL", "1") == "1"   # root conv: BN + ReLU inside the max-pool that follows
 FUSE_ROOT_WGRAD = __import__("os").environ.get("OCR_RESNET_FUSE_ROOT_WGRAD", "1") == "1"   # root conv: BN-backward apply inside its weight gradient
 MASK_BITS = __import__("os").environ.get("OCR_RESNET_MASK_BITS", "0") == "1"   # tail mask as bits instead of the output tensor: measured SLOWER (byte stores +8 % on the writers, byte loads no faster in the latency-bound tail epilogue), off
 
@@ -267,7 +268,16 @@ def root_block(g, x4, scope="conv1", cout=64, is_training=True):
     else:
         ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
     a = Act(g.empty(y.shape), name=scope)
-    ops.bn_relu(y, scale, shift, True, 0, a.data, None)
+
+    def fill():
+        ops.bn_relu(y, scale, shift, True, 0, a._data, None)
+    if is_training and FUSE_ROOT_POOL:
+        # the 3x3/2 max-pool that follows (nets/resnet_v1.py:194) is the activation's only reader: it evaluates
+        # relu(bn(y)) per window element (layers.max_pool2d) and the 64-channel half-resolution activation is never written
+        a.deferred = fill
+        a.bn_fwd = (y, scale, shift, True)
+    else:
+        fill()
 
     def backward():
         if a.grad is None:

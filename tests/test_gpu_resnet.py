@@ -372,3 +372,63 @@ def test_block_output_with_a_foreign_consumer(device):
         if k.startswith("a/") and k.endswith(("weights", "gamma", "beta")):
             r = _rel2(g.store.vars[k].grad.cpu().numpy(), tp[k].grad.numpy())
             assert r < 4e-2 * TOL, (k, r)
+
+
+@pytest.mark.parametrize("n,h,w,c,k,stride", [(2, 37, 50, 64, 3, 2), (1, 16, 16, 128, 3, 1), (2, 9, 12, 64, 2, 2)])
+def test_bn_relu_maxpool_equals_the_two_pass_form(device, n, h, w, c, k, stride):
+    """ocr_bn_relu_maxpool_f16 (ResNet root: the 3x3/2 max-pool evaluates relu(bn(y)) per window element from the raw conv
+    output) against ocr_bn_relu_f16 followed by ocr_maxpool_f16: pooled values AND first-max indices bit for bit."""
+    from tensorflow_ocr_amd import ops
+    rng = np.random.default_rng(h * w)
+    y = torch.from_numpy(np.round(rng.standard_normal((n, h, w, c)) * 4) / 4).to(O.STORAGE).to(device)      # many ties
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).to(device)
+    shift = torch.from_numpy(rng.normal(0, 0.3, c).astype(np.float32)).to(device)
+    oh, pt = ops.same_pad(h, k, stride)
+    ow, pl = ops.same_pad(w, k, stride)
+    a = torch.empty_like(y)
+    ops.bn_relu(y, scale, shift, True, 0, a, None)
+    p_ref = torch.empty((n, oh, ow, c), dtype=O.STORAGE, device=device)
+    i_ref = torch.zeros((n, oh, ow, c), dtype=torch.uint8, device=device)
+    ops.maxpool(a, k, stride, (pt, pl), p_ref, i_ref)
+    p = torch.empty_like(p_ref)
+    i = torch.zeros_like(i_ref)
+    ops.bn_relu_maxpool(y, scale, shift, True, k, stride, (pt, pl), p, i)
+    torch.cuda.synchronize()
+    assert torch.equal(p, p_ref) and torch.equal(i, i_ref)
+
+
+def test_root_block_and_pool_deferred_activation(device):
+    """root_block + max_pool2d as resnet_v1 chains them: with the activation deferred into the pool the pooled output and
+    every gradient equal the run that materialises it (OCR_RESNET_FUSE_ROOT_POOL off), bit for bit."""
+    from tensorflow_ocr_amd import layers, resnet_layers
+    from tensorflow_ocr_amd.graph import Graph
+    rng = np.random.default_rng(3)
+    n, h, w = 2, 44, 60
+    img = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    p = {"conv1/weights": _h(rng.standard_normal((7, 7, 3, 64)) * 0.02)}
+    O._bn_init(p, "conv1", 64)
+
+    def run(fuse):
+        old = resnet_layers.FUSE_ROOT_POOL
+        resnet_layers.FUSE_ROOT_POOL = fuse
+        try:
+            g = Graph(device, loss_scale=1.0)
+            x4 = layers.prep_images(g, torch.from_numpy(img).to(device))
+            layers.max_pool2d(g, resnet_layers.root_block(g, x4), 3, 2)
+            g.reset_tape()
+            g.store.load_state_dict(p)
+            a = resnet_layers.root_block(g, x4)
+            out = layers.max_pool2d(g, a, 3, 2)
+            assert (a.deferred is not None) == fuse          # fused: nobody wrote the activation
+            gout = _h(np.random.default_rng(4).standard_normal(out.shape) * 0.1)
+            out.grad = torch.from_numpy(gout).to(O.STORAGE).to(device)
+            g.backward()
+            torch.cuda.synchronize()
+            return out.data.clone(), {k: v.grad.clone() for k, v in g.store.vars.items() if v.trainable}
+        finally:
+            resnet_layers.FUSE_ROOT_POOL = old
+    of, gf = run(True)
+    ou, gu = run(False)
+    assert torch.equal(of, ou)
+    for k in gf:
+        assert torch.equal(gf[k], gu[k]), k
