@@ -88,10 +88,17 @@ int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap);
 /* Input-gradient convolution fused with the batch-norm BACKWARD reduction of the layer below:
  * y (= gradient w.r.t. that layer's activation) is written as usual and `partial`
  * [ocr_conv2d_num_mtiles][2][cout] receives (sum dz, sum dz*xhat) per tile, dz = y * [relu(bn(bn_y)) > 0],
- * so ocr_bn_relu_bwd_apply_f16 can skip the reduction pass over the two tensors. */
+ * so ocr_bn_relu_bwd_apply_f16 can skip the reduction pass over the two tensors.
+ * store_masked != 0: the STORED value is dz itself (the gradient past the layer's ReLU), not the raw gradient — for
+ * layers without batch norm (PixelLink's VGG: activation = relu(conv + bias), nets/pixellink.py:41-48) pass their
+ * activation as bn_y with scale 1, shift 0, mean 0, invstd 1: y then holds the gradient of (conv + bias) directly,
+ * partial row kind 0 sums to the bias gradient (ocr_bn_bwd_sums) and ocr_bias_relu_bwd_f16's pass disappears. */
 int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y, void* partial,
                          const void* bn_y, const void* bn_scale, const void* bn_shift,
-                         const void* bn_mean, const void* bn_invstd, int bn_relu, void* stream);
+                         const void* bn_mean, const void* bn_invstd, int bn_relu, int store_masked, void* stream);
+/* Column sums of such partial rows [T][2][c] -> out0 (kind 0), out1 (kind 1); fixed order, one launch. */
+int ocr_bn_bwd_sums(const void* partial, int T, int c, void* out0, void* out1, void* workspace, size_t ws_bytes,
+                    void* stream);
 
 /* Input-gradient convolution into the OUTPUT of a ResNet bottleneck, out = relu(shortcut + bn(bn_y))
  * (nets/resnet_v1.py:108-110), as the LAST contribution to that output's gradient (OCR_CONV_ACCUM_F16 adds

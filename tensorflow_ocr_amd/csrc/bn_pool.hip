@@ -1086,6 +1086,21 @@ extern "C" int ocr_bn_relu_bwd_f16(const void* y, const void* scale, const void*
   return ocr_launch_status();
 }
 
+// Column sums of fused-reduction partial rows [T][2][c]: out0[c] = sum of row kind 0 (sum dz: a bias gradient, or
+// dbeta), out1[c] = row kind 1 (sum dz*xhat: dgamma).  The finalize launch of the BN backward on its own.
+extern "C" int ocr_bn_bwd_sums(const void* partial, int T, int c, void* out0, void* out1, void* workspace,
+                               size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(partial && out0 && out1 && workspace && T > 0 && c > 0);
+  if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
+  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
+  hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFin>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(partial),
+                     static_cast<double*>(workspace), T, c, bn_ticket_slot(), rows,
+                     BnBwdFin{static_cast<float*>(out1), static_cast<float*>(out0)});
+  return ocr_launch_status();
+}
+
 // The reduction half of ocr_bn_relu_bwd_f16 with the apply step handed to a consumer as coefficients
 // (dy = A*dz + B*y + C): for layers whose dy has a single reader that can apply it on load — the first / root
 // convolutions' weight gradients (ocr_conv2d_first_wgrad_bn_f16, ocr_conv2d_stem_wgrad_bn_f16).

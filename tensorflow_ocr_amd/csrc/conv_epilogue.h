@@ -32,6 +32,10 @@ struct BnRed {
   // tail mode, instead of `mask`: the ReLU mask as BITS, one byte per 8 channels (bit e = out[.. + e] > 0), written
   // by the kernel that produced the output (bn_add_relu_kernel / conv_pwx_kernel): 1/16 of the bytes of `out`
   const unsigned char* mask_bits;
+  // plain (non-tail) mode with relu: STORE dz = value * [relu(bn(y)) > 0] instead of the value — for layers whose
+  // activation is relu(conv + bias) (scale 1, shift 0: y IS the activation) there is no BN-backward pass that could
+  // apply the mask later, and partial row 0 (sum dz) is their bias gradient (PixelLink's VGG, nets/pixellink.py:41-48)
+  int store_dz;
 };
 
 // LDS needed by the epilogue for a BN-wide tile.
@@ -136,6 +140,10 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
         } else if (tail) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = (float)mk[u][e] > 0.f ? w[e] : (half_t)0.f;
+        } else if (remask && br->store_dz) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (!((float)yv[u][e] * bsc[e] + bsh[e] > OCR_RELU_TIE)) w[e] = (half_t)0.f;
         }
         *reinterpret_cast<half8_t*>(y + off) = w;
         if (do_stats) {
@@ -195,6 +203,11 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
           const half8_t mk = *reinterpret_cast<const half8_t*>(br->mask + off);
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = (float)mk[e] > 0.f ? w[e] : (half_t)0.f;
+        } else if (remask && br->store_dz) {
+          const half8_t yv0 = *reinterpret_cast<const half8_t*>(br->y + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (!((float)yv0[e] * bsc[e] + bsh[e] > OCR_RELU_TIE)) w[e] = (half_t)0.f;
         }
         *reinterpret_cast<half8_t*>(y + off) = w;
         if (do_stats) {

@@ -937,6 +937,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[2][8], bsh[2][8];
     const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;   // no ReLU: every element passes
+    const bool sdz = has_br && p.br.store_dz != 0;
     if (has_br) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
@@ -1014,6 +1015,11 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
             if (accum) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
+            }
+            if (sdz) {                                // store the gradient PAST the ReLU (BnRed::store_dz)
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (!((float)yq[it % PF][k][e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
             }
             *reinterpret_cast<half8_t*>(y + off) = v;
             if (do_stats) {
@@ -1290,6 +1296,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[NW][8], bsh[NW][8];
     const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;   // no ReLU: every element passes
+    const bool sdz = has_br && p.br.store_dz != 0;
     if (has_br) {
 #pragma unroll
       for (int hf = 0; hf < NW; ++hf)
@@ -1364,6 +1371,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
             if (accum) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
+            }
+            if (sdz) {                                // store the gradient PAST the ReLU (BnRed::store_dz)
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (!((float)yq[it % PF][k][e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
             }
             *reinterpret_cast<half8_t*>(y + off) = v;
             if (do_stats) {
@@ -1544,6 +1556,7 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   const int c8 = lane & 7, pg = lane >> 3;
   float s[8], q2[8], bsc[8], bsh[8];
   const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;
+  const bool sdz = has_br && p.br.store_dz != 0;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     s[e] = 0.f;
@@ -1666,6 +1679,11 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
         if (accum) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[kk][e]);
+        }
+        if (sdz) {                                    // store the gradient PAST the ReLU (BnRed::store_dz)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (!((float)yq[kk][e] * bsc[e] + bsh[e] > relu_thr)) v[e] = (half_t)0.f;
         }
         if ((C64_ABL & 2) == 0 || v[0] == (half_t)12345.f) *reinterpret_cast<half8_t*>(y + off) = v;
         if (do_stats) {
@@ -2104,7 +2122,7 @@ extern "C" int ocr_conv2d_f16(const ocr_conv_desc* d, const void* x, const void*
 extern "C" int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y,
                                     void* partial, const void* bn_y, const void* bn_scale,
                                     const void* bn_shift, const void* bn_mean, const void* bn_invstd,
-                                    int bn_relu, void* stream) {
+                                    int bn_relu, int store_masked, void* stream) {
   ConvP p;
   TileCfg cfg;
   int rc = fill_params(d, &p, &cfg);
@@ -2115,6 +2133,7 @@ extern "C" int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const
   p.br = BnRed{static_cast<const half_t*>(bn_y), static_cast<const float*>(bn_scale),
                static_cast<const float*>(bn_shift), static_cast<const float*>(bn_mean),
                static_cast<const float*>(bn_invstd), bn_relu};
+  p.br.store_dz = store_masked;
   return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }
 

@@ -158,7 +158,8 @@ class Act:
     element-wise pass first, so consumers that know nothing about this stay correct."""
 
     __slots__ = ("_data", "grad", "requires_grad", "name", "bn_ctx", "bn_partial", "tail_ctx", "tail_partial",
-                 "pending", "sub_grad", "deferred", "tail_fwd", "pending_owner", "consumed", "bn_fwd")
+                 "pending", "sub_grad", "deferred", "tail_fwd", "pending_owner", "consumed", "bn_fwd", "bias_ctx",
+                 "bias_partial", "sole_consumer")
 
     def __init__(self, data, requires_grad=True, name=""):
         self._data = data
@@ -178,6 +179,9 @@ class Act:
         self.consumed = False     # a convolution has read it already (tail fusion must then stay off: build order)
         self.sub_grad = None      # gradient of this output's stride-2 subsample, waiting for the fused tail conv
         self.deferred = None      # callable that fills _data (the plain pass), while nobody has computed it yet
+        self.bias_ctx = None      # bias + ReLU producers: bn_ctx-shaped tuple (activation, 1, 0, 0, 1, relu) for the consumer's epilogue
+        self.bias_partial = None  # (partial, T): the consumer stored dz and left the bias-gradient partial sums
+        self.sole_consumer = False  # set by the NET for activations read by exactly one convolution (nets/vgg.py)
         self.bn_fwd = None        # (y, scale, shift, relu): a deferred relu(bn(y)) a fusing consumer (max-pool) can evaluate itself
         self.tail_fwd = None      # (y3, scale, shift, shortcut tensor, sc_scale, sc_shift, bits): what a fusing consumer needs
 

@@ -43,6 +43,19 @@ def _packs(g, w, first):
     return g.packed(w, "kc_ck", mk)
 
 
+FUSE_BIAS_RELU = __import__("os").environ.get("OCR_FUSE_BIAS_RELU", "1") == "1"   # bias nets: ReLU mask + bias gradient in the consumer's dgrad epilogue
+
+
+def _const_vec(g, n, value):
+    """A cached per-graph constant f32 vector (filled once, outside any recorded step)."""
+    cache = g.__dict__.setdefault("_const_vecs", {})
+    t = cache.get((n, value))
+    if t is None:
+        t = cache[(n, value)] = torch.full((n,), float(value), dtype=F32, device=g.device)
+    return t
+
+
+FUSE_BN_W4_MAXHW = int(__import__("os").environ.get("OCR_FUSE_BN_W4_MAXHW", "1000000"))
 FUSE_FIRST_WGRAD = __import__("os").environ.get("OCR_FUSE_FIRST_WGRAD", "1") == "1"    # measurement switch
 
 
@@ -174,12 +187,25 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         d.flags = flags
         ops.conv2d(d, x.data, w_fwd, y, bias.data, None)
     a_full = Act(y, name=scope)
+    if relu and is_training:
+        # (activation, scale 1, shift 0, mean 0, 1/std 1, relu): lets the ONE convolution that consumes this activation
+        # store the gradient past the ReLU and sum the bias gradient in its input-gradient epilogue (_conv_backward);
+        # used only when the net marks the activation `sole_consumer` (nets/vgg.py)
+        a_full.bias_ctx = (y, _const_vec(g, cout, 1.0), _const_vec(g, cout, 0.0), _const_vec(g, cout, 0.0),
+                           _const_vec(g, cout, 1.0), True)
 
     def backward_bias():
         if a_full.grad is None:
             return
-        dz = g.empty(y.shape)
-        ops.bias_relu_bwd(y, a_full.grad, relu, dz, bias.grad, ws)
+        if a_full.bias_partial is not None:
+            # a_full.grad IS dz already (masked by the consumer's input-gradient kernel); its partial rows sum to dbias
+            part_f, T_f = a_full.bias_partial
+            ops.bn_bwd_sums(part_f, T_f, cout, bias.grad, g.ws_small.get(cout * 4)[:cout * 4].view(F32), ws)
+            dz = a_full.grad
+            a_full.bias_partial = None
+        else:
+            dz = g.empty(y.shape)
+            ops.bias_relu_bwd(y, a_full.grad, relu, dz, bias.grad, ws)
         _conv_backward(g, x, wv, w_dg, d, dz, first)
         a_full.grad = None
     g.record(backward_bias, (wv, bias))
@@ -209,9 +235,21 @@ def _conv_backward(g, x, wv, w_dg, d, dy, first):
     else:
         flags |= CONV_ACCUM_F16
         x.bn_partial = None     # an earlier consumer's fused BN-backward sums no longer cover the full gradient
+        x.bias_partial = None   # ... nor its masked store (backward_bias then masks the whole sum again: idempotent)
     dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1,
                       flags)
-    if x.bn_ctx is not None and not flags and FUSE_BN_REDUCE:
+    if x.bias_ctx is not None and x.sole_consumer and not flags and FUSE_BIAS_RELU:
+        # bias + ReLU producer whose only reader is this convolution: dz and the bias-gradient partial sums come out of
+        # this kernel's epilogue, the producer's bias_relu_bwd pass (read a, read da, write dz) disappears
+        T = ops.conv2d_num_mtiles(dg)
+        partial = g.empty((T, 2, d.cin), F32)
+        ops.conv2d_bnred(dg, dy, w_dg, x.grad, partial, x.bias_ctx, store_masked=True)
+        x.bias_partial = (partial, T)
+        return
+    fuse = x.bn_ctx is not None and not flags and FUSE_BN_REDUCE
+    if fuse and d.h >= FUSE_BN_W4_MAXHW and ops.conv2d_variant(dg) == "conv3x3_w4_kernel":
+        fuse = False        # (measurement switch: the one-wave-per-SIMD kernel cannot overlap its epilogue with anything)
+    if fuse:
         T = ops.conv2d_num_mtiles(dg)
         partial = g.empty((T, 2, d.cin), F32)
         ops.conv2d_bnred(dg, dy, w_dg, x.grad, partial, x.bn_ctx)

@@ -51,6 +51,9 @@ def basenet(inputs, scope='vgg16', *, graph=None, normalizer="bn", is_training=T
                     net = full
                     if last:
                         end_points[name] = full
+                    else:
+                        # conv1_1, conv2_1, conv3_1/2, conv4_1/2, conv5_1/2: not an end point, read only by the next conv
+                        full.sole_consumer = True
     net = layers.max_pool2d(g, net, 3, 1, scope="pool5")
     net, _ = layers.conv2d(g, net, 1024, 3, "fc6", rate=6, **kw)
     end_points['fc6'] = net

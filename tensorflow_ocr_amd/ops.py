@@ -105,11 +105,12 @@ def conv2d(d, x, w_kc, y, bias=None, stats=None):
         L.RECORDER.tag_last(tag)
 
 
-def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx):
-    """Input-gradient conv fused with the BN-backward reduction of the layer below."""
+def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx, store_masked=False):
+    """Input-gradient conv fused with the BN-backward reduction of the layer below.  store_masked: y receives the
+    gradient PAST that layer's ReLU (bias nets: bn_ctx = (activation, ones, zeros, zeros, ones, True))."""
     by, sc, sh, mu, istd, relu = bn_ctx
     L.call("ocr_conv2d_bnred_f16", byref(d), ptr(x), ptr(w_kc), ptr(y), ptr(partial), ptr(by), ptr(sc),
-           ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), _st())
+           ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), c_int(int(store_masked)), _st())
     if L.RECORDER is not None:
         flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
         L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
@@ -148,6 +149,13 @@ def conv2d_pw_bnbwd_bnred(d, dz, y_above, coef, dy_out, w_kc, dx, partial, bn_ct
     if L.RECORDER is not None:
         flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin
         L.RECORDER.tag_last((conv2d_variant(d).replace("conv_pw_kernel", "conv_pwx_kernel"), flops, "dgrad"))
+
+
+def bn_bwd_sums(partial, T, c, out0, out1, ws):
+    """Column sums of fused-reduction partial rows [T][2][c] (kind 0 -> out0, kind 1 -> out1)."""
+    stage = ws.get(bn_reduce_workspace(T, c))
+    L.call("ocr_bn_bwd_sums", ptr(partial), c_int(T), c_int(c), ptr(out0), ptr(out1), ptr(stage),
+           c_size_t(stage.numel()), _st())
 
 
 def bn_bwd_coefficients(partial, T, c, count, scale, save_mean, save_invstd, dgamma, dbeta, coef, ws):
