@@ -197,7 +197,10 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
     def backward_bias():
         if a_full.grad is None:
             return
-        if a_full.bias_partial is not None:
+        if a_full.bias_done:
+            dz = a_full.grad                       # masked and summed on the POOLED tensors (max_pool2d below)
+            a_full.bias_done = False
+        elif a_full.bias_partial is not None:
             # a_full.grad IS dz already (masked by the consumer's input-gradient kernel); its partial rows sum to dbias
             part_f, T_f = a_full.bias_partial
             ops.bn_bwd_sums(part_f, T_f, cout, bias.grad, g.ws_small.get(cout * 4)[:cout * 4].view(F32), ws)
@@ -209,7 +212,7 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         _conv_backward(g, x, wv, w_dg, d, dz, first)
         a_full.grad = None
     g.record(backward_bias, (wv, bias))
-    a_pool = max_pool2d(g, a_full, 2, 2, scope=scope + "/pool") if pool else None
+    a_pool = max_pool2d(g, a_full, 2, 2, scope=scope + "/pool", bias_relu=bias if (relu and is_training) else None) if pool else None
     return a_full, a_pool
 
 
@@ -258,8 +261,12 @@ def _conv_backward(g, x, wv, w_dg, d, dy, first):
         ops.conv2d(dg, dy, w_dg, x.grad, None, None)
 
 
-def max_pool2d(g, x, k, stride, scope="pool"):
-    """slim.max_pool2d(padding='SAME') as a standalone op (pool5 3x3/1, ResNet pool1, subsample)."""
+def max_pool2d(g, x, k, stride, scope="pool", bias_relu=None):
+    """slim.max_pool2d(padding='SAME') as a standalone op (pool5 3x3/1, ResNet pool1, subsample).
+    bias_relu: x = relu(conv + bias) and this is that layer's own pool (`bias_relu` = its bias variable): when the pool
+    is the first to contribute to x's gradient, the ReLU mask and the bias gradient are taken on the POOLED tensors
+    (the window maximum is positive iff the element the gradient is routed to is) and the routed gradient IS dz — the
+    layer's full-resolution bias_relu_bwd pass disappears (PixelLink conv1_2 / conv2_2: 3 GiB and 1.5 GiB per step)."""
     if g.precision == "f32":
         from . import layers_f32
         return layers_f32.max_pool2d(g, x, k, stride, scope)
@@ -281,6 +288,14 @@ def max_pool2d(g, x, k, stride, scope="pool"):
 
     def backward():
         if out.grad is None or not x.requires_grad:
+            return
+        if bias_relu is not None and x.grad is None and argmax is not None and FUSE_BIAS_RELU:
+            dzp = g.empty(out.shape)
+            ops.bias_relu_bwd(out.data, out.grad, True, dzp, bias_relu.grad, g.workspace())
+            x.grad = g.empty(x.shape)
+            ops.maxpool_bwd(x._data, dzp, k, stride, (pt, pl), x.grad, False, argmax=argmax, in_shape=x.shape)
+            x.bias_done = True
+            out.grad = None
             return
         acc = x.grad is not None
         if not acc:
