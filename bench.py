@@ -165,6 +165,13 @@ def main():
     if rc is not None:
         sys.exit(rc)
 
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's five-line version banner when a
+    # communicator comes up, gloo's connection notes): from here on file descriptor 1 points at stderr, and the line
+    # at the end is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from tensorflow_ocr_amd import _lib, dist, ops, synthetic
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.nets import model_vgg_16 as M
@@ -353,7 +360,8 @@ def main():
             out["configs"] = config_legs()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, os.cpu_count() or 1)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if td.is_available() and td.is_initialized():
         td.barrier()
         td.destroy_process_group()

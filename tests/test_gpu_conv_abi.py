@@ -207,6 +207,14 @@ def test_bottleneck_tail_conv_vs_numpy(device, n, h, w, cin, cout, with_sub):
     ctx = (dev(by), torch.from_numpy(mean).to(device), torch.from_numpy(invstd).to(device), dev(out))
     ops.conv2d_bnred_tail(d, dev(x), w_kc, y, part, ctx, dev(sub) if with_sub else None)
     torch.cuda.synchronize()
+    # the same launch with the ReLU mask as BITS (one byte per 8 channels, bit e = out[.. + e] > 0; OCR_RESNET_MASK_BITS=1
+    # path: measured slower and off by default, kept correct): identical stores and partial sums
+    bits = torch.from_numpy(np.packbits((out > 0).reshape(-1, 8), axis=1, bitorder="little").reshape(-1)).to(device)
+    y_b = dev(old).clone()
+    part_b = torch.zeros_like(part)
+    ops.conv2d_bnred_tail(d, dev(x), w_kc, y_b, part_b, ctx + (bits,), dev(sub) if with_sub else None)
+    torch.cuda.synchronize()
+    assert torch.equal(y_b, y) and torch.equal(part_b, part)
     # restatement: 16-bit roundings where the kernel rounds (conv result, + old, + sub)
     conv = _h(x.reshape(-1, cin).astype(np.float64) @ wt.reshape(cin, cout).astype(np.float64)).reshape(n, h, w, cout)
     tot = _h(conv + old)

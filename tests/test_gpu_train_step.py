@@ -341,8 +341,9 @@ def _bench(args, timeout=540):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=timeout)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    # the contract: stdout is the ONE JSON line, nothing else (RCCL / gloo banners go to stderr: bench.py re-points fd 1)
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout.decode()[-2000:]
     return json.loads(lines[0])
 
 
