@@ -89,3 +89,32 @@ def test_reference_dfs_mode_edge_cases(device):
             assert nc[b] == ref.max()
     with pytest.raises(ValueError):
         _decode(g, ps, ls, 0.8, 0.9, 0, "dfs")
+
+
+def test_reference_dfs_mode_at_baseline_map_size(device):
+    """configs[4]'s map size: 256 x 256 (1024^2 input at 1/4), weak asymmetric links, four images — bit-exact against
+    the literal script restatement, and the device time of both modes printed (the directed refinement is one workgroup
+    per image walking rounds of frontier expansions: an exactness mode, not the throughput path)."""
+    import time
+    from tensorflow_ocr_amd.graph import Graph
+    g = Graph(device)
+    ps, ls = _maps(11, 4, 256, 1.5)
+    lab, nc, comps = _decode(g, ps, ls, 0.8, 0.9, 10, "reference_dfs")
+    n_diff = 0
+    for b in range(4):
+        ref = O.link_cc_reference_dfs(ps[b], [ls[d, b] for d in range(8)], 0.8, 0.9, 10)
+        assert np.array_equal(lab[b], ref), (b, int((lab[b] != ref).sum()))
+        assert nc[b] == ref.max()
+        U, _ = O.link_cc_union_fast(ps[b], [ls[d, b] for d in range(8)], 0.8, 0.9, 10)
+        n_diff += int(((ref > 0) != (U > 0)).sum())
+    times = {}
+    for mode in ("union", "reference_dfs"):
+        _decode(g, ps, ls, 0.8, 0.9, 10, mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            _decode(g, ps, ls, 0.8, 0.9, 10, mode)
+        torch.cuda.synchronize()
+        times[mode] = (time.perf_counter() - t0) / 5 * 1e3
+    print("4 x 256^2, %d components, %d pixels differ between the two groupings | union %.3f ms, reference_dfs %.3f ms (incl. H2D of the maps)" % (
+        int(nc.sum()), n_diff, times["union"], times["reference_dfs"]))
