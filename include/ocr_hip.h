@@ -85,6 +85,14 @@ int ocr_conv2d_num_mtiles(const ocr_conv_desc* d);
  * as it appears (mangled) in rocprofv3 kernel traces.  Measurement only. */
 int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap);
 
+/* conv3x3 + bias + ReLU + 2x2/2 max-pool (SAME: windows over an odd edge ignore the missing pixels) in one kernel for
+ * 64 -> 64 channel layers on maps of >= 128 tiles (the persistent 64-channel kernel; OCR_ERR_UNSUPPORTED otherwise):
+ * pooled [n][ceil(oh/2)][ceil(ow/2)][cout] f16 and argmax_u8 (may be NULL; ocr_maxpool_f16's format, position dy*2+dx of
+ * the first maximum) are the ONLY outputs — for bias nets whose full-resolution activation nobody reads
+ * (nets/vgg.py:17-18 under nets/pixellink.py:41-48: conv1_2 -> pool1).  d->flags: OCR_CONV_BIAS | OCR_CONV_RELU. */
+int ocr_conv2d_relu_pool_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, const void* bias, void* pooled,
+                             void* argmax_u8, void* stream);
+
 /* Input-gradient convolution fused with the batch-norm BACKWARD reduction of the layer below:
  * y (= gradient w.r.t. that layer's activation) is written as usual and `partial`
  * [ocr_conv2d_num_mtiles][2][cout] receives (sum dz, sum dz*xhat) per tile, dz = y * [relu(bn(bn_y)) > 0],

@@ -36,6 +36,8 @@ struct ConvP {
   long long npix; // n * oh * ow
   int m16;        // 1: v_mfma_f32_16x16x32_f16 tiles, 0: v_mfma_f32_32x32x16_f16
   BnRed br;       // br.y != nullptr: fused BN-backward reduction (see conv_epilogue.h)
+  half_t* pool_out;          // conv_c64_persist_kernel<64, true>: [n][ceil(oh/2)][ceil(ow/2)][cout] pooled output
+  unsigned char* pool_idx;   // ... and its first-max positions (ocr_maxpool_f16's argmax format), may be null
 };
 
 
@@ -1468,7 +1470,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
 constexpr int C64_NH = 6;                                          // halo DMA rounds of 512 slots (2720 slots used)
 constexpr int C64_LDS = 2 * W4_HBYTES + 9 * 64 * 128;              // 163840 = the whole LDS
 
-template <int BN>
+template <int BN, bool POOL = false>
 __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
@@ -1669,6 +1671,47 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (POOL) {
+      // bias + ReLU layers followed by their 2x2/2 max-pool, the full-resolution activation read by nobody else
+      // (PixelLink's conv1_2: nets/vgg.py:17-18): the two tile rows of a wave pair are staged side by side, so after a
+      // workgroup barrier each lane pools one 2x2 window of 8 channels and ONLY the pooled tile (+ first-max positions,
+      // window order (dy, dx) as ocr_maxpool_f16) leaves the CU — 1/4 of the bytes, and no pooling pass afterwards
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* pair = smem + hb * W4_HBYTES + (wave & ~1) * 4096;
+      const int pp = (wave & 1) * 8 + pg;                     // pooled pixel of the row pair
+      const int oy0 = tyi * TH + (wave & ~1), ox0 = txi * TILE_W + 2 * pp;
+      const int poh = (p.oh + 1) >> 1, pow2 = (p.ow + 1) >> 1;
+      const int poy = oy0 >> 1, pox = ox0 >> 1;
+      if (poy < poh && pox < pow2) {
+        float m[8];
+        unsigned long long am = 0ull;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            if (oy0 + dy < p.oh && ox0 + dx < p.ow) {
+              const int px = 2 * pp + dx;
+              const half8_t v = *reinterpret_cast<const half8_t*>(pair + dy * 4096 + px * 128 + ((c8 ^ (px & 7)) << 4));
+              const unsigned long long pos = (unsigned long long)(dy * 2 + dx);
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if ((float)v[e] > m[e]) {
+                  m[e] = (float)v[e];
+                  am = (am & ~(0xffull << (8 * e))) | (pos << (8 * e));
+                }
+            }
+          }
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
+        const size_t off = (((size_t)img * poh + poy) * pow2 + pox) * p.cout + co0 + c8 * 8;
+        *reinterpret_cast<half8_t*>(p.pool_out + off) = o;
+        if (p.pool_idx != nullptr) *reinterpret_cast<unsigned long long*>(p.pool_idx + off) = am;
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int px = kk * 8 + pg;
@@ -1705,6 +1748,7 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
           }
         }
       }
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own staging reads are done ...
     __builtin_amdgcn_s_barrier();                         // ... and everyone's: the buffer may receive the halo of tile k+2
@@ -1848,9 +1892,10 @@ static int c64_per(const ConvP& p) {
   return per;
 }
 
+template <bool POOL = false>
 static int launch_c64(const ConvP& p0, const void* x, const void* w, const void* bias, void* y, void* stats,
                       hipStream_t st) {
-  auto kern = conv_c64_persist_kernel<64>;
+  auto kern = conv_c64_persist_kernel<64, POOL>;
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1962,6 +2007,8 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
   OCR_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0);
   OCR_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dilation > 0);
   OCR_CHECK_SHAPE(d->cin % 32 == 0 && d->cout % 32 == 0);
+  p->pool_out = nullptr;
+  p->pool_idx = nullptr;
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
   p->kh = d->kh; p->kw = d->kw; p->stride = d->stride; p->dil = d->dilation;
@@ -2097,7 +2144,7 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     case 646408:
       if (conv_c64_ok(p)) {
         if (tail) return OCR_ERR_UNSUPPORTED;      // (ocr_conv2d_num_mtiles sized the partials for launch_c64)
-        return launch_c64(p, x, w_kc, bias, y, stats, st);
+        return launch_c64<false>(p, x, w_kc, bias, y, stats, st);
       }
       return launch<64, 64, 2>(p, x, w_kc, bias, y, stats, st);
     case 643208: return launch<64, 32, 2>(p, x, w_kc, bias, y, stats, st);
@@ -2182,6 +2229,23 @@ extern "C" int ocr_conv2d_pw_bnbwd_bnred_f16(const ocr_conv_desc* d, const void*
         static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), nullptr, static_cast<half_t*>(dy_out),
         nullptr};
   return dispatch_pwx<2>(p, cfg, t, w_kc, dx, partial, static_cast<hipStream_t>(stream));
+}
+
+// conv + bias + ReLU + 2x2/2 max-pool in one kernel for 64 -> 64 channel 3x3 layers (PixelLink's conv1_2 and the same
+// layer at 1024^2 inference): only the pooled activation and its first-max positions are written.
+extern "C" int ocr_conv2d_relu_pool_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, const void* bias,
+                                        void* pooled, void* argmax_u8, void* stream) {
+  ConvP p;
+  TileCfg cfg;
+  int rc = fill_params(d, &p, &cfg);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x && w_kc && pooled);
+  OCR_CHECK_ARG(!(d->flags & OCR_CONV_BIAS) || bias);
+  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_STATS | OCR_CONV_ACCUM_F16)));
+  if (p.pw || cfg.bn != 64 || cfg.ck != 64 || !conv_c64_ok(p)) return OCR_ERR_UNSUPPORTED;
+  p.pool_out = static_cast<half_t*>(pooled);
+  p.pool_idx = static_cast<unsigned char*>(argmax_u8);
+  return launch_c64<true>(p, x, w_kc, bias, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 // q = (P * m) >> (31 + l) == P / d for every P < 2^31 (round-up method: m = ceil(2^(31+l) / d), l = ceil(log2 d))

@@ -43,6 +43,7 @@ def _packs(g, w, first):
     return g.packed(w, "kc_ck", mk)
 
 
+FUSE_BIAS_POOL = __import__("os").environ.get("OCR_FUSE_BIAS_POOL", "1") == "1"   # bias nets: conv1_2's bias + ReLU + pool in the conv epilogue
 FUSE_BIAS_RELU = __import__("os").environ.get("OCR_FUSE_BIAS_RELU", "1") == "1"   # bias nets: ReLU mask + bias gradient in the consumer's dgrad epilogue
 
 
@@ -181,6 +182,31 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
 
     # bias (+ReLU) path: PixelLinkNet's VGG (nets/pixellink.py:41-48)
     flags = CONV_BIAS | (CONV_RELU if relu else 0)
+    if (pool == 2 and relu and not keep_full and not first and FUSE_BIAS_POOL
+            and ops.conv2d_variant(d) == "conv_c64_persist_kernel<64>"):
+        # conv1_2 (64 -> 64 at full resolution) followed by its pool, the full-resolution activation wanted by nobody:
+        # bias + ReLU + 2x2 max-pool inside the convolution's epilogue, only the pooled activation (+ first-max
+        # positions while training) is written — 1/4 of the bytes and no pooling pass
+        ph, pw_ = (oh + 1) // 2, (ow + 1) // 2
+        pooled = g.empty((n, ph, pw_, cout))
+        argmax = g.empty((n, ph, pw_, cout), torch.uint8) if is_training else None
+        d.flags = flags
+        ops.conv2d_relu_pool(d, x.data, w_fwd, bias.data, pooled, argmax)
+        a_pool = Act(pooled, name=scope + "/pool")
+
+        def backward_pool():
+            if a_pool.grad is None:
+                return
+            # ReLU mask and bias gradient on the pooled tensors (a window maximum is positive iff the element its
+            # gradient is routed to is), then the routed gradient IS dz of the convolution
+            dzp = g.empty(pooled.shape)
+            ops.bias_relu_bwd(pooled, a_pool.grad, True, dzp, bias.grad, ws)
+            dz = g.empty((n, oh, ow, cout))
+            ops.maxpool_bwd(None, dzp, 2, 2, (0, 0), dz, False, argmax=argmax, in_shape=(n, oh, ow, cout))
+            _conv_backward(g, x, wv, w_dg, d, dz, first)
+            a_pool.grad = None
+        g.record(backward_pool, (wv, bias))
+        return None, a_pool
     if first:
         ops.conv2d_first(x.data, w_fwd, y, flags, bias.data, None)
     else:

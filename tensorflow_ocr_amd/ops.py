@@ -105,6 +105,22 @@ def conv2d(d, x, w_kc, y, bias=None, stats=None):
         L.RECORDER.tag_last(tag)
 
 
+def conv2d_relu_pool(d, x, w_kc, bias, pooled, argmax=None):
+    """conv3x3 + bias + ReLU + 2x2/2 max-pool in one kernel (64 -> 64 channels): pooled output (+ first-max positions) only."""
+    flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+    tag = (conv2d_variant(d), flops, "fwd")
+    if KERNEL_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.call("ocr_conv2d_relu_pool_f16", byref(d), ptr(x), ptr(w_kc), ptr(bias), ptr(pooled), ptr(argmax), _st())
+        e1.record()
+        KERNEL_TIMING.append(tag + (e0, e1))
+    else:
+        L.call("ocr_conv2d_relu_pool_f16", byref(d), ptr(x), ptr(w_kc), ptr(bias), ptr(pooled), ptr(argmax), _st())
+    if L.RECORDER is not None:
+        L.RECORDER.tag_last(tag)
+
+
 def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx, store_masked=False):
     """Input-gradient conv fused with the BN-backward reduction of the layer below.  store_masked: y receives the
     gradient PAST that layer's ReLU (bias nets: bn_ctx = (activation, ones, zeros, zeros, ones, True))."""

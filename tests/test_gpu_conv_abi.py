@@ -398,3 +398,41 @@ def test_pw_bnbwd_bnred_equals_the_two_pass_form(device, n, h, w, c4, c):
     assert torch.equal(dx, dx_c) and torch.equal(part, part_c)
     dxf, dxr = dx.float().cpu().numpy(), dx_r.float().cpu().numpy()
     assert np.abs(dxf - dxr).max() <= 2 * tol * np.abs(dxr).max()
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 100, 130), (3, 203, 230), (9, 64, 64), (2, 129, 97)])
+def test_conv_relu_pool_equals_the_two_pass_form(device, n, h, w):
+    """ocr_conv2d_relu_pool_f16 (64 -> 64 channel 3x3 conv + bias + ReLU + 2x2/2 max-pool in the persistent kernel's
+    epilogue, only the pooled tile written) against ocr_conv2d_f16 followed by ocr_maxpool_f16: pooled activations and
+    first-max positions bit for bit — even and odd map sizes (SAME pooling ignores the missing row / column), ragged
+    tiles, more images than tiles per image."""
+    from tensorflow_ocr_amd import ops
+    rng = np.random.default_rng(h + w)
+    c = 64
+    x = _h(rng.standard_normal((n, h, w, c)))
+    wt = _h(rng.standard_normal((3, 3, c, c)) * np.sqrt(2.0 / (9 * c)))
+    bias = torch.from_numpy((0.1 * rng.standard_normal(c)).astype(np.float32)).to(device)
+    xd = torch.from_numpy(x).to(O.STORAGE).to(device)
+    w_kc = torch.empty((9, c, c), dtype=O.STORAGE, device=device)
+    w_ck = torch.empty((9, c, c), dtype=O.STORAGE, device=device)
+    ops.pack_weights(torch.from_numpy(wt).to(device), w_kc, w_ck)
+    d = ops.conv_desc((n, h, w, c), c, 3, 3, 1, 1)
+    assert ops.conv2d_variant(d) == "conv_c64_persist_kernel<64>"
+    d.flags = ops.CONV_BIAS | ops.CONV_RELU
+    a = torch.empty((n, h, w, c), dtype=O.STORAGE, device=device)
+    ops.conv2d(d, xd, w_kc, a, bias)
+    ph, pw = (h + 1) // 2, (w + 1) // 2
+    p_ref = torch.empty((n, ph, pw, c), dtype=O.STORAGE, device=device)
+    i_ref = torch.zeros((n, ph, pw, c), dtype=torch.uint8, device=device)
+    ops.maxpool(a, 2, 2, (0, 0), p_ref, i_ref)
+    p = torch.full((n, ph, pw, c), float("nan"), dtype=O.STORAGE, device=device)
+    i = torch.full((n, ph, pw, c), 0xEE, dtype=torch.uint8, device=device)
+    ops.conv2d_relu_pool(d, xd, w_kc, bias, p, i)
+    torch.cuda.synchronize()
+    assert torch.equal(p, p_ref), (int(torch.isnan(p.float()).sum()), int((p != p_ref).sum()))
+    assert torch.equal(i, i_ref), int((i != i_ref).sum())
+    # and without the index tensor (inference)
+    p2 = torch.empty_like(p)
+    ops.conv2d_relu_pool(d, xd, w_kc, bias, p2, None)
+    torch.cuda.synchronize()
+    assert torch.equal(p2, p_ref)
