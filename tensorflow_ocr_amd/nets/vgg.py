@@ -56,7 +56,8 @@ def basenet(inputs, scope='vgg16', *, graph=None, normalizer="bn", is_training=T
                         full.sole_consumer = True
     net = layers.max_pool2d(g, net, 3, 1, scope="pool5")
     net, _ = layers.conv2d(g, net, 1024, 3, "fc6", rate=6, **kw)
-    end_points['fc6'] = net
+    net.sole_consumer = True        # fc7 below; anything else that reads end_points['fc6'] is built later, contributes its
+    end_points['fc6'] = net         # gradient earlier and switches the shortcut off (layers._conv_backward)
     net, _ = layers.conv2d(g, net, 1024, 1, "fc7", **kw)
     end_points['fc7'] = net
     return net, end_points
