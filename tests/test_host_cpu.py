@@ -478,3 +478,54 @@ def test_unique_id_rendezvous_is_binary_safe(tmp_path):
             raise
     for p, o in zip(ps, outs):
         assert p.returncode == 0 and "ok" in o, o[-2000:]
+
+
+def test_steady_stats_script_drops_the_build_steps(tmp_path):
+    """scripts/steady_stats.py: per-kernel statistics from a rocprofv3 kernel trace AFTER the first N steps (a step ends
+    at the optimiser launch), same columns as rocprofv3's own table — the cold first launch of a kernel (lazy code-object
+    load) must not reach the average the roofline is checked against."""
+    import csv
+    d = tmp_path / "prof" / "host"
+    d.mkdir(parents=True)
+    rows, t = [], 1000
+    for step in range(5):
+        for name, dur in (("conv3x3_w4_kernel(...)", 30000000 if step == 0 else 350000), ("bn_relu_kernel<1,0>", 90000),
+                          ("adam_kernel(AdamP)", 120000)):
+            rows.append({"Kernel_Name": name, "Start_Timestamp": t, "End_Timestamp": t + dur, "Dispatch_Id": len(rows) + 1})
+            t += dur + 1000
+    with open(d / "1_kernel_trace.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "steady_stats.py"), str(tmp_path / "prof"),
+                        "--skip-steps", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 0, r.stderr.decode()
+    out = {x["Name"]: x for x in csv.DictReader(r.stdout.decode().splitlines())}
+    assert set(out) == {"conv3x3_w4_kernel(...)", "bn_relu_kernel<1,0>", "adam_kernel(AdamP)"}
+    assert int(out["conv3x3_w4_kernel(...)"]["Calls"]) == 3 and float(out["conv3x3_w4_kernel(...)"]["AverageNs"]) == 350000.0
+    assert b"3 steps" in r.stderr
+    assert abs(sum(float(x["Percentage"]) for x in out.values()) - 100.0) < 1e-3
+
+
+def test_counter_provenance_gates_the_reported_fields(tmp_path, monkeypatch):
+    """bench.counters_from_profiles: a profiler-derived field is reported only while the file's `_provenance.csrc_sha16`
+    equals the fingerprint of the current kernel sources."""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from tensorflow_ocr_amd import _lib
+    now = _lib.csrc_fingerprint()
+    assert len(now) == 16 and now == _lib.csrc_fingerprint()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    dom = "conv3x3_w4_kernel"
+    good = {"_provenance": {"csrc_sha16": now, "date": "d"}, dom: {"hbm_bytes_per_launch": 123, "mfma_busy_frac": 0.5}}
+    (prof / (bench.PROFILE_ROUND + "_pmc_traffic.json")).write_text(json.dumps(good))
+    stale = {"_provenance": {"csrc_sha16": "0" * 16, "date": "d"}, dom: {"mfma_busy_frac": 0.9}}
+    (prof / (bench.PROFILE_ROUND + "_pmc_mfma.json")).write_text(json.dumps(stale))
+    vals, src = bench.counters_from_profiles(dom)
+    assert vals == {"traffic": 123, "mfma_busy": None, "clock_ghz": None}
+    assert src["files"]["traffic"]["current"] and not src["files"]["mfma_busy"]["current"]
+    assert src["files"]["clock_ghz"]["file"] is None and src["csrc_sha16_now"] == now
