@@ -730,6 +730,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
   constexpr int BN = 256, TH = 8, WT = W4_WT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wbuf = smem + 2 * W4_HBYTES;
+  OCR_DIAG_WG_BEGIN()
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1087,6 +1088,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
         stats[((size_t)mt8 * 2 + (i >> 8)) * p.cout + co0 + (i & 255)] = red[i] + red[512 + i];
     }
   }
+  OCR_DIAG_WG_END(ocr_diag_conv)
 }
 
 // ---------------------------------------------------------------------------------------------
