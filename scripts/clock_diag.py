@@ -83,7 +83,19 @@ def run_case(kind, hw, cin, cout, zero):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 100
     med, p10, p90, cyc = clock(reader, slots)
-    return {"kernel": variant, "operands": "zero" if zero else "random", "launch_ms_diag_build": round(ms, 4),
+    wg = None
+    if kind == "conv" and variant == "conv3x3_w4_kernel":
+        # whole-workgroup cycles (kernel entry -> end of wave 0's epilogue instruction stream): tile = main loop + the rest
+        buf = (ctypes.c_ulonglong * slots)()
+        fn = getattr(L.load(), reader + "_wg")
+        fn.restype = ctypes.c_int
+        assert fn(buf, ctypes.c_int(slots)) == 0
+        a = np.frombuffer(buf, dtype=np.uint64).astype(np.float64)
+        wg = float(np.median(a[a > 0]))
+    extra = {} if wg is None else {"workgroup_cycles_median": round(wg), "prologue_epilogue_cycles": round(wg - cyc),
+                                   "prologue_epilogue_share": round((wg - cyc) / wg, 3),
+                                   "prologue_epilogue_us": round((wg - cyc) / (med * 1e3), 2)}
+    return {**extra, "kernel": variant, "operands": "zero" if zero else "random", "launch_ms_diag_build": round(ms, 4),
             "tflops_diag_build": round(flops / ms / 1e9, 1), "clock_ghz_median": round(med, 3), "clock_ghz_p10": round(p10, 3),
             "clock_ghz_p90": round(p90, 3), "main_loop_cycles_median": round(cyc)}
 
