@@ -86,13 +86,16 @@ def run_case(kind, hw, cin, cout, zero):
     wg = None
     if kind == "conv" and variant == "conv3x3_w4_kernel":
         # whole-workgroup cycles (kernel entry -> end of wave 0's epilogue instruction stream): tile = main loop + the rest
-        buf = (ctypes.c_ulonglong * slots)()
+        buf = (ctypes.c_ulonglong * (2 * slots))()
         fn = getattr(L.load(), reader + "_wg")
         fn.restype = ctypes.c_int
         assert fn(buf, ctypes.c_int(slots)) == 0
-        a = np.frombuffer(buf, dtype=np.uint64).astype(np.float64)
-        wg = float(np.median(a[a > 0]))
-    extra = {} if wg is None else {"workgroup_cycles_median": round(wg), "prologue_epilogue_cycles": round(wg - cyc),
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(slots, 2).astype(np.float64)
+        okw = a[:, 0] > 0
+        wg = float(np.median(a[okw, 0]))
+        pro = float(np.median(a[okw, 1]))
+    extra = {} if wg is None else {"workgroup_cycles_median": round(wg), "prologue_cycles": round(pro),
+                                   "epilogue_cycles": round(wg - cyc - pro), "prologue_epilogue_cycles": round(wg - cyc),
                                    "prologue_epilogue_share": round((wg - cyc) / wg, 3),
                                    "prologue_epilogue_us": round((wg - cyc) / (med * 1e3), 2)}
     return {**extra, "kernel": variant, "operands": "zero" if zero else "random", "launch_ms_diag_build": round(ms, 4),

@@ -39,7 +39,7 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 #define OCR_DIAG_SLOTS 4096
 struct OcrDiagStamp { unsigned long long t0, r0; };
 #define OCR_DIAG_DECLARE(name) static __device__ unsigned long long name[OCR_DIAG_SLOTS][2]; \
-  static __device__ unsigned long long name##_wg[OCR_DIAG_SLOTS];
+  static __device__ unsigned long long name##_wg[OCR_DIAG_SLOTS][2];
 // whole-workgroup stamp (kernel entry -> end of the epilogue's instruction stream of wave 0): with the main-loop stamp
 // it splits a tile's cycles into main loop and prologue + epilogue
 #define OCR_DIAG_WG_BEGIN() const unsigned long long diag_wg0_ = __builtin_amdgcn_s_memtime();
@@ -47,7 +47,10 @@ struct OcrDiagStamp { unsigned long long t0, r0; };
   {                                                                   \
     const unsigned long long tw_ = __builtin_amdgcn_s_memtime();      \
     __builtin_amdgcn_s_waitcnt(0xC07F);                               \
-    if (threadIdx.x == 0) name##_wg[blockIdx.x % OCR_DIAG_SLOTS] = tw_ - diag_wg0_; \
+    if (threadIdx.x == 0) {                                           \
+      name##_wg[blockIdx.x % OCR_DIAG_SLOTS][0] = tw_ - diag_wg0_;    \
+      name##_wg[blockIdx.x % OCR_DIAG_SLOTS][1] = diag_.t0 - diag_wg0_;   /* entry -> main loop: the prologue */ \
+    }                                                                 \
   }
 #define OCR_DIAG_BEGIN()                                              \
   OcrDiagStamp diag_;                                                 \
@@ -71,7 +74,7 @@ struct OcrDiagStamp { unsigned long long t0, r0; };
   }                                                                                      \
   extern "C" int fn##_wg(void* host_out, int slots) {                                    \
     if (!host_out || slots <= 0 || slots > OCR_DIAG_SLOTS) return OCR_ERR_INVALID_ARG;   \
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(name##_wg), (size_t)slots * 8) == hipSuccess ? OCR_OK : OCR_ERR_HIP; \
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(name##_wg), (size_t)slots * 16) == hipSuccess ? OCR_OK : OCR_ERR_HIP; \
   }
 #else
 #define OCR_DIAG_DECLARE(name)
