@@ -724,6 +724,13 @@ constexpr int W4_WSTEP = 256 * 64;                                   // bytes of
 constexpr int W4_RING = 4, W4_AHEAD = 3;
 constexpr int W4_LDS = 2 * W4_HBYTES + W4_RING * W4_WSTEP;           // 155648
 
+// EPI: the epilogue's mode as a COMPILE-TIME constant.  With the flags read at run time every round carried the
+// machinery of all modes (the ACCUM add computed and selected away, the ReLU and mask compares, the BN-backward operand's
+// conversions behind uniform branches): 32.9 k of a tile's 126-205 k cycles were epilogue (in-kernel stamps,
+// libocr_hip_diag.so) — 16 rounds x 2 k cycles on a single wave per SIMD, where every issued instruction is serial time.
+//   0 generic (run-time flags: ACCUM and anything else)   1 STATS (forward, BN nets)        2 STATS + fused BN-backward sums
+//   3 BIAS + RELU (forward, bias nets)                     4 as 2, storing dz (store_dz)    5 plain store
+template <int EPI>
 __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
@@ -918,9 +925,11 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
   {
     const int mt8 = (img * p.tiles_y + tyi) * p.tiles_x + txi;
     char* const stage = smem + wave * 2048;
-    const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
-    const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
-    const bool has_br = p.br.y != nullptr;      // (fields read by value: a pointer to p.br would pin the kernel arguments in scratch)
+    const bool has_bias = EPI == 0 ? (p.flags & OCR_CONV_BIAS) != 0 : EPI == 3;
+    const bool relu = EPI == 0 ? (p.flags & OCR_CONV_RELU) != 0 : EPI == 3;
+    const bool accum = EPI == 0 ? (p.flags & OCR_CONV_ACCUM_F16) != 0 : false;
+    const bool do_stats = EPI == 0 ? (p.flags & OCR_CONV_STATS) != 0 : (EPI == 1 || EPI == 2 || EPI == 4);
+    const bool has_br = EPI == 0 ? p.br.y != nullptr : (EPI == 2 || EPI == 4);      // (fields read by value: a pointer to p.br would pin the kernel arguments in scratch)
     const int g4 = lane >> 4;                        // accumulator layout: pixel L, couts 4*g4..+3 of a 16x16 tile
     const int c8 = lane & 7, pg = lane >> 3;         // read-back layout: 16-byte chunk of a pixel's 64 couts, pixel
     const int cow = co0 + wco * 128;
@@ -940,7 +949,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[2][8], bsh[2][8];
     const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;   // no ReLU: every element passes
-    const bool sdz = has_br && p.br.store_dz != 0;
+    const bool sdz = EPI == 0 ? (has_br && p.br.store_dz != 0) : EPI == 4;
     if (has_br) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
@@ -1923,13 +1932,26 @@ static bool conv_w4_ok(const ConvP& p) {
 
 static int launch_w4(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
                      hipStream_t st) {
-  auto kern = conv3x3_w4_kernel;
-  static bool configured = false;
-  if (!configured) {
+  // the epilogue mode, compile-time (see the kernel): anything unusual takes the generic instantiation
+  const bool br = p.br.y != nullptr;
+  const int fl = p.flags;
+  int epi = 0;
+  if (fl == OCR_CONV_STATS && !br) epi = 1;
+  else if (fl == OCR_CONV_STATS && br && p.br.mask == nullptr && p.br.mask_bits == nullptr) epi = p.br.store_dz ? 4 : 2;
+  else if (fl == (OCR_CONV_BIAS | OCR_CONV_RELU) && !br) epi = 3;
+  else if (fl == 0 && !br) epi = 5;
+  static const int force_generic = [] { const char* e = getenv("OCR_W4_GENERIC_EPI"); return e ? atoi(e) : 0; }();
+  if (force_generic) epi = 0;
+  typedef void (*KernT)(ConvP, const half_t*, const half_t*, const float*, half_t*, float*);
+  static const KernT kerns[6] = {conv3x3_w4_kernel<0>, conv3x3_w4_kernel<1>, conv3x3_w4_kernel<2>,
+                                 conv3x3_w4_kernel<3>, conv3x3_w4_kernel<4>, conv3x3_w4_kernel<5>};
+  const KernT kern = kerns[epi];
+  static bool configured[6] = {false, false, false, false, false, false};
+  if (!configured[epi]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(160 * 1024)) != hipSuccess)
       return OCR_ERR_HIP;
-    configured = true;
+    configured[epi] = true;
   }
   const int m_tiles = p.n * p.tiles_x * p.tiles_y;
   dim3 grid((unsigned)(m_tiles * p.n_tiles));
