@@ -1123,7 +1123,7 @@ constexpr int w4s_ring(int bn) { return bn == 64 ? 8 : 4; }
 constexpr int w4s_ahead(int bn) { return bn == 64 ? 6 : 3; }
 constexpr int w4s_lds(int bn) { return 2 * W4S_HBYTES + w4s_ring(bn) * bn * 64; }
 
-template <int BN>
+template <int BN, int EPI>                       // EPI: the epilogue mode at compile time (see conv3x3_w4_kernel)
 __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
@@ -1289,9 +1289,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
   {
     const int mt8 = (img * p.tiles_y + tyi) * p.tiles_x + txi;
     char* const stage = smem + wave * 2048;
-    const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
-    const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
-    const bool has_br = p.br.y != nullptr;
+    const bool has_bias = EPI == 0 ? (p.flags & OCR_CONV_BIAS) != 0 : EPI == 3;
+    const bool relu = EPI == 0 ? (p.flags & OCR_CONV_RELU) != 0 : EPI == 3;
+    const bool accum = EPI == 0 ? (p.flags & OCR_CONV_ACCUM_F16) != 0 : false;
+    const bool do_stats = EPI == 0 ? (p.flags & OCR_CONV_STATS) != 0 : (EPI == 1 || EPI == 2 || EPI == 4);
+    const bool has_br = EPI == 0 ? p.br.y != nullptr : (EPI == 2 || EPI == 4);
     const int g4 = lane >> 4;
     const int c8 = lane & 7, pg = lane >> 3;
     // the tile's BN bias values through LDS (see conv3x3_w4_kernel)
@@ -1309,7 +1311,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[NW][8], bsh[NW][8];
     const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;   // no ReLU: every element passes
-    const bool sdz = has_br && p.br.store_dz != 0;
+    const bool sdz = EPI == 0 ? (has_br && p.br.store_dz != 0) : EPI == 4;
     if (has_br) {
 #pragma unroll
       for (int hf = 0; hf < NW; ++hf)
@@ -1481,7 +1483,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
 constexpr int C64_NH = 6;                                          // halo DMA rounds of 512 slots (2720 slots used)
 constexpr int C64_LDS = 2 * W4_HBYTES + 9 * 64 * 128;              // 163840 = the whole LDS
 
-template <int BN, bool POOL = false>
+template <int BN, bool POOL = false, int EPI = 0>   // EPI: the epilogue mode at compile time (see conv3x3_w4_kernel)
 __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
@@ -1499,9 +1501,11 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   const int m_first = blockIdx.x / p.n_tiles, m_step = gridDim.x / p.n_tiles;
   const int m_tiles = p.n * p.tiles_x * p.tiles_y;
   const int ntile = m_first < m_tiles ? (m_tiles - m_first + m_step - 1) / m_step : 0;
-  const bool has_bias = (p.flags & OCR_CONV_BIAS) != 0, relu = (p.flags & OCR_CONV_RELU) != 0;
-  const bool accum = (p.flags & OCR_CONV_ACCUM_F16) != 0, do_stats = (p.flags & OCR_CONV_STATS) != 0;
-  const bool has_br = p.br.y != nullptr;              // (fields read by value: a pointer to p.br would pin the arguments in scratch)
+  const bool has_bias = EPI == 0 ? (p.flags & OCR_CONV_BIAS) != 0 : EPI == 3;
+  const bool relu = EPI == 0 ? (p.flags & OCR_CONV_RELU) != 0 : EPI == 3;
+  const bool accum = EPI == 0 ? (p.flags & OCR_CONV_ACCUM_F16) != 0 : false;
+  const bool do_stats = EPI == 0 ? (p.flags & OCR_CONV_STATS) != 0 : (EPI == 1 || EPI == 2 || EPI == 4);
+  const bool has_br = EPI == 0 ? p.br.y != nullptr : (EPI == 2 || EPI == 4);              // (fields read by value: a pointer to p.br would pin the arguments in scratch)
 
   // weights -> LDS, once: slot tap*512 + tid -> row tid>>3, stored chunk tid&7 holds logical chunk c ^ swz
   {
@@ -1569,7 +1573,7 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   const int c8 = lane & 7, pg = lane >> 3;
   float s[8], q2[8], bsc[8], bsh[8];
   const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;
-  const bool sdz = has_br && p.br.store_dz != 0;
+  const bool sdz = EPI == 0 ? (has_br && p.br.store_dz != 0) : EPI == 4;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     s[e] = 0.f;
@@ -1903,16 +1907,37 @@ static int c64_per(const ConvP& p) {
   return per;
 }
 
+// the epilogue mode of the wave-private-epilogue kernels, a compile-time constant in the kernel (see
+// conv3x3_w4_kernel): anything unusual takes the generic instantiation (0), which reads the flags at run time
+static int epi_mode(const ConvP& p) {
+  static const int force_generic = [] { const char* e = getenv("OCR_W4_GENERIC_EPI"); return e ? atoi(e) : 0; }();
+  if (force_generic) return 0;
+  const bool br = p.br.y != nullptr;
+  const int fl = p.flags;
+  if (fl == OCR_CONV_STATS && !br) return 1;
+  if (fl == OCR_CONV_STATS && br && p.br.mask == nullptr && p.br.mask_bits == nullptr) return p.br.store_dz ? 4 : 2;
+  if (fl == (OCR_CONV_BIAS | OCR_CONV_RELU) && !br) return 3;
+  if (fl == 0 && !br) return 5;
+  return 0;
+}
+typedef void (*ConvKernT)(ConvP, const half_t*, const half_t*, const float*, half_t*, float*);
+
 template <bool POOL = false>
 static int launch_c64(const ConvP& p0, const void* x, const void* w, const void* bias, void* y, void* stats,
                       hipStream_t st) {
-  auto kern = conv_c64_persist_kernel<64, POOL>;
-  static bool configured = false;
-  if (!configured) {
+  // (the pooled variant exists for bias + ReLU layers only: its other modes are the generic instantiation)
+  constexpr bool P = POOL;
+  const int epi = P && epi_mode(p0) != 3 ? 0 : epi_mode(p0);
+  static const ConvKernT kerns[6] = {conv_c64_persist_kernel<64, P, 0>, conv_c64_persist_kernel<64, P, P ? 0 : 1>,
+                                     conv_c64_persist_kernel<64, P, P ? 0 : 2>, conv_c64_persist_kernel<64, P, 3>,
+                                     conv_c64_persist_kernel<64, P, P ? 0 : 4>, conv_c64_persist_kernel<64, P, P ? 0 : 5>};
+  const ConvKernT kern = kerns[epi];
+  static bool configured[6] = {false, false, false, false, false, false};
+  if (!configured[epi]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(160 * 1024)) != hipSuccess)
       return OCR_ERR_HIP;
-    configured = true;
+    configured[epi] = true;
   }
   ConvP p = p0;
   p.tiles_y = ocr_cdiv(p.oh, 8);                 // (the tile configuration may have chosen 16-row tiles)
@@ -1932,17 +1957,8 @@ static bool conv_w4_ok(const ConvP& p) {
 
 static int launch_w4(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
                      hipStream_t st) {
-  // the epilogue mode, compile-time (see the kernel): anything unusual takes the generic instantiation
-  const bool br = p.br.y != nullptr;
-  const int fl = p.flags;
-  int epi = 0;
-  if (fl == OCR_CONV_STATS && !br) epi = 1;
-  else if (fl == OCR_CONV_STATS && br && p.br.mask == nullptr && p.br.mask_bits == nullptr) epi = p.br.store_dz ? 4 : 2;
-  else if (fl == (OCR_CONV_BIAS | OCR_CONV_RELU) && !br) epi = 3;
-  else if (fl == 0 && !br) epi = 5;
-  static const int force_generic = [] { const char* e = getenv("OCR_W4_GENERIC_EPI"); return e ? atoi(e) : 0; }();
-  if (force_generic) epi = 0;
-  typedef void (*KernT)(ConvP, const half_t*, const half_t*, const float*, half_t*, float*);
+  const int epi = epi_mode(p);
+  typedef ConvKernT KernT;
   static const KernT kerns[6] = {conv3x3_w4_kernel<0>, conv3x3_w4_kernel<1>, conv3x3_w4_kernel<2>,
                                  conv3x3_w4_kernel<3>, conv3x3_w4_kernel<4>, conv3x3_w4_kernel<5>};
   const KernT kern = kerns[epi];
@@ -1985,13 +2001,16 @@ static bool uses_c64(const ConvP& p, const TileCfg& c) {
 template <int BN>
 static int launch_w4s(const ConvP& p0, const void* x, const void* w, const void* bias, void* y, void* stats,
                       hipStream_t st) {
-  auto kern = conv3x3_w4s_kernel<BN>;
-  static bool configured = false;
-  if (!configured) {
+  const int epi = epi_mode(p0);
+  static const ConvKernT kerns[6] = {conv3x3_w4s_kernel<BN, 0>, conv3x3_w4s_kernel<BN, 1>, conv3x3_w4s_kernel<BN, 2>,
+                                     conv3x3_w4s_kernel<BN, 3>, conv3x3_w4s_kernel<BN, 4>, conv3x3_w4s_kernel<BN, 5>};
+  const ConvKernT kern = kerns[epi];
+  static bool configured[6] = {false, false, false, false, false, false};
+  if (!configured[epi]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(160 * 1024)) != hipSuccess)
       return OCR_ERR_HIP;
-    configured = true;
+    configured[epi] = true;
   }
   ConvP p = p0;
   p.tiles_y = ocr_cdiv(p.oh, 8);                 // (the tile configuration may have chosen 16-row tiles)
