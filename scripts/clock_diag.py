@@ -48,9 +48,25 @@ def run_case(kind, hw, cin, cout, zero):
     dy = torch.randn(B, hw, hw, cout, device=dev).half()
     if zero:
         x.zero_(); w.zero_(); dy.zero_()
-    d = L.ConvDesc(B, hw, hw, cin, hw, hw, cout, 3, 3, 1, 1, 1, 1, 0, L.CONV_STATS if kind == "conv" else 0)
+    d = L.ConvDesc(B, hw, hw, cin, hw, hw, cout, 3, 3, 1, 1, 1, 1, 0, L.CONV_STATS if kind.startswith("conv") else 0)
     flops = 2.0 * B * hw * hw * cout * cin * 9
-    if kind == "conv":
+    if kind == "conv+bnred":
+        # the input-gradient form with the fused BN-backward reduction of the layer below (epilogue mode 2): the
+        # epilogue also reads the operand tile `bn_y` and folds (sum dz, sum dz*xhat) per channel
+        y = torch.empty(B, hw, hw, cout, dtype=torch.half, device=dev)
+        mt = L.call_int("ocr_conv2d_num_mtiles", ctypes.byref(d))
+        st = torch.zeros(mt, 2, cout, device=dev)
+        by = torch.randn(B, hw, hw, cout, device=dev).half()
+        sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
+        mu, istd = torch.randn(cout, device=dev) * 0.1, torch.rand(cout, device=dev) + 0.5
+        if zero:
+            by.zero_()
+        f = lambda: L.call("ocr_conv2d_bnred_f16", ctypes.byref(d), L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(st), L.ptr(by),
+                           L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(istd), ctypes.c_int(1), ctypes.c_int(0), L.stream_ptr())
+        name = ctypes.create_string_buffer(128)
+        L.load().ocr_conv2d_variant(ctypes.byref(d), name, ctypes.c_size_t(128))
+        variant, reader, slots = name.value.decode(), "ocr_diag_read_conv", 1024
+    elif kind == "conv":
         y = torch.empty(B, hw, hw, cout, dtype=torch.half, device=dev)
         mt = L.call_int("ocr_conv2d_num_mtiles", ctypes.byref(d))
         st = torch.zeros(mt, 2, cout, device=dev)
@@ -84,7 +100,7 @@ def run_case(kind, hw, cin, cout, zero):
     ms = e0.elapsed_time(e1) / 100
     med, p10, p90, cyc = clock(reader, slots)
     wg = None
-    if kind == "conv" and variant == "conv3x3_w4_kernel":
+    if kind.startswith("conv") and variant == "conv3x3_w4_kernel":
         # whole-workgroup cycles (kernel entry -> end of wave 0's epilogue instruction stream): tile = main loop + the rest
         buf = (ctypes.c_ulonglong * (2 * slots))()
         fn = getattr(L.load(), reader + "_wg")
@@ -106,7 +122,9 @@ def run_case(kind, hw, cin, cout, zero):
 def main():
     out = {}
     for label, (hw, cin, cout) in CASES.items():
-        for kind in ("conv", "wgrad"):
+        for kind in ("conv", "conv+bnred", "wgrad"):
+            if kind == "conv+bnred" and cout % 256:
+                continue                                     # the stamped epilogue split exists in conv3x3_w4_kernel only
             for zero in (False, True):
                 r = run_case(kind, hw, cin, cout, zero)
                 out["%s | %s | %s" % (label, kind, r["operands"])] = r

@@ -52,6 +52,12 @@ def short(name):
         args = []
         if rest.startswith("I"):
             args = re.findall(r"L[ib](\d+)E", rest[:rest.find("EEv") + 1] if "EEv" in rest else rest)
+        # the wave-private-epilogue kernels carry their epilogue mode as a LAST template argument (conv_igemm.hip:
+        # epi_mode): the instantiations of one kernel are reported together, under the name ocr_conv2d_variant prints
+        if ident in ("conv3x3_w4_kernel", "conv3x3_w4s_kernel", "conv_c64_persist_kernel") and args:
+            args = args[:-1]
+            if ident == "conv_c64_persist_kernel":
+                args = args[:1] if args[1:] == ["0"] else args
         return ident + ("<" + ",".join(args) + ">" if args else "")
     return name[:80]
 

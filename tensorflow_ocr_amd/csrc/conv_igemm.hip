@@ -959,12 +959,13 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
           bsc[hf][e] = p.br.scale[cc]; bsh[hf][e] = p.br.shift[cc];
         }
     }
-    // Round it = 2*t + hf (16 rounds).  The global operands of a round — the BN-backward operand `p.br.y`, the old
-    // gradient under ACCUM — are requested FOUR ROUNDS AHEAD: a load placed behind a store waits for it (the
-    // tensors may alias as far as the compiler knows), and with one wave per SIMD a round that waits for its
-    // own loads pays the whole HBM latency (measured: +0.16 ms on a 0.52 ms launch, 16 x 1.5 us per tile).
-    constexpr int PF = 4;
-    half8_t yq[PF][2], oq[2];
+    // Round it = 2*t + hf (16 rounds).  The BN-backward operand `p.br.y` of the WHOLE tile (128 KB: the main loop's
+    // LDS is free now) is fetched by LDS-DMA up front, 32 one-KB transfers per wave all in flight at once, each lane
+    // fetching the 16 bytes it will read back itself (slot = lane: no swizzle needed).  Fetched round by round into
+    // registers (four rounds ahead, all the registers allowed) the loads shared the vmcnt queue with the rounds'
+    // stores, so every round waited for a store's acknowledgement: the fused reduction cost conv3's input gradients
+    // +155 us on 465 (per-layer table, profiles/r03_w4_per_layer.json) — more than a separate pass over both tensors.
+    half8_t oq[2];
     // element offset of (round, k): a per-lane base computed once + a wave-uniform delta; bounds as "rows / columns
     // left" (the epilogue is bound by instruction issue: a dozen 64-bit address and compare instructions per
     // store were a tenth of it)
@@ -975,17 +976,21 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
       ok = ((t >> 1) < rows_left) & ((t & 1) * 16 + k * 8 < cols_left);
       return pbase + (size_t)(((t >> 1) * p.ow + (t & 1) * 16 + k * 8) * p.cout + hf * 64);
     };
-    auto request = [&](int it) __attribute__((always_inline)) {
+    char* const ylds = smem + 16384 + wave * 32768;   // past the staging rows, the partial sums and the bias values
+    if (has_br) {
+      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<half_t*>(p.br.y) + (size_t)img * p.oh * p.ow * p.cout, 0, p.oh * p.ow * p.cout * 2, 0x00020000);
+      const unsigned ybase = (unsigned)((((tyi * TH + wpx * 4) * p.ow + txi * TILE_W + pg) * p.cout + cow + c8 * 8) * 2);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        bool ok;
-        const size_t off = round_off(it, k, ok);
-        if (ok && do_stats && has_br) yq[it % PF][k] = *reinterpret_cast<const half8_t*>(p.br.y + off);
-      }
-    };
-    if (do_stats && has_br) {
+      for (int it = 0; it < 16; ++it)
 #pragma unroll
-      for (int it = 0; it < PF; ++it) request(it);
+        for (int k = 0; k < 2; ++k) {
+          const int t = it >> 1, hf = it & 1;
+          const bool ok = ((t >> 1) < rows_left) & ((t & 1) * 16 + k * 8 < cols_left);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              yrs, (__attribute__((address_space(3))) void*)(ylds + (it * 2 + k) * 1024), 16, ok ? ybase : 0x80000000u,
+              (((t >> 1) * p.ow + (t & 1) * 16 + k * 8) * p.cout + hf * 64) * 2, 0, 0);
+        }
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -1014,6 +1019,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
           }
           *reinterpret_cast<half4_t*>(stage + L * 128 + (((ii * 2 + (g4 >> 1)) ^ (L & 7)) << 4) + (g4 & 1) * 8) = o;
         }
+        if (it == 0 && has_br) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the operand tile has landed (behind round 0's staging)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1024,6 +1030,8 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
           const int px = k * 8 + pg;
           if (ok) {
             half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
+            half8_t yv;
+            if (has_br) yv = *reinterpret_cast<const half8_t*>(ylds + (it * 2 + k) * 1024 + lane * 16);
             if (accum) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
@@ -1031,14 +1039,14 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
             if (sdz) {                                // store the gradient PAST the ReLU (BnRed::store_dz)
 #pragma unroll
               for (int e = 0; e < 8; ++e)
-                if (!((float)yq[it % PF][k][e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
+                if (!((float)yv[e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
             }
             *reinterpret_cast<half8_t*>(y + off) = v;
             if (do_stats) {
               if (has_br) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  const float yf = (float)yq[it % PF][k][e];
+                  const float yf = (float)yv[e];
                   const float dz = yf * bsc[hf][e] + bsh[hf][e] > relu_thr ? (float)v[e] : 0.f;   // mask of the stored activation
                   s[hf][e] += dz;
                   q2[hf][e] += dz * yf;
@@ -1054,7 +1062,6 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
             }
           }
         }
-        if (do_stats && has_br && it + PF < 16) request(it + PF);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();          // the next round's writes come after these reads (in-order LDS)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
