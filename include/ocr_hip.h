@@ -306,11 +306,20 @@ int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const void* shif
  * goes to the first maximum) without recomputing the candidates' activations.  Same results as
  * ocr_bn_relu_f16(pool=2) / ocr_bn_relu_bwd_f16(pool=2, da_full=NULL). */
 int ocr_bn_relu_pool_idx_f16(const void* y, const void* scale, const void* shift, int n, int h, int w, int c,
-                             int relu, void* a_full, void* a_pool, void* argmax_u8, void* stream);
+                             int relu, void* a_full, void* a_pool, void* argmax_u8, void* y_pool, void* stream);
 int ocr_bn_relu_pool_bwd_idx_f16(const void* y, const void* scale, const void* save_mean, const void* save_invstd,
                                  const void* a_pool, const void* argmax_u8, const void* da_pool, int n, int h,
                                  int w, int c, int relu, void* dgamma, void* dbeta, void* dy, void* partial,
                                  void* workspace, size_t ws_bytes, void* stream);
+/* y_pool (optional output of ocr_bn_relu_pool_idx_f16, [n][oh][ow][c] f16): the conv output y AT each window's first
+ * maximum.  The layer's dz is zero away from those positions, so the BN-backward sums of the whole layer are sums over
+ * the POOLED positions: the input-gradient kernel that produces da_pool takes them in its epilogue
+ * (ocr_conv2d_bnred_f16 with bn_y = y_pool and the layer's scale / shift / mean / invstd), and the backward is this
+ * apply-only form — the reduction pass over y (1 GiB at conv1_2 of nets/vgg.py:17) disappears. */
+int ocr_bn_relu_pool_bwd_idx_apply_f16(const void* y, const void* scale, const void* save_mean,
+                                       const void* save_invstd, const void* argmax_u8, const void* da_pool, int n,
+                                       int h, int w, int c, int relu, const void* partial, int T, void* dgamma,
+                                       void* dbeta, void* dy, void* workspace, size_t ws_bytes, void* stream);
 
 
 /* slim.max_pool2d k x k / stride SAME as a standalone op (pool5 3x3/1 nets/vgg.py:32; ResNet

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
                                                       const float* __restrict__ shift, int n, int h,
                                                       int w, int c, half_t* __restrict__ a_full,
                                                       half_t* __restrict__ a_pool,
-                                                      unsigned char* __restrict__ argmax = nullptr) {
+                                                      unsigned char* __restrict__ argmax = nullptr,
+                                                      half_t* __restrict__ y_pool = nullptr) {
   const int chunks = c >> 3;
   const int oh = POOL ? (h + 1) / 2 : h, ow = POOL ? (w + 1) / 2 : w;
   const size_t units = (size_t)n * oh * ow;
@@ -287,9 +288,10 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
       const int oy = (int)(t % oh);
       const int img = (int)(t / oh);
       float m[8];
+      half8_t ym;                                   // the conv output AT the first maximum (y_pool)
       unsigned long long am = 0ull;                 // first-max candidate (dy*2+dx) of each channel, one byte each
 #pragma unroll
-      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+      for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; ym[e] = (half_t)0.f; }
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
               float fr = (float)o[e];
               if (fr > m[e]) {
                 m[e] = fr;
+                ym[e] = v[e];
                 am = (am & ~(0xffull << (8 * e))) | ((unsigned long long)(dy * 2 + dx) << (8 * e));
               }
             }
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
       *reinterpret_cast<half8_t*>(a_pool + u * c + ch * 8) = o;
+      if (y_pool) *reinterpret_cast<half8_t*>(y_pool + u * c + ch * 8) = ym;
       if (argmax) {
         // bit 2 of each byte: the pooled activation is positive (the backward's ReLU mask, so that it
         // need not read a_pool)
@@ -1324,7 +1328,7 @@ extern "C" int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const
 
 extern "C" int ocr_bn_relu_pool_idx_f16(const void* y, const void* scale, const void* shift, int n, int h, int w,
                                         int c, int relu, void* a_full, void* a_pool, void* argmax_u8,
-                                        void* stream) {
+                                        void* y_pool, void* stream) {
   OCR_CHECK_ARG(y && scale && shift && a_pool && argmax_u8 && n > 0 && h > 0 && w > 0);
   OCR_CHECK_SHAPE(c % 8 == 0);
   const int oh = (h + 1) / 2, ow = (w + 1) / 2;
@@ -1337,8 +1341,9 @@ extern "C" int ocr_bn_relu_pool_idx_f16(const void* y, const void* scale, const 
   half_t* af = static_cast<half_t*>(a_full);
   half_t* ap = static_cast<half_t*>(a_pool);
   unsigned char* am = static_cast<unsigned char*>(argmax_u8);
-  if (relu) hipLaunchKernelGGL((bn_relu_kernel<true, 2>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap, am);
-  else hipLaunchKernelGGL((bn_relu_kernel<false, 2>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap, am);
+  half_t* ypl = static_cast<half_t*>(y_pool);
+  if (relu) hipLaunchKernelGGL((bn_relu_kernel<true, 2>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap, am, ypl);
+  else hipLaunchKernelGGL((bn_relu_kernel<false, 2>), grid, dim3(256), 0, st, yp, sc, sh, n, h, w, c, af, ap, am, ypl);
   return ocr_launch_status();
 }
 
@@ -1370,5 +1375,34 @@ extern "C" int ocr_bn_relu_pool_bwd_idx_f16(const void* y, const void* scale, co
                      static_cast<const float*>(dgamma), static_cast<const float*>(dbeta),
                      static_cast<const half_t*>(a_pool), static_cast<const unsigned char*>(argmax_u8),
                      static_cast<const half_t*>(da_pool), (float*)nullptr, static_cast<half_t*>(dy));
+  return ocr_launch_status();
+}
+
+// ocr_bn_relu_pool_bwd_idx_f16 without its reduction pass: the (sum dz, sum dz*xhat) partials [T][2][c] come from the
+// input-gradient kernel that produced da_pool (ocr_conv2d_bnred_f16 with bn_y = y_pool, the conv output at each window's
+// first maximum: dz is zero everywhere else, so the sums over the pooled positions ARE the layer's sums).
+extern "C" int ocr_bn_relu_pool_bwd_idx_apply_f16(const void* y, const void* scale, const void* save_mean,
+                                                  const void* save_invstd, const void* argmax_u8, const void* da_pool,
+                                                  int n, int h, int w, int c, int relu, const void* partial, int T,
+                                                  void* dgamma, void* dbeta, void* dy, void* workspace,
+                                                  size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(y && scale && save_mean && save_invstd && argmax_u8 && da_pool && partial && dgamma && dbeta && dy);
+  OCR_CHECK_ARG(workspace && T > 0 && n > 0 && h > 0 && w > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
+  if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
+  hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFin>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(),
+                     rows, BnBwdFin{static_cast<float*>(dgamma), static_cast<float*>(dbeta)});
+  BnBwdP p{n, h, w, c, relu, 2, (float)(1.0 / ((double)n * h * w))};
+  const int B = bwd_blocks(n, h, w, c, 2);
+  hipLaunchKernelGGL(bn_pool_bwd_idx_kernel<1>, dim3(B), dim3(256), 0, st, p, static_cast<const half_t*>(y),
+                     static_cast<const float*>(scale), static_cast<const float*>(save_mean),
+                     static_cast<const float*>(save_invstd), static_cast<const float*>(dgamma),
+                     static_cast<const float*>(dbeta), (const half_t*)nullptr,
+                     static_cast<const unsigned char*>(argmax_u8), static_cast<const half_t*>(da_pool),
+                     (float*)nullptr, static_cast<half_t*>(dy));
   return ocr_launch_status();
 }

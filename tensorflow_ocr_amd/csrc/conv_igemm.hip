@@ -1328,10 +1328,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
           bsc[hf][e] = p.br.scale[cc]; bsh[hf][e] = p.br.shift[cc];
         }
     }
-    // Round it = NW*t + hf; global operands of a round (BN-backward operand, old gradient under ACCUM) are
-    // requested PF rounds ahead, never behind a store (see conv3x3_w4_kernel's epilogue)
-    constexpr int NR = AT * NW, PF = 2;           // two rounds ahead: 128 vector registers here
-    half8_t yq[PF][2], oq[2];
+    // Round it = NW*t + hf.  The BN-backward operand of the whole tile (32 KB x NW: the main loop's LDS is free) comes
+    // by LDS-DMA up front, all transfers in flight at once, each lane fetching the 16 bytes it reads back itself (see
+    // conv3x3_w4_kernel's epilogue: register prefetches share the vmcnt queue with the rounds' stores)
+    constexpr int NR = AT * NW;
+    half8_t oq[2];
     // element offset of (round, k): per-lane base + wave-uniform delta; bounds as rows / columns left (see conv3x3_w4)
     const size_t pbase = (((size_t)img * p.oh + tyi * TH + wave * 2) * p.ow + txi * TILE_W + pg) * p.cout + co0 + c8 * 8;
     const int rows_left = p.oh - (tyi * TH + wave * 2), cols_left = p.ow - (txi * TILE_W + pg);
@@ -1340,18 +1341,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
       ok = ((t >> 1) < rows_left) & ((t & 1) * 16 + k * 8 < cols_left);
       return pbase + (size_t)(((t >> 1) * p.ow + (t & 1) * 16 + k * 8) * p.cout + hf * 64);
     };
-    const bool gops = do_stats && has_br;
-    auto request = [&](int it) __attribute__((always_inline)) {
+    static_assert(16384 + 4 * NR * 2048 <= w4s_lds(BN), "operand tile past the kernel's LDS");
+    char* const ylds = smem + 16384 + wave * (NR * 2048);   // past the staging rows, the partial sums and the bias values
+    if (has_br) {
+      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<half_t*>(p.br.y) + (size_t)img * p.oh * p.ow * p.cout, 0, p.oh * p.ow * p.cout * 2, 0x00020000);
+      const unsigned ybase = (unsigned)((((tyi * TH + wave * 2) * p.ow + txi * TILE_W + pg) * p.cout + co0 + c8 * 8) * 2);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        bool ok;
-        const size_t off = round_off(it, k, ok);
-        if (ok && do_stats && has_br) yq[it % PF][k] = *reinterpret_cast<const half8_t*>(p.br.y + off);
-      }
-    };
-    if (gops) {
+      for (int it = 0; it < NR; ++it)
 #pragma unroll
-      for (int it = 0; it < PF; ++it) request(it);
+        for (int k = 0; k < 2; ++k) {
+          const int t = it / NW, hf = it % NW;
+          const bool ok = ((t >> 1) < rows_left) & ((t & 1) * 16 + k * 8 < cols_left);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              yrs, (__attribute__((address_space(3))) void*)(ylds + (it * 2 + k) * 1024), 16, ok ? ybase : 0x80000000u,
+              (((t >> 1) * p.ow + (t & 1) * 16 + k * 8) * p.cout + hf * 64) * 2, 0, 0);
+        }
     }
 #pragma unroll
     for (int t = 0; t < AT; ++t) {
@@ -1380,6 +1385,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
           }
           *reinterpret_cast<half4_t*>(stage + L * 128 + (((ii * 2 + (g4 >> 1)) ^ (L & 7)) << 4) + (g4 & 1) * 8) = o;
         }
+        if (it == 0 && has_br) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the operand tile has landed (behind round 0's staging)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1390,6 +1396,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
           const int px = k * 8 + pg;
           if (ok) {
             half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
+            half8_t yv;
+            if (has_br) yv = *reinterpret_cast<const half8_t*>(ylds + (it * 2 + k) * 1024 + lane * 16);
             if (accum) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
@@ -1397,14 +1405,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
             if (sdz) {                                // store the gradient PAST the ReLU (BnRed::store_dz)
 #pragma unroll
               for (int e = 0; e < 8; ++e)
-                if (!((float)yq[it % PF][k][e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
+                if (!((float)yv[e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
             }
             *reinterpret_cast<half8_t*>(y + off) = v;
             if (do_stats) {
               if (has_br) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  const float yf = (float)yq[it % PF][k][e];
+                  const float yf = (float)yv[e];
                   const float dz = yf * bsc[hf][e] + bsh[hf][e] > relu_thr ? (float)v[e] : 0.f;   // mask of the stored activation
                   s[hf][e] += dz;
                   q2[hf][e] += dz * yf;
@@ -1420,7 +1428,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
             }
           }
         }
-        if (gops && it + PF < NR) request(it + PF);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

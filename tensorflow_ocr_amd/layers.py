@@ -57,6 +57,7 @@ def _const_vec(g, n, value):
 
 
 FUSE_BN_W4_MAXHW = int(__import__("os").environ.get("OCR_FUSE_BN_W4_MAXHW", "1000000"))
+FUSE_BN_POOL_REDUCE = __import__("os").environ.get("OCR_FUSE_BN_POOL_REDUCE", "1") == "1"    # measurement switch
 FUSE_FIRST_WGRAD = __import__("os").environ.get("OCR_FUSE_FIRST_WGRAD", "1") == "1"    # measurement switch
 
 
@@ -117,7 +118,7 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         else:
             ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
         full = pooled = None
-        argmax = None
+        argmax = y_pool = None
         if pool:
             pooled = g.empty((n, (oh + 1) // 2, (ow + 1) // 2, cout))
             if keep_full:
@@ -127,7 +128,11 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 # the pool is the only consumer: keep the first-max position so that the backward routes
                 # the pooled gradient without re-deriving the four candidates' activations
                 argmax = g.empty(pooled.shape, torch.uint8)
-                ops.bn_relu_pool_idx(y, scale, shift, relu, None, pooled, argmax)
+                # ... and, while training, the conv output AT that position: dz is zero everywhere else, so the conv
+                # that consumes the pooled activation can sum this layer's BN-backward terms over the pooled
+                # positions in its input-gradient epilogue (a_pool.bn_ctx below) and the reduction pass over y goes
+                y_pool = g.empty(pooled.shape) if (train_stats and FUSE_BN_POOL_REDUCE) else None
+                ops.bn_relu_pool_idx(y, scale, shift, relu, None, pooled, argmax, y_pool)
         else:
             full = g.empty((n, oh, ow, cout))
             ops.bn_relu(y, scale, shift, relu, 0, full, None)
@@ -136,6 +141,8 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         if not pool and train_stats:
             # lets the consumer conv's input-gradient kernel do this layer's BN-backward reduction
             a_full.bn_ctx = (y, scale, shift, mean, invstd, relu)
+        if pool and argmax is not None and y_pool is not None:
+            a_pool.bn_ctx = (y_pool, scale, shift, mean, invstd, relu)
 
         def backward():
             if not train_stats:
@@ -166,6 +173,11 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 ops.bn_relu_bwd_apply(y, scale, shift, mean, invstd, da_full, relu, part_f, T_f,
                                       gamma.grad, beta.grad, dy, ws)
                 a_full.bn_partial = None
+            elif pool and argmax is not None and da_full is None and a_pool.bn_partial is not None:
+                part_p, T_p = a_pool.bn_partial
+                ops.bn_relu_pool_bwd_idx_apply(y, scale, mean, invstd, argmax, da_pool, relu, part_p, T_p,
+                                               gamma.grad, beta.grad, dy, ws)
+                a_pool.bn_partial = None
             elif pool and argmax is not None and da_full is None:
                 ops.bn_relu_pool_bwd_idx(y, scale, mean, invstd, a_pool.data, argmax, da_pool, relu,
                                          gamma.grad, beta.grad, dy, ws)

@@ -377,11 +377,22 @@ def bn_relu(y, scale, shift, relu, pool, a_full=None, a_pool=None):
            c_int(int(relu)), c_int(pool), ptr(a_full), ptr(a_pool), _st())
 
 
-def bn_relu_pool_idx(y, scale, shift, relu, a_full, a_pool, argmax):
-    """bn+ReLU+2x2 max-pool that also stores the first-max position (uint8 [n,oh,ow,c])."""
+def bn_relu_pool_idx(y, scale, shift, relu, a_full, a_pool, argmax, y_pool=None):
+    """bn+ReLU+2x2 max-pool that also stores the first-max position (uint8 [n,oh,ow,c]) and, with `y_pool`, the conv
+    output AT that position (the BN-backward operand of the pooled positions: bn_relu_pool_bwd_idx_apply)."""
     n, h, w, c = y.shape
     L.call("ocr_bn_relu_pool_idx_f16", ptr(y), ptr(scale), ptr(shift), c_int(n), c_int(h), c_int(w), c_int(c),
-           c_int(int(relu)), ptr(a_full), ptr(a_pool), ptr(argmax), _st())
+           c_int(int(relu)), ptr(a_full), ptr(a_pool), ptr(argmax), ptr(y_pool), _st())
+
+
+def bn_relu_pool_bwd_idx_apply(y, scale, save_mean, save_invstd, argmax, da_pool, relu, partial, T, dgamma, dbeta, dy, ws):
+    """bn_relu_pool_bwd_idx without its reduction pass: `partial` [T][2][c] from the input-gradient kernel that wrote
+    da_pool (conv2d_bnred with bn_y = y_pool)."""
+    n, h, w, c = y.shape
+    stage = ws.get(bn_reduce_workspace(T, c))
+    L.call("ocr_bn_relu_pool_bwd_idx_apply_f16", ptr(y), ptr(scale), ptr(save_mean), ptr(save_invstd), ptr(argmax),
+           ptr(da_pool), c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(partial), c_int(T), ptr(dgamma),
+           ptr(dbeta), ptr(dy), ptr(stage), c_size_t(stage.numel()), _st())
 
 
 def bn_relu_pool_bwd_idx(y, scale, save_mean, save_invstd, a_pool, argmax, da_pool, relu, dgamma, dbeta, dy, ws):

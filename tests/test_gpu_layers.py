@@ -264,6 +264,44 @@ def test_pooled_bn_backward_with_stored_argmax_equals_recomputing_path(device, n
     assert float(outs[0][0].abs().sum()) > 0
 
 
+def test_pooled_bn_layer_backward_sums_from_the_consumer_convolution(device):
+    """conv a (+BN+ReLU, 2x2 pool its only reader) -> conv b: b's input-gradient kernel sums a's BN-backward terms over
+    the POOLED positions (bn_y = y_pool, the conv output at each window's first maximum) and a's backward is the
+    apply-only ocr_bn_relu_pool_bwd_idx_apply_f16.  Same gradients as the path with its own reduction pass over y, up
+    to the grouping of the f32 sums; odd sizes: partial edge windows."""
+    from tensorflow_ocr_amd import layers
+    from tensorflow_ocr_amd.graph import Graph
+    rng = np.random.default_rng(21)
+    n, h, w, cin, ca, cb = 2, 30, 66, 64, 64, 128
+    x = _h(rng.standard_normal((n, h, w, cin)))
+    gout = _h(rng.standard_normal((n, (h + 1) // 2, (w + 1) // 2, cb)) * 0.1)
+
+    def run(fused):
+        old = layers.FUSE_BN_POOL_REDUCE
+        layers.FUSE_BN_POOL_REDUCE = fused
+        try:
+            g = Graph(device, loss_scale=1.0, seed=5)
+            from tensorflow_ocr_amd.graph import Act, F16
+            xa = Act(torch.from_numpy(x).to(F16).to(device), name="x")
+            xa.requires_grad = True
+            _, pa = layers.conv2d(g, xa, ca, 3, "a", pool=2, keep_full=False)
+            assert (pa.bn_ctx is not None) == fused
+            fb, _ = layers.conv2d(g, pa, cb, 3, "b")
+            fb.grad = torch.from_numpy(gout).to(F16).to(device)
+            g.backward()
+            torch.cuda.synchronize()
+            names = ("a/weights", "a/BatchNorm/gamma", "a/BatchNorm/beta", "b/weights", "b/BatchNorm/gamma")
+            return {k: g.store.vars[k].grad.float().cpu().numpy().copy() for k in names}, xa.grad.float().cpu().numpy().copy()
+        finally:
+            layers.FUSE_BN_POOL_REDUCE = old
+    gf, dxf = run(True)
+    gu, dxu = run(False)
+    for k in gf:
+        ref = np.abs(gu[k]).max()
+        assert ref > 0 and np.abs(gf[k] - gu[k]).max() <= 2e-3 * ref, (k, np.abs(gf[k] - gu[k]).max(), ref)
+    assert np.abs(dxf - dxu).max() <= 2e-3 * np.abs(dxu).max()
+
+
 def test_first_conv_weight_gradient_with_bn_backward_applied_on_load(device):
     """conv1_1 -> conv1_2 (both conv + BN + ReLU): conv1_2's input-gradient kernel leaves conv1_1's BN-backward sums,
     and conv1_1 — which has no input gradient — computes dy = A*dz + B*y + C inside its weight-gradient kernel
