@@ -378,7 +378,8 @@ def head_conv_bn(g, feat, names, couts, is_training=True, relu=True):
     Returns (z, scale, shift, ctx): z = raw conv output [n,h,w,sum(couts)] f32."""
     n, h, w, cin = feat.shape
     C = sum(couts)
-    ws = g.workspace()
+    chain = g.current_chain                 # (graph.Graph.chain: the net runs the four sources as independent chains)
+    ws, ws_small = g.chain_workspaces()
     # one merged parameter per source; columns map onto the reference variables `names`
     with g.variable_scope("+".join(names)):
         wv = g.get_variable("weights", (cin, C), _merged_init(g, cin, couts), regularized=True)
@@ -401,7 +402,7 @@ def head_conv_bn(g, feat, names, couts, is_training=True, relu=True):
     mean, invstd = g.empty((C,), F32), g.empty((C,), F32)
     if is_training:
         T = ops.sc_num_partials(P, C)
-        part, stage = g.ws_small.two(T * 2 * C * 4, ops.bn_reduce_workspace(T, C))
+        part, stage = ws_small.two(T * 2 * C * 4, ops.bn_reduce_workspace(T, C))
         ops.sc_stats(z, C, part)
         ops.bn_finalize(part, T, C, float(P), gamma.data, beta.data, BN_EPS, BN_DECAY, mm.data, mv.data,
                         scale, shift, mean, invstd, stage)
@@ -412,14 +413,15 @@ def head_conv_bn(g, feat, names, couts, is_training=True, relu=True):
     def backward():
         if out.grad is None:
             return
-        dz = g.empty(z.shape, F32)
-        ops.sc_bn_bwd(z, scale, shift, mean, invstd, out.grad, relu, gamma.grad, beta.grad, dz, ws)
-        ops.conv1x1_small_wgrad(feat.data, dz, C, wv.grad, ws)
-        if feat.requires_grad:
-            acc = feat.grad is not None
-            if not acc:
-                feat.grad = g.empty(feat.shape)
-            ops.conv1x1_small_dgrad(dz, w_ck32, C, feat.grad, acc)
+        with g.chain(chain):
+            dz = g.empty(z.shape, F32)
+            ops.sc_bn_bwd(z, scale, shift, mean, invstd, out.grad, relu, gamma.grad, beta.grad, dz, ws)
+            ops.conv1x1_small_wgrad(feat.data, dz, C, wv.grad, ws)
+            if feat.requires_grad:
+                acc = feat.grad is not None
+                if not acc:
+                    feat.grad = g.empty(feat.shape)
+                ops.conv1x1_small_dgrad(dz, w_ck32, C, feat.grad, acc)
         out.grad = None
     g.record(backward, (wv, gamma, beta))
     return out, scale, shift
@@ -431,7 +433,8 @@ def head_conv_bias(g, feat, names, couts, initializer=None):
     Returns (z, None, None) in the triple form `fuse` consumes."""
     n, h, w, cin = feat.shape
     C = sum(couts)
-    ws = g.workspace()
+    chain = g.current_chain
+    ws, _ = g.chain_workspaces()
     with g.variable_scope("+".join(names)):
         init = _merged_init(g, cin, couts, initializer or xavier_uniform)
         wv = g.get_variable("weights", (cin, C), init, regularized=True)
@@ -454,13 +457,14 @@ def head_conv_bias(g, feat, names, couts, initializer=None):
     def backward():
         if out.grad is None:
             return
-        ops.sc_colsum(out.grad, C, bias.grad, ws)
-        ops.conv1x1_small_wgrad(feat.data, out.grad, C, wv.grad, ws)
-        if feat.requires_grad:
-            acc = feat.grad is not None
-            if not acc:
-                feat.grad = g.empty(feat.shape)
-            ops.conv1x1_small_dgrad(out.grad, w_ck32, C, feat.grad, acc)
+        with g.chain(chain):
+            ops.sc_colsum(out.grad, C, bias.grad, ws)
+            ops.conv1x1_small_wgrad(feat.data, out.grad, C, wv.grad, ws)
+            if feat.requires_grad:
+                acc = feat.grad is not None
+                if not acc:
+                    feat.grad = g.empty(feat.shape)
+                ops.conv1x1_small_dgrad(out.grad, w_ck32, C, feat.grad, acc)
         out.grad = None
     g.record(backward, (wv, bias))
     return out, None, None

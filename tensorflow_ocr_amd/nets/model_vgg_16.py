@@ -75,8 +75,9 @@ def model_vgg(images, weight_decay=1e-5, is_training=True, graph=None):
         srcs = [('fc7', ('Conv', 'Conv_5')), ('conv5_3', ('Conv_1', 'Conv_6')),
                 ('conv4_3', ('Conv_2', 'Conv_7')), ('conv3_3', ('Conv_3', 'Conv_8'))]
         heads = {}
-        for key, names in srcs:
-            heads[key] = layers.head_conv_bn(g, end_points[key], names, (2, 16), is_training=is_training)
+        for k, (key, names) in enumerate(srcs):
+            with g.chain(k):          # four feature maps, four independent chains of small launches (graph.Graph.chain)
+                heads[key] = layers.head_conv_bn(g, end_points[key], names, (2, 16), is_training=is_training)
         n, h, w, _ = end_points['fc7'].shape
         s1 = layers.fuse(g, (n, h, w, 18), a=heads['fc7'], b=heads['conv5_3'])
         s2 = layers.fuse(g, (n, 2 * h, 2 * w, 18), a=heads['conv4_3'], prev=s1)

@@ -82,9 +82,10 @@ class PixelLinkNet(object):
         g = self.g
         srcs = [('fc7', 'stage_6'), ('conv5_3', 'stage_5'), ('conv4_3', 'stage_4'), ('conv3_3', 'stage_3')]
         heads = {}
-        for key, st in srcs:
-            heads[key] = layers.head_conv_bias(g, end_points[key], (st + '_pixel_fuse', st + '_link_fuse'),
-                                               (2, 16), initializer=xavier_uniform)
+        for k, (key, st) in enumerate(srcs):
+            with g.chain(k):          # independent chains of small launches (graph.Graph.chain)
+                heads[key] = layers.head_conv_bias(g, end_points[key], (st + '_pixel_fuse', st + '_link_fuse'),
+                                                   (2, 16), initializer=xavier_uniform)
         n, h, w, _ = end_points['fc7'].shape
         s1 = layers.fuse(g, (n, h, w, 18), a=heads['fc7'], b=heads['conv5_3'])
         s2 = layers.fuse(g, (n, 2 * h, 2 * w, 18), a=heads['conv4_3'], prev=s1)

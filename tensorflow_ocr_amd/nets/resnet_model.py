@@ -19,7 +19,10 @@ def model_resnet50_pixellink(images, weight_decay=1e-5, is_training=True, graph=
     f = [end_points['pool5'], end_points['pool4'], end_points['pool3'], end_points['pool2']]
     with g.variable_scope('feature_fusion'):
         names = [('Conv', 'Conv_4'), ('Conv_1', 'Conv_5'), ('Conv_2', 'Conv_6'), ('Conv_3', 'Conv_7')]
-        heads = [layers.head_conv_bn(g, fm, nm, (2, 16), is_training=is_training) for fm, nm in zip(f, names)]
+        heads = []
+        for k, (fm, nm) in enumerate(zip(f, names)):
+            with g.chain(k):          # independent chains of small launches (graph.Graph.chain)
+                heads.append(layers.head_conv_bn(g, fm, nm, (2, 16), is_training=is_training))
         n, h, w, _ = f[0].shape
         s0 = layers.fuse(g, (n, h, w, 18), a=heads[0])                          # relu(bn(conv(pool5)))
         s1 = layers.fuse(g, (n, 2 * h, 2 * w, 18), a=heads[1], prev=s0)       # unpool(.) + conv(pool4)

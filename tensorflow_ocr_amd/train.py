@@ -14,6 +14,11 @@ import torch
 from . import ops
 from .graph import F32
 
+# independent chains (graph.Graph.chain) on streams of their own: measured SLOWER than the one-stream order (headline step
+# 20.37 vs 20.03 ms, PixelLink 16.87 vs 16.44: the cross-queue fork / join signals cost more than the overlap of ~24 small
+# launches gains), so off by default; the path stays tested (tests/test_gpu_train_step.py)
+USE_CHAINS = __import__("os").environ.get("OCR_CHAINS", "0") == "1"
+
 
 def exponential_decay(learning_rate, global_step, decay_steps=5000, decay_rate=0.94, staircase=True):
     """tf.train.exponential_decay (multigpu_train.py:104)."""
@@ -229,6 +234,8 @@ class TrainStep:
         self.loss = None
         self.side_stream = None
         self.side_ptr = None
+        self.chain_streams = {}       # chain id -> (torch stream, its handle): graph.Graph.chain
+        self.fork_event = None
         self._packed_version = None
         # weight gradients on a second stream: measured neutral-to-negative once the wgrad kernels
         # reached the conv kernels' efficiency (both saturate the VGPR file, so they time-slice rather
@@ -317,22 +324,56 @@ class TrainStep:
                 dst.copy_(src, non_blocking=True)
         timing = ops.KERNEL_TIMING
         main = torch.cuda.current_stream()
+        if self.fork_event is None:
+            self.fork_event = torch.cuda.Event()
         if self.side_stream is None:
             self.side_stream = torch.cuda.Stream()
             self.side_ptr = ctypes.c_void_p(self.side_stream.cuda_stream)
             if self.reducer is not None:
                 self.reducer.extra_streams = [self.side_stream]
         side, side_ptr, side_used = self.side_stream, self.side_ptr, False
+        chains = self.chain_streams if USE_CHAINS else None
+        group_open, forked = False, []
         for e in self.plan:
             if e[0] == "c":
                 tag = e[4]
                 if tag is not None and tag[0] == "xchg":
                     # the gradient exchange as C-ABI calls (dist.GradientAllReduce, abi mode)
                     if self.reducer.enabled:
+                        if group_open:
+                            for k in forked:
+                                main.wait_stream(chains[k][0])
+                            group_open, forked = False, []
                         rc = e[1](*e[2])
                         if rc != 0:
                             _lib.check(rc, e[3])
                     continue
+            # independent chains (graph.Graph.chain): chain k > 0 on its own stream, forked from the main stream where the
+            # group begins (the first chained call after an unchained one), joined before the next unchained entry
+            k = e[5] if (chains is not None and e[0] == "c") else None
+            if k is None:
+                if group_open:
+                    for j in forked:
+                        main.wait_stream(chains[j][0])
+                    group_open, forked = False, []
+            else:
+                if not group_open:
+                    group_open = True
+                    self.fork_event.record(main)
+                if k > 0:
+                    if k not in chains:
+                        st = torch.cuda.Stream()
+                        chains[k] = (st, ctypes.c_void_p(st.cuda_stream))
+                    st, st_ptr = chains[k]
+                    if k not in forked:
+                        st.wait_event(self.fork_event)
+                        forked.append(k)
+                    rc = e[1](*(e[2][:-1] + (st_ptr,)))
+                    if rc != 0:
+                        _lib.check(rc, e[3])
+                    continue
+            if e[0] == "c":
+                tag = e[4]
                 if tag is not None and tag[0] == "side" and self.use_side_stream:
                     # weight gradient: only the optimiser (and the all-reduce) consumes it
                     side.wait_stream(main)
@@ -353,6 +394,8 @@ class TrainStep:
                     main.wait_stream(side)       # optimiser / end of step: weight gradients done
                     side_used = False
                 e[1]()
+        for j in forked:
+            main.wait_stream(chains[j][0])
         if side_used:
             main.wait_stream(side)
         return self.loss

@@ -25,7 +25,10 @@ def _make(device, replay):
     return g, batch, TrainStep(g, fl, lambda gr: AdamOptimizer(gr, learning_rate=1e-3), replay=replay)
 
 
-def test_replay_equals_eager_bitwise(device):
+@pytest.mark.parametrize("chains", [False, True])
+def test_replay_equals_eager_bitwise(device, chains, monkeypatch):
+    from tensorflow_ocr_amd import train
+    monkeypatch.setattr(train, "USE_CHAINS", chains)
     ge, be, se = _make(device, False)
     gr, br, sr = _make(device, True)
     le, lr = [], []
@@ -35,6 +38,10 @@ def test_replay_equals_eager_bitwise(device):
     assert sr.plan is not None and se.plan is None
     assert le == lr, (le, lr)
     assert le[-1] < le[0]
+    # the four head sources are independent chains (graph.Graph.chain): with train.USE_CHAINS the replayed plan runs three
+    # of them on streams of their own, forward and backward, and still agrees with the one-stream eager run bit for bit
+    assert sorted({e[5] for e in sr.plan if e[0] == "c" and e[5] is not None}) == [0, 1, 2, 3]
+    assert sorted(sr.chain_streams) == ([1, 2, 3] if chains else [])
     assert torch.equal(ge.store.flat, gr.store.flat)
     assert torch.equal(ge.store.flat_aux, gr.store.flat_aux)
     # fresh data goes through the recorded input buffers
