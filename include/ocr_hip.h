@@ -171,10 +171,18 @@ int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const void* x4,
 /* The same weight gradient with conv1_1's batch-norm backward APPLY computed while the tile is staged: `da` is the
  * gradient of the layer's activation relu(bn(bn_y)); dy = A*dz + B*bn_y + C, dz = da * [bn_y*A + bn_shift rounds to a
  * positive 16-bit value] (relu) — coefficients from ocr_bn_bwd_coefficients (A = the layer's scale).  conv1_1 has no
- * input gradient, so nothing else reads dy: the apply pass and its 1 GiB output disappear (nets/vgg.py:14). */
+ * input gradient, so nothing else reads dy: the apply pass and its 1 GiB output disappear (nets/vgg.py:14).
+ * With w_first (the forward's packed weights) the kernel does not read bn_y either (it may be NULL): the tile's y is
+ * evaluated again from the image halo it stages anyway, by the forward's own MFMA sequence (bit-identical 16-bit y). */
 int ocr_conv2d_first_wgrad_bn_f16(int n, int h, int w, int cout, const void* x4, const void* da, const void* bn_y,
-                                  const void* bn_shift, const void* coef_a, const void* coef_b, const void* coef_c,
-                                  int relu, void* dw, void* workspace, size_t ws_bytes, void* stream);
+                                  const void* w_first, const void* bn_shift, const void* coef_a, const void* coef_b,
+                                  const void* coef_c, int relu, void* dw, void* workspace, size_t ws_bytes,
+                                  void* stream);
+/* conv1_1 of the batch-norm nets, SECOND pass (the first, ocr_conv2d_first_f16 with OCR_CONV_STATS, produced the
+ * statistics): a = relu(scale * y + shift) with y evaluated again from the image — 67 MB read instead of the 1 GiB of
+ * y that ocr_bn_relu_f16 reads at 32 x 512^2; same values as that pass on the stored y. */
+int ocr_conv2d_first_bn_relu_f16(int n, int h, int w, int cout, const void* x4, const void* w_first,
+                                 const void* scale, const void* shift, int relu, void* a, void* stream);
 size_t ocr_conv2d_first_wgrad_workspace(int n, int h, int w, int cout);
 
 /* ResNet root convolution: 7x7 stride 2, cin = 3 (image [n,h,w,4] f16), explicit (3,3) padding of

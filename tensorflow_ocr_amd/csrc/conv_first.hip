@@ -33,42 +33,28 @@ __device__ __forceinline__ void load_halo4(const half_t* __restrict__ x4, char* 
   }
 }
 
-__global__ __launch_bounds__(256) void conv_first_kernel(FirstP p, const half_t* __restrict__ x4,
-                                                         const half_t* __restrict__ wf,
-                                                         const float* __restrict__ bias,
-                                                         half_t* __restrict__ y,
-                                                         float* __restrict__ stats) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* halo = smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// The layer's arithmetic, shared by every kernel that evaluates it (the forward, its batch-norm-apply form and the
+// weight gradient that recomputes y instead of reading it): the SAME MFMA sequence on the same operand layout gives
+// the same f32 accumulators, hence bit-identical 16-bit y wherever it is evaluated.  Wave w owns tile rows 2w, 2w+1.
+__device__ __forceinline__ void first_weights(const half_t* __restrict__ wf, int cout, int co0, int lane,
+                                              half8_t (&a)[3][2]) {
   const int r = lane & 31, hh = lane >> 5;
-  const int n_tiles = p.cout / 64;
-  const int nt = blockIdx.x % n_tiles;
-  const int mt = blockIdx.x / n_tiles;
-  const int txi = mt % p.tiles_x;
-  const int tmp = mt / p.tiles_x;
-  const int tyi = tmp % p.tiles_y;
-  const int img = tmp / p.tiles_y;
-  const int co0 = nt * 64;
-
-  half8_t a[3][2];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      a[ky][i] = *reinterpret_cast<const half8_t*>(wf + ((size_t)(ky * p.cout + co0 + i * 32 + r)) * 16 + 8 * hh);
+      a[ky][i] = *reinterpret_cast<const half8_t*>(wf + ((size_t)(ky * cout + co0 + i * 32 + r)) * 16 + 8 * hh);
+}
 
-  load_halo4(x4, halo, img, p.h, p.w, tyi * TILE_H - 1, txi * TILE_W - 1);
-  __syncthreads();
-
-  f32x16 acc[2][2];
+__device__ __forceinline__ void first_mfma(const char* halo, const half8_t (&a)[3][2], int wave, int lane,
+                                           f32x16 (&acc)[2][2]) {
+  const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.f;
-
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -83,9 +69,70 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstP p, const half_t*
         acc[i][t] = OCR_MFMA_32x32x16(a[ky][i], b, acc[i][t], 0, 0, 0);
     }
   }
+}
+
+// BNAPPLY (conv + batch norm + ReLU nets, second pass of conv1_1): the statistics exist (the first pass), so the
+// convolution is evaluated AGAIN — 67 MB of image instead of the 1 GiB of y the element-wise pass would read — and
+// the tile leaves as the activation a = relu(scale * y16 + shift), y16 = the 16-bit value the first pass stored.
+struct FirstAct {
+  const float *scale, *shift;
+  int relu;
+};
+
+template <bool BNAPPLY>
+__global__ __launch_bounds__(256) void conv_first_kernel(FirstP p, const half_t* __restrict__ x4,
+                                                         const half_t* __restrict__ wf,
+                                                         const float* __restrict__ bias,
+                                                         half_t* __restrict__ y,
+                                                         float* __restrict__ stats, FirstAct act) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_tiles = p.cout / 64;
+  const int nt = blockIdx.x % n_tiles;
+  const int mt = blockIdx.x / n_tiles;
+  const int txi = mt % p.tiles_x;
+  const int tmp = mt / p.tiles_x;
+  const int tyi = tmp % p.tiles_y;
+  const int img = tmp / p.tiles_y;
+  const int co0 = nt * 64;
+
+  half8_t a[3][2];
+  first_weights(wf, p.cout, co0, lane, a);
+  load_halo4(x4, halo, img, p.h, p.w, tyi * TILE_H - 1, txi * TILE_W - 1);
   __syncthreads();
-  conv_epilogue<64, 2, 2, 1>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt, co0, p.h, p.w,
-                             p.cout, 0, wave, true);
+  f32x16 acc[2][2];
+  first_mfma(halo, a, wave, lane, acc);
+  __syncthreads();
+  if constexpr (BNAPPLY) {
+    constexpr int OSTR = 64 * 2 + 16;                 // conv_epilogue's staging layout
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = i * 32 + q * 8 + hh * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(act.scale + co0 + col);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(act.shift + co0 + col);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int px = (wave * 2 + t) * 32 + r;
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y16 = (float)(half_t)acc[i][t][q * 4 + e];
+            float f = __builtin_fmaf(y16, sc[e], sh[e]);
+            if (act.relu) f = f > 0.f ? f : 0.f;
+            o[e] = (half_t)f;
+          }
+          *reinterpret_cast<half4_t*>(smem + px * OSTR + col * 2) = o;
+        }
+      }
+    conv_epilogue_store<64, 256>(smem, 0, y, nullptr, img, tyi, txi, mt, co0, p.h, p.w, p.cout, nullptr);
+  } else {
+    conv_epilogue<64, 2, 2, 1>(acc, smem, p.flags, bias, y, stats, img, tyi, txi, mt, co0, p.h, p.w,
+                               p.cout, 0, wave, true);
+  }
 }
 
 // ---- weight gradient -------------------------------------------------------
@@ -112,16 +159,21 @@ constexpr int DSTRF = 64 * 2 + 64;  // bytes per dy row
 // is computed while the tile is staged — conv1_1 has no input gradient, so the weight gradient is the ONLY reader
 // of dy and the separate apply pass (read y, read da, write dy: 3 GiB at 32 x 512^2) plus this kernel's read of dy
 // become one read of y and da.
+// RECOMPUTE: y is not read either — the tile's y16 is evaluated from the halo the kernel stages anyway (first_mfma:
+// 12 MFMAs per wave and tile) into the dy staging rows, where each thread then replaces its own eight chunks by dy.
+// The kernel is bound by its HBM streams: one (da) instead of two.
 struct FirstBn {
   const half_t* y;
   const float *A, *B, *C, *shift;
   int relu;
+  const half_t* wf;        // RECOMPUTE: the forward's packed weights [3][cout][16]
 };
 
-template <bool BNAPPLY>
+template <bool BNAPPLY, bool RECOMPUTE = false>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const half_t* __restrict__ x4,
                                                                const half_t* __restrict__ dy, FirstBn bn,
                                                                float* __restrict__ partial) {
+  static_assert(!RECOMPUTE || BNAPPLY, "y is only needed by the batch-norm apply");
   __shared__ __attribute__((aligned(16))) char halo[10 * HW * 8];
   __shared__ __attribute__((aligned(16))) char patch[256 * PSTRF];
   __shared__ __attribute__((aligned(16))) char dyt[256 * DSTRF];
@@ -139,7 +191,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
   // the dy tile (32 KB, the stream that bounds this kernel) of tile t+1 is fetched into registers
   // while tile t's patch rows are built and multiplied
   u32x4 dreg[8];
-  u32x4 yreg[BNAPPLY ? 8 : 1];
+  u32x4 yreg[BNAPPLY && !RECOMPUTE ? 8 : 1];
+  u32x4 yrec[RECOMPUTE ? 8 : 1];
+  constexpr int YSTRF = 64 * 2 + 16;
+  half8_t wa[RECOMPUTE ? 3 : 1][2];
+  if constexpr (RECOMPUTE) first_weights(bn.wf, p.cout, co0, lane, wa);
   float cA[8], cB[8], cC[8], cS[8];
   if (BNAPPLY) {
 #pragma unroll
@@ -159,20 +215,20 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
       const int px = idx >> 3, c = idx & 7;
       const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
       dreg[u] = u32x4{0u, 0u, 0u, 0u};
-      if (BNAPPLY) yreg[u] = u32x4{0u, 0u, 0u, 0u};
+      if (BNAPPLY && !RECOMPUTE) yreg[u] = u32x4{0u, 0u, 0u, 0u};
       if (oy < p.h && ox < p.w) {
         const size_t off = (((size_t)img * p.h + oy) * p.w + ox) * p.cout + co0 + c * 8;
         dreg[u] = *reinterpret_cast<const u32x4*>(dy + off);
-        if (BNAPPLY) yreg[u] = *reinterpret_cast<const u32x4*>(bn.y + off);
+        if (BNAPPLY && !RECOMPUTE) yreg[u] = *reinterpret_cast<const u32x4*>(bn.y + off);
       }
     }
   };
   // (tiles are whole multiples of the image here or zero padded: a pixel outside the image stages dy = 0)
-  auto staged = [&](int u, bool inside) -> u32x4 {
+  auto staged = [&](int u, bool inside, u32x4 yv) -> u32x4 {
     if (!BNAPPLY) return dreg[u];
     if (!inside) return u32x4{0u, 0u, 0u, 0u};
     const half8_t g8 = __builtin_bit_cast(half8_t, dreg[u]);
-    const half8_t y8 = __builtin_bit_cast(half8_t, yreg[u]);
+    const half8_t y8 = __builtin_bit_cast(half8_t, yv);
     half8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -191,12 +247,40 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
     const int img = tmp / p.tiles_y;
     __syncthreads();
     load_halo4(x4, halo, img, p.h, p.w, tyi * TILE_H - 1, txi * TILE_W - 1);
+    if constexpr (RECOMPUTE) {
+      __syncthreads();
+      f32x16 yacc[2][2];
+      first_mfma(halo, wa, wave, lane, yacc);
+      const int r = lane & 31, h5 = lane >> 5;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)yacc[i][t][qq * 4 + e];
+            // (a layout of its own inside the dy staging area: 144-byte rows, the conflict-free pitch of conv_epilogue)
+            *reinterpret_cast<half4_t*>(dyt + ((wave * 2 + t) * 32 + r) * YSTRF + (i * 32 + qq * 8 + h5 * 4) * 2) = o;
+          }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = u * 256 + tid;
+        yrec[u] = *reinterpret_cast<const u32x4*>(dyt + (idx >> 3) * YSTRF + (idx & 7) * 16);
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int idx = u * 256 + tid;
       const int px = idx >> 3;
       const bool inside = tyi * TILE_H + (px >> 5) < p.h && txi * TILE_W + (px & 31) < p.w;
-      *reinterpret_cast<u32x4*>(dyt + px * DSTRF + (idx & 7) * 16) = staged(u, inside);
+      u32x4 yv = u32x4{0u, 0u, 0u, 0u};
+      if constexpr (RECOMPUTE) yv = yrec[u];
+      else if constexpr (BNAPPLY) yv = yreg[u];
+      *reinterpret_cast<u32x4*>(dyt + px * DSTRF + (idx & 7) * 16) = staged(u, inside, yv);
     }
     if (mt + (int)gridDim.x < p.m_tiles) load_dy(mt + gridDim.x);
     __syncthreads();
@@ -298,10 +382,25 @@ extern "C" int ocr_conv2d_first_f16(int n, int h, int w, int cout, const void* x
   OCR_CHECK_ARG(!(flags & OCR_CONV_BIAS) || bias);
   OCR_CHECK_ARG(!(flags & OCR_CONV_STATS) || stats);
   const size_t lds = conv_epilogue_lds(64);
-  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(p.m_tiles * (cout / 64))), dim3(256), lds,
+  hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)(p.m_tiles * (cout / 64))), dim3(256), lds,
                      static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x4),
                      static_cast<const half_t*>(w_first), static_cast<const float*>(bias),
-                     static_cast<half_t*>(y), static_cast<float*>(stats));
+                     static_cast<half_t*>(y), static_cast<float*>(stats), FirstAct{});
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_conv2d_first_bn_relu_f16(int n, int h, int w, int cout, const void* x4, const void* w_first,
+                                            const void* scale, const void* shift, int relu, void* a,
+                                            void* stream) {
+  FirstP p;
+  int rc = fill(&p, n, h, w, cout, 0);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x4 && w_first && scale && shift && a);
+  const size_t lds = conv_epilogue_lds(64);
+  hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)(p.m_tiles * (cout / 64))), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x4),
+                     static_cast<const half_t*>(w_first), (const float*)nullptr, static_cast<half_t*>(a),
+                     (float*)nullptr, FirstAct{static_cast<const float*>(scale), static_cast<const float*>(shift), relu});
   return ocr_launch_status();
 }
 
@@ -330,21 +429,27 @@ extern "C" int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const v
 }
 
 extern "C" int ocr_conv2d_first_wgrad_bn_f16(int n, int h, int w, int cout, const void* x4, const void* da,
-                                             const void* bn_y, const void* bn_shift, const void* coef_a,
-                                             const void* coef_b, const void* coef_c, int relu, void* dw,
-                                             void* workspace, size_t ws_bytes, void* stream) {
+                                             const void* bn_y, const void* w_first, const void* bn_shift,
+                                             const void* coef_a, const void* coef_b, const void* coef_c, int relu,
+                                             void* dw, void* workspace, size_t ws_bytes, void* stream) {
   FirstP p;
   int rc = fill(&p, n, h, w, cout, 0);
   if (rc != OCR_OK) return rc;
-  OCR_CHECK_ARG(x4 && da && bn_y && bn_shift && coef_a && coef_b && coef_c && dw && workspace);
+  OCR_CHECK_ARG(x4 && da && (bn_y || w_first) && bn_shift && coef_a && coef_b && coef_c && dw && workspace);
   if (ws_bytes < ocr_conv2d_first_wgrad_workspace(n, h, w, cout)) return OCR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int blocks = wgrad_blocks(p.m_tiles);
   FirstBn bn{static_cast<const half_t*>(bn_y), static_cast<const float*>(coef_a), static_cast<const float*>(coef_b),
-             static_cast<const float*>(coef_c), static_cast<const float*>(bn_shift), relu};
-  hipLaunchKernelGGL(conv_first_wgrad_kernel<true>, dim3(blocks, cout / 64), dim3(256), 0, st, p,
-                     static_cast<const half_t*>(x4), static_cast<const half_t*>(da), bn,
-                     static_cast<float*>(workspace));
+             static_cast<const float*>(coef_c), static_cast<const float*>(bn_shift), relu,
+             static_cast<const half_t*>(w_first)};
+  if (w_first != nullptr)
+    hipLaunchKernelGGL((conv_first_wgrad_kernel<true, true>), dim3(blocks, cout / 64), dim3(256), 0, st, p,
+                       static_cast<const half_t*>(x4), static_cast<const half_t*>(da), bn,
+                       static_cast<float*>(workspace));
+  else
+    hipLaunchKernelGGL((conv_first_wgrad_kernel<true, false>), dim3(blocks, cout / 64), dim3(256), 0, st, p,
+                       static_cast<const half_t*>(x4), static_cast<const half_t*>(da), bn,
+                       static_cast<float*>(workspace));
   const int elems = 27 * cout;
   hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(elems)), dim3(256), 0, st,
                      static_cast<const float*>(workspace), static_cast<float*>(dw), elems, blocks * 2, 1.f);

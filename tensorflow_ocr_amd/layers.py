@@ -58,6 +58,10 @@ def _const_vec(g, n, value):
 
 FUSE_BN_W4_MAXHW = int(__import__("os").environ.get("OCR_FUSE_BN_W4_MAXHW", "1000000"))
 FUSE_BN_POOL_REDUCE = __import__("os").environ.get("OCR_FUSE_BN_POOL_REDUCE", "1") == "1"    # measurement switch
+FIRST_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_RECOMPUTE", "1") == "1"            # measurement switch (forward: 439 -> 318 us)
+# conv1_1's weight gradient recomputing y as well: bit-identical, but no faster (413 vs 402 us at 32 x 512^2: with one
+# stream instead of two the kernel is bound by its per-tile LDS work, not by HBM) — off until y need not be stored at all
+FIRST_WGRAD_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_WGRAD_RECOMPUTE", "0") == "1"
 FUSE_FIRST_WGRAD = __import__("os").environ.get("OCR_FUSE_FIRST_WGRAD", "1") == "1"    # measurement switch
 
 
@@ -135,7 +139,11 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 ops.bn_relu_pool_idx(y, scale, shift, relu, None, pooled, argmax, y_pool)
         else:
             full = g.empty((n, oh, ow, cout))
-            ops.bn_relu(y, scale, shift, relu, 0, full, None)
+            if first and FIRST_RECOMPUTE:
+                # conv1_1: evaluating the 3-channel convolution again costs 67 MB of reads, the element-wise pass 1 GiB
+                ops.conv2d_first_bn_relu(x.data, w_fwd, scale, shift, relu, full)
+            else:
+                ops.bn_relu(y, scale, shift, relu, 0, full, None)
         a_full = Act(full, name=scope) if full is not None else None
         a_pool = Act(pooled, name=scope + "/pool") if pooled is not None else None
         if not pool and train_stats:
@@ -163,7 +171,8 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
                 ops.bn_bwd_coefficients(part_f, T_f, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
                                         beta.grad, coef, ws)
-                ops.conv2d_first_wgrad_bn(x.data, da_full, y, shift, coef, relu, wv.grad, ws)
+                ops.conv2d_first_wgrad_bn(x.data, da_full, y, shift, coef, relu, wv.grad, ws,
+                                          w_first=w_fwd if FIRST_WGRAD_RECOMPUTE else None)
                 a_full.bn_partial = None
                 a_full.grad = None
                 return

@@ -239,15 +239,24 @@ def conv2d_first_wgrad(x4, dy, dw, ws):
            ptr(dw), ptr(buf), c_size_t(nbytes), _st())
 
 
-def conv2d_first_wgrad_bn(x4, da, y, shift, coef, relu, dw, ws):
-    """conv1_1's weight gradient with its BN-backward apply computed on load (coef: bn_bwd_coefficients)."""
+def conv2d_first_wgrad_bn(x4, da, y, shift, coef, relu, dw, ws, w_first=None):
+    """conv1_1's weight gradient with its BN-backward apply computed on load (coef: bn_bwd_coefficients); with
+    `w_first` y is recomputed from the image instead of read."""
     n, h, w, _ = x4.shape
     cout = da.shape[-1]
     nbytes = L.call_size("ocr_conv2d_first_wgrad_workspace", c_int(n), c_int(h), c_int(w), c_int(cout))
     buf = ws.get(nbytes)
     a, b, c = coef
-    L.call("ocr_conv2d_first_wgrad_bn_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(da), ptr(y),
-           ptr(shift), ptr(a), ptr(b), ptr(c), c_int(int(relu)), ptr(dw), ptr(buf), c_size_t(nbytes), _st())
+    L.call("ocr_conv2d_first_wgrad_bn_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(da),
+           ptr(None if w_first is not None else y), ptr(w_first), ptr(shift), ptr(a), ptr(b), ptr(c), c_int(int(relu)),
+           ptr(dw), ptr(buf), c_size_t(nbytes), _st())
+
+
+def conv2d_first_bn_relu(x4, w_first, scale, shift, relu, a):
+    """conv1_1's activation relu(bn(conv(x))) with the convolution evaluated again (second pass; the statistics exist)."""
+    n, h, w, _ = x4.shape
+    L.call("ocr_conv2d_first_bn_relu_f16", c_int(n), c_int(h), c_int(w), c_int(a.shape[-1]), ptr(x4), ptr(w_first),
+           ptr(scale), ptr(shift), c_int(int(relu)), ptr(a), _st())
 
 
 def conv2d_stem_num_mtiles(n, h, w):

@@ -264,6 +264,43 @@ def test_pooled_bn_backward_with_stored_argmax_equals_recomputing_path(device, n
     assert float(outs[0][0].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 40, 72), (1, 21, 45)])
+def test_first_conv_recomputed_instead_of_read_is_bit_identical(device, n, h, w):
+    """conv1_1's second pass (ocr_conv2d_first_bn_relu_f16: the activation from the convolution evaluated AGAIN) and its
+    weight gradient with y recomputed from the image (ocr_conv2d_first_wgrad_bn_f16 with w_first): the same MFMA
+    sequence on the same operands, so bit-identical to the passes that read the stored y; ragged tile edges included."""
+    from tensorflow_ocr_amd import layers, ops
+    from tensorflow_ocr_amd.graph import Graph, F32
+    rng = np.random.default_rng(h)
+    cout = 64
+    g = Graph(device, loss_scale=1.0)
+    img = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    x4 = layers.prep_images(g, torch.from_numpy(img).to(device)).data
+    wt = torch.from_numpy((rng.standard_normal((3, 3, 3, cout)) * 0.05).astype(np.float32)).to(device)
+    wf = torch.empty((3, cout, 16), dtype=O.STORAGE, device=device)
+    ops.pack_weights_first(wt, wf)
+    y = torch.empty((n, h, w, cout), dtype=O.STORAGE, device=device)
+    ops.conv2d_first(x4, wf, y)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(device)
+    scale[3] = -0.7
+    shift = torch.from_numpy(rng.normal(0, 0.3, cout).astype(np.float32)).to(device)
+    for relu in (True, False):
+        a_ref, a_new = torch.empty_like(y), torch.empty_like(y)
+        ops.bn_relu(y, scale, shift, relu, 0, a_ref, None)
+        ops.conv2d_first_bn_relu(x4, wf, scale, shift, relu, a_new)
+        assert torch.equal(a_ref, a_new), int((a_ref != a_new).sum())
+    da = torch.from_numpy((rng.standard_normal((n, h, w, cout)) * 0.1).astype(np.float32)).to(O.STORAGE).to(device)
+    coef = tuple(torch.from_numpy(rng.normal(0, 0.5, cout).astype(np.float32)).to(device) for _ in range(3))
+    coef = (scale, coef[1], coef[2])                      # A = the layer's scale (the mask reads it)
+    ws = ops.Workspace(device, 16 << 20)
+    dw0 = torch.zeros((3, 3, 3, cout), dtype=F32, device=device)
+    dw1 = torch.zeros_like(dw0)
+    ops.conv2d_first_wgrad_bn(x4, da, y, shift, coef, True, dw0, ws)
+    ops.conv2d_first_wgrad_bn(x4, da, None, shift, coef, True, dw1, ws, w_first=wf)
+    torch.cuda.synchronize()
+    assert float(dw0.abs().sum()) > 0 and torch.equal(dw0, dw1), float((dw0 - dw1).abs().max())
+
+
 def test_pooled_bn_layer_backward_sums_from_the_consumer_convolution(device):
     """conv a (+BN+ReLU, 2x2 pool its only reader) -> conv b: b's input-gradient kernel sums a's BN-backward terms over
     the POOLED positions (bn_y = y_pool, the conv output at each window's first maximum) and a's backward is the
