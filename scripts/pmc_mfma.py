@@ -40,26 +40,31 @@ def provenance(command):
 
 
 def short(name):
+    """Kernel name as `ocr_conv2d_variant` / bench.py print it: identifier + the integer template arguments."""
     name = re.sub(r"\(anonymous namespace\)::", "", name)
+    ident, args = None, []
     m = re.match(r"(?:void )?([A-Za-z0-9_]+)(<[^>]*>)?", name)
     if m and not name.startswith("_Z"):
-        return m.group(1) + (m.group(2) or "")
-    m = re.match(r"_ZN\d+_GLOBAL__N_1(\d+)", name)
-    if m:                                   # Itanium mangling: <len><identifier>[I<template args>E]...
-        n0 = m.end()
-        ident = name[n0:n0 + int(m.group(1))]
-        rest = name[n0 + int(m.group(1)):]
-        args = []
-        if rest.startswith("I"):
-            args = re.findall(r"L[ib](\d+)E", rest[:rest.find("EEv") + 1] if "EEv" in rest else rest)
-        # the wave-private-epilogue kernels carry their epilogue mode as a LAST template argument (conv_igemm.hip:
-        # epi_mode): the instantiations of one kernel are reported together, under the name ocr_conv2d_variant prints
-        if ident in ("conv3x3_w4_kernel", "conv3x3_w4s_kernel", "conv_c64_persist_kernel") and args:
-            args = args[:-1]
-            if ident == "conv_c64_persist_kernel":
-                args = args[:1] if args[1:] == ["0"] else args
-        return ident + ("<" + ",".join(args) + ">" if args else "")
-    return name[:80]
+        ident = m.group(1)
+        if m.group(2):
+            args = [{"true": "1", "false": "0"}.get(a.strip(), a.strip()) for a in m.group(2)[1:-1].split(",")]
+    else:
+        m = re.match(r"_ZN\d+_GLOBAL__N_1(\d+)", name)
+        if m:                                   # Itanium mangling: <len><identifier>[I<template args>E]...
+            n0 = m.end()
+            ident = name[n0:n0 + int(m.group(1))]
+            rest = name[n0 + int(m.group(1)):]
+            if rest.startswith("I"):
+                args = re.findall(r"L[ib](\d+)E", rest[:rest.find("EEv") + 1] if "EEv" in rest else rest)
+    if ident is None:
+        return name[:80]
+    # the wave-private-epilogue kernels carry their epilogue mode as a LAST template argument (conv_igemm.hip:
+    # epi_mode): the instantiations of one kernel are reported together, under the name ocr_conv2d_variant prints
+    if ident in ("conv3x3_w4_kernel", "conv3x3_w4s_kernel", "conv_c64_persist_kernel") and args:
+        args = args[:-1]
+        if ident == "conv_c64_persist_kernel":
+            args = args[:1] if args[1:] == ["0"] else args
+    return ident + ("<" + ",".join(args) + ">" if args else "")
 
 
 def main(d):
