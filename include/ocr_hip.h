@@ -104,6 +104,15 @@ int ocr_conv2d_relu_pool_f16(const ocr_conv_desc* d, const void* x, const void* 
 int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y, void* partial,
                          const void* bn_y, const void* bn_scale, const void* bn_shift,
                          const void* bn_mean, const void* bn_invstd, int bn_relu, int store_masked, void* stream);
+/* The same for the convolution that consumes conv1_1's activation (conv1_2, nets/vgg.py:17; 64 -> 64 channels: the
+ * persistent 64-channel kernel only, OCR_ERR_UNSUPPORTED otherwise): conv1_1's y is not read but evaluated again in the
+ * epilogue from the prepared image x4 [n][h][w][4] and conv1_1's packed weights (ocr_pack_weights_first_f16) by the
+ * forward's own MFMA sequence — the same 16-bit values — so that y need not be stored at all: the forward then runs
+ * ocr_conv2d_first_f16 with y = NULL (statistics only), ocr_conv2d_first_bn_relu_f16 for the activation, and the
+ * backward this entry and ocr_conv2d_first_wgrad_bn_f16 with w_first. */
+int ocr_conv2d_bnred_first_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y, void* partial,
+                               const void* x4, const void* w_first, const void* bn_scale, const void* bn_shift,
+                               const void* bn_mean, const void* bn_invstd, int bn_relu, void* stream);
 /* Column sums of such partial rows [T][2][c] -> out0 (kind 0), out1 (kind 1); fixed order, one launch. */
 int ocr_bn_bwd_sums(const void* partial, int T, int c, void* out0, void* out1, void* workspace, size_t ws_bytes,
                     void* stream);

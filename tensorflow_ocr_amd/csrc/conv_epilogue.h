@@ -36,6 +36,11 @@ struct BnRed {
   // activation is relu(conv + bias) (scale 1, shift 0: y IS the activation) there is no BN-backward pass that could
   // apply the mask later, and partial row 0 (sum dz) is their bias gradient (PixelLink's VGG, nets/pixellink.py:41-48)
   int store_dz;
+  // conv1_1 as the producing layer (conv_c64_persist_kernel, epilogue mode 6): y is NOT read — nobody stored it — but
+  // evaluated again per tile from the prepared image [n][oh][ow][4] and the first layer's packed weights [3][cout][16]
+  // by the forward's own MFMA sequence (conv_first.hip: first_mfma), hence the same 16-bit values
+  const half_t* first_x4;
+  const half_t* first_wf;
 };
 
 // LDS needed by the epilogue for a BN-wide tile.
@@ -145,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
           for (int e = 0; e < 8; ++e)
             if (!((float)yv[u][e] * bsc[e] + bsh[e] > OCR_RELU_TIE)) w[e] = (half_t)0.f;
         }
-        *reinterpret_cast<half8_t*>(y + off) = w;
+        if (y != nullptr) *reinterpret_cast<half8_t*>(y + off) = w;   // (null: a statistics-only launch)
         if (do_stats) {
           if (br != nullptr) {
 #pragma unroll
@@ -209,7 +214,7 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
           for (int e = 0; e < 8; ++e)
             if (!((float)yv0[e] * bsc[e] + bsh[e] > OCR_RELU_TIE)) w[e] = (half_t)0.f;
         }
-        *reinterpret_cast<half8_t*>(y + off) = w;
+        if (y != nullptr) *reinterpret_cast<half8_t*>(y + off) = w;   // (null: a statistics-only launch)
         if (do_stats) {
           if (br != nullptr) {
             const half8_t yv = *reinterpret_cast<const half8_t*>(br->y + off);

@@ -378,7 +378,8 @@ extern "C" int ocr_conv2d_first_f16(int n, int h, int w, int cout, const void* x
   FirstP p;
   int rc = fill(&p, n, h, w, cout, flags);
   if (rc != OCR_OK) return rc;
-  OCR_CHECK_ARG(x4 && w_first && y);
+  OCR_CHECK_ARG(x4 && w_first);
+  OCR_CHECK_ARG(y || (flags & OCR_CONV_STATS));          // y == NULL: a statistics-only launch (nothing is stored)
   OCR_CHECK_ARG(!(flags & OCR_CONV_BIAS) || bias);
   OCR_CHECK_ARG(!(flags & OCR_CONV_STATS) || stats);
   const size_t lds = conv_epilogue_lds(64);

@@ -1518,8 +1518,19 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   const bool has_bias = EPI == 0 ? (p.flags & OCR_CONV_BIAS) != 0 : EPI == 3;
   const bool relu = EPI == 0 ? (p.flags & OCR_CONV_RELU) != 0 : EPI == 3;
   const bool accum = EPI == 0 ? (p.flags & OCR_CONV_ACCUM_F16) != 0 : false;
-  const bool do_stats = EPI == 0 ? (p.flags & OCR_CONV_STATS) != 0 : (EPI == 1 || EPI == 2 || EPI == 4);
-  const bool has_br = EPI == 0 ? p.br.y != nullptr : (EPI == 2 || EPI == 4);              // (fields read by value: a pointer to p.br would pin the arguments in scratch)
+  const bool do_stats = EPI == 0 ? (p.flags & OCR_CONV_STATS) != 0 : (EPI == 1 || EPI == 2 || EPI == 4 || EPI == 6);
+  const bool has_br = EPI == 0 ? p.br.y != nullptr : (EPI == 2 || EPI == 4 || EPI == 6);              // (fields read by value: a pointer to p.br would pin the arguments in scratch)
+  // mode 6 = mode 2 with the producing layer's y RECOMPUTED (BnRed::first_x4): conv1_1 under conv1_2's input gradient
+  constexpr bool RECOMP = EPI == 6;
+  const int r32 = lane & 31, h32 = lane >> 5;         // the 32x32x16 MFMA's lane -> (row / pixel, k half) map
+  half8_t fw[RECOMP ? 3 : 1][2];                      // first-layer weights: the same for every tile
+  if constexpr (RECOMP) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fw[ky][i] = *reinterpret_cast<const half8_t*>(p.br.first_wf + ((size_t)(ky * p.cout + co0 + i * 32 + r32)) * 16 + 8 * h32);
+  }
 
   // weights -> LDS, once: slot tap*512 + tid -> row tid>>3, stored chunk tid&7 holds logical chunk c ^ swz
   {
@@ -1624,10 +1635,25 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
         const int ox = txi * TILE_W + kk * 8 + pg;
         if (oy < p.oh && ox < p.ow) {
           const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c8 * 8;
-          if (do_stats && has_br) yq[kk] = *reinterpret_cast<const half8_t*>(p.br.y + off);
+          if (!RECOMP && do_stats && has_br) yq[kk] = *reinterpret_cast<const half8_t*>(p.br.y + off);
           if (accum) oq[kk] = *reinterpret_cast<const half8_t*>(y + off);
         }
       }
+    }
+    // mode 6: the image pixels of this wave's row of the first layer instead — per kernel row ky two adjacent pixels
+    // (8 bytes each, 4 channels) per lane, exactly the fragment first_mfma reads from its LDS halo; zero outside
+    u32x2 fim[RECOMP ? 3 : 1][2];
+    if constexpr (RECOMP) {
+      const half_t* xim = p.br.first_x4 + (size_t)img * p.oh * p.ow * 4;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int iy = oy + ky - 1, ix = txi * TILE_W + r32 + 2 * h32 - 1 + j;
+          fim[ky][j] = u32x2{0u, 0u};
+          if ((unsigned)iy < (unsigned)p.oh && (unsigned)ix < (unsigned)p.ow)
+            fim[ky][j] = *reinterpret_cast<const u32x2*>(xim + ((size_t)iy * p.ow + ix) * 4);
+        }
     }
 
     f32x4 acc[AI][AT];
@@ -1741,12 +1767,56 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
         if (p.pool_idx != nullptr) *reinterpret_cast<unsigned long long*>(p.pool_idx + off) = am;
       }
     } else {
+    half8_t vq[RECOMP ? 4 : 1];
+    if constexpr (RECOMP) {
+      // the gradient chunks out of the staging rows first, then the same rows carry this wave's row of y: six MFMAs on
+      // the fragments fetched above (first_mfma's sequence for one tile row), rounded to the storage type as the
+      // forward rounds it, staged in the layout the chunks are read back in
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int px = kk * 8 + pg;
+        vq[kk] = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
+      }
+      f32x16 ya[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ya[i][e] = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const half4_t lo = __builtin_bit_cast(half4_t, fim[ky][0]), hi = __builtin_bit_cast(half4_t, fim[ky][1]);
+        const half8_t b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ya[i] = OCR_MFMA_32x32x16(fw[ky][i], b, ya[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                    // every lane holds its gradient chunks
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)ya[i][q * 4 + e];
+          *reinterpret_cast<half4_t*>(stage + r32 * 128 + (((i * 4 + q) ^ (r32 & 7)) << 4) + h32 * 8) = o;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int px = kk * 8 + pg;
+        yq[kk] = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int px = kk * 8 + pg;
       const int ox = txi * TILE_W + px;
       if (oy < p.oh && ox < p.ow) {
-        half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
+        half8_t v;
+        if constexpr (RECOMP) v = vq[kk];
+        else v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
         const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c8 * 8;
         if (accum) {
 #pragma unroll
@@ -1928,6 +1998,7 @@ static int epi_mode(const ConvP& p) {
   if (force_generic) return 0;
   const bool br = p.br.y != nullptr;
   const int fl = p.flags;
+  if (p.br.first_x4 != nullptr) return 6;      // (conv_c64_persist_kernel only: the entry point checks the variant)
   if (fl == OCR_CONV_STATS && !br) return 1;
   if (fl == OCR_CONV_STATS && br && p.br.mask == nullptr && p.br.mask_bits == nullptr) return p.br.store_dz ? 4 : 2;
   if (fl == (OCR_CONV_BIAS | OCR_CONV_RELU) && !br) return 3;
@@ -1942,11 +2013,12 @@ static int launch_c64(const ConvP& p0, const void* x, const void* w, const void*
   // (the pooled variant exists for bias + ReLU layers only: its other modes are the generic instantiation)
   constexpr bool P = POOL;
   const int epi = P && epi_mode(p0) != 3 ? 0 : epi_mode(p0);
-  static const ConvKernT kerns[6] = {conv_c64_persist_kernel<64, P, 0>, conv_c64_persist_kernel<64, P, P ? 0 : 1>,
+  static const ConvKernT kerns[7] = {conv_c64_persist_kernel<64, P, 0>, conv_c64_persist_kernel<64, P, P ? 0 : 1>,
                                      conv_c64_persist_kernel<64, P, P ? 0 : 2>, conv_c64_persist_kernel<64, P, 3>,
-                                     conv_c64_persist_kernel<64, P, P ? 0 : 4>, conv_c64_persist_kernel<64, P, P ? 0 : 5>};
+                                     conv_c64_persist_kernel<64, P, P ? 0 : 4>, conv_c64_persist_kernel<64, P, P ? 0 : 5>,
+                                     conv_c64_persist_kernel<64, P, P ? 0 : 6>};
   const ConvKernT kern = kerns[epi];
-  static bool configured[6] = {false, false, false, false, false, false};
+  static bool configured[7] = {false, false, false, false, false, false, false};
   if (!configured[epi]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(160 * 1024)) != hipSuccess)
@@ -2239,6 +2311,28 @@ extern "C" int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const
                static_cast<const float*>(bn_invstd), bn_relu};
   p.br.store_dz = store_masked;
   return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
+}
+
+// ocr_conv2d_bnred_f16 for the convolution that consumes conv1_1's activation (conv1_2 of nets/vgg.py:17): the fused
+// BN-backward sums need conv1_1's y, and instead of reading 128 B per pixel the epilogue evaluates it again from the
+// 8-byte image pixels (BnRed::first_x4).  conv_c64_persist_kernel only (64 -> 64 channels, the shape of that layer).
+extern "C" int ocr_conv2d_bnred_first_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y,
+                                          void* partial, const void* x4, const void* w_first,
+                                          const void* bn_scale, const void* bn_shift, const void* bn_mean,
+                                          const void* bn_invstd, int bn_relu, void* stream) {
+  ConvP p;
+  TileCfg cfg;
+  int rc = fill_params(d, &p, &cfg);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x && w_kc && y && partial && x4 && w_first && bn_scale && bn_shift && bn_mean && bn_invstd);
+  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_BIAS | OCR_CONV_RELU | OCR_CONV_ACCUM_F16)));
+  if (!uses_c64(p, cfg) || p.cout != 64) return OCR_ERR_UNSUPPORTED;
+  p.flags |= OCR_CONV_STATS;
+  p.br = BnRed{nullptr, static_cast<const float*>(bn_scale), static_cast<const float*>(bn_shift),
+               static_cast<const float*>(bn_mean), static_cast<const float*>(bn_invstd), bn_relu};
+  p.br.first_x4 = static_cast<const half_t*>(x4);
+  p.br.first_wf = static_cast<const half_t*>(w_first);
+  return launch_c64<false>(p, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }
 
 // 1x1 convolution whose input is the previous bottleneck's output relu(bn(conv3) + shortcut), computed while the

@@ -59,6 +59,7 @@ def _const_vec(g, n, value):
 FUSE_BN_W4_MAXHW = int(__import__("os").environ.get("OCR_FUSE_BN_W4_MAXHW", "1000000"))
 FUSE_BN_POOL_REDUCE = __import__("os").environ.get("OCR_FUSE_BN_POOL_REDUCE", "1") == "1"    # measurement switch
 FIRST_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_RECOMPUTE", "1") == "1"            # measurement switch (forward: 439 -> 318 us)
+FIRST_DROP_Y = __import__("os").environ.get("OCR_FIRST_DROP_Y", "1") == "1"                  # conv1_1's y is never stored (ops.LazyFirstY)
 # conv1_1's weight gradient recomputing y as well: bit-identical, but no faster (413 vs 402 us at 32 x 512^2: with one
 # stream instead of two the kernel is bound by its per-tile LDS work, not by HBM) — off until y need not be stored at all
 FIRST_WGRAD_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_WGRAD_RECOMPUTE", "0") == "1"
@@ -103,14 +104,19 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         d = ops.conv_desc((n, h, w, cin), cout, k, k, stride, rate)
         oh, ow = d.oh, d.ow
         mt = ops.conv2d_num_mtiles(d)
-    y = g.empty((n, oh, ow, cout))
+    # conv1_1 under training-mode batch norm: y is never stored — the statistics pass writes nothing, the activation and
+    # the two readers of y in the backward pass (conv1_2's fused BN-backward sums, conv1_1's own weight gradient)
+    # evaluate the 3-channel convolution again; a consumer that cannot asks the LazyFirstY for the tensor
+    drop_y = (first and normalizer == "bn" and not pool and cout == 64 and FIRST_RECOMPUTE and FIRST_DROP_Y
+              and (is_training if bn_training is None else bn_training) and FUSE_FIRST_WGRAD)
+    y = ops.LazyFirstY(g.empty, x.data, w_fwd, (n, oh, ow, cout)) if drop_y else g.empty((n, oh, ow, cout))
 
     if normalizer == "bn":
         train_stats = bn_training
         flags = CONV_STATS if train_stats else 0
         part, stage = g.ws_small.two(mt * 2 * cout * 4, ops.bn_reduce_workspace(mt, cout))
         if first:
-            ops.conv2d_first(x.data, w_fwd, y, flags, None, part if train_stats else None)
+            ops.conv2d_first(x.data, w_fwd, None if drop_y else y, flags, None, part if train_stats else None, cout=cout)
         else:
             d.flags = flags
             ops.conv2d(d, x.data, w_fwd, y, None, part if train_stats else None)
@@ -143,7 +149,7 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 # conv1_1: evaluating the 3-channel convolution again costs 67 MB of reads, the element-wise pass 1 GiB
                 ops.conv2d_first_bn_relu(x.data, w_fwd, scale, shift, relu, full)
             else:
-                ops.bn_relu(y, scale, shift, relu, 0, full, None)
+                ops.bn_relu(y.tensor() if isinstance(y, ops.LazyFirstY) else y, scale, shift, relu, 0, full, None)
         a_full = Act(full, name=scope) if full is not None else None
         a_pool = Act(pooled, name=scope + "/pool") if pooled is not None else None
         if not pool and train_stats:
@@ -171,27 +177,36 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
                 ops.bn_bwd_coefficients(part_f, T_f, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
                                         beta.grad, coef, ws)
-                ops.conv2d_first_wgrad_bn(x.data, da_full, y, shift, coef, relu, wv.grad, ws,
-                                          w_first=w_fwd if FIRST_WGRAD_RECOMPUTE else None)
+                lazy = isinstance(y, ops.LazyFirstY)
+                if lazy and y.t is not None:
+                    lazy, y_t = False, y.t                # somebody had it evaluated: read it
+                else:
+                    y_t = None if lazy else y
+                ops.conv2d_first_wgrad_bn(x.data, da_full, y_t, shift, coef, relu, wv.grad, ws,
+                                          w_first=w_fwd if (lazy or FIRST_WGRAD_RECOMPUTE) else None)
                 a_full.bn_partial = None
                 a_full.grad = None
                 return
-            dy = g.empty(y.shape)
+            if isinstance(y, ops.LazyFirstY):
+                y_b = y.tensor()                  # (the unfused routes below read y)
+            else:
+                y_b = y
+            dy = g.empty(y_b.shape)
             if not pool and a_full.bn_partial is not None:
                 part_f, T_f = a_full.bn_partial
-                ops.bn_relu_bwd_apply(y, scale, shift, mean, invstd, da_full, relu, part_f, T_f,
+                ops.bn_relu_bwd_apply(y_b, scale, shift, mean, invstd, da_full, relu, part_f, T_f,
                                       gamma.grad, beta.grad, dy, ws)
                 a_full.bn_partial = None
             elif pool and argmax is not None and da_full is None and a_pool.bn_partial is not None:
                 part_p, T_p = a_pool.bn_partial
-                ops.bn_relu_pool_bwd_idx_apply(y, scale, mean, invstd, argmax, da_pool, relu, part_p, T_p,
+                ops.bn_relu_pool_bwd_idx_apply(y_b, scale, mean, invstd, argmax, da_pool, relu, part_p, T_p,
                                                gamma.grad, beta.grad, dy, ws)
                 a_pool.bn_partial = None
             elif pool and argmax is not None and da_full is None:
-                ops.bn_relu_pool_bwd_idx(y, scale, mean, invstd, a_pool.data, argmax, da_pool, relu,
+                ops.bn_relu_pool_bwd_idx(y_b, scale, mean, invstd, a_pool.data, argmax, da_pool, relu,
                                          gamma.grad, beta.grad, dy, ws)
             else:
-                ops.bn_relu_bwd(y, scale, shift, mean, invstd, da_full, da_pool, relu, 2 if pool else 0,
+                ops.bn_relu_bwd(y_b, scale, shift, mean, invstd, da_full, da_pool, relu, 2 if pool else 0,
                                 gamma.grad, beta.grad, dy, ws)
             _conv_backward(g, x, wv, w_dg, d, dy, first)
             if a_full is not None:
@@ -302,7 +317,13 @@ def _conv_backward(g, x, wv, w_dg, d, dy, first):
     if fuse:
         T = ops.conv2d_num_mtiles(dg)
         partial = g.empty((T, 2, d.cin), F32)
-        ops.conv2d_bnred(dg, dy, w_dg, x.grad, partial, x.bn_ctx)
+        by = x.bn_ctx[0]
+        if (isinstance(by, ops.LazyFirstY) and by.t is None and d.cin == 64
+                and ops.conv2d_variant(dg) == "conv_c64_persist_kernel<64>"):
+            # the consumer of conv1_1's activation (conv1_2): conv1_1's y is recomputed in the epilogue, not read
+            ops.conv2d_bnred_first(dg, dy, w_dg, x.grad, partial, (by.x4, by.w_first) + tuple(x.bn_ctx[1:]))
+        else:
+            ops.conv2d_bnred(dg, dy, w_dg, x.grad, partial, x.bn_ctx)
         x.bn_partial = (partial, T)
     else:
         ops.conv2d(dg, dy, w_dg, x.grad, None, None)

@@ -125,8 +125,37 @@ def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx, store_masked=False):
     """Input-gradient conv fused with the BN-backward reduction of the layer below.  store_masked: y receives the
     gradient PAST that layer's ReLU (bias nets: bn_ctx = (activation, ones, zeros, zeros, ones, True))."""
     by, sc, sh, mu, istd, relu = bn_ctx
+    if isinstance(by, LazyFirstY):
+        by = by.tensor()                 # a consumer that cannot recompute conv1_1's y: evaluate and store it now
     L.call("ocr_conv2d_bnred_f16", byref(d), ptr(x), ptr(w_kc), ptr(y), ptr(partial), ptr(by), ptr(sc),
            ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), c_int(int(store_masked)), _st())
+    if L.RECORDER is not None:
+        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+        L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
+
+
+class LazyFirstY:
+    """conv1_1's raw output y, which the batch-norm training step no longer stores (the statistics pass writes nothing,
+    the activation and both readers of y in the backward pass evaluate the 3-channel convolution again): `tensor()`
+    evaluates and stores it for a consumer that cannot."""
+
+    def __init__(self, alloc, x4, w_first, shape):
+        self.alloc, self.x4, self.w_first, self.shape = alloc, x4, w_first, shape
+        self.t = None
+
+    def tensor(self):
+        if self.t is None:
+            self.t = self.alloc(self.shape)
+            conv2d_first(self.x4, self.w_first, self.t)
+        return self.t
+
+
+def conv2d_bnred_first(d, x, w_kc, y, partial, first_ctx):
+    """conv2d_bnred for the consumer of conv1_1's activation with conv1_1's y recomputed from the image instead of read:
+    first_ctx = (x4, w_first, scale, shift, mean, invstd, relu)."""
+    x4, wf, sc, sh, mu, istd, relu = first_ctx
+    L.call("ocr_conv2d_bnred_first_f16", byref(d), ptr(x), ptr(w_kc), ptr(y), ptr(partial), ptr(x4), ptr(wf), ptr(sc),
+           ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), _st())
     if L.RECORDER is not None:
         flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
         L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
@@ -159,6 +188,8 @@ def conv2d_pw_bnbwd_bnred(d, dz, y_above, coef, dy_out, w_kc, dx, partial, bn_ct
     """1x1 input-gradient conv whose operand dy = A*dz + B*y_above + C is computed while it is loaded and written to
     dy_out; fused BN-backward reduction of the layer below as in conv2d_bnred."""
     by, sc, sh, mu, istd, relu = bn_ctx
+    if isinstance(by, LazyFirstY):
+        by = by.tensor()
     a, b, c = coef
     L.call("ocr_conv2d_pw_bnbwd_bnred_f16", byref(d), ptr(dz), ptr(y_above), ptr(a), ptr(b), ptr(c), ptr(dy_out),
            ptr(w_kc), ptr(dx), ptr(partial), ptr(by), ptr(sc), ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), _st())
@@ -223,9 +254,10 @@ def conv2d_first_num_mtiles(n, h, w):
     return L.call_int("ocr_conv2d_first_num_mtiles", c_int(n), c_int(h), c_int(w))
 
 
-def conv2d_first(x4, w_first, y, flags=0, bias=None, stats=None):
+def conv2d_first(x4, w_first, y, flags=0, bias=None, stats=None, cout=None):
+    """y = None with CONV_STATS: a statistics-only launch (pass `cout`)."""
     n, h, w, _ = x4.shape
-    cout = y.shape[-1]
+    cout = y.shape[-1] if y is not None else cout
     L.call("ocr_conv2d_first_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(w_first),
            ptr(bias), c_int(flags), ptr(y), ptr(stats), _st())
 

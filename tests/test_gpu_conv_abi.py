@@ -150,6 +150,59 @@ def test_special_kernels_are_selected_and_emit_stats(device, n, h, w, c, variant
     assert np.allclose(got2[1], (dz * xh).sum((0, 1, 2)), rtol=1e-3, atol=5e-2)
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 100, 130), (9, 64, 64), (2, 129, 97)])
+def test_fused_reduction_with_conv1_1_recomputed_equals_reading_it(device, n, h, w):
+    """ocr_conv2d_bnred_first_f16 (the persistent 64-channel kernel's epilogue mode 6): conv1_2's input gradient with
+    conv1_1's BN-backward sums, conv1_1's y evaluated again from the image in the epilogue instead of read — the
+    forward's own MFMA sequence, so output and partial rows are bit-identical to ocr_conv2d_bnred_f16 on the stored y;
+    ragged tiles and image borders included.  A shape another kernel would run is refused."""
+    from tensorflow_ocr_amd import layers, ops
+    from tensorflow_ocr_amd.graph import Graph
+    rng = np.random.default_rng(h)
+    c = 64
+    g = Graph(device, loss_scale=1.0)
+    img = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    x4 = layers.prep_images(g, torch.from_numpy(img).to(device)).data
+    wt1 = torch.from_numpy((rng.standard_normal((3, 3, 3, c)) * 0.05).astype(np.float32)).to(device)
+    wf = torch.empty((3, c, 16), dtype=O.STORAGE, device=device)
+    ops.pack_weights_first(wt1, wf)
+    y1 = torch.empty((n, h, w, c), dtype=O.STORAGE, device=device)
+    ops.conv2d_first(x4, wf, y1)
+    # statistics-only launch: same partial rows, nothing stored
+    T1 = ops.conv2d_first_num_mtiles(n, h, w)
+    pa = torch.zeros((T1, 2, c), dtype=torch.float32, device=device)
+    pb = torch.zeros_like(pa)
+    y1b = torch.empty_like(y1)
+    ops.conv2d_first(x4, wf, y1b, ops.CONV_STATS, None, pa)
+    ops.conv2d_first(x4, wf, None, ops.CONV_STATS, None, pb, cout=c)
+    assert torch.equal(y1, y1b) and torch.equal(pa, pb) and float(pa.abs().sum()) > 0
+    # conv1_2's input gradient
+    dy = torch.from_numpy(_h(rng.standard_normal((n, h, w, c)) * 0.1)).to(O.STORAGE).to(device)
+    w2 = torch.from_numpy(_h(rng.standard_normal((3, 3, c, c)) * np.sqrt(2.0 / (9 * c)))).to(device)
+    w_kc = torch.empty((9, c, c), dtype=O.STORAGE, device=device)
+    w_ck = torch.empty((9, c, c), dtype=O.STORAGE, device=device)
+    ops.pack_weights(w2, w_kc, w_ck)
+    dg = ops.ConvDesc(n, h, w, c, h, w, c, 3, 3, 1, 1, 1, 1, 1, 0)
+    assert ops.conv2d_variant(dg) == "conv_c64_persist_kernel<64>"
+    T = ops.conv2d_num_mtiles(dg)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).to(device)
+    scale[5] = -0.8
+    ctx = (scale,) + tuple(torch.from_numpy(a.astype(np.float32)).to(device) for a in (
+        rng.normal(0, 0.3, c), rng.normal(0, 0.2, c), rng.uniform(0.7, 1.3, c)))
+    dx_r, dx_f = torch.empty_like(y1), torch.empty_like(y1)
+    part_r = torch.zeros((T, 2, c), dtype=torch.float32, device=device)
+    part_f = torch.zeros_like(part_r)
+    ops.conv2d_bnred(dg, dy, w_ck, dx_r, part_r, (y1,) + ctx + (True,))
+    ops.conv2d_bnred_first(dg, dy, w_ck, dx_f, part_f, (x4, wf) + ctx + (True,))
+    torch.cuda.synchronize()
+    assert torch.equal(dx_r, dx_f)
+    assert float(part_r.abs().sum()) > 0 and torch.equal(part_r, part_f), float((part_r - part_f).abs().max())
+    d128 = ops.ConvDesc(n, h, w, 128, h, w, 64, 3, 3, 1, 1, 1, 1, 1, 0)
+    from tensorflow_ocr_amd._lib import OcrHipError
+    with pytest.raises(OcrHipError):
+        ops.conv2d_bnred_first(d128, dy, w_ck, dx_f, part_f, (x4, wf) + ctx + (True,))
+
+
 def test_batched_weight_repack_equals_per_layer(device):
     """ocr_pack_weights_batch_f16 (every conv layer's two operand layouts in one launch, after the optimiser step)
     writes exactly what ocr_pack_weights_f16 writes layer by layer — including ragged 32-tiles and a NULL layout."""
