@@ -60,8 +60,9 @@ FUSE_BN_W4_MAXHW = int(__import__("os").environ.get("OCR_FUSE_BN_W4_MAXHW", "100
 FUSE_BN_POOL_REDUCE = __import__("os").environ.get("OCR_FUSE_BN_POOL_REDUCE", "1") == "1"    # measurement switch
 FIRST_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_RECOMPUTE", "1") == "1"            # measurement switch (forward: 439 -> 318 us)
 FIRST_DROP_Y = __import__("os").environ.get("OCR_FIRST_DROP_Y", "1") == "1"                  # conv1_1's y is never stored (ops.LazyFirstY)
-# conv1_1's weight gradient recomputing y as well: bit-identical, but no faster (413 vs 402 us at 32 x 512^2: with one
-# stream instead of two the kernel is bound by its per-tile LDS work, not by HBM) — off until y need not be stored at all
+# conv1_1's weight gradient recomputing y even when y IS stored: bit-identical, but no faster by itself (413 vs 402 us at
+# 32 x 512^2: with one stream instead of two the kernel is bound by its per-tile LDS work, not by HBM).  With
+# FIRST_DROP_Y (y never stored) the recomputing form is what runs regardless of this switch.
 FIRST_WGRAD_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_WGRAD_RECOMPUTE", "0") == "1"
 FUSE_FIRST_WGRAD = __import__("os").environ.get("OCR_FUSE_FIRST_WGRAD", "1") == "1"    # measurement switch
 
