@@ -100,7 +100,7 @@ def run_case(kind, hw, cin, cout, zero):
     ms = e0.elapsed_time(e1) / 100
     med, p10, p90, cyc = clock(reader, slots)
     wg = None
-    if kind.startswith("conv") and variant == "conv3x3_w4_kernel":
+    if kind.startswith("conv") and variant.startswith(("conv3x3_w4_kernel", "conv3x3_w4s_kernel")):
         # whole-workgroup cycles (kernel entry -> end of wave 0's epilogue instruction stream): tile = main loop + the rest
         buf = (ctypes.c_ulonglong * (2 * slots))()
         fn = getattr(L.load(), reader + "_wg")
@@ -123,8 +123,8 @@ def main():
     out = {}
     for label, (hw, cin, cout) in CASES.items():
         for kind in ("conv", "conv+bnred", "wgrad"):
-            if kind == "conv+bnred" and cout % 256:
-                continue                                     # the stamped epilogue split exists in conv3x3_w4_kernel only
+            if kind == "conv+bnred" and cout % 128:
+                continue                                     # the stamped epilogue split exists in the w4 / w4s kernels only
             for zero in (False, True):
                 r = run_case(kind, hw, cin, cout, zero)
                 out["%s | %s | %s" % (label, kind, r["operands"])] = r

@@ -1139,6 +1139,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
   // halo pieces of the next chunk: two per step in the chunk's first three steps (6 pieces), so that the last
   // one has five steps to land before the fragments of the next chunk's first step are read (step 8)
   constexpr int HPS = 2, HSTEPS = W4S_NH / HPS;
+  OCR_DIAG_WG_BEGIN()
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wbuf = smem + 2 * W4S_HBYTES;
 
@@ -1471,6 +1472,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
             ((red[tid] + red[2 * BN + tid]) + red[4 * BN + tid]) + red[6 * BN + tid];
     }
   }
+  OCR_DIAG_WG_END(ocr_diag_conv)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2105,7 +2107,10 @@ static int launch_w4s(const ConvP& p0, const void* x, const void* w, const void*
   dim3 grid((unsigned)(m_tiles * p.n_tiles));
   static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 2; }();
   p.xcd_swizzle = (swz & 1) && grid.x % 8 == 0;
-  hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)w4s_lds(BN), st, p, static_cast<const half_t*>(x),
+  // OCR_W4S_SOLO=1 (measurement switch): ask for the whole LDS, so that ONE workgroup fits a CU — what a wave of this
+  // kernel does without a partner on its SIMD (scripts/clock_diag.py)
+  static const int solo = [] { const char* e = getenv("OCR_W4S_SOLO"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL(kern, grid, dim3(256), solo ? (size_t)(160 * 1024) : (size_t)w4s_lds(BN), st, p, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats));
   return ocr_launch_status();
