@@ -12,6 +12,8 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct DiceP {
   int P, pc, G;
 };
@@ -41,6 +43,54 @@ __global__ __launch_bounds__(256) void dice_reduce_kernel(DiceP d, const float* 
       const float y = ytl[p * 8 + i];
       float ps = 0.f;
       for (int j = 0; j < d.G; ++j) ps += ypl[p * 8 * d.G + i * d.G + j];
+      s[3 + 3 * i] += y * ps * m;
+      s[4 + 3 * i] += y * m;
+      s[5 + 3 * i] += ps * m;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 27; ++j) {
+    float v = wave_sum(s[j]);
+    if (lane == 0) red[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27)
+    partial[(size_t)blockIdx.x * 27 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// pc = G = 2 (every net of the reference: 2 pixel logits, 8 x 2 link logits): whole 16-byte vectors per pixel — 4 of
+// link predictions, 2 of link labels — instead of 27 scalar loads at run-time strides; same sums in the same order.
+__global__ __launch_bounds__(256) void dice_reduce22_kernel(DiceP d, const float* __restrict__ ytp,
+                                                            const float* __restrict__ ypp,
+                                                            const float* __restrict__ ytl,
+                                                            const float* __restrict__ ypl,
+                                                            const float* __restrict__ mask,
+                                                            float* __restrict__ partial) {
+  __shared__ float red[4][27];
+  float s[27];
+#pragma unroll
+  for (int j = 0; j < 27; ++j) s[j] = 0.f;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)d.P; p += (size_t)gridDim.x * 256) {
+    const float m = mask[p];
+    const float y0 = ytp[p];
+    const f32x2 pp = *reinterpret_cast<const f32x2*>(ypp + p * 2);
+    f32x4 yl[2], pl[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) yl[k] = *reinterpret_cast<const f32x4*>(ytl + p * 8 + k * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pl[k] = *reinterpret_cast<const f32x4*>(ypl + p * 16 + k * 4);
+    {
+      const float ps = 0.f + pp[0] + pp[1];
+      s[0] += y0 * ps * m;
+      s[1] += y0 * m;
+      s[2] += ps * m;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float y = yl[i >> 2][i & 3];
+      const float ps = 0.f + pl[i >> 1][(i & 1) * 2] + pl[i >> 1][(i & 1) * 2 + 1];
       s[3 + 3 * i] += y * ps * m;
       s[4 + 3 * i] += y * m;
       s[5 + 3 * i] += ps * m;
@@ -114,6 +164,34 @@ __global__ void dice_bwd_kernel(DiceP d, const float* __restrict__ ytp,
   }
 }
 
+__global__ void dice_bwd22_kernel(DiceP d, const float* __restrict__ ytp, const float* __restrict__ ytl,
+                                  const float* __restrict__ mask, const float* __restrict__ sums, float gscale,
+                                  float* __restrict__ dpp, float* __restrict__ dpl) {
+  __shared__ float cI[9], cU[9];
+  if (threadIdx.x < 9) {
+    const int k = threadIdx.x;
+    const float I = sums[3 * k], U = sums[3 * k + 1] + sums[3 * k + 2] + 1e-5f;
+    const float wk = (k == 0 ? 2.f : 1.f) * gscale;
+    cU[k] = -2.f * wk / U;
+    cI[k] = 2.f * wk * I / (U * U);
+  }
+  __syncthreads();
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)d.P; p += (size_t)gridDim.x * 256) {
+    const float m = mask[p];
+    const float gp = m * (ytp[p] * cU[0] + cI[0]);
+    *reinterpret_cast<f32x2*>(dpp + p * 2) = f32x2{gp, gp};
+    f32x4 yl[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) yl[k] = *reinterpret_cast<const f32x4*>(ytl + p * 8 + k * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g0 = m * (yl[k >> 1][(k & 1) * 2] * cU[1 + 2 * k] + cI[1 + 2 * k]);
+      const float g1 = m * (yl[k >> 1][(k & 1) * 2 + 1] * cU[2 + 2 * k] + cI[2 + 2 * k]);
+      *reinterpret_cast<f32x4*>(dpl + p * 16 + k * 4) = f32x4{g0, g0, g1, g1};
+    }
+  }
+}
+
 int dice_blocks(int P) {
   int b = ocr_cdiv(P, 256 * 4);
   if (b > 1024) b = 1024;
@@ -135,7 +213,7 @@ extern "C" int ocr_dice_loss_fwd(const void* y_true_pixel, const void* y_pred_pi
   hipStream_t st = static_cast<hipStream_t>(stream);
   DiceP d{P, pc, G};
   const int T = dice_blocks(P);
-  hipLaunchKernelGGL(dice_reduce_kernel, dim3(T), dim3(256), 0, st, d,
+  hipLaunchKernelGGL(pc == 2 && G == 2 ? dice_reduce22_kernel : dice_reduce_kernel, dim3(T), dim3(256), 0, st, d,
                      static_cast<const float*>(y_true_pixel), static_cast<const float*>(y_pred_pixel),
                      static_cast<const float*>(y_true_link), static_cast<const float*>(y_pred_link),
                      static_cast<const float*>(training_mask), static_cast<float*>(workspace));
@@ -152,7 +230,7 @@ extern "C" int ocr_dice_loss_bwd(const void* y_true_pixel, int pc, const void* y
   OCR_CHECK_ARG(y_true_pixel && y_true_link && training_mask && sums27 && d_pred_pixel && d_pred_link);
   OCR_CHECK_ARG(P > 0 && pc >= 1 && G >= 1);
   DiceP d{P, pc, G};
-  hipLaunchKernelGGL(dice_bwd_kernel, dim3(dice_blocks(P) * 2), dim3(256), 0,
+  hipLaunchKernelGGL(pc == 2 && G == 2 ? dice_bwd22_kernel : dice_bwd_kernel, dim3(dice_blocks(P) * 2), dim3(256), 0,
                      static_cast<hipStream_t>(stream), d, static_cast<const float*>(y_true_pixel),
                      static_cast<const float*>(y_true_link), static_cast<const float*>(training_mask),
                      static_cast<const float*>(sums27), grad_scale,
