@@ -32,3 +32,4 @@ for f in ("pmc_mfma", "pmc_traffic", "clock_diag", "w4_per_layer", "step_calls")
     for p in sorted(glob.glob("profiles/*_%s.json" % f))[-1:]:
         print(p, json.load(open(p))["_provenance"]["csrc_sha16"], "current" if json.load(open(p))["_provenance"]["csrc_sha16"] == now else "STALE (sources changed since)")
 P
+python scripts/design_tables.py $N
