@@ -529,3 +529,27 @@ def test_counter_provenance_gates_the_reported_fields(tmp_path, monkeypatch):
     assert vals == {"traffic": 123, "mfma_busy": None, "clock_ghz": None}
     assert src["files"]["traffic"]["current"] and not src["files"]["mfma_busy"]["current"]
     assert src["files"]["clock_ghz"]["file"] is None and src["csrc_sha16_now"] == now
+
+
+def test_design_tables_show_the_committed_profiles(tmp_path):
+    """DESIGN.md section 5's per-layer table of the dominant kernel and its per-step kernel table are GENERATED from
+    profiles/r03_* (scripts/design_tables.py): regenerating them changes nothing — the text cannot drift from the
+    committed measurements — and the kernel-name folding puts the epilogue-mode instantiations under one name."""
+    import importlib.util
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("design_tables", os.path.join(root, "scripts", "design_tables.py"))
+    dt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dt)
+    before = open(os.path.join(root, "DESIGN.md")).read()
+    for name, text in (("w4_per_layer", dt.w4_table("r03")), ("step_kernels", dt.step_table("r03"))):
+        start = before.index("<!-- generated: %s -->\n" % name) + len("<!-- generated: %s -->\n" % name)
+        end = before.index("\n<!-- end generated -->", start)
+        assert before[start:end] == text, name
+    assert "| `conv3x3_w4_kernel` | 17 |" in dt.step_table("r03")
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    from pmc_mfma import short
+    assert short("_ZN12_GLOBAL__N_117conv3x3_w4_kernelILi2EEEvNS_5ConvPEPKDF16_S3_PKfPDF16_Pf") == "conv3x3_w4_kernel"
+    assert short("void conv3x3_w4s_kernel<128, 1>(ConvP, bool)") == "conv3x3_w4s_kernel<128>"
+    assert short("void conv_c64_persist_kernel<64, false, 6>(ConvP)") == "conv_c64_persist_kernel<64>"
+    assert short("void conv_pw_kernel<256, 4, true>(ConvP)") == "conv_pw_kernel<256,4,1>"
