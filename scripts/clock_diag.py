@@ -18,7 +18,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["OCR_HIP_LIB"] = os.path.join(ROOT, "tensorflow_ocr_amd", "libocr_hip_diag.so")
+# (OCR_DIAG_LIB: another diagnostic build, e.g. one compiled with a -DW4_ABL ablation; OCR_DIAG_CASES: substring filter)
+os.environ["OCR_HIP_LIB"] = os.environ.get("OCR_DIAG_LIB") or os.path.join(ROOT, "tensorflow_ocr_amd", "libocr_hip_diag.so")
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -121,8 +122,11 @@ def run_case(kind, hw, cin, cout, zero):
 
 def main():
     out = {}
+    only = os.environ.get("OCR_DIAG_CASES", "")
     for label, (hw, cin, cout) in CASES.items():
-        for kind in ("conv", "conv+bnred", "wgrad"):
+        if only and only not in label:
+            continue
+        for kind in (("conv",) if only else ("conv", "conv+bnred", "wgrad")):
             if kind == "conv+bnred" and cout % 128:
                 continue                                     # the stamped epilogue split exists in the w4 / w4s kernels only
             for zero in (False, True):
