@@ -301,6 +301,44 @@ def test_first_conv_recomputed_instead_of_read_is_bit_identical(device, n, h, w)
     assert float(dw0.abs().sum()) > 0 and torch.equal(dw0, dw1), float((dw0 - dw1).abs().max())
 
 
+@pytest.mark.parametrize("cb", [64, 128])
+def test_first_conv_y_not_stored_and_the_fallback_that_evaluates_it(device, cb):
+    """conv1_1's y is never stored (ops.LazyFirstY): with a 64-channel consumer the persistent kernel's epilogue recomputes
+    it (nobody calls .tensor()); a 128-channel consumer runs another kernel family, which cannot — conv2d_bnred asks the
+    LazyFirstY for the tensor, conv1_1's weight gradient then reads that tensor.  Either way the gradients equal those of
+    the run that stores y (bit for bit: recomputed y is the stored y)."""
+    from tensorflow_ocr_amd import layers, ops
+    from tensorflow_ocr_amd.graph import Graph
+    rng = np.random.default_rng(31 + cb)
+    n, h, w = 2, 100, 130
+    img = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    gout = _h(rng.standard_normal((n, h, w, cb)) * 0.1)
+    seen = {}
+
+    def run(drop):
+        old = layers.FIRST_DROP_Y
+        layers.FIRST_DROP_Y = drop
+        try:
+            g = Graph(device, loss_scale=1.0, seed=9)
+            x4 = layers.prep_images(g, torch.from_numpy(img).to(device))
+            a, _ = layers.conv2d(g, x4, 64, 3, "a", first=True)
+            lazy = a.bn_ctx[0]
+            assert isinstance(lazy, ops.LazyFirstY) == drop
+            b, _ = layers.conv2d(g, a, cb, 3, "b")
+            b.grad = torch.from_numpy(gout).to(O.STORAGE).to(device)
+            g.backward()
+            torch.cuda.synchronize()
+            if drop:
+                seen["materialised"] = lazy.t is not None
+            return {k: v.grad.cpu().numpy().copy() for k, v in g.store.vars.items() if v.trainable}
+        finally:
+            layers.FIRST_DROP_Y = old
+    gd, gs = run(True), run(False)
+    assert seen["materialised"] == (cb != 64)
+    for k in gs:
+        assert np.abs(gs[k]).max() > 0 and np.array_equal(gd[k], gs[k]), (k, np.abs(gd[k] - gs[k]).max())
+
+
 def test_pooled_bn_layer_backward_sums_from_the_consumer_convolution(device):
     """conv a (+BN+ReLU, 2x2 pool its only reader) -> conv b: b's input-gradient kernel sums a's BN-backward terms over
     the POOLED positions (bn_y = y_pool, the conv output at each window's first maximum) and a's backward is the
