@@ -22,7 +22,11 @@
 extern "C" {
 #endif
 
-#define OCR_ABI_VERSION 1
+/* Bumped whenever an exported entry point changes its argument list (round 3 added arguments to
+ * ocr_conv2d_bnred_f16, ocr_conv2d_bnred_tail_f16, ocr_bn_add_relu_f16, ocr_bn_relu_pool_idx_f16; round 4: the
+ * batched head entry points and the seed-rank argument of ocr_link_cc_directed).  The Python host refuses a
+ * library whose ocr_abi_version() differs from the value it was written against (_lib.ABI_VERSION). */
+#define OCR_ABI_VERSION 4
 
 enum {
   OCR_OK = 0,
@@ -468,19 +472,30 @@ int ocr_link_cc(const void* pixel_score, const void* link_score, int link_elem_s
                 int link_elem_offset, int n, int h, int w, float pixel_thresh, float link_thresh,
                 int min_size, void* labels_i32, void* ncomp_i32, void* comps_i32, int max_comps,
                 void* workspace, size_t ws_bytes, void* stream);
-/* The reference's own grouping rule, exactly (test_pixellink_fast.py:153-178; Python-2 dict order restated as
- * ascending pixel index): DIRECTED reachability from the smallest unassigned key through unassigned pixels,
- * a set gets a gid only if it has more than min_size members, sets that fail stay 0 and can be collected
- * again.  Refines ocr_link_cc's weakly-connected components (directed sets never leave one):
- * union_labels / union_ncomp are ocr_link_cc's outputs for the SAME maps and thresholds; labels (a different
- * buffer), ncomp, comps [n][max_comps][2] = (seed pixel, size) as for ocr_link_cc, gids in ascending seed
- * order.  Bit-exact against oracle.ocr_oracle.link_cc_reference_dfs. */
+/* The reference's own grouping rule, exactly (test_pixellink_fast.py:153-178): DIRECTED reachability from each
+ * unassigned key, in the order `for i in graph.keys()` meets the keys, through unassigned pixels; a set gets a gid
+ * only if it has more than min_size members, sets that fail stay 0 and can be collected again.  Refines
+ * ocr_link_cc's weakly-connected components (directed sets never leave one): union_labels / union_ncomp are
+ * ocr_link_cc's outputs for the SAME maps and thresholds; labels (a different buffer), ncomp, comps
+ * [n][max_comps][2] = (seed pixel, size) as for ocr_link_cc, gids in the order the script meets its successful
+ * seeds.  seed_order_i32 [n][h*w] (device): the keys (y*w + x of the interior segment pixels) in the script's
+ * iteration order, padded with -1 — the Python-2 dict order, from ocr_py27_dict_order below; NULL = ascending
+ * pixel index (the order rounds 1-3 of this build used).  Bit-exact against
+ * oracle.ocr_oracle.link_cc_reference_dfs(key_order="py27" | "ascending").
+ * Cost: ONE 1024-thread workgroup per image, rounds x sweeps of full-image scans: ~1 ms per 256 x 256 map, but
+ * seconds per image at 720 x 1280 with many failing seeds — an exactness mode, opt-in, never the throughput path. */
 size_t ocr_link_cc_directed_workspace(int n, int h, int w);
 int ocr_link_cc_directed(const void* pixel_score, const void* link_score, int link_elem_stride,
                          int link_elem_offset, int n, int h, int w, float pixel_thresh, float link_thresh,
                          int min_size, const void* union_labels_i32, const void* union_ncomp_i32,
-                         void* labels_i32, void* ncomp_i32, void* comps_i32, int max_comps,
-                         void* workspace, size_t ws_bytes, void* stream);
+                         const void* seed_order_i32, void* labels_i32, void* ncomp_i32, void* comps_i32,
+                         int max_comps, void* workspace, size_t ws_bytes, void* stream);
+/* HOST routine (both pointers are HOST memory; no GPU work): the iteration order of the CPython-2.7 dict the script
+ * fills with the keys y*w + x of the interior pixels with pixel_score_host[y*w + x] > pixel_thresh (the f32 comparison
+ * the kernels make), x outer / y inner (test_pixellink_fast.py:111,119-150,171).  Writes the keys in that order to order_host[0 .. count), -1 beyond, up to
+ * h*w entries; returns count (>= 0) or a negative status.  Sequential by nature (every probe depends on the table's
+ * history): ~1 us per key. */
+int ocr_py27_dict_order(const float* pixel_score_host, float pixel_thresh, int h, int w, int32_t* order_host);
 
 /* ------------------------------------------------------------------------- *
  * Locality-aware NMS (EAST, Zhou et al. CVPR 2017, Algorithm 1).  ABSENT from the reference tree

@@ -554,10 +554,51 @@ def pixel_detect(score_map, geo_map, score_map_thresh=0.8, link_thresh=0.8):
     return res
 
 
-def link_cc_reference_dfs(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, min_size=10):
-    """Literal restatement of test_pixellink_fast.py:110-178 for one map: neighbour graph of the
-    INTERIOR pixels, directed-edge DFS, keep components with len > min_size.  Python-2 dict order is
-    replaced by ascending key order.  Returns int32 labels [h,w] (gid from 1)."""
+def py27_dict_key_order(keys):
+    """Iteration order (`graph.keys()`, test_pixellink_fast.py:171) of a CPython-2.7 dict whose keys are the
+    DISTINCT non-negative ints `keys`, inserted in that sequence and never deleted.  The interpreter is absent
+    here (SURVEY 8c); this restates its published algorithm (Objects/dictobject.c, 2.7): hash(int) = the int;
+    open addressing in a power-of-two table, first slot `hash & mask`, then `i = 5*i + perturb + 1` with
+    `perturb = hash` shifted right by 5 AFTER each probe; after an insertion that leaves fill*3 >= size*2 the
+    table is rebuilt at the smallest power of two > (4 if used <= 50000 else 2) * used, re-inserting the old
+    slots in slot order; keys() walks the slots in index order.  (With a table larger than every key the order
+    is ascending; a 192 x 320 map with a few thousand keys sits in a 8192- or 32768-slot table, so keys wrap
+    and the order is NOT ascending.)"""
+    mask = 7
+    table = [-1] * 8
+    used = 0
+
+    def place(tab, msk, k):
+        i = k & msk
+        if tab[i] >= 0:
+            perturb = k
+            while True:
+                i = (i << 2) + i + perturb + 1
+                perturb >>= 5
+                if tab[i & msk] < 0:
+                    i &= msk
+                    break
+        tab[i] = k
+
+    for k in keys:
+        k = int(k)
+        place(table, mask, k)
+        used += 1
+        if used * 3 >= (mask + 1) * 2:
+            minused = (2 if used > 50000 else 4) * used
+            newsize = 8
+            while newsize <= minused:
+                newsize <<= 1
+            old, table, mask = table, [-1] * newsize, newsize - 1
+            for e in old:
+                if e >= 0:
+                    place(table, mask, e)
+    return [e for e in table if e >= 0]
+
+
+def _link_graph(pixel_score, link_scores, pixel_thresh, link_thresh):
+    """Neighbour lists of the INTERIOR segment pixels in the script's insertion sequence: x outer, y inner
+    (test_pixellink_fast.py:119-150)."""
     h, w = pixel_score.shape
     seg = pixel_score > pixel_thresh
     graph = {}
@@ -569,9 +610,31 @@ def link_cc_reference_dfs(pixel_score, link_scores, pixel_thresh=0.8, link_thres
                     if link_scores[d][y, x] > link_thresh and seg[y + dy, x + dx]:
                         nb.append((y + dy) * w + x + dx)
                 graph[y * w + x] = nb
+    return graph
+
+
+def reference_key_order(pixel_score, pixel_thresh=0.8, key_order="py27"):
+    """The order in which the script's `for i in graph.keys()` meets the keys of one map."""
+    h, w = pixel_score.shape
+    seg = pixel_score > pixel_thresh
+    inserted = [y * w + x for x in range(1, w - 1) for y in range(1, h - 1) if seg[y, x]]
+    if key_order == "ascending":
+        return sorted(inserted)
+    if key_order != "py27":
+        raise ValueError("key_order must be 'py27' or 'ascending'")
+    return py27_dict_key_order(inserted)
+
+
+def link_cc_reference_dfs(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, min_size=10, key_order="py27"):
+    """Literal restatement of test_pixellink_fast.py:110-178 for one map: neighbour graph of the
+    INTERIOR pixels, directed-edge DFS, keep components with len > min_size.  Seeds are met in the
+    iteration order of the script's Python-2 dict (`py27_dict_key_order`; key_order="ascending" = the
+    order rounds 1-3 used instead).  Returns int32 labels [h,w] (gid from 1)."""
+    h, w = pixel_score.shape
+    graph = _link_graph(pixel_score, link_scores, pixel_thresh, link_thresh)
     group = np.zeros(h * w, np.int32)
     gid = 1
-    for key in sorted(graph.keys()):
+    for key in reference_key_order(pixel_score, pixel_thresh, key_order):
         if group[key] != 0:
             continue
         stack, label, seen = [key], [], set()
@@ -589,16 +652,17 @@ def link_cc_reference_dfs(pixel_score, link_scores, pixel_thresh=0.8, link_thres
     return group.reshape(h, w)
 
 
-def link_cc_directed_rounds(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, min_size=10):
+def link_cc_directed_rounds(pixel_score, link_scores, pixel_thresh=0.8, link_thresh=0.9, min_size=10, key_order="py27"):
     """The schedule `ocr_link_cc_directed` runs (csrc/decode.hip: cc_directed_kernel), restated on the CPU so that
     its equivalence with the literal script (`link_cc_reference_dfs`) is checked without a GPU: inside every
-    weakly-connected component, rounds of (seed = smallest key that is unassigned and not known to fail;
-    R = forward-reachable set through unassigned pixels; |R| > min_size ? assign : all of R known to fail),
-    gids in ascending seed order.  Returns int32 labels [h,w]."""
+    weakly-connected component, rounds of (seed = the key of smallest RANK in the script's key order that is
+    unassigned and not known to fail; R = forward-reachable set through unassigned pixels; |R| > min_size ? assign :
+    all of R known to fail), gids in ascending rank of the seeds.  Returns int32 labels [h,w]."""
     h, w = pixel_score.shape
     seg = pixel_score > pixel_thresh
     ulab, _ = link_cc_union(pixel_score, link_scores, pixel_thresh, link_thresh, min_size)
     ulab = ulab.ravel()
+    order = reference_key_order(pixel_score, pixel_thresh, key_order)
     edges = {}
     for y in range(1, h - 1):
         for x in range(1, w - 1):
@@ -610,8 +674,8 @@ def link_cc_directed_rounds(pixel_score, link_scores, pixel_thresh=0.8, link_thr
     group = np.zeros(h * w, np.int64)
     while True:
         seeds = {}
-        for k in sorted(edges):
-            if state[k] == 1 and not dead[k] and ulab[k] not in seeds:
+        for k in order:
+            if k in edges and state[k] == 1 and not dead[k] and ulab[k] not in seeds:
                 seeds[ulab[k]] = k
         if not seeds:
             break
@@ -631,9 +695,12 @@ def link_cc_directed_rounds(pixel_score, link_scores, pixel_thresh=0.8, link_thr
                 state[R] = 2
             else:
                 dead[R] = True
-    seeds_ok = np.nonzero(group == np.arange(h * w) + 1)[0]
     ids = np.zeros(h * w + 1, np.int32)
-    ids[seeds_ok + 1] = np.arange(1, len(seeds_ok) + 1)
+    nid = 0
+    for k in order:                       # gids in the order the script meets its successful seeds
+        if group[k] == k + 1:
+            nid += 1
+            ids[k + 1] = nid
     return ids[group].reshape(h, w).astype(np.int32)
 
 

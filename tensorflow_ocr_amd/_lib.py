@@ -37,6 +37,9 @@ class SoftmaxLossDesc(ctypes.Structure):
                [(n, ctypes.c_float) for n in ("neg_ratio", "alpha", "gamma")]
 
 _lib = None
+# the value of OCR_ABI_VERSION (include/ocr_hip.h) this host layer was written against: a library built from
+# other sources would take its pointers shifted by a slot and write wildly instead of returning an OCR_ERR
+ABI_VERSION = 4
 
 
 def load():
@@ -56,6 +59,9 @@ def load():
     lib.ocr_status_string.argtypes = [ctypes.c_int]
     lib.ocr_abi_version.restype = ctypes.c_int
     lib.ocr_storage_dtype.restype = ctypes.c_char_p
+    if lib.ocr_abi_version() != ABI_VERSION:
+        raise OcrHipError("%s exports ABI version %d, the Python host expects %d: rebuild it (`make -C "
+                          "tensorflow_ocr_amd/csrc`)" % (LIB_PATH, lib.ocr_abi_version(), ABI_VERSION))
     if lib.ocr_storage_dtype().decode() != STORAGE:
         raise OcrHipError("%s stores %s but OCR_STORAGE=%s" % (LIB_PATH, lib.ocr_storage_dtype().decode(), STORAGE))
     _lib = lib

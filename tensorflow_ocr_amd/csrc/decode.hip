@@ -338,7 +338,9 @@ __global__ void zero_pixels_kernel(unsigned char* __restrict__ mask, const int* 
 __global__ __launch_bounds__(1024) void cc_directed_kernel(CcP p, const float* __restrict__ score,
                                                            const float* __restrict__ link,
                                                            const int* __restrict__ ulabel_all,
-                                                           const int* __restrict__ uncomp, unsigned char* __restrict__ ws8,
+                                                           const int* __restrict__ uncomp,
+                                                           const int* __restrict__ order_all,
+                                                           unsigned char* __restrict__ ws8,
                                                            int* __restrict__ ws32, int* __restrict__ labels_all,
                                                            int* __restrict__ ncomp_out, int* __restrict__ comps_out,
                                                            int max_comps) {
@@ -350,10 +352,14 @@ __global__ __launch_bounds__(1024) void cc_directed_kernel(CcP p, const float* _
   unsigned char* state = edges + hw;      // 0 outside every kept component, 1 unassigned, 2 assigned
   unsigned char* reach = state + hw;      // 0, 1 = reached, not expanded yet, 2 = expanded
   unsigned char* dead = reach + hw;       // key that cannot seed a group any more
-  int* group = ws32 + (size_t)img * hw * 4;   // seed index + 1 of the pixel's group (0: none)
-  int* seed = group + hw;                 // per union label: this round's seed; later: dense ids per pixel
+  int* group = ws32 + (size_t)img * hw * 5;   // seed index + 1 of the pixel's group (0: none)
+  int* seed = group + hw;                 // per union label: RANK of this round's seed; later: dense ids per pixel
   int* cnt = seed + hw;                   // per union label: |R| of this round
   int* gsize = cnt + hw;                  // per seed pixel: size of its group
+  int* rank = gsize + hw;                 // per pixel: position of the key in the script's key order (INT_MAX: not a key)
+  // order[r] = the r-th key the script's `for i in graph.keys()` meets (-1 padded), NULL = ascending pixel index
+  const int* order = order_all ? order_all + (size_t)img * hw : nullptr;
+#define CCD_PIX(r) (order ? order[r] : (r))
   int* labels = labels_all + (size_t)img * hw;
   const float* sc = score + (size_t)img * hw;
   const int K = min(uncomp[img], hw - 1);
@@ -374,20 +380,29 @@ __global__ __launch_bounds__(1024) void cc_directed_kernel(CcP p, const float* _
     dead[i] = 0;
     group[i] = 0;
     gsize[i] = 0;
+    const bool interior = x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2;
+    rank[i] = (order == nullptr && interior) ? i : 0x7fffffff;
   }
   for (int c = tid; c <= K; c += 1024) { seed[c] = 0x7fffffff; cnt[c] = 0; }
   __syncthreads();
+  if (order) {
+    for (int r = tid; r < hw; r += 1024) {
+      const int k = order[r];
+      if (k >= 0 && k < hw) rank[k] = r;
+    }
+    __syncthreads();
+  }
   for (int round = 0; round < hw; ++round) {
     for (int i = tid; i < hw; i += 1024) {
       if (state[i] == 1 && !dead[i]) {
-        const int x = i % p.w, y = i / p.w;
-        if (x >= 1 && x <= p.w - 2 && y >= 1 && y <= p.h - 2 && i < seed[ulabel[i]]) atomicMin(seed + ulabel[i], i);
+        const int rk = rank[i];
+        if (rk < seed[ulabel[i]]) atomicMin(seed + ulabel[i], rk);
       }
     }
     __syncthreads();
     int any = 0;
     for (int c = 1 + tid; c <= K; c += 1024)
-      if (seed[c] != 0x7fffffff) { reach[seed[c]] = 1; any = 1; }
+      if (seed[c] != 0x7fffffff) { reach[CCD_PIX(seed[c])] = 1; any = 1; }
     if (!__syncthreads_or(any)) break;
     for (int sweep = 0; sweep < hw; ++sweep) {
       int changed = 0;
@@ -412,9 +427,10 @@ __global__ __launch_bounds__(1024) void cc_directed_kernel(CcP p, const float* _
       if (!reach[i]) continue;
       const int c = ulabel[i];
       if (cnt[c] > p.min_size) {
-        group[i] = seed[c] + 1;
+        const int sp = CCD_PIX(seed[c]);
+        group[i] = sp + 1;
         state[i] = 2;
-        if (i == seed[c]) gsize[i] = cnt[c];
+        if (i == sp) gsize[i] = cnt[c];
       } else {
         dead[i] = 1;
       }
@@ -425,13 +441,14 @@ __global__ __launch_bounds__(1024) void cc_directed_kernel(CcP p, const float* _
     __syncthreads();
   }
   __syncthreads();
-  // dense ids in ascending seed order: a pixel is a successful seed iff group[i] == i + 1
+  // dense ids in the order the script meets its successful seeds (ascending rank): a pixel is one iff group[i] == i + 1
   if (tid == 0) s_base = 0;
   __syncthreads();
   int* ids = seed;                          // the per-label slots are dead now
   for (int i0 = 0; i0 < hw; i0 += 1024) {
-    const int i = i0 + tid;
-    const bool flag = i < hw && group[i] == i + 1;
+    const int r = i0 + tid;
+    const int i = r < hw ? CCD_PIX(r) : -1;
+    const bool flag = i >= 0 && i < hw && group[i] == i + 1;
     const unsigned long long vote = __ballot(flag);
     if ((tid & 63) == 0) s_scan[tid >> 6] = __popcll(vote);
     __syncthreads();
@@ -456,6 +473,7 @@ __global__ __launch_bounds__(1024) void cc_directed_kernel(CcP p, const float* _
   }
   for (int i = tid; i < hw; i += 1024) labels[i] = group[i] ? ids[group[i] - 1] : 0;
   if (tid == 0) ncomp_out[img] = s_base;
+#undef CCD_PIX
 }
 
 unsigned dgrid(size_t items) {
@@ -539,14 +557,67 @@ extern "C" int ocr_link_cc(const void* pixel_score, const void* link_score, int 
 }
 
 extern "C" size_t ocr_link_cc_directed_workspace(int n, int h, int w) {
-  return (size_t)n * h * w * (4 + 4 * sizeof(int));
+  return (size_t)n * h * w * (4 + 5 * sizeof(int));
+}
+
+// HOST routine.  The script fills a Python-2 dict with the keys y*w + x of the interior segment pixels, x outer / y inner
+// (test_pixellink_fast.py:119-150), and meets its seeds in `graph.keys()` order (:171): the slot order of CPython 2.7's
+// open-addressing table for int keys (hash = the int; first slot hash & mask, then i = 5*i + perturb + 1 with perturb =
+// hash, shifted right by 5 after each probe; rebuilt at the smallest power of two > (used > 50000 ? 2 : 4) * used once
+// fill*3 >= size*2, old slots re-inserted in slot order).  Restated from Objects/dictobject.c (2.7); the same algorithm in
+// Python is oracle/ocr_oracle.py: py27_dict_key_order, and tests hold the two equal.
+static void py27_place(int32_t* tab, size_t mask, int32_t key) {
+  size_t i = (size_t)key & mask;
+  if (tab[i] >= 0) {
+    size_t perturb = (size_t)key;
+    for (;;) {
+      i = (i << 2) + i + perturb + 1;
+      perturb >>= 5;
+      if (tab[i & mask] < 0) { i &= mask; break; }
+    }
+  }
+  tab[i] = key;
+}
+
+extern "C" int ocr_py27_dict_order(const float* pixel_score_host, float pixel_thresh, int h, int w,
+                                   int32_t* order_host) {
+  if (!pixel_score_host || !order_host || h <= 2 || w <= 2 || (int64_t)h * w > (1 << 30)) return OCR_ERR_INVALID_ARG;
+  size_t size = 8, used = 0;
+  int32_t* tab = static_cast<int32_t*>(malloc(size * sizeof(int32_t)));
+  if (!tab) return OCR_ERR_INVALID_ARG;
+  for (size_t i = 0; i < size; ++i) tab[i] = -1;
+  for (int x = 1; x < w - 1; ++x)
+    for (int y = 1; y < h - 1; ++y) {
+      if (!(pixel_score_host[(size_t)y * w + x] > pixel_thresh)) continue;   // `pixel_seg = pixel_score > threshold`, f32
+      py27_place(tab, size - 1, y * w + x);
+      ++used;
+      if (used * 3 >= size * 2) {
+        const size_t minused = (used > 50000 ? 2 : 4) * used;
+        size_t nsize = 8;
+        while (nsize <= minused) nsize <<= 1;
+        int32_t* nt = static_cast<int32_t*>(malloc(nsize * sizeof(int32_t)));
+        if (!nt) { free(tab); return OCR_ERR_INVALID_ARG; }
+        for (size_t i = 0; i < nsize; ++i) nt[i] = -1;
+        for (size_t i = 0; i < size; ++i)
+          if (tab[i] >= 0) py27_place(nt, nsize - 1, tab[i]);
+        free(tab);
+        tab = nt;
+        size = nsize;
+      }
+    }
+  size_t r = 0;
+  for (size_t i = 0; i < size; ++i)
+    if (tab[i] >= 0) order_host[r++] = tab[i];
+  free(tab);
+  for (size_t i = r; i < (size_t)h * w; ++i) order_host[i] = -1;
+  return (int)r;
 }
 
 extern "C" int ocr_link_cc_directed(const void* pixel_score, const void* link_score, int link_elem_stride,
                                     int link_elem_offset, int n, int h, int w, float pixel_thresh, float link_thresh,
                                     int min_size, const void* union_labels_i32, const void* union_ncomp_i32,
-                                    void* labels_i32, void* ncomp_i32, void* comps_i32, int max_comps,
-                                    void* workspace, size_t ws_bytes, void* stream) {
+                                    const void* seed_order_i32, void* labels_i32, void* ncomp_i32, void* comps_i32,
+                                    int max_comps, void* workspace, size_t ws_bytes, void* stream) {
   OCR_CHECK_ARG(pixel_score && link_score && union_labels_i32 && union_ncomp_i32 && labels_i32 && ncomp_i32 && comps_i32 &&
                 workspace);
   OCR_CHECK_ARG(n > 0 && h > 2 && w > 2 && max_comps > 0 && labels_i32 != union_labels_i32);
@@ -555,10 +626,11 @@ extern "C" int ocr_link_cc_directed(const void* pixel_score, const void* link_sc
   CcP p{n, h, w, min_size, pixel_thresh, link_thresh, link_elem_stride, link_elem_offset};
   const size_t total = (size_t)n * h * w;
   int* ws32 = static_cast<int*>(workspace);                                  // 16-byte aligned part first
-  unsigned char* ws8 = reinterpret_cast<unsigned char*>(ws32 + total * 4);
+  unsigned char* ws8 = reinterpret_cast<unsigned char*>(ws32 + total * 5);
   hipLaunchKernelGGL(cc_directed_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), p,
                      static_cast<const float*>(pixel_score), static_cast<const float*>(link_score),
-                     static_cast<const int*>(union_labels_i32), static_cast<const int*>(union_ncomp_i32), ws8, ws32,
+                     static_cast<const int*>(union_labels_i32), static_cast<const int*>(union_ncomp_i32),
+                     static_cast<const int*>(seed_order_i32), ws8, ws32,
                      static_cast<int*>(labels_i32), static_cast<int*>(ncomp_i32), static_cast<int*>(comps_i32), max_comps);
   return ocr_launch_status();
 }

@@ -216,10 +216,24 @@ class GradientAllReduce:
                 grouped = td.is_available() and td.is_initialized()
                 rank = td.get_rank() if grouped else 0
                 err = None
+                # agree on availability BEFORE anybody enters the rendezvous: a rank that cannot load RCCL (or cannot
+                # reach the key-value store) must not go to the collective below while the healthy ranks already sit in
+                # ncclCommInitRank waiting for it — that would hang instead of falling back
+                kv = None
                 try:
-                    self.comm = AbiComm(rank, world_size)
-                except Exception as e:                      # RCCL missing, communicator refused, ...
+                    if not L.call_int("ocr_comm_available"):
+                        raise L.OcrHipError("RCCL is not available: %s" % _last_comm_error())
+                    if grouped and world_size > 1:
+                        kv = td.distributed_c10d._get_default_store()
+                except Exception as e:
                     err = e
+                if grouped and world_size > 1 and any_rank(err is not None):
+                    err = err or L.OcrHipError("RCCL is not available on another rank")
+                else:
+                    try:
+                        self.comm = AbiComm(rank, world_size, store=kv)
+                    except Exception as e:                  # unique id / communicator refused, ...
+                        err = e
                 # every rank takes the SAME path: if any rank failed, all exchange through torch.distributed instead
                 if grouped and world_size > 1 and any_rank(err is not None):
                     if self.comm is not None:
@@ -337,7 +351,19 @@ class GradientAllReduce:
         if self.op == "mean" and not self.fold_mean:
             if self.cuda:
                 from . import ops
-                ops.scale_(self.store.flat_grad, 1.0 / self.world)
+                if self.mode == "abi":
+                    # part of the exchange: replayed only while the exchange is enabled
+                    self._xcall("ocr_scale_f32", _lib.ptr(self.store.flat_grad),
+                                __import__("ctypes").c_int64(self.store.flat_grad.numel()),
+                                __import__("ctypes").c_float(1.0 / self.world), _lib.stream_ptr())
+                else:
+                    # torch mode: the recorded host callback above re-runs finish() on every replay, so the scale
+                    # itself must not ALSO enter the plan as a C entry (it would divide by the world size twice)
+                    saved, _lib.RECORDER = _lib.RECORDER, None
+                    try:
+                        ops.scale_(self.store.flat_grad, 1.0 / self.world)
+                    finally:
+                        _lib.RECORDER = saved
             else:
                 self.store.flat_grad.mul_(1.0 / self.world)
         self.reset()

@@ -234,6 +234,11 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         def backward_pool():
             if a_pool.grad is None:
                 return
+            if argmax is None:
+                # an is_training=False build is forward-only here as it is under batch norm: the first-max positions
+                # the routing needs were not kept, and the full-resolution activation was never written
+                raise NotImplementedError("backward through a conv + ReLU + pool built with is_training=False "
+                                          "(the first-max positions are kept only while training)")
             # ReLU mask and bias gradient on the pooled tensors (a window maximum is positive iff the element its
             # gradient is routed to is), then the routed gradient IS dz of the convolution
             dzp = g.empty(pooled.shape)

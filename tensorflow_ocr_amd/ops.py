@@ -679,13 +679,30 @@ def link_cc(pixel_score, link_score, stride, offset, n, h, w, pixel_thresh, link
 
 
 def link_cc_directed(pixel_score, link_score, stride, offset, n, h, w, pixel_thresh, link_thresh, min_size,
-                     union_labels, union_ncomp, labels, ncomp, comps, ws):
-    """The reference's directed-DFS grouping, refining ocr_link_cc's components (include/ocr_hip.h)."""
+                     union_labels, union_ncomp, labels, ncomp, comps, ws, seed_order=None):
+    """The reference's directed-DFS grouping, refining ocr_link_cc's components (include/ocr_hip.h).
+    seed_order: int32 [n, h*w] device tensor from `py27_dict_order` (None: ascending pixel index)."""
     nbytes = L.call_size("ocr_link_cc_directed_workspace", c_int(n), c_int(h), c_int(w))
     buf = ws.get(nbytes)
     L.call("ocr_link_cc_directed", ptr(pixel_score), ptr(link_score), c_int(stride), c_int(offset), c_int(n),
            c_int(h), c_int(w), c_float(pixel_thresh), c_float(link_thresh), c_int(min_size), ptr(union_labels),
-           ptr(union_ncomp), ptr(labels), ptr(ncomp), ptr(comps), c_int(comps.shape[1]), ptr(buf), c_size_t(nbytes), _st())
+           ptr(union_ncomp), ptr(seed_order), ptr(labels), ptr(ncomp), ptr(comps), c_int(comps.shape[1]), ptr(buf),
+           c_size_t(nbytes), _st())
+
+
+def py27_dict_order(pixel_score_host, pixel_thresh):
+    """HOST routine: pixel scores f32 [n,h,w] CPU tensor -> int32 [n, h*w] CPU tensor, per image the keys of the script's
+    Python-2 dict in `graph.keys()` order, -1 padded (ocr_py27_dict_order)."""
+    t = pixel_score_host
+    assert t.dtype == torch.float32 and not t.is_cuda and t.is_contiguous()
+    n, h, w = t.shape
+    out = torch.empty((n, h * w), dtype=torch.int32)
+    fn = L._fn("ocr_py27_dict_order", c_int)
+    for b in range(n):
+        rc = fn(ctypes.c_void_p(t[b].data_ptr()), c_float(pixel_thresh), c_int(h), c_int(w), ctypes.c_void_p(out[b].data_ptr()))
+        if rc < 0:
+            L.check(rc, "ocr_py27_dict_order")
+    return out
 
 
 def lanms(boxes, counts, iou_thresh, merged, n_merged, keep_idx, n_keep, ws):

@@ -55,17 +55,23 @@ def tf_pixel_detect(score_map, geo_map, score_map_thresh, link_thresh, graph=Non
 
 
 def link_cc_decode(pixel_score, link_score, pixel_conf_threshold=0.8, link_conf_threshold=0.9,
-                   min_size=10, max_comps=4096, graph=None, mode="union"):
+                   min_size=10, max_comps=4096, graph=None, mode="union", key_order="py27"):
     """test_pixellink_fast.py:110-178 for a whole batch.  pixel_score [N,h,w] = softmax(pixel_cls)
     [...,1]; link_score [8,N,h,w,2] (stacked softmaxes) or [8,N,h,w].  Returns (labels int32
     [N,h,w], ncomp int32 [N], comps int32 [N,max_comps,2] = (smallest pixel index, size)).
 
     mode="union" (default): weakly-connected components of the link graph (order independent; equals the
     script's result whenever the link predictions are symmetric).  mode="reference_dfs": the script's own
-    rule, exactly — directed reachability from each unassigned key in ascending pixel order, groups of more
-    than min_size pixels only (:153-178); comps = (seed pixel, size)."""
+    rule, exactly — directed reachability from each unassigned key in the order its `for i in graph.keys()`
+    meets them, groups of more than min_size pixels only (:153-178); comps = (seed pixel, size).
+    key_order="py27": the iteration order of the script's Python-2 dict (keys inserted x-major; restated
+    from CPython 2.7's dictobject.c, a HOST step: the segment mask crosses to the host, ~1 us per key, the order
+    comes back); "ascending": ascending pixel index.  reference_dfs runs ONE workgroup per image in rounds of
+    full-image sweeps — ~1 ms per 256 x 256 map, seconds per image at 720 x 1280: an exactness mode, opt-in."""
     if mode not in ("union", "reference_dfs"):
         raise ValueError("mode must be 'union' or 'reference_dfs'")
+    if key_order not in ("py27", "ascending"):
+        raise ValueError("key_order must be 'py27' or 'ascending'")
     g = graph or get_default_graph()
     ps = _dev(g, pixel_score)
     lk = _dev(g, link_score)
@@ -78,11 +84,15 @@ def link_cc_decode(pixel_score, link_score, pixel_conf_threshold=0.8, link_conf_
                 int(min_size), labels, ncomp, comps, g.workspace())
     if mode == "union":
         return labels, ncomp, comps
+    order = None
+    if key_order == "py27":
+        # the dict holds the interior pixels with pixel_score > threshold: the scores cross to the host, the order comes back
+        order = ops.py27_dict_order(ps.cpu().contiguous(), float(pixel_conf_threshold)).to(g.device)
     labels_d = torch.empty_like(labels)
     ncomp_d = torch.empty_like(ncomp)
     comps_d = torch.zeros_like(comps)
     ops.link_cc_directed(ps, lk, stride, off, n, h, w, float(pixel_conf_threshold), float(link_conf_threshold),
-                         int(min_size), labels, ncomp, labels_d, ncomp_d, comps_d, g.workspace())
+                         int(min_size), labels, ncomp, labels_d, ncomp_d, comps_d, g.workspace(), seed_order=order)
     return labels_d, ncomp_d, comps_d
 
 

@@ -23,10 +23,10 @@ def _maps(seed, n, q4, strength):
     return ps, ls
 
 
-def _decode(g, ps, ls, pt, lt, ms, mode, max_comps=4096):
+def _decode(g, ps, ls, pt, lt, ms, mode, max_comps=4096, key_order="py27"):
     from tensorflow_ocr_amd.tool import pixellink_fn as PF
     lab, nc, comps = PF.link_cc_decode(torch.from_numpy(ps), torch.from_numpy(ls), pt, lt, min_size=ms,
-                                       max_comps=max_comps, graph=g, mode=mode)
+                                       max_comps=max_comps, graph=g, mode=mode, key_order=key_order)
     return lab.cpu().numpy(), nc.cpu().numpy(), comps.cpu().numpy()
 
 
@@ -38,19 +38,44 @@ def _decode(g, ps, ls, pt, lt, ms, mode, max_comps=4096):
     (4, 1, 96, 2.0, 0.8, 0.9, 10),
     (5, 2, 33, 1.0, 0.7, 0.8, 5),       # odd size: tiles of the union pass are ragged
 ])
-def test_reference_dfs_mode_bit_exact(device, seed, n, q4, strength, pt, lt, ms):
+@pytest.mark.parametrize("key_order", ["py27", "ascending"])
+def test_reference_dfs_mode_bit_exact(device, seed, n, q4, strength, pt, lt, ms, key_order):
+    """key_order="py27": seeds in the iteration order of the script's Python-2 dict (VERDICT r3 item 6) — the default;
+    "ascending": the order rounds 1-3 used."""
     from tensorflow_ocr_amd.graph import Graph
     g = Graph(device)
     ps, ls = _maps(seed, n, q4, strength)
-    lab, nc, comps = _decode(g, ps, ls, pt, lt, ms, "reference_dfs")
+    lab, nc, comps = _decode(g, ps, ls, pt, lt, ms, "reference_dfs", key_order=key_order)
     for b in range(n):
-        ref = O.link_cc_reference_dfs(ps[b], [ls[d, b] for d in range(8)], pt, lt, ms)
+        ref = O.link_cc_reference_dfs(ps[b], [ls[d, b] for d in range(8)], pt, lt, ms, key_order=key_order)
         assert np.array_equal(lab[b], ref), (b, int((lab[b] != ref).sum()))
         k = int(ref.max())
         assert nc[b] == k
-        for gid in range(1, min(k, comps.shape[1]) + 1):        # comps = (seed = smallest key of the group's search, size)
+        order = O.reference_key_order(ps[b], np.float32(pt), key_order)
+        for gid in range(1, min(k, comps.shape[1]) + 1):        # comps = (seed = first key of the group the script meets, size)
             members = np.nonzero(ref.ravel() == gid)[0]
+            first = next(kk for kk in order if ref.ravel()[kk] == gid)
             assert comps[b, gid - 1, 1] == len(members) and comps[b, gid - 1, 0] in members
+            if key_order == "ascending":
+                assert comps[b, gid - 1, 0] == first
+
+
+def test_reference_dfs_dict_order_differs_from_ascending_on_a_one_way_chain(device):
+    """148 keys 962..1109 of a "right"-links-only chain sit in a 512-slot dict: 1024..1109 are met first (slots 0..85),
+    so x >= 64 becomes group 1 and x < 64 group 2; in ascending order the head collects the whole chain."""
+    from tensorflow_ocr_amd.graph import Graph
+    g = Graph(device)
+    ps = np.zeros((1, 24, 160), np.float32)
+    ls = np.zeros((8, 1, 24, 160), np.float32)
+    ps[0, 6, 2:150] = 0.9
+    ls[3, 0, 6, 2:150] = 0.95
+    for ko, want_groups in (("py27", 2), ("ascending", 1)):
+        lab, nc, comps = _decode(g, ps, ls, 0.8, 0.9, 10, "reference_dfs", key_order=ko)
+        ref = O.link_cc_reference_dfs(ps[0], [ls[d, 0] for d in range(8)], 0.8, 0.9, 10, key_order=ko)
+        assert np.array_equal(lab[0], ref) and nc[0] == want_groups == ref.max()
+    lab, _, comps = _decode(g, ps, ls, 0.8, 0.9, 10, "reference_dfs")
+    assert (lab[0, 6, 64:150] == 1).all() and (lab[0, 6, 2:64] == 2).all()
+    assert comps[0, 0].tolist() == [6 * 160 + 64, 86] and comps[0, 1].tolist() == [6 * 160 + 2, 62]
 
 
 def test_reference_dfs_differs_from_union_only_where_the_oracles_do(device):

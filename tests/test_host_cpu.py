@@ -31,7 +31,9 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.ocr_abi_version.restype = ctypes.c_int
-    assert lib.ocr_abi_version() == 1
+    # the header's OCR_ABI_VERSION, the library's answer and the value the Python host checks in _lib.load() are one number
+    hdr = int(re.search(r"#define OCR_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "ocr_hip.h")).read()).group(1))
+    assert lib.ocr_abi_version() == hdr == _lib.ABI_VERSION
     lib.ocr_status_string.restype = ctypes.c_char_p
     assert lib.ocr_status_string(0) == b"ok" and b"unsupported" in lib.ocr_status_string(-2)
     lib.ocr_storage_dtype.restype = ctypes.c_char_p
@@ -41,6 +43,16 @@ def test_library_exports_every_declared_symbol():
     assert not [n for n in names if not hasattr(bf, n)]
     bf.ocr_storage_dtype.restype = ctypes.c_char_p
     assert bf.ocr_storage_dtype() == b"bf16"
+
+
+def test_loader_refuses_a_library_of_another_abi_version(monkeypatch):
+    """entry points changed their argument lists; a stale libocr_hip.so must be refused at load time, not
+    called with its pointers shifted by a slot."""
+    from tensorflow_ocr_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.OcrHipError, match="ABI version"):
+        _lib.load()
 
 
 def test_verification_kernels_live_in_their_own_library():

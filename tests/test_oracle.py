@@ -166,37 +166,69 @@ def test_directed_rounds_schedule_equals_the_literal_dfs():
         pl, ll = O.synthetic_decode_maps(rng, 1, q4, strength)
         ps = sm(pl[0])[..., 1]
         ls = [sm(ll[0][..., 2 * d:2 * d + 2])[..., 1] for d in range(8)]
-        A = O.link_cc_reference_dfs(ps, ls, pt, lt, ms)
-        B = O.link_cc_directed_rounds(ps, ls, pt, lt, ms)
-        assert np.array_equal(A, B), (seed, int((A != B).sum()))
+        for ko in ("py27", "ascending"):
+            A = O.link_cc_reference_dfs(ps, ls, pt, lt, ms, key_order=ko)
+            B = O.link_cc_directed_rounds(ps, ls, pt, lt, ms, key_order=ko)
+            assert np.array_equal(A, B), (seed, ko, int((A != B).sum()))
         U, _ = O.link_cc_union(ps, ls, pt, lt, ms)
         differs_from_union += int(((A > 0) != (U > 0)).sum())
     assert differs_from_union > 0          # the cases do exercise the directed / union difference
 
 
-def test_link_cc_union_fast_equals_the_loop_version():
-    def sm(l):
-        e = np.exp(l - l.max(-1, keepdims=True))
-        return e / e.sum(-1, keepdims=True)
-    for seed, strength in ((0, 3.0), (1, 1.5), (2, 0.8)):
-        rng = np.random.default_rng(seed)
-        pl, ll = O.synthetic_decode_maps(rng, 1, 48, strength)
-        ps = sm(pl[0])[..., 1]
-        ls = [sm(ll[0][..., 2 * d:2 * d + 2])[..., 1] for d in range(8)]
-        a, ca = O.link_cc_union(ps, ls, 0.8, 0.9, 10)
-        b, cb = O.link_cc_union_fast(ps, ls, 0.8, 0.9, 10)
-        assert np.array_equal(a, b) and ca == cb and (strength < 1 or len(ca) > 0)
+def test_py27_dict_key_order_hand_derived():
+    """the script meets its seeds in `graph.keys()` order of a CPython-2.7 dict
+    (test_pixellink_fast.py:171).  Cases derived BY HAND from Objects/dictobject.c (2.7): 8-slot table, first slot
+    key & 7, then i = 5 i + perturb + 1 with perturb = key, >>= 5 after each probe; growth to 32 slots when the 6th key
+    lands (6 * 3 >= 8 * 2; 4 * 6 = 24 -> 32), old slots re-inserted in slot order."""
+    f = O.py27_dict_key_order
+    assert f([]) == [] and f([3]) == [3]
+    assert f([4, 2, 0, 3, 1]) == [0, 1, 2, 3, 4]          # no collision: slot order = ascending
+    assert f([8, 0]) == [8, 0]                            # 0 probes 5*0 + 0 + 1 = slot 1
+    assert f([40, 8]) == [40, 8]                          # 8 probes 5*0 + 8 + 1 = 9 -> slot 1
+    # 9: slot 1 taken, 5*1 + 9 + 1 = 15 -> slot 7; 17: 5*1 + 17 + 1 = 23 -> slot 7 taken, perturb 17 >> 5 = 0, 5*23 + 1 = 116 -> slot 4
+    assert f([1, 9, 17]) == [1, 17, 9]
+    # the 6th key triggers the rebuild at 32 slots; then 40 -> slot 8, 8 -> slot 8 taken, 5*8 + 8 + 1 = 49 -> slot 17
+    assert f([0, 1, 2, 3, 4, 5, 40, 8]) == [0, 1, 2, 3, 4, 5, 40, 8]
+    # six keys = 7 (mod 8): slots 7, 3, 0, 1, 6, 4 in the 8-slot table (by hand), rebuilt in slot order 23, 31, 15, 47, 39, 7
+    # into 32 slots: 23, 31, 15 direct, 47 -> 15 taken -> 5*15 + 47 + 1 = 123 -> 27, 39 -> 7, 7 -> 7 taken -> 43 -> 11
+    assert f([7, 15, 23, 31, 39, 47]) == [39, 7, 15, 23, 47, 31]
+    # a table larger than every key holds them at slot = key: ascending, whatever the insertion order
+    rng = np.random.default_rng(0)
+    keys = rng.permutation(2000)[:400].tolist()           # 400 keys: rebuilt at the 342nd into 2048 slots > 1999
+    assert f(keys) == sorted(keys)
+    # ... and a 192 x 320 map with a tenth of its pixels set wraps (table 8192 or 32768 < 61440): not ascending
+    seg = rng.random((192, 320)) < 0.1
+    order = O.reference_key_order(seg.astype(np.float32), 0.5)
+    assert sorted(order) != order and sorted(order) == sorted(y * 320 + x for y in range(1, 191) for x in range(1, 319) if seg[y, x])
 
 
-def test_vgg_taps_do_not_change_the_forward():
-    rng = np.random.default_rng(3)
-    p = O.init_model_vgg_params(rng, width_div=8)
-    images, _, _, _ = O.synthetic_batch(rng, 1, 32)
-    tp = O.to_torch_params(p)
-    a, b, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=True)
-    taps = {}
-    c, d, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=True, taps=taps)
-    assert torch.equal(a, c) and torch.equal(b, d)
-    assert len(taps) == 15 and "pool" in taps["conv1/conv1_2"] and "pool" not in taps["conv5/conv5_3"]
-    (c.sum() + d.sum()).backward()
-    assert taps["conv3/conv3_2"]["a"].grad is not None and taps["conv3/conv3_2"]["x"].grad is not None
+def test_py27_dict_order_host_routine_equals_the_oracle():
+    """The library's HOST routine (ocr_py27_dict_order: plain C, no GPU) against the oracle's restatement of the same
+    algorithm, incl. the > 50 000-key growth rule (x2 instead of x4)."""
+    import torch
+    from tensorflow_ocr_amd import ops
+    rng = np.random.default_rng(1)
+    for h, w, dens in ((20, 30, 0.5), (64, 64, 0.3), (192, 320, 0.1), (192, 320, 0.9), (256, 256, 0.95), (33, 47, 1.0), (3, 3, 1.0)):
+        ps = rng.random((2, h, w)).astype(np.float32)
+        thr = float(np.float32(1.0 - dens))
+        got = ops.py27_dict_order(torch.from_numpy(ps), thr).numpy()
+        for b in range(2):
+            want = O.reference_key_order(ps[b], np.float32(thr))
+            assert got[b, :len(want)].tolist() == want and (got[b, len(want):] == -1).all(), (h, w, b)
+
+
+def test_reference_dfs_key_order_changes_the_grouping():
+    """The two key orders give different groups on asymmetric links with the size filter (why item 6 matters): a one-way
+    chain is collected whole from its head but fails piecewise from its tail."""
+    q = 24
+    ps = np.zeros((q, 160), np.float32)
+    ls = [np.zeros((q, 160), np.float32) for _ in range(8)]
+    ps[6, 2:150] = 0.9
+    ls[3][6, 2:150] = 0.95                               # "right" links only
+    A = O.link_cc_reference_dfs(ps, ls, 0.8, 0.9, 10, key_order="ascending")
+    B = O.link_cc_reference_dfs(ps, ls, 0.8, 0.9, 10, key_order="py27")
+    assert A.max() == 1 and (A[6, 2:150] == 1).all()     # ascending: the head is met first and reaches everything
+    # dict order: 148 keys 962..1109 in a 512-slot table (rebuilt at the 86th key): 1024..1109 sit in slots 0..85 and are
+    # met first -> x = 64.. becomes group 1, then key 962 (x = 2) collects what is left as group 2
+    assert B.max() == 2 and (B[6, 64:150] == 1).all() and (B[6, 2:64] == 2).all()
+    assert np.array_equal(O.link_cc_directed_rounds(ps, ls, 0.8, 0.9, 10, key_order="py27"), B)
