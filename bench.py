@@ -26,30 +26,49 @@ MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH
 TRAIN_GFLOP_PER_IMG = 516.5       # BASELINE.md §2, VGG-16 + PixelLink heads at 512x512
 
 
-def cpu_baseline(size, threads, batch=2, runs=5):
-    """The oracle's (CPU restatement, f32) full train step on a bounded sample: a batch of `batch` images of the
-    benchmark's size (SURVEY 8d asks for batch 32; one image costs ~2.4 s of host time, so 32 x 7 runs would
-    not fit the few-minutes budget of the default run), forward + loss + backward, MEDIAN of `runs` after one
-    warm-up."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(size, host_cpus, budget_s=60.0, runs=5, warmups=2):
+    """The oracle's (CPU restatement, f32) full train step — forward + dice loss + backward — on a bounded sample: a
+    batch of B images of the benchmark's size, B = the largest batch (<= 32, SURVEY 8d's) whose `warmups` + `runs`
+    passes fit `budget_s` seconds of host time, sized from a probe pass at batch 2; MEDIAN of `runs` after `warmups`
+    warm-ups.  Threads: all host CPUs up to 64 (small-batch oneDNN convolutions stop scaling before that)."""
     from oracle import ocr_oracle as O
-    threads = min(threads, 64)            # small-batch convs stop scaling long before 256 threads
+    threads = max(1, min(host_cpus, 64))
     torch.set_num_threads(threads)
     rng = np.random.default_rng(0)
     p = O.init_model_vgg_params(rng)
-    images, pixel, link, mask = O.synthetic_batch(rng, batch, size)
-    times = []
-    for it in range(runs + 1):
+
+    def one_pass(data):
+        images, pixel, link, mask = data
         t0 = time.time()
         tp = O.to_torch_params(p)
         px, lk, _ = O.model_vgg(torch.from_numpy(images), tp, True, mixed=False)
         L = O.dice_loss(torch.from_numpy(pixel), px, torch.from_numpy(link), lk, torch.from_numpy(mask))
         L.backward()
-        times.append(time.time() - t0)
-    med = float(np.median(times[1:]))
-    return {"value": round(batch / med, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "batch of %d %dx%d images (1/%d of the step's batch), forward+loss+backward, median of %d after a "
-                      "warm-up, torch-CPU f32 oracle (%.1f s of CPU work in all)" % (batch, size, size, 32 // batch, runs,
-                                                                                    sum(times))}
+        return time.time() - t0
+    probe = one_pass(O.synthetic_batch(np.random.default_rng(1), 2, size))       # also pages oneDNN in
+    per_img = probe / 2.0
+    batch = int(budget_s / ((runs + warmups) * per_img))
+    batch = max(2, min(32, batch - batch % 2))
+    data = O.synthetic_batch(rng, batch, size)
+    times = [one_pass(data) for _ in range(warmups + runs)]
+    med = float(np.median(times[warmups:]))
+    return {"value": round(batch / med, 4), "unit": "images/sec", "cores": threads, "host_cpus": host_cpus,
+            "cpu_model": _cpu_model(), "kind": "port", "batch": batch,
+            "sample": "batch of %d %dx%d images (the largest batch <= 32 whose %d passes fit a %.0f s budget, sized from "
+                      "a probe pass at batch 2: %.1f s), forward+loss+backward, median of %d after %d warm-ups, torch-CPU "
+                      "f32 oracle on %d threads (%.1f s of CPU work in all)"
+                      % (batch, size, size, runs + warmups, budget_s, probe, runs, warmups, threads, probe + sum(times))}
 
 
 CONFIG_LEGS = (

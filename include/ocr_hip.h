@@ -451,6 +451,25 @@ int ocr_softmax_loss_bwd(const ocr_softmax_loss_desc* d, const void* pixel_logit
                          const void* ohnm_threshold, const void* sums34, float grad_scale,
                          void* d_pixel_logits, void* d_link_logits, void* stream);
 
+/* The reference's loss HELPERS as entry points of their own (callable names of SURVEY 8b; the training losses above fuse
+ * them).  get_pos_and_neg_masks (nets/model.py:199-201): pos = labels == 1, neg = labels == 0 (label_rule 1: > 0 / not)
+ * as bytes. */
+int ocr_label_masks(const void* labels_f32, int64_t count, int label_rule, void* pos_u8, void* neg_u8, void* stream);
+/* OHNM_single_image / OHNM_batch (nets/model.py:161-197) on GIVEN scores [n][hw] (P(negative class), >= 0) and byte masks:
+ * per image k = min(n_pos * neg_ratio, #negatives), threshold = k-th smallest score among the negatives, selected_neg =
+ * neg & score <= threshold (1.0 / 0.0; all zero when n_pos == 0), selected = float(pos) + selected_neg.  n_pos_i32 [n]
+ * overrides the count of pos_mask (OHNM_single_image's argument; pos_mask may then be NULL); either output may be NULL. */
+int ocr_ohnm_select(const void* scores, const void* pos_mask_u8, const void* neg_mask_u8, const void* n_pos_i32,
+                    int n, int hw, float neg_ratio, void* selected_neg_f32, void* selected_f32, void* stream);
+/* cal_link_loss (nets/model_vgg_16.py:227-241) for one direction: link_gt element r at [r * gt_stride], logit pair r at
+ * [r * pred_stride .. +1] (tf.split slices of the 8- / 16-channel maps are strided rows), w_pixel [count] f32.
+ * sums4 = (sum CE Wpos, sum Wpos, sum CE Wneg, sum Wneg), loss1 = s0/s1 + s2/s3 (unguarded like the reference). */
+size_t ocr_link_ce_workspace(int64_t count);
+int ocr_link_ce_fwd(const void* link_gt, int gt_stride, const void* link_pred, int pred_stride, const void* w_pixel,
+                    int64_t count, void* sums4, void* loss1, void* workspace, size_t ws_bytes, void* stream);
+int ocr_link_ce_bwd(const void* link_gt, int gt_stride, const void* link_pred, int pred_stride, const void* w_pixel,
+                    int64_t count, const void* sums4, float grad_scale, void* d_link_pred, int d_stride, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * PixelLink decode (test_pixellink_fast.py:53-64,110-178; tool/pixellink_fn.py:120-158).
  * ------------------------------------------------------------------------- */

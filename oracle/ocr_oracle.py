@@ -494,6 +494,21 @@ def model_loss_ohnm(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, traini
     return total, cls, links, sel
 
 
+def cal_link_loss(link_gt, link_pred, w_pixel):
+    """nets/model_vgg_16.py:227-241 for one direction (torch tensors; differentiable in link_pred)."""
+    ll = link_gt.reshape(-1)
+    lce = _ce2(link_pred.reshape(-1, 2), ll)
+    wp = (ll == 1).float() * w_pixel
+    wn = (ll == 0).float() * w_pixel
+    return (lce * wp).sum() / wp.sum() + (lce * wn).sum() / wn.sum()
+
+
+def get_pos_and_neg_masks(labels):
+    """nets/model.py:199-201."""
+    labels = np.asarray(labels)
+    return labels == 1, labels == 0
+
+
 def ohem_loss(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mask=None):
     """nets/model_vgg_16.py:243-282 (+ cal_link_loss :227-241): positives-only weights."""
     label = y_true_pixel.reshape(-1)

@@ -295,6 +295,140 @@ __global__ void sl_selected_kernel(SlP p, const float* __restrict__ pl, const fl
   }
 }
 
+// ---- the reference's mining helpers as entry points of their own (nets/model.py:161-201) ----------------------------
+// get_pos_and_neg_masks: pos = (labels == 1), neg = (labels == 0) (label_rule 0) as bytes
+__global__ void label_masks_kernel(const float* __restrict__ lab, size_t total, int rule, unsigned char* __restrict__ pos,
+                                   unsigned char* __restrict__ neg) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const float y = lab[i];
+    pos[i] = is_pos(y, rule) ? 1 : 0;
+    neg[i] = is_neg(y, rule) ? 1 : 0;
+  }
+}
+
+// OHNM_single_image / OHNM_batch on GIVEN scores and masks: per image k = min(n_pos * ratio, #neg), threshold = the k-th
+// smallest score among the negatives (exact: 4-pass 8-bit radix select on the float bits, scores >= 0), selected negatives
+// = neg & score <= threshold (tie-inclusive, like `tf.nn.top_k` + `<=`); nothing when n_pos == 0.
+__global__ __launch_bounds__(1024) void ohnm_select_kernel(int hw, float ratio, const float* __restrict__ scores,
+                                                           const unsigned char* __restrict__ pos_all,
+                                                           const unsigned char* __restrict__ neg_all,
+                                                           const int* __restrict__ n_pos_in, float* __restrict__ sel_neg,
+                                                           float* __restrict__ selected) {
+  __shared__ int hist[256];
+  __shared__ int s_cnt[2];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_k;
+  const int img = blockIdx.x;
+  const float* sc = scores + (size_t)img * hw;
+  const unsigned char* pos = pos_all ? pos_all + (size_t)img * hw : nullptr;
+  const unsigned char* neg = neg_all + (size_t)img * hw;
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int np = 0, nn = 0;
+  for (int i = threadIdx.x; i < hw; i += 1024) {
+    np += (pos && pos[i]) ? 1 : 0;
+    nn += neg[i] ? 1 : 0;
+  }
+  atomicAdd(&s_cnt[0], np);
+  atomicAdd(&s_cnt[1], nn);
+  __syncthreads();
+  const int n_pos = n_pos_in ? n_pos_in[img] : s_cnt[0], n_neg = s_cnt[1];
+  const int k = (int)fminf((float)n_pos * ratio, (float)n_neg);
+  float thr = -1.f;                                   // nothing is selected (scores are >= 0)
+  if (n_pos > 0 && k > 0) {
+    if (threadIdx.x == 0) { s_prefix = 0u; s_k = k; }
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+      const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+      for (int i = threadIdx.x; i < hw; i += 1024) {
+        if (!neg[i]) continue;
+        const unsigned u = __float_as_uint(sc[i]);
+        if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int kk = s_k, cum = 0, d = 0;
+        for (; d < 256; ++d) {
+          if (cum + hist[d] >= kk) break;
+          cum += hist[d];
+        }
+        s_prefix = prefix | ((unsigned)d << shift);
+        s_k = kk - cum;
+      }
+      __syncthreads();
+    }
+    thr = __uint_as_float(s_prefix);
+  }
+  for (int i = threadIdx.x; i < hw; i += 1024) {
+    const float sn = (neg[i] && sc[i] <= thr) ? 1.f : 0.f;
+    if (sel_neg) sel_neg[(size_t)img * hw + i] = sn;
+    if (selected) selected[(size_t)img * hw + i] = ((pos && pos[i]) ? 1.f : 0.f) + sn;   // cast(pos_mask) + selected_neg_mask
+  }
+}
+
+// cal_link_loss (nets/model_vgg_16.py:227-241) for ONE direction: CE of the logit pairs against link_gt, weighted by
+// W_pixel, sum(CE * Wpos) / sum(Wpos) + sum(CE * Wneg) / sum(Wneg), unguarded like the reference.  Rows may be strided
+// (a tf.split slice of the 8- / 16-channel maps): element r of gt at gt[r * gs], pair r at pred[r * ps .. + 1].
+__global__ __launch_bounds__(256) void link_ce_reduce_kernel(const float* __restrict__ gt, int gs, const float* __restrict__ pred,
+                                                             int ps, const float* __restrict__ W, size_t P,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[4][4];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (size_t)gridDim.x * 256) {
+    const float y = gt[i * gs], w = W[i];
+    const bool lp = is_pos(y, 0), ln = is_neg(y, 0);
+    float dummy;
+    const float L = ce2(pred[i * ps], pred[i * ps + 1], lp ? 1 : 0, &dummy);
+    const float wp = lp ? w : 0.f, wn = ln ? w : 0.f;
+    s[0] += L * wp; s[1] += wp; s[2] += L * wn; s[3] += wn;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v = wave_sum(s[j]);
+    if (lane == 0) red[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    partial[(size_t)blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void link_ce_finalize_kernel(const float* __restrict__ partial, int T, float* __restrict__ sums4, float* __restrict__ loss) {
+  __shared__ double part[64][4];
+  const int j = threadIdx.x & 3, g = threadIdx.x >> 2;
+  double a = 0.0;
+  for (int t = g; t < T; t += 64) a += (double)partial[(size_t)t * 4 + j];
+  part[g][j] = a;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double v = 0.0;
+    for (int k = 0; k < 64; ++k) v += part[k][threadIdx.x];
+    sums4[threadIdx.x] = (float)v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = sums4[0] / sums4[1] + sums4[2] / sums4[3];
+}
+__global__ __launch_bounds__(256) void link_ce_bwd_kernel(const float* __restrict__ gt, int gs, const float* __restrict__ pred,
+                                                          int ps, const float* __restrict__ W, size_t P,
+                                                          const float* __restrict__ sums4, float gscale,
+                                                          float* __restrict__ dpred, int ds) {
+  const float cp = gscale / sums4[1], cn = gscale / sums4[3];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (size_t)gridDim.x * 256) {
+    const float y = gt[i * gs], w = W[i];
+    const bool lp = is_pos(y, 0), ln = is_neg(y, 0);
+    float q1;
+    ce2(pred[i * ps], pred[i * ps + 1], lp ? 1 : 0, &q1);
+    float coef = 0.f;                                   // weights that are exactly zero contribute nothing even at 0/0
+    if (lp && w != 0.f) coef += w * cp;
+    if (ln && w != 0.f) coef += w * cn;
+    const float gl = (q1 - (lp ? 1.f : 0.f)) * coef;
+    dpred[i * ds] = -gl;
+    dpred[i * ds + 1] = gl;
+  }
+}
+
 int sl_blocks(size_t total) {
   size_t b = (total + 256 * 4 - 1) / (256 * 4);
   if (b > 1024) b = 1024;
@@ -376,5 +510,52 @@ extern "C" int ocr_softmax_loss_bwd(const ocr_softmax_loss_desc* d, const void* 
                      static_cast<const float*>(ohnm_threshold), static_cast<const float*>(sums34),
                      grad_scale, static_cast<float*>(d_pixel_logits),
                      static_cast<float*>(d_link_logits));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_label_masks(const void* labels, int64_t count, int label_rule, void* pos_u8, void* neg_u8, void* stream) {
+  OCR_CHECK_ARG(labels && pos_u8 && neg_u8 && count > 0 && (label_rule == 0 || label_rule == 1));
+  hipLaunchKernelGGL(label_masks_kernel, dim3(sl_blocks((size_t)count)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(labels), (size_t)count, label_rule, static_cast<unsigned char*>(pos_u8),
+                     static_cast<unsigned char*>(neg_u8));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_ohnm_select(const void* scores, const void* pos_mask_u8, const void* neg_mask_u8, const void* n_pos_i32,
+                               int n, int hw, float neg_ratio, void* selected_neg_f32, void* selected_f32, void* stream) {
+  OCR_CHECK_ARG(scores && neg_mask_u8 && (pos_mask_u8 || n_pos_i32) && (selected_neg_f32 || selected_f32));
+  OCR_CHECK_ARG(n > 0 && hw > 0 && neg_ratio >= 0.f);
+  hipLaunchKernelGGL(ohnm_select_kernel, dim3(n), dim3(1024), 0, static_cast<hipStream_t>(stream), hw, neg_ratio,
+                     static_cast<const float*>(scores), static_cast<const unsigned char*>(pos_mask_u8),
+                     static_cast<const unsigned char*>(neg_mask_u8), static_cast<const int*>(n_pos_i32),
+                     static_cast<float*>(selected_neg_f32), static_cast<float*>(selected_f32));
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_link_ce_workspace(int64_t count) { return (size_t)sl_blocks((size_t)(count > 0 ? count : 1)) * 4 * sizeof(float); }
+
+extern "C" int ocr_link_ce_fwd(const void* link_gt, int gt_stride, const void* link_pred, int pred_stride, const void* w_pixel,
+                               int64_t count, void* sums4, void* loss1, void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(link_gt && link_pred && w_pixel && sums4 && loss1 && workspace && count > 0 && gt_stride >= 1 && pred_stride >= 2);
+  if (ws_bytes < ocr_link_ce_workspace(count)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int T = sl_blocks((size_t)count);
+  hipLaunchKernelGGL(link_ce_reduce_kernel, dim3(T), dim3(256), 0, st, static_cast<const float*>(link_gt), gt_stride,
+                     static_cast<const float*>(link_pred), pred_stride, static_cast<const float*>(w_pixel), (size_t)count,
+                     static_cast<float*>(workspace));
+  hipLaunchKernelGGL(link_ce_finalize_kernel, dim3(1), dim3(256), 0, st, static_cast<const float*>(workspace), T,
+                     static_cast<float*>(sums4), static_cast<float*>(loss1));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_link_ce_bwd(const void* link_gt, int gt_stride, const void* link_pred, int pred_stride, const void* w_pixel,
+                               int64_t count, const void* sums4, float grad_scale, void* d_link_pred, int d_stride,
+                               void* stream) {
+  OCR_CHECK_ARG(link_gt && link_pred && w_pixel && sums4 && d_link_pred && count > 0 && gt_stride >= 1 && pred_stride >= 2 &&
+                d_stride >= 2);
+  hipLaunchKernelGGL(link_ce_bwd_kernel, dim3(sl_blocks((size_t)count) * 2), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(link_gt), gt_stride, static_cast<const float*>(link_pred), pred_stride,
+                     static_cast<const float*>(w_pixel), (size_t)count, static_cast<const float*>(sums4), grad_scale,
+                     static_cast<float*>(d_link_pred), d_stride);
   return ocr_launch_status();
 }

@@ -139,3 +139,49 @@ def ohem_loss(y_true_pixel, y_pred_pixel, y_true_link, y_pred_link, training_mas
     g = graph or get_default_graph()
     return losses.softmax_loss(g, y_pred_pixel, y_pred_link, y_true_pixel, y_true_link,
                                pixel_rule=1, label_rule=0, link_gate=True)
+
+
+def cal_link_loss(link_gt, link_pred, W_pixel, graph=None):
+    """nets/model_vgg_16.py:227-241 for one direction: link_gt [...,1] (or [...]) 0/1 labels, link_pred [...,2] logits —
+    tensors, tf.split-style channel slices of the 8- / 16-channel maps (strided views are read in place), or a head handle
+    (`.data`, `.grad`) — W_pixel [pixels] weights.  sum(CE Wpos)/sum(Wpos) + sum(CE Wneg)/sum(Wneg), unguarded like the
+    reference.  Returns a device Scalar; with a head handle the backward seed is recorded (its `.grad` = d loss / d logits)."""
+    g = graph or get_default_graph()
+    handle = link_pred if (hasattr(link_pred, "grad") and hasattr(link_pred, "data") and not isinstance(link_pred, torch.Tensor)) else None
+    pred = handle.data if handle is not None else link_pred
+    gt = link_gt.data if (hasattr(link_gt, "data") and not isinstance(link_gt, (torch.Tensor, np.ndarray))) else link_gt
+
+    def dev(t):
+        if not isinstance(t, torch.Tensor):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+        return t.to(device=g.device, dtype=F32)          # a view stays a view
+
+    def rows(t, width):
+        """(tensor, row stride in elements) of a [..., width] view whose rows are uniformly strided."""
+        if t.dim() == 0 or t.shape[-1] != width:
+            if width == 1:
+                t = t.unsqueeze(-1)
+            else:
+                raise ValueError("link_pred must end in 2 logits")
+        if t.stride(-1) != 1 and width > 1:
+            raise ValueError("the logit pair must be contiguous")
+        lead = t.dim() - 1
+        step = t.stride(lead - 1) if lead >= 1 else width
+        for i in range(lead - 1):
+            if t.shape[i + 1] != 1 and t.stride(i) != t.stride(i + 1) * t.shape[i + 1]:
+                raise ValueError("rows are not uniformly strided: pass a contiguous tensor or a channel slice of one")
+        return t, int(step)
+    gt_t, gs = rows(dev(gt), 1)
+    pr_t, ps = rows(dev(pred), 2)
+    W = dev(W_pixel).contiguous().reshape(-1)
+    P = pr_t.numel() // 2
+    if gt_t.numel() != P or W.numel() != P:
+        raise ValueError("link_gt, link_pred and W_pixel must cover the same pixels")
+    sums, out = g.empty((4,), F32), g.empty((1,), F32)
+    ops.link_ce_fwd(gt_t, gs, pr_t, ps, W, P, sums, out, g.workspace())
+    if handle is not None:
+        def backward():
+            handle.grad = g.empty(pr_t.shape, F32)
+            ops.link_ce_bwd(gt_t, gs, pr_t, ps, W, P, sums, g.seed_scale(), handle.grad, 2)
+        g.record(backward)
+    return Scalar(out)

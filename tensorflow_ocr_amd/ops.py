@@ -655,6 +655,27 @@ def softmax_loss_bwd(desc, pixel_logits, link_logits, pixel_labels, link_labels,
            ptr(link_labels), ptr(thr), ptr(sums34), c_float(grad_scale), ptr(d_pixel), ptr(d_link), _st())
 
 
+def label_masks(labels, label_rule, pos_u8, neg_u8):
+    L.call("ocr_label_masks", ptr(labels), c_int64(labels.numel()), c_int(label_rule), ptr(pos_u8), ptr(neg_u8), _st())
+
+
+def ohnm_select(scores, pos_u8, neg_u8, n_pos_i32, n, hw, neg_ratio, selected_neg, selected):
+    L.call("ocr_ohnm_select", ptr(scores), ptr(pos_u8), ptr(neg_u8), ptr(n_pos_i32), c_int(n), c_int(hw),
+           c_float(neg_ratio), ptr(selected_neg), ptr(selected), _st())
+
+
+def link_ce_fwd(gt, gt_stride, pred, pred_stride, w_pixel, count, sums4, loss1, ws):
+    nbytes = L.call_size("ocr_link_ce_workspace", c_int64(count))
+    buf = ws.get(nbytes)
+    L.call("ocr_link_ce_fwd", ptr(gt), c_int(gt_stride), ptr(pred), c_int(pred_stride), ptr(w_pixel), c_int64(count),
+           ptr(sums4), ptr(loss1), ptr(buf), c_size_t(nbytes), _st())
+
+
+def link_ce_bwd(gt, gt_stride, pred, pred_stride, w_pixel, count, sums4, grad_scale, d_pred, d_stride):
+    L.call("ocr_link_ce_bwd", ptr(gt), c_int(gt_stride), ptr(pred), c_int(pred_stride), ptr(w_pixel), c_int64(count),
+           ptr(sums4), c_float(grad_scale), ptr(d_pred), c_int(d_stride), _st())
+
+
 # ----------------------------------------------------------------------------- decode
 def softmax_pairs(logits, probs):
     L.call("ocr_softmax_pairs", ptr(logits), c_int64(logits.numel() // 2), ptr(probs), _st())

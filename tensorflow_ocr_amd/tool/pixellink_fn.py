@@ -215,6 +215,14 @@ def generate_rbox(h, w, xs, ys, bboxes, ignored, graph=None):
     return s[0].cpu().numpy(), l[0].cpu().numpy(), sb[0]
 
 
+def tf_pixellink_get_rbox(img_size, xs, ys, bboxes, ignored, graph=None):
+    """tool/pixellink_fn.py:112-118 (the tf.py_func wrapper of generate_rbox): img_size = (h, w); returns DEVICE tensors
+    pixel_map [h/4, w/4], link_map [h/4, w/4, 8] and show_bboxes [200, 4] (the shapes the reference sets)."""
+    h, w = img_size
+    s, l, sb = generate_rbox_batch(h, w, [xs], [ys], [bboxes], [ignored], graph=graph)
+    return s[0], l[0], torch.from_numpy(sb[0]).to(s.device)
+
+
 def generate_rbox_batch(h, w, xs_list, ys_list, bboxes_list, ignored_list, graph=None):
     """generate_rbox for a batch: device tensors score [n,h/4,w/4], link [n,h/4,w/4,8]; show_bboxes
     [n,200,4] stays a NumPy copy of the inputs (:66,77)."""
