@@ -226,11 +226,13 @@ int ocr_pack_weights_first_f16(const void* w_hwio_f32, int cout, void* w_first, 
  * ocr_pack_weights_batch_table fills a HOST table of ocr_pack_weights_batch_table_bytes(n) bytes from n
  * (weights, taps, cin, cout, w_kc, w_ck) tuples of DEVICE pointers (w_kc[i] or w_ck[i] may be NULL) and returns the
  * launch grid; the caller copies the table to device memory once (the pointers are static) and passes the
- * device copy to ocr_pack_weights_batch_f16 every step. */
+ * device copy to ocr_pack_weights_batch_f16 every step.  ld_ck (may be NULL): row length of w_ck[i], 0 = cout[i]; the
+ * fuse heads' pair (w_kc32 [32][cin], w_ck32 [cin][32]; rows / columns >= cout stay as the caller zeroed them) is
+ * (taps 1, cout, ld_ck 32). */
 size_t ocr_pack_weights_batch_table_bytes(int n);
 int ocr_pack_weights_batch_table(int n, const void* const* w_hwio_f32, const int* taps, const int* cin,
-                                 const int* cout, void* const* w_kc, void* const* w_ck, void* table_host,
-                                 int* grid_out);
+                                 const int* cout, void* const* w_kc, void* const* w_ck, const int* ld_ck,
+                                 void* table_host, int* grid_out);
 int ocr_pack_weights_batch_f16(const void* table_dev, int n, int grid, void* stream);
 /* head weights f32 [cin][cout<=32] -> w_kc32 f16 [32][cin] and w_ck32 f16 [cin][32], zero padded */
 int ocr_pack_weights_small_f16(const void* w_f32, int cin, int cout, void* w_kc32, void* w_ck32,
@@ -450,6 +452,89 @@ int ocr_softmax_loss_bwd(const ocr_softmax_loss_desc* d, const void* pixel_logit
                          const void* link_logits, const void* pixel_labels, const void* link_labels,
                          const void* ohnm_threshold, const void* sums34, float grad_scale,
                          void* d_pixel_logits, void* d_link_logits, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Fuse heads, BATCHED (round 4): one launch per kernel kind over the (up to four) feature maps the heads read
+ * (nets/model_vgg_16.py:160-172: fc7, conv5_3, conv4_3, conv3_3; nets/pixellink.py:58-67; nets/model.py:129-141) instead
+ * of one per map, and the two predication convolutions (:166,173 / :61,67) as one pass over the fused tensor.  `items` are
+ * HOST arrays of the descriptors below (copied into the kernel arguments, like ocr_conv_desc); the pointers INSIDE them
+ * are device pointers.  Results equal the per-map entry points' (ocr_conv1x1_small_*, ocr_sc_*) bit for bit, except the
+ * forward statistics (another, equally fixed, summation order) and the weight gradient (f32 dz rounded on load).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;             /* f16 [P][cin] feature map */
+  const void* w_kc32;        /* f16 [32][cin], rows >= cout zero */
+  const void* bias;          /* f32 [cout] or NULL */
+  void* out;                 /* f32 [P][cout] */
+  void* stats_partial;       /* NULL, or f32 [rows][2][cout]: per-workgroup sums of out and out^2, rows =
+                                ocr_conv1x1_small_batch_rows(P) <= 1024 (for ocr_bn_finalize_batch) */
+  int32_t P, cin, cout;
+} ocr_head_conv_item;
+int ocr_conv1x1_small_batch_rows(int P);
+int ocr_conv1x1_small_batch_f16(const ocr_head_conv_item* items, int count, void* stream);
+typedef struct {
+  const void* dz;            /* f32 [P][cout] */
+  const void* w_ck32;        /* f16 [cin][32] */
+  void* dx;                  /* f16 [P][cin] */
+  int32_t P, cin, cout, accumulate;
+} ocr_head_dgrad_item;
+int ocr_conv1x1_small_dgrad_batch_f16(const ocr_head_dgrad_item* items, int count, float grad_scale, void* stream);
+typedef struct {
+  const void* x;             /* f16 [P][cin], cin % 128 == 0 */
+  const void* dz;            /* f32 [P][cout] (rounded to the 16-bit storage type on load) */
+  void* dw;                  /* f32 [cin][cout] */
+  void* slab;                /* scratch: ocr_conv1x1_small_wgrad_batch_slab_bytes(P, cin) bytes of its own */
+  int32_t P, cin, cout;
+} ocr_head_wgrad_item;
+size_t ocr_conv1x1_small_wgrad_batch_slab_bytes(int P, int cin);
+int ocr_conv1x1_small_wgrad_batch_f16(const ocr_head_wgrad_item* items, int count, void* stream);
+/* batched finalisation of SMALL batch-norm reductions (T <= 2048 rows, C <= 32; up to 8 per launch): fields as the
+ * arguments of ocr_bn_finalize / ocr_bn_bwd_sums */
+typedef struct {
+  const void* partial;       /* f32 [T][2][C] */
+  int32_t T, C;
+  double count;
+  const void *gamma, *beta;
+  void *moving_mean, *moving_var, *scale, *shift, *save_mean, *save_invstd;
+} ocr_bn_finalize_item;
+int ocr_bn_finalize_batch(const ocr_bn_finalize_item* items, int count, float eps, float decay, void* stream);
+typedef struct {
+  const void* partial;       /* f32 [T][2][C] */
+  int32_t T, C;
+  void *out0, *out1;         /* column sums of kind 0 / kind 1 */
+} ocr_bn_sums_item;
+int ocr_bn_bwd_sums_batch(const ocr_bn_sums_item* items, int count, void* stream);
+typedef struct {
+  const void *z, *scale, *shift, *save_mean, *save_invstd, *dout;
+  void *dgamma, *dbeta, *dz;
+  void* partial;             /* scratch of its own: ocr_sc_num_partials(P, C) * 2 * C floats */
+  int32_t P, C, relu;
+} ocr_sc_bn_bwd_item;
+int ocr_sc_bn_bwd_batch(const ocr_sc_bn_bwd_item* items, int count, void* stream);
+typedef struct {
+  const void* x;             /* f32 [P][C] */
+  void* out;                 /* f32 [C]: column sums */
+  void* partial;             /* scratch of its own: (ocr_sc_num_partials(P, C) + 1) * 2 * C floats */
+  int32_t P, C;
+} ocr_sc_colsum_item;
+int ocr_sc_colsum_batch(const ocr_sc_colsum_item* items, int count, void* stream);
+typedef struct {
+  const void *z, *scale, *shift;
+  void* out;                 /* out = act(z * scale[c] + shift[c]) */
+  int64_t total;             /* elements */
+  int32_t C;
+} ocr_sc_act_item;
+int ocr_sc_act_batch(const ocr_sc_act_item* items, int count, int relu, void* stream);
+/* x18 f32 [P][18] (channels 0..1: pixel head, 2..17: link head): z_px = x18[:, :2] w_px (+ b_px) [P][2], z_lk =
+ * x18[:, 2:] w_lk (+ b_lk) [P][16]; with partial_* (f32 [rows][2][2] / [rows][2][16], rows =
+ * ocr_sc_pointwise_pair_num_partials(P)) also the batch-norm statistics partials of both outputs. */
+int ocr_sc_pointwise_pair_num_partials(int P);
+int ocr_sc_pointwise_pair_fwd(const void* x18, const void* w_px, const void* b_px, const void* w_lk, const void* b_lk,
+                              int P, void* z_px, void* z_lk, void* partial_px, void* partial_lk, void* stream);
+size_t ocr_sc_pointwise_pair_bwd_workspace(void);
+int ocr_sc_pointwise_pair_bwd(const void* x18, const void* dz_px, const void* dz_lk, const void* w_px, const void* w_lk,
+                              int P, void* dx18, void* dw_px, void* db_px, void* dw_lk, void* db_lk, void* workspace,
+                              size_t ws_bytes, void* stream);
 
 /* The reference's loss HELPERS as entry points of their own (callable names of SURVEY 8b; the training losses above fuse
  * them).  get_pos_and_neg_masks (nets/model.py:199-201): pos = labels == 1, neg = labels == 0 (label_rule 1: > 0 / not)

@@ -222,6 +222,52 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
     bn_fin_apply(fin, c, red[0][0][threadIdx.x] + red[1][0][threadIdx.x], red[0][1][threadIdx.x] + red[1][1][threadIdx.x]);
 }
 
+// Up to eight SMALL reductions (T <= 2048 partial rows, C <= 32 channels: the fuse heads' batch norms) finalised in one
+// launch, one 1024-thread block each: thread = (kind, channel) column x one of 16 row lanes, eight rows in flight, rows
+// added in row order per lane, the 16 lanes in lane order — bitwise reproducible, no tickets.
+struct BnBatchItem {
+  const float* partial;
+  int T, C;
+  int mode;                 // 0: BnFin (forward statistics), 1: BnBwdFin (dbeta, dgamma)
+  BnFin fin;
+  BnBwdFin bwd;
+};
+struct BnBatchTab {
+  BnBatchItem it[8];
+};
+__global__ __launch_bounds__(1024) void bn_finalize_batch_kernel(BnBatchTab tab) {
+  __shared__ double red[16][64];
+  const BnBatchItem& it = tab.it[blockIdx.x];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int kind = col >> 5, c = col & 31;
+  double acc = 0.0;
+  if (c < it.C) {
+    const float* base = it.partial + (size_t)kind * it.C + c;
+    for (int t0 = rl; t0 < it.T; t0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int t = t0 + 16 * k;
+        v[k] = t < it.T ? base[(size_t)t * 2 * it.C] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += (double)v[k];
+    }
+  }
+  red[rl][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < 32 && c < it.C) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      s += red[k][c];
+      q += red[k][32 + c];
+    }
+    if (it.mode == 0) bn_fin_apply<BnFin>(it.fin, c, s, q);
+    else bn_fin_apply<BnBwdFin>(it.bwd, c, s, q);
+  }
+}
+
 // launches on one stream are ordered; the rotating slot keeps launches that might overlap on
 // DIFFERENT streams (side-stream experiments) off each other's counters
 static int bn_ticket_slot() {
@@ -1404,5 +1450,45 @@ extern "C" int ocr_bn_relu_pool_bwd_idx_apply_f16(const void* y, const void* sca
                      static_cast<const float*>(dbeta), (const half_t*)nullptr,
                      static_cast<const unsigned char*>(argmax_u8), static_cast<const half_t*>(da_pool),
                      (float*)nullptr, static_cast<half_t*>(dy));
+  return ocr_launch_status();
+}
+
+// ---- batched finalisation of small reductions (the fuse heads: up to 8 per launch) -----------------------------------
+extern "C" int ocr_bn_finalize_batch(const ocr_bn_finalize_item* items, int count, float eps, float decay, void* stream) {
+  OCR_CHECK_ARG(items && count > 0 && count <= 8);
+  BnBatchTab tab;
+  for (int i = 0; i < count; ++i) {
+    const ocr_bn_finalize_item& a = items[i];
+    OCR_CHECK_ARG(a.partial && a.scale && a.shift && a.count > 0.0);
+    OCR_CHECK_SHAPE(a.T > 0 && a.T <= 2048 && a.C > 0 && a.C <= 32);
+    tab.it[i].partial = static_cast<const float*>(a.partial);
+    tab.it[i].T = a.T;
+    tab.it[i].C = a.C;
+    tab.it[i].mode = 0;
+    tab.it[i].fin = BnFin{a.count, static_cast<const float*>(a.gamma), static_cast<const float*>(a.beta), eps, decay,
+                          static_cast<float*>(a.moving_mean), static_cast<float*>(a.moving_var),
+                          static_cast<float*>(a.scale), static_cast<float*>(a.shift),
+                          static_cast<float*>(a.save_mean), static_cast<float*>(a.save_invstd)};
+    tab.it[i].bwd = BnBwdFin{nullptr, nullptr};
+  }
+  hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3(count), dim3(1024), 0, static_cast<hipStream_t>(stream), tab);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_bwd_sums_batch(const ocr_bn_sums_item* items, int count, void* stream) {
+  OCR_CHECK_ARG(items && count > 0 && count <= 8);
+  BnBatchTab tab;
+  for (int i = 0; i < count; ++i) {
+    const ocr_bn_sums_item& a = items[i];
+    OCR_CHECK_ARG(a.partial && a.out0 && a.out1);
+    OCR_CHECK_SHAPE(a.T > 0 && a.T <= 2048 && a.C > 0 && a.C <= 32);
+    tab.it[i].partial = static_cast<const float*>(a.partial);
+    tab.it[i].T = a.T;
+    tab.it[i].C = a.C;
+    tab.it[i].mode = 1;
+    tab.it[i].fin = BnFin{1.0, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    tab.it[i].bwd = BnBwdFin{static_cast<float*>(a.out1), static_cast<float*>(a.out0)};   // (dgamma <- kind 1, dbeta <- kind 0)
+  }
+  hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3(count), dim3(1024), 0, static_cast<hipStream_t>(stream), tab);
   return ocr_launch_status();
 }

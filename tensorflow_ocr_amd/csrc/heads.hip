@@ -20,18 +20,16 @@ namespace {
 // wave fetches 32 px x 64 ch tiles with whole 128-byte lines (8 lanes per pixel row), parks them in its own
 // 4.6 KB of LDS (row stride 144 B: the sixteen 16-byte fragment reads of a phase hit sixteen bank groups) and
 // takes the fragments from there.
-__global__ __launch_bounds__(256) void conv1x1_small_kernel(const half_t* __restrict__ x,
-                                                            const half_t* __restrict__ w,
-                                                            const float* __restrict__ bias, int P,
-                                                            int cin, int cout,
-                                                            float* __restrict__ out) {
-  constexpr int RS = 144;
-  __shared__ __attribute__((aligned(16))) char s_x[4][32 * RS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One wave, one 32-pixel group starting at p0; sx = the wave's 32 * RS bytes of LDS.  On return the wave's 32 x cout
+// outputs sit in sx as f32 [32][cout] (rows >= P - p0: zero + bias) and have been written to `out`.
+constexpr int kSmallRS = 144;
+__device__ __forceinline__ void conv1x1_small_group(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                    const float* __restrict__ bias, int P, int cin, int cout,
+                                                    float* __restrict__ out, int p0, char* sx) {
+  constexpr int RS = kSmallRS;
+  const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;
-  const int p0 = (blockIdx.x * 4 + wave) * 32;
   const half_t* wp = w + (size_t)r * cin + 8 * hh;
-  char* sx = s_x[wave];
   const int lrow = lane >> 3, lc = lane & 7;
   f32x16 acc;
 #pragma unroll
@@ -81,24 +79,91 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const half_t* __rest
   for (int i = lane; i < npx * cout; i += 64) dst[i] = so[i];
 }
 
+__global__ __launch_bounds__(256) void conv1x1_small_kernel(const half_t* __restrict__ x,
+                                                            const half_t* __restrict__ w,
+                                                            const float* __restrict__ bias, int P,
+                                                            int cin, int cout,
+                                                            float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) char s_x[4][32 * kSmallRS];
+  const int wave = threadIdx.x >> 6;
+  conv1x1_small_group(x, w, bias, P, cin, cout, out, (blockIdx.x * 4 + wave) * 32, s_x[wave]);
+}
+
+// The same convolution for up to FOUR feature maps in one launch (the four fuse-head sources of
+// nets/model_vgg_16.py:160-172 / nets/pixellink.py:58-67: launched one by one they are 4 x (conv + statistics) small
+// launches that each leave most of the chip idle), with the batch-norm statistics of the output in the epilogue: a
+// workgroup walks `iters` consecutive 128-pixel groups, every wave keeps per-channel sums of z and z^2 of its rows in
+// registers (lane = half * 32 + channel: 16 of the 32 staged rows each), and the workgroup leaves ONE partial row
+// [2][cout] — at most 1024 rows per map, which one block per map finalises directly (bn_finalize_batch_kernel).
+struct HeadConvItem {
+  const half_t* x;
+  const half_t* w;
+  const float* bias;
+  float* out;
+  float* partial;
+  int P, cin, cout, iters, block0;
+};
+struct HeadConvTab {
+  HeadConvItem it[4];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void conv1x1_small_batch_kernel(HeadConvTab tab) {
+  __shared__ __attribute__((aligned(16))) char s_x[4][32 * kSmallRS];
+  __shared__ float red[4][2][32];
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < tab.count && (int)blockIdx.x >= tab.it[j].block0) k = j;
+  const HeadConvItem it = tab.it[k];
+  const int bx = (int)blockIdx.x - it.block0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, half = lane >> 5;
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < it.iters; ++i) {
+    const int p0 = ((bx * it.iters + i) * 4 + wave) * 32;
+    if (p0 >= it.P) break;                                   // (wave-uniform)
+    conv1x1_small_group(it.x, it.w, it.bias, it.P, it.cin, it.cout, it.out, p0, s_x[wave]);
+    if (it.partial && c < it.cout) {
+      const float* so = reinterpret_cast<const float*>(s_x[wave]);
+      const int r1 = min(16 * half + 16, it.P - p0);
+      for (int r = 16 * half; r < r1; ++r) {
+        const float v = so[r * it.cout + c];
+        s += v;
+        q += v * v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                         // the staged rows have been summed before the next group lands
+  }
+  if (!it.partial) return;
+  s += __shfl(s, (lane + 32) & 63, 64);
+  q += __shfl(q, (lane + 32) & 63, 64);
+  if (half == 0) { red[wave][0][c] = s; red[wave][1][c] = q; }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * it.cout) {
+    const int which = threadIdx.x / it.cout, cc = threadIdx.x % it.cout;
+    it.partial[((size_t)bx * 2 + which) * it.cout + cc] =
+        ((red[0][which][cc] + red[1][which][cc]) + red[2][which][cc]) + red[3][which][cc];
+  }
+}
+
 // dx[p][ci] (+)= sum_co dz[p][co] * w[ci][co]     (w_ck f16 [cin][32], cols >= cout zero)
 // One wave = 32 pixels; the accumulator holds, per lane, 4-channel pieces of ONE pixel, so written directly every
 // store touches 32 different lines with 8 bytes each.  Two 32-channel blocks are parked in the wave's LDS tile
 // ([32 px][64 ch], row stride 144 B) and leave as whole 128-byte lines (8 lanes per pixel row); the
 // accumulate form reads the old gradient the same way.
-__global__ __launch_bounds__(256) void conv1x1_small_dgrad_kernel(const float* __restrict__ dz,
-                                                                  const half_t* __restrict__ w_ck,
-                                                                  int P, int cin, int cout,
-                                                                  half_t* __restrict__ dx,
-                                                                  int accumulate, float gscale) {
-  constexpr int RS = 64 * 4 + 16;                           // f32 staging: the result is rounded once, after the add
-  __shared__ __attribute__((aligned(16))) char s_o[4][32 * RS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+constexpr int kDgradRS = 64 * 4 + 16;                       // f32 staging: the result is rounded once, after the add
+__device__ __forceinline__ void conv1x1_small_dgrad_group(const float* __restrict__ dz,
+                                                          const half_t* __restrict__ w_ck,
+                                                          int P, int cin, int cout,
+                                                          half_t* __restrict__ dx,
+                                                          int accumulate, float gscale, int p0, char* so) {
+  constexpr int RS = kDgradRS;
+  const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;
-  const int p0 = (blockIdx.x * 4 + wave) * 32;
   const int p = p0 + r;
   const bool ok = p < P;
-  char* so = s_o[wave];
   const int lrow = lane >> 3, lc = lane & 7;
   half8_t b[2];
 #pragma unroll
@@ -155,6 +220,40 @@ __global__ __launch_bounds__(256) void conv1x1_small_dgrad_kernel(const float* _
   }
 }
 
+__global__ __launch_bounds__(256) void conv1x1_small_dgrad_kernel(const float* __restrict__ dz,
+                                                                  const half_t* __restrict__ w_ck,
+                                                                  int P, int cin, int cout,
+                                                                  half_t* __restrict__ dx,
+                                                                  int accumulate, float gscale) {
+  __shared__ __attribute__((aligned(16))) char s_o[4][32 * kDgradRS];
+  const int wave = threadIdx.x >> 6;
+  conv1x1_small_dgrad_group(dz, w_ck, P, cin, cout, dx, accumulate, gscale, (blockIdx.x * 4 + wave) * 32, s_o[wave]);
+}
+
+// ... and for up to four feature maps in one launch (one 128-pixel group per workgroup, as above)
+struct HeadDgradItem {
+  const float* dz;
+  const half_t* w_ck;
+  half_t* dx;
+  int P, cin, cout, accumulate, block0;
+};
+struct HeadDgradTab {
+  HeadDgradItem it[4];
+  int count;
+  float gscale;
+};
+__global__ __launch_bounds__(256) void conv1x1_small_dgrad_batch_kernel(HeadDgradTab tab) {
+  __shared__ __attribute__((aligned(16))) char s_o[4][32 * kDgradRS];
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < tab.count && (int)blockIdx.x >= tab.it[j].block0) k = j;
+  const HeadDgradItem it = tab.it[k];
+  const int wave = threadIdx.x >> 6;
+  const int p0 = (((int)blockIdx.x - it.block0) * 4 + wave) * 32;
+  if (p0 < it.P) conv1x1_small_dgrad_group(it.dz, it.w_ck, it.P, it.cin, it.cout, it.dx, it.accumulate, tab.gscale, p0, s_o[wave]);
+}
+
 // partial[s][ci][co] = sum over the strip's pixels of x[p][ci] * dz[p][co]
 template <int COUT>
 __global__ __launch_bounds__(256) void conv1x1_small_wgrad_kernel(const half_t* __restrict__ x,
@@ -181,6 +280,175 @@ __global__ __launch_bounds__(256) void conv1x1_small_wgrad_kernel(const half_t* 
   }
 }
 
+// ---- weight gradient of the head convolutions for up to four feature maps in one launch -------------------------------
+// dw[ci][co] = sum_p x[p][ci] * dz[p][co]: M = ci, N = co (18 padded to 32), K = pixels, both operands K-major in HBM.  The
+// construction of wgrad_pw_kernel (conv_wgrad_pw.hip: 64-pixel stages double-buffered in LDS, fragments by
+// ds_read_b64_tr_b16 with the K order permuted identically for both operands, buffer loads whose range check does the
+// zero padding) on a 128 ci x 32 co block: 8 waves = 4 (ci) x 2 (co), wave tile 32 ci x 16 co.  dz is read as it stands
+// — f32 [P][cout] — and rounded to the 16-bit storage type on its way into LDS (the separate pad pass wrote and re-read
+// a [P][64] copy).  The launch is bound by the one pass over x: 49 KB of LDS per workgroup, three workgroups per CU.
+// Split-K partial blocks go to a [split][cin][32] f32 slab, summed in fixed order by head_wgrad_reduce_kernel.
+typedef short hw_short4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) hw_short4v* hw_lds_s4_ptr;
+__device__ __forceinline__ half8_t hw_tr_pair16(const char* base, int second_off) {
+  hw_short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((hw_lds_s4_ptr)(base));
+  hw_short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((hw_lds_s4_ptr)(base + second_off));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  short8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(half8_t, v);
+}
+
+struct HeadWgradItem {
+  const half_t* x;
+  const float* dz;
+  float* slab;
+  int P, cin, cout, m_tiles, tiles_per_split, nci, block0;
+};
+struct HeadWgradTab {
+  HeadWgradItem it[4];
+  int count;
+};
+
+constexpr int kHwCIB = 128, kHwPXS = 64;
+constexpr int kHwXS = kHwCIB * 2 + 32, kHwDS = 32 * 2 + 32;
+constexpr int kHwStage = kHwPXS * (kHwXS + kHwDS);
+
+__global__ __launch_bounds__(512) void head_wgrad_kernel(HeadWgradTab tab) {
+  constexpr int NT = 512, CIB = kHwCIB, PXS = kHwPXS, XS = kHwXS, DS = kHwDS, STAGE = kHwStage;
+  constexpr int XCH = CIB / 8;                      // 16-byte chunks per pixel row of the x tile
+  constexpr int NX = PXS * XCH / NT;                // 2
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < tab.count && (int)blockIdx.x >= tab.it[j].block0) k = j;
+  const HeadWgradItem it = tab.it[k];
+  const int b = (int)blockIdx.x - it.block0;
+  const int cib = b % it.nci, split = b / it.nci;
+  const int ci0 = cib * CIB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wci = wave & 3, wco = wave >> 2;
+  const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
+  // columns cout..31 of the dz tiles are never written: zero both buffers' dz tiles once
+  for (int i = tid; i < 2 * PXS * (DS / 4); i += NT) {
+    const int buf = i / (PXS * (DS / 4)), r = i % (PXS * (DS / 4));
+    reinterpret_cast<unsigned*>(smem + buf * STAGE + PXS * XS)[r] = 0u;
+  }
+  f32x4 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  const int a_lane = (4 * g + q) * XS + (wci * 32 + 4 * pp) * 2;
+  const int b_lane = (4 * g + q) * DS + (wco * 16 + 4 * pp) * 2;
+  const int mt_begin = split * it.tiles_per_split;
+  int mt_end = mt_begin + it.tiles_per_split;
+  if (mt_end > it.m_tiles) mt_end = it.m_tiles;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<half_t*>(it.x), 0, (int)((size_t)it.P * it.cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(it.dz), 0, (int)((size_t)it.P * it.cout * 4), 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
+  const int dq = PXS * it.cout / 4;                 // 16-byte pieces of one stage's dz span (64 * cout * 4 B, contiguous)
+  u32x4 xr[NX];
+  f32x4 dr = {0.f, 0.f, 0.f, 0.f};
+  auto load_tile = [&](int mt) {
+    const int p0 = mt * PXS;
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int idx = u * NT + tid;
+      const int px = idx / XCH, c = idx % XCH;
+      const bool ok = p0 + px < it.P;
+      const unsigned off = ok ? (unsigned)(((size_t)(p0 + px) * it.cin + ci0 + c * 8) * 2) : OOB;
+      xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+    }
+    // whatever lies beyond the last pixel reads as zero (range check, num_records = P * cout * 4); a 16-byte piece that
+    // straddles the end (P odd) is fetched dword by dword so that its valid half is not lost with the rest
+    const size_t dbytes = (size_t)it.P * it.cout * 4, dby0 = (size_t)p0 * it.cout * 4 + (size_t)tid * 16;
+    if (tid >= dq || dby0 >= dbytes || dby0 + 16 <= dbytes) {
+      const unsigned doff = (tid < dq && dby0 < dbytes) ? (unsigned)dby0 : OOB;
+      dr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, doff, 0, 0));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dr[j] = (dby0 + 4 * j < dbytes) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, (unsigned)(dby0 + 4 * j), 0, 0)) : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* xs = smem + buf * STAGE;
+    char* ds = xs + PXS * XS;
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int idx = u * NT + tid;
+      *reinterpret_cast<u32x4*>(xs + (idx / XCH) * XS + (idx % XCH) * 16) = xr[u];
+    }
+    if (tid < dq) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = tid * 4 + j;
+        const int px = e / it.cout, co = e - px * it.cout;
+        *reinterpret_cast<half_t*>(ds + px * DS + co * 2) = (half_t)dr[j];
+      }
+    }
+  };
+  if (mt_begin < mt_end) {
+    load_tile(mt_begin);
+    __syncthreads();                                // the zero fill above is done
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int mt = mt_begin; mt < mt_end; ++mt) {
+    const int buf = (mt - mt_begin) & 1;
+    const bool more = mt + 1 < mt_end;
+    if (more) load_tile(mt + 1);
+    const char* xs = smem + buf * STAGE;
+    const char* ds = xs + PXS * XS;
+#pragma unroll
+    for (int s2 = 0; s2 < PXS / 32; ++s2) {
+      half8_t a[2], bb;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = hw_tr_pair16(xs + a_lane + s2 * 32 * XS + i * 32, 16 * XS);
+      bb = hw_tr_pair16(ds + b_lane + s2 * 32 * DS, 16 * DS);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = OCR_MFMA_16x16x32(a[i], bb, acc[i], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  // D block: lane (li, g) holds rows (ci) 4g..4g+3 of column (co) li
+  float* dst = it.slab + ((size_t)split * it.cin + ci0 + wci * 32 + 4 * g) * 32 + wco * 16 + li;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[(size_t)(i * 16 + e) * 32] = acc[i][e];
+}
+
+// dw[ci][co] (co < cout) = sum over the splits of slab[split][ci][co], one wave per output element, fixed order
+struct HeadWgradRedItem {
+  const float* slab;
+  float* dw;
+  int cin, cout, splits, block0;
+};
+struct HeadWgradRedTab {
+  HeadWgradRedItem it[4];
+  int count;
+};
+__global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(HeadWgradRedTab tab) {
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < tab.count && (int)blockIdx.x >= tab.it[j].block0) k = j;
+  const HeadWgradRedItem it = tab.it[k];
+  const int i = ((int)blockIdx.x - it.block0) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= it.cin * it.cout) return;
+  const int ci = i / it.cout, co = i - ci * it.cout;
+  float a = 0.f;
+  for (int s2 = lane; s2 < it.splits; s2 += 64) a += it.slab[((size_t)s2 * it.cin + ci) * 32 + co];
+  a = wave_sum(a);
+  if (lane == 0) it.dw[i] = a;
+}
+
 __global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                     int elems, int S, float scale) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,14 +460,13 @@ __global__ void sum_partials_kernel(const float* __restrict__ partial, float* __
 
 // ---------------------------------------------------- small-channel f32 ops
 // per-channel sum / sum of squares partials of x [P][C]
-__global__ __launch_bounds__(256) void sc_stats_kernel(const float* __restrict__ x, int P, int C,
-                                                       float* __restrict__ partial) {
-  __shared__ float red[2][256];
+__device__ __forceinline__ void sc_stats_body(const float* __restrict__ x, int P, int C, float* __restrict__ partial,
+                                              int bx, int gdim, float (*red)[256]) {
   const int lanes = 256 / C;
   const int c = threadIdx.x % C, l = threadIdx.x / C;
   float s = 0.f, q = 0.f;
   if (l < lanes) {
-    for (size_t p = (size_t)blockIdx.x * lanes + l; p < (size_t)P; p += (size_t)gridDim.x * lanes) {
+    for (size_t p = (size_t)bx * lanes + l; p < (size_t)P; p += (size_t)gdim * lanes) {
       float v = x[p * C + c];
       s += v;
       q += v * v;
@@ -212,8 +479,13 @@ __global__ __launch_bounds__(256) void sc_stats_kernel(const float* __restrict__
     const int which = threadIdx.x / C, cc = threadIdx.x % C;
     float t = 0.f;
     for (int k = 0; k < lanes; ++k) t += red[which][k * C + cc];
-    partial[((size_t)blockIdx.x * 2 + which) * C + cc] = t;
+    partial[((size_t)bx * 2 + which) * C + cc] = t;
   }
+}
+__global__ __launch_bounds__(256) void sc_stats_kernel(const float* __restrict__ x, int P, int C,
+                                                       float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  sc_stats_body(x, P, C, partial, (int)blockIdx.x, (int)gridDim.x, red);
 }
 
 __device__ __forceinline__ float sc_act(float z, float sc, float sh, int relu) {
@@ -298,27 +570,22 @@ __global__ void sc_unpool_bwd_kernel(const float* __restrict__ dout, int n, int 
   }
 }
 
-// BN(+ReLU) backward on [P][C] f32.  MODE 0: partial sums; MODE 1: dz.
+// BN(+ReLU) backward on [P][C] f32.  MODE 0: partial sums; MODE 1: dz.  (bx, gdim): the block's index and the number of
+// blocks of ITS problem — the batched launch below runs several problems in one grid.
 template <int MODE>
-__global__ __launch_bounds__(256) void sc_bn_bwd_kernel(const float* __restrict__ z,
-                                                        const float* __restrict__ scale,
-                                                        const float* __restrict__ shift,
-                                                        const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd,
-                                                        const float* __restrict__ dgamma,
-                                                        const float* __restrict__ dbeta,
-                                                        const float* __restrict__ dout, int P, int C,
-                                                        int relu, float inv_count,
-                                                        float* __restrict__ partial,
-                                                        float* __restrict__ dz) {
-  __shared__ float red[2][256];
+__device__ __forceinline__ void sc_bn_bwd_body(const float* __restrict__ z, const float* __restrict__ scale,
+                                               const float* __restrict__ shift, const float* __restrict__ mean,
+                                               const float* __restrict__ invstd, const float* __restrict__ dgamma,
+                                               const float* __restrict__ dbeta, const float* __restrict__ dout, int P,
+                                               int C, int relu, float inv_count, float* __restrict__ partial,
+                                               float* __restrict__ dz, int bx, int gdim, float (*red)[256]) {
   const int lanes = 256 / C;
   const int c = threadIdx.x % C, l = threadIdx.x / C;
   float s = 0.f, q = 0.f;
   if (l < lanes) {
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const float kd = MODE ? dbeta[c] * inv_count : 0.f, kx = MODE ? dgamma[c] * inv_count : 0.f;
-    for (size_t p = (size_t)blockIdx.x * lanes + l; p < (size_t)P; p += (size_t)gridDim.x * lanes) {
+    for (size_t p = (size_t)bx * lanes + l; p < (size_t)P; p += (size_t)gdim * lanes) {
       const float zv = z[p * C + c];
       const float a = zv * sc + sh;
       const float g = (!relu || a > 0.f) ? dout[p * C + c] : 0.f;
@@ -339,8 +606,92 @@ __global__ __launch_bounds__(256) void sc_bn_bwd_kernel(const float* __restrict_
       const int which = threadIdx.x / C, cc = threadIdx.x % C;
       float t = 0.f;
       for (int k = 0; k < lanes; ++k) t += red[which][k * C + cc];
-      partial[((size_t)blockIdx.x * 2 + which) * C + cc] = t;
+      partial[((size_t)bx * 2 + which) * C + cc] = t;
     }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sc_bn_bwd_kernel(const float* __restrict__ z,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        const float* __restrict__ dgamma,
+                                                        const float* __restrict__ dbeta,
+                                                        const float* __restrict__ dout, int P, int C,
+                                                        int relu, float inv_count,
+                                                        float* __restrict__ partial,
+                                                        float* __restrict__ dz) {
+  __shared__ float red[2][256];
+  sc_bn_bwd_body<MODE>(z, scale, shift, mean, invstd, dgamma, dbeta, dout, P, C, relu, inv_count, partial, dz,
+                       (int)blockIdx.x, (int)gridDim.x, red);
+}
+
+struct ScBnBwdItem {
+  const float *z, *scale, *shift, *mean, *invstd, *dout;
+  float *dgamma, *dbeta, *dz, *partial;
+  int P, C, relu, T, block0;
+};
+struct ScBnBwdTab {
+  ScBnBwdItem it[4];
+  int count;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void sc_bn_bwd_batch_kernel(ScBnBwdTab tab) {
+  __shared__ float red[2][256];
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < tab.count && (int)blockIdx.x >= tab.it[j].block0) k = j;
+  const ScBnBwdItem it = tab.it[k];
+  sc_bn_bwd_body<MODE>(it.z, it.scale, it.shift, it.mean, it.invstd, it.dgamma, it.dbeta, it.dout, it.P, it.C, it.relu,
+                       (float)(1.0 / (double)it.P), it.partial, it.dz, (int)blockIdx.x - it.block0, it.T, red);
+}
+
+// per-channel column sums (bias gradients of the un-normalised PixelLink heads) for up to four maps: sc_stats_kernel's
+// partial rows, batched
+struct ScStatsItem {
+  const float* x;
+  float* partial;
+  int P, C, T, block0;
+};
+struct ScStatsTab {
+  ScStatsItem it[4];
+  int count;
+};
+__global__ __launch_bounds__(256) void sc_stats_batch_kernel(ScStatsTab tab) {
+  __shared__ float red[2][256];
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < tab.count && (int)blockIdx.x >= tab.it[j].block0) k = j;
+  const ScStatsItem it = tab.it[k];
+  sc_stats_body(it.x, it.P, it.C, it.partial, (int)blockIdx.x - it.block0, it.T, red);
+}
+
+// out = act(z * scale + shift) for up to four [P][C] tensors in one launch (the two predication heads' final batch norm)
+struct ScActItem {
+  const float *z, *scale, *shift;
+  float* out;
+  size_t total;
+  int C, block0, nblocks;
+};
+struct ScActTab {
+  ScActItem it[4];
+  int count, relu;
+};
+__global__ __launch_bounds__(256) void sc_act_batch_kernel(ScActTab tab) {
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < tab.count && (int)blockIdx.x >= tab.it[j].block0) k = j;
+  const ScActItem it = tab.it[k];
+  const int bx = (int)blockIdx.x - it.block0;
+  for (size_t i = (size_t)bx * 256 + threadIdx.x; i < it.total; i += (size_t)it.nblocks * 256) {
+    const int c = (int)(i % it.C);
+    const float v = it.z[i] * it.scale[c] + it.shift[c];
+    it.out[i] = (tab.relu && v < 0.f) ? 0.f : v;
   }
 }
 
@@ -441,13 +792,12 @@ __global__ __launch_bounds__(256) void sc_pointwise_wgrad_kernel(
 // co, 16 accumulators in registers) x 16 pixel lanes; a pixel lane walks every 16th pixel of the
 // strip reading its 4 + 4 values straight from global memory (no LDS in the loop: the generic kernel
 // pays two LDS reads per FMA).  The 16 lane sums are combined in lane order: deterministic.
-__global__ __launch_bounds__(256) void sc_pointwise_wgrad16_kernel(
+__device__ __forceinline__ void sc_pointwise_wgrad16_body(
     const float* __restrict__ x, int ldx, int xo, const float* __restrict__ dout, int ldo, int oo, int P,
-    int strip, float* __restrict__ partial) {
-  __shared__ float red[16][16 * 16 + 16];
+    int strip, float* __restrict__ partial, int bx, float (*red)[16 * 16 + 16]) {
   const int pb = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int cib = pb >> 2, cob = pb & 3;
-  const int p0 = blockIdx.x * strip;
+  const int p0 = bx * strip;
   int p1 = p0 + strip;
   if (p1 > P) p1 = P;
   float acc[4][4], bacc[4];
@@ -482,17 +832,22 @@ __global__ __launch_bounds__(256) void sc_pointwise_wgrad16_kernel(
     float t = 0.f;
 #pragma unroll
     for (int l = 0; l < 16; ++l) t += red[l][j];
-    partial[(size_t)blockIdx.x * (16 * 16 + 16) + j] = t;
+    partial[(size_t)bx * (16 * 16 + 16) + j] = t;
   }
+}
+__global__ __launch_bounds__(256) void sc_pointwise_wgrad16_kernel(
+    const float* __restrict__ x, int ldx, int xo, const float* __restrict__ dout, int ldo, int oo, int P,
+    int strip, float* __restrict__ partial) {
+  __shared__ float red[16][16 * 16 + 16];
+  sc_pointwise_wgrad16_body(x, ldx, xo, dout, ldo, oo, P, strip, partial, (int)blockIdx.x, red);
 }
 
 // 2 -> 2 fast path (the pixel predication conv): every thread walks pixels and keeps all 2x2 + 2 sums;
 // wave butterfly, then the four waves in order.
-__global__ __launch_bounds__(256) void sc_pointwise_wgrad2_kernel(
+__device__ __forceinline__ void sc_pointwise_wgrad2_body(
     const float* __restrict__ x, int ldx, int xo, const float* __restrict__ dout, int ldo, int oo, int P,
-    int strip, float* __restrict__ partial) {
-  __shared__ float red[4][6];
-  const int p0 = blockIdx.x * strip;
+    int strip, float* __restrict__ partial, int bx, float (*red)[6]) {
+  const int p0 = bx * strip;
   int p1 = p0 + strip;
   if (p1 > P) p1 = P;
   float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // w00 w01 w10 w11 b0 b1
@@ -508,8 +863,143 @@ __global__ __launch_bounds__(256) void sc_pointwise_wgrad2_kernel(
   }
   __syncthreads();
   if (threadIdx.x < 6)
-    partial[(size_t)blockIdx.x * 6 + threadIdx.x] =
+    partial[(size_t)bx * 6 + threadIdx.x] =
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void sc_pointwise_wgrad2_kernel(
+    const float* __restrict__ x, int ldx, int xo, const float* __restrict__ dout, int ldo, int oo, int P,
+    int strip, float* __restrict__ partial) {
+  __shared__ float red[4][6];
+  sc_pointwise_wgrad2_body(x, ldx, xo, dout, ldo, oo, P, strip, partial, (int)blockIdx.x, red);
+}
+
+// both predication convolutions' weight (+ bias) gradients in one launch: blocks [0, B) the 16 -> 16 link head on
+// x[:, 2:18], blocks [B, 2B) the 2 -> 2 pixel head on x[:, 0:2]; then ONE fixed-order reduction of both partial slabs
+__global__ __launch_bounds__(256) void sc_pointwise_pair_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dza, const float* __restrict__ dzb, int P, int B, int strip,
+    float* __restrict__ part_a, float* __restrict__ part_b) {
+  __shared__ float red16[16][16 * 16 + 16];
+  __shared__ float red2[4][6];
+  if ((int)blockIdx.x < B) sc_pointwise_wgrad16_body(x, 18, 2, dzb, 16, 0, P, strip, part_b, (int)blockIdx.x, red16);
+  else sc_pointwise_wgrad2_body(x, 18, 0, dza, 2, 0, P, strip, part_a, (int)blockIdx.x - B, red2);
+}
+struct SumRowsItem {
+  const float* partial;
+  float *out_a, *out_b;
+  int n_a, elems, S, block0;
+};
+struct SumRowsTab {
+  SumRowsItem it[4];
+  int count;
+};
+__global__ __launch_bounds__(256) void sum_rows_batch_kernel(SumRowsTab tab) {
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < tab.count && (int)blockIdx.x >= tab.it[j].block0) k = j;
+  const SumRowsItem it = tab.it[k];
+  const int i = ((int)blockIdx.x - it.block0) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= it.elems) return;
+  float a = 0.f;
+  for (int s2 = lane; s2 < it.S; s2 += 64) a += it.partial[(size_t)s2 * it.elems + i];
+  a = wave_sum(a);
+  if (lane == 0) {
+    if (i < it.n_a) { if (it.out_a) it.out_a[i] = a; }
+    else if (it.out_b) it.out_b[i - it.n_a] = a;
+  }
+}
+
+// ---- the two predication convolutions as ONE pass over the fused head tensor -------------------------------------------
+// x [P][CA + CB] (channels [0, CA): pixel head, [CA, CA + CB): link head; nets/model_vgg_16.py:166,173,
+// nets/pixellink.py:61,67): za = x[:, :CA] wa (+ ba), zb = x[:, CA:] wb (+ bb), one thread per pixel, the weights in LDS,
+// the same summation order per output as sc_pointwise_square_kernel (ascending input channel) — and, for the batch-normed
+// variant, the statistics of both outputs in the same pass (per-thread sums over its pixels, one partial row per block).
+template <int CA, int CB>
+__global__ __launch_bounds__(256) void sc_pointwise_pair_fwd_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ wa, const float* __restrict__ ba,
+                                                                    const float* __restrict__ wb, const float* __restrict__ bb,
+                                                                    int P, float* __restrict__ za, float* __restrict__ zb,
+                                                                    float* __restrict__ pa, float* __restrict__ pb) {
+  constexpr int C = CA + CB;
+  __shared__ float wsa[CA * CA], wsb[CB * CB];
+  __shared__ float red[4][2 * C];
+  for (int i = threadIdx.x; i < CA * CA; i += 256) wsa[i] = wa[i];
+  for (int i = threadIdx.x; i < CB * CB; i += 256) wsb[i] = wb[i];
+  __syncthreads();
+  float s[C], q[C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)P; p += (size_t)gridDim.x * 256) {
+    float v[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) v[k] = x[p * C + k];
+#pragma unroll
+    for (int j = 0; j < CA; ++j) {
+      float a = ba ? ba[j] : 0.f;
+#pragma unroll
+      for (int k = 0; k < CA; ++k) a += v[k] * wsa[k * CA + j];
+      za[p * CA + j] = a;
+      s[j] += a;
+      q[j] += a * a;
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      float a = bb ? bb[j] : 0.f;
+#pragma unroll
+      for (int k = 0; k < CB; ++k) a += v[CA + k] * wsb[k * CB + j];
+      zb[p * CB + j] = a;
+      s[CA + j] += a;
+      q[CA + j] += a * a;
+    }
+  }
+  if (!pa) return;                                   // (uniform: no statistics wanted)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const float ts = wave_sum(s[j]), tq = wave_sum(q[j]);
+    if (lane == 0) { red[wave][j] = ts; red[wave][C + j] = tq; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * C) {
+    const int which = threadIdx.x / C, j = threadIdx.x % C;
+    const float t = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (j < CA) pa[((size_t)blockIdx.x * 2 + which) * CA + j] = t;
+    else pb[((size_t)blockIdx.x * 2 + which) * CB + (j - CA)] = t;
+  }
+}
+
+// dx[p] = [dza[p] wa^T | dzb[p] wb^T]: the input gradient of both predication convolutions, every channel of dx written
+template <int CA, int CB>
+__global__ __launch_bounds__(256) void sc_pointwise_pair_dgrad_kernel(const float* __restrict__ dza, const float* __restrict__ wa,
+                                                                      const float* __restrict__ dzb, const float* __restrict__ wb,
+                                                                      int P, float* __restrict__ dx) {
+  constexpr int C = CA + CB;
+  __shared__ float wsa[CA * CA], wsb[CB * CB];       // ws[k][j]: in k -> out j  (transposed weights)
+  for (int i = threadIdx.x; i < CA * CA; i += 256) wsa[i] = wa[(i % CA) * CA + i / CA];
+  for (int i = threadIdx.x; i < CB * CB; i += 256) wsb[i] = wb[(i % CB) * CB + i / CB];
+  __syncthreads();
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < (size_t)P; p += (size_t)gridDim.x * 256) {
+    float va[CA], vb[CB];
+#pragma unroll
+    for (int k = 0; k < CA; ++k) va[k] = dza[p * CA + k];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) vb[k] = dzb[p * CB + k];
+#pragma unroll
+    for (int j = 0; j < CA; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < CA; ++k) a += va[k] * wsa[k * CA + j];
+      dx[p * C + j] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < CB; ++k) a += vb[k] * wsb[k * CB + j];
+      dx[p * C + CA + j] = a;
+    }
+  }
 }
 
 unsigned sgrid(size_t items) {
@@ -824,5 +1314,218 @@ extern "C" int ocr_sc_sigmoid_bwd(const void* out, const void* dout, int64_t n, 
   hipLaunchKernelGGL(sc_sigmoid_bwd_kernel, dim3(sgrid((size_t)n)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const float*>(out),
                      static_cast<const float*>(dout), (size_t)n, static_cast<float*>(dz));
+  return ocr_launch_status();
+}
+
+// =================================================================================================================
+// Batched entry points of the fuse heads: one launch per kernel KIND over the (up to four)
+// feature maps instead of one per map.  `items` are HOST arrays of small descriptors (like ocr_conv_desc), copied
+// into the kernel arguments; the pointers inside them are device pointers.
+// =================================================================================================================
+extern "C" int ocr_conv1x1_small_batch_rows(int P) {
+  if (P <= 0) return OCR_ERR_INVALID_ARG;
+  const int iters = ocr_cdiv(P, 128 * 1024);
+  return ocr_cdiv(P, 128 * iters);
+}
+
+extern "C" int ocr_conv1x1_small_batch_f16(const ocr_head_conv_item* items, int count, void* stream) {
+  OCR_CHECK_ARG(items && count > 0 && count <= 4);
+  HeadConvTab tab;
+  tab.count = count;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const ocr_head_conv_item& a = items[i];
+    OCR_CHECK_ARG(a.x && a.w_kc32 && a.out && a.P > 0);
+    OCR_CHECK_SHAPE(a.cin % 16 == 0 && a.cout >= 1 && a.cout <= 32);
+    const int iters = ocr_cdiv(a.P, 128 * 1024);
+    tab.it[i] = HeadConvItem{static_cast<const half_t*>(a.x), static_cast<const half_t*>(a.w_kc32),
+                             static_cast<const float*>(a.bias), static_cast<float*>(a.out),
+                             static_cast<float*>(a.stats_partial), a.P, a.cin, a.cout, iters, blocks};
+    blocks += ocr_cdiv(a.P, 128 * iters);
+  }
+  for (int i = count; i < 4; ++i) tab.it[i] = tab.it[0];
+  hipLaunchKernelGGL(conv1x1_small_batch_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tab);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_conv1x1_small_dgrad_batch_f16(const ocr_head_dgrad_item* items, int count, float grad_scale, void* stream) {
+  OCR_CHECK_ARG(items && count > 0 && count <= 4);
+  HeadDgradTab tab;
+  tab.count = count;
+  tab.gscale = grad_scale;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const ocr_head_dgrad_item& a = items[i];
+    OCR_CHECK_ARG(a.dz && a.w_ck32 && a.dx && a.P > 0);
+    OCR_CHECK_SHAPE(a.cin % 32 == 0 && a.cout >= 1 && a.cout <= 32);
+    tab.it[i] = HeadDgradItem{static_cast<const float*>(a.dz), static_cast<const half_t*>(a.w_ck32),
+                              static_cast<half_t*>(a.dx), a.P, a.cin, a.cout, a.accumulate, blocks};
+    blocks += ocr_cdiv(a.P, 128);
+  }
+  for (int i = count; i < 4; ++i) tab.it[i] = tab.it[0];
+  hipLaunchKernelGGL(conv1x1_small_dgrad_batch_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tab);
+  return ocr_launch_status();
+}
+
+static void head_wgrad_plan(int P, int cin, int* m_tiles, int* tiles_per_split, int* splits) {
+  *m_tiles = ocr_cdiv(P, kHwPXS);
+  int sp = ocr_cdiv(*m_tiles, 32);                      // ~32 stages (2048 pixels x 128 channels = 512 KB of x) per workgroup
+  if (sp > 256) sp = 256;
+  if (sp < 1) sp = 1;
+  *tiles_per_split = ocr_cdiv(*m_tiles, sp);
+  *splits = ocr_cdiv(*m_tiles, *tiles_per_split);
+  (void)cin;
+}
+
+extern "C" size_t ocr_conv1x1_small_wgrad_batch_slab_bytes(int P, int cin) {
+  if (P <= 0 || cin <= 0) return 0;
+  int m, t, sp;
+  head_wgrad_plan(P, cin, &m, &t, &sp);
+  return (size_t)sp * cin * 32 * sizeof(float);
+}
+
+extern "C" int ocr_conv1x1_small_wgrad_batch_f16(const ocr_head_wgrad_item* items, int count, void* stream) {
+  OCR_CHECK_ARG(items && count > 0 && count <= 4);
+  HeadWgradTab tab;
+  HeadWgradRedTab red;
+  tab.count = red.count = count;
+  int blocks = 0, rblocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const ocr_head_wgrad_item& a = items[i];
+    OCR_CHECK_ARG(a.x && a.dz && a.dw && a.slab && a.P > 0);
+    OCR_CHECK_SHAPE(a.cin % kHwCIB == 0 && a.cout >= 1 && a.cout <= 32);
+    OCR_CHECK_SHAPE((size_t)a.P * a.cin * 2 < (1ull << 31) && (size_t)a.P * a.cout * 4 < (1ull << 31));   // 32-bit buffer offsets
+    int m, t, sp;
+    head_wgrad_plan(a.P, a.cin, &m, &t, &sp);
+    tab.it[i] = HeadWgradItem{static_cast<const half_t*>(a.x), static_cast<const float*>(a.dz),
+                              static_cast<float*>(a.slab), a.P, a.cin, a.cout, m, t, a.cin / kHwCIB, blocks};
+    blocks += sp * (a.cin / kHwCIB);
+    red.it[i] = HeadWgradRedItem{static_cast<const float*>(a.slab), static_cast<float*>(a.dw), a.cin, a.cout, sp, rblocks};
+    rblocks += ocr_cdiv(a.cin * a.cout, 4);
+  }
+  for (int i = count; i < 4; ++i) { tab.it[i] = tab.it[0]; red.it[i] = red.it[0]; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(blocks), dim3(512), 0, st, tab);
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, st, red);
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_bn_bwd_sums_batch(const ocr_bn_sums_item* items, int count, void* stream);
+
+// BN(+ReLU) backward of up to four [P][C] f32 head tensors: partial sums, their finalisation (dgamma, dbeta) and the apply
+// step — three launches for all of them (ocr_sc_bn_bwd: three per tensor).  partial: ocr_sc_num_partials(P, C) * 2 * C floats each.
+extern "C" int ocr_sc_bn_bwd_batch(const ocr_sc_bn_bwd_item* items, int count, void* stream) {
+  OCR_CHECK_ARG(items && count > 0 && count <= 4);
+  ScBnBwdTab tab;
+  ocr_bn_sums_item sums[4];
+  tab.count = count;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const ocr_sc_bn_bwd_item& a = items[i];
+    OCR_CHECK_ARG(a.z && a.scale && a.shift && a.save_mean && a.save_invstd && a.dout && a.dgamma && a.dbeta && a.dz && a.partial);
+    OCR_CHECK_SHAPE(a.C > 0 && a.C <= 32 && a.P > 0);
+    const int T = sc_blocks(a.P, a.C);
+    tab.it[i] = ScBnBwdItem{static_cast<const float*>(a.z), static_cast<const float*>(a.scale),
+                            static_cast<const float*>(a.shift), static_cast<const float*>(a.save_mean),
+                            static_cast<const float*>(a.save_invstd), static_cast<const float*>(a.dout),
+                            static_cast<float*>(a.dgamma), static_cast<float*>(a.dbeta), static_cast<float*>(a.dz),
+                            static_cast<float*>(a.partial), a.P, a.C, a.relu, T, blocks};
+    sums[i] = ocr_bn_sums_item{a.partial, T, a.C, a.dbeta, a.dgamma};
+    blocks += T;
+  }
+  for (int i = count; i < 4; ++i) tab.it[i] = tab.it[0];
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sc_bn_bwd_batch_kernel<0>, dim3(blocks), dim3(256), 0, st, tab);
+  int rc = ocr_bn_bwd_sums_batch(sums, count, stream);
+  if (rc != OCR_OK) return rc;
+  hipLaunchKernelGGL(sc_bn_bwd_batch_kernel<1>, dim3(blocks), dim3(256), 0, st, tab);
+  return ocr_launch_status();
+}
+
+// out[c] = sum_p x[p][c] for up to four [P][C] tensors (the bias gradients of the un-normalised heads): two launches
+extern "C" int ocr_sc_colsum_batch(const ocr_sc_colsum_item* items, int count, void* stream) {
+  OCR_CHECK_ARG(items && count > 0 && count <= 4);
+  ScStatsTab tab;
+  ocr_bn_sums_item sums[4];
+  tab.count = count;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const ocr_sc_colsum_item& a = items[i];
+    OCR_CHECK_ARG(a.x && a.out && a.partial && a.P > 0);
+    OCR_CHECK_SHAPE(a.C > 0 && a.C <= 32);
+    const int T = sc_blocks(a.P, a.C);
+    tab.it[i] = ScStatsItem{static_cast<const float*>(a.x), static_cast<float*>(a.partial), a.P, a.C, T, blocks};
+    // kind 0 (sums) -> out; kind 1 (sums of squares) -> the row behind the partial rows (scratch, unused)
+    sums[i] = ocr_bn_sums_item{a.partial, T, a.C, a.out, static_cast<float*>(a.partial) + (size_t)T * 2 * a.C};
+    blocks += T;
+  }
+  for (int i = count; i < 4; ++i) tab.it[i] = tab.it[0];
+  hipLaunchKernelGGL(sc_stats_batch_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tab);
+  return ocr_bn_bwd_sums_batch(sums, count, stream);
+}
+
+extern "C" int ocr_sc_act_batch(const ocr_sc_act_item* items, int count, int relu, void* stream) {
+  OCR_CHECK_ARG(items && count > 0 && count <= 4);
+  ScActTab tab;
+  tab.count = count;
+  tab.relu = relu;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const ocr_sc_act_item& a = items[i];
+    OCR_CHECK_ARG(a.z && a.scale && a.shift && a.out && a.total > 0 && a.C > 0);
+    const int nb = (int)sgrid((size_t)a.total);
+    tab.it[i] = ScActItem{static_cast<const float*>(a.z), static_cast<const float*>(a.scale),
+                          static_cast<const float*>(a.shift), static_cast<float*>(a.out), (size_t)a.total, a.C, blocks, nb};
+    blocks += nb;
+  }
+  for (int i = count; i < 4; ++i) tab.it[i] = tab.it[0];
+  hipLaunchKernelGGL(sc_act_batch_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tab);
+  return ocr_launch_status();
+}
+
+// ---- the two predication convolutions (2 -> 2 pixel, 16 -> 16 link) on the 18-channel fused head tensor, as one pass ---
+extern "C" int ocr_sc_pointwise_pair_num_partials(int P) {
+  if (P <= 0) return OCR_ERR_INVALID_ARG;
+  int b = ocr_cdiv(P, 256 * 4);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return b;
+}
+
+extern "C" int ocr_sc_pointwise_pair_fwd(const void* x18, const void* w_px, const void* b_px, const void* w_lk,
+                                         const void* b_lk, int P, void* z_px, void* z_lk, void* partial_px,
+                                         void* partial_lk, void* stream) {
+  OCR_CHECK_ARG(x18 && w_px && w_lk && z_px && z_lk && P > 0 && ((partial_px == nullptr) == (partial_lk == nullptr)));
+  hipLaunchKernelGGL((sc_pointwise_pair_fwd_kernel<2, 16>), dim3(ocr_sc_pointwise_pair_num_partials(P)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(x18), static_cast<const float*>(w_px),
+                     static_cast<const float*>(b_px), static_cast<const float*>(w_lk), static_cast<const float*>(b_lk), P,
+                     static_cast<float*>(z_px), static_cast<float*>(z_lk), static_cast<float*>(partial_px),
+                     static_cast<float*>(partial_lk));
+  return ocr_launch_status();
+}
+
+extern "C" size_t ocr_sc_pointwise_pair_bwd_workspace(void) { return (size_t)256 * (16 * 16 + 16 + 6) * sizeof(float); }
+
+// dx18 = [dz_px w_px^T | dz_lk w_lk^T]; dw / db of both convolutions (db_* may be NULL): three launches
+extern "C" int ocr_sc_pointwise_pair_bwd(const void* x18, const void* dz_px, const void* dz_lk, const void* w_px,
+                                         const void* w_lk, int P, void* dx18, void* dw_px, void* db_px, void* dw_lk,
+                                         void* db_lk, void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(x18 && dz_px && dz_lk && w_px && w_lk && dx18 && dw_px && dw_lk && workspace && P > 0);
+  if (ws_bytes < ocr_sc_pointwise_pair_bwd_workspace()) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int B = 256;
+  float* part_b = static_cast<float*>(workspace);                  // [B][16*16 + 16]
+  float* part_a = part_b + (size_t)B * (16 * 16 + 16);             // [B][2*2 + 2]
+  hipLaunchKernelGGL((sc_pointwise_pair_dgrad_kernel<2, 16>), dim3(sgrid((size_t)P)), dim3(256), 0, st,
+                     static_cast<const float*>(dz_px), static_cast<const float*>(w_px), static_cast<const float*>(dz_lk),
+                     static_cast<const float*>(w_lk), P, static_cast<float*>(dx18));
+  hipLaunchKernelGGL(sc_pointwise_pair_wgrad_kernel, dim3(2 * B), dim3(256), 0, st, static_cast<const float*>(x18),
+                     static_cast<const float*>(dz_px), static_cast<const float*>(dz_lk), P, B, ocr_cdiv(P, B), part_a, part_b);
+  SumRowsTab tab;
+  tab.count = 2;
+  tab.it[0] = SumRowsItem{part_b, static_cast<float*>(dw_lk), static_cast<float*>(db_lk), 256, 256 + 16, B, 0};
+  tab.it[1] = SumRowsItem{part_a, static_cast<float*>(dw_px), static_cast<float*>(db_px), 4, 4 + 2, B, (256 + 16 + 3) / 4};
+  tab.it[2] = tab.it[3] = tab.it[0];
+  hipLaunchKernelGGL(sum_rows_batch_kernel, dim3((256 + 16 + 3) / 4 + 2), dim3(256), 0, st, tab);
   return ocr_launch_status();
 }

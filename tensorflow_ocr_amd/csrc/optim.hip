@@ -91,6 +91,7 @@ struct PackItem {
   half_t* w_kc;
   half_t* w_ck;
   int taps, cin, cout, tiles_ci, tiles_co;
+  int ld_ck;                 // row length of w_ck: cout, or 32 for the fuse heads' zero-padded [cin][32] copy
 };
 
 __global__ void pack_weights_batch_kernel(const PackItem* __restrict__ items, const int* __restrict__ block_first, int n) {
@@ -114,7 +115,7 @@ __global__ void pack_weights_batch_kernel(const PackItem* __restrict__ items, co
     const int ci = ci0 + k, co = co0 + tx;
     const float v = (ci < it.cin && co < it.cout) ? wt[(size_t)ci * it.cout + co] : 0.f;
     tile[k][tx] = v;
-    if (it.w_ck && ci < it.cin && co < it.cout) it.w_ck[((size_t)tap * it.cin + ci) * it.cout + co] = (half_t)v;
+    if (it.w_ck && ci < it.cin && co < it.cout) it.w_ck[((size_t)tap * it.cin + ci) * it.ld_ck + co] = (half_t)v;
   }
   __syncthreads();
   if (it.w_kc) {
@@ -234,8 +235,8 @@ extern "C" int ocr_pack_weights_f16(const void* w_hwio_f32, int taps, int cin, i
 extern "C" size_t ocr_pack_weights_batch_table_bytes(int n) { return (size_t)n * sizeof(PackItem) + (size_t)(n + 1) * sizeof(int); }
 
 extern "C" int ocr_pack_weights_batch_table(int n, const void* const* w_hwio_f32, const int* taps, const int* cin,
-                                            const int* cout, void* const* w_kc, void* const* w_ck, void* table_host,
-                                            int* grid_out) {
+                                            const int* cout, void* const* w_kc, void* const* w_ck, const int* ld_ck,
+                                            void* table_host, int* grid_out) {
   OCR_CHECK_ARG(n > 0 && w_hwio_f32 && taps && cin && cout && w_kc && w_ck && table_host && grid_out);
   PackItem* items = static_cast<PackItem*>(table_host);
   int* first = reinterpret_cast<int*>(items + n);
@@ -243,7 +244,9 @@ extern "C" int ocr_pack_weights_batch_table(int n, const void* const* w_hwio_f32
   for (int i = 0; i < n; ++i) {
     OCR_CHECK_ARG(w_hwio_f32[i] && (w_kc[i] || w_ck[i]) && taps[i] > 0 && cin[i] > 0 && cout[i] > 0);
     items[i] = PackItem{static_cast<const float*>(w_hwio_f32[i]), static_cast<half_t*>(w_kc[i]),
-                        static_cast<half_t*>(w_ck[i]), taps[i], cin[i], cout[i], ocr_cdiv(cin[i], 32), ocr_cdiv(cout[i], 32)};
+                        static_cast<half_t*>(w_ck[i]), taps[i], cin[i], cout[i], ocr_cdiv(cin[i], 32), ocr_cdiv(cout[i], 32),
+                        (ld_ck && ld_ck[i] > 0) ? ld_ck[i] : cout[i]};
+    OCR_CHECK_ARG(items[i].ld_ck >= cout[i]);
     first[i] = g;
     g += taps[i] * items[i].tiles_ci * items[i].tiles_co;
   }

@@ -316,20 +316,27 @@ class Graph:
         return ent[1]
 
     def repack_all(self):
-        """Refresh every [tap][cout][cin] / [tap][cin][cout] operand pack in ONE launch (after the optimiser step;
-        the packs' own lazy refresh in `packed` then finds them current).  Other pack kinds stay lazy."""
+        """Refresh every [tap][cout][cin] / [tap][cin][cout] operand pack — and the fuse heads' zero-padded [32][cin] /
+        [cin][32] pairs — in ONE launch (after the optimiser step; the packs' own lazy refresh in `packed` then finds
+        them current).  Other pack kinds stay lazy."""
         from . import ops
-        ents = [(v, v.packed["kc_ck"]) for v in self.store.vars.values() if "kc_ck" in getattr(v, "packed", {})]
+        ents = []
+        for v in self.store.vars.values():
+            pk = getattr(v, "packed", {})
+            if "kc_ck" in pk:
+                ents.append((v, "kc_ck", pk["kc_ck"], 0))
+            if "small" in pk:
+                ents.append((v, "small", pk["small"], 32))
         if not ents:
             return
-        key = tuple(id(e[1][1]) for e in ents)
+        key = tuple(id(e[2][1]) for e in ents)
         pb = getattr(self, "_pack_batch", None)
         if pb is None or pb[0] != key:
-            pb = (key, ops.PackBatch([(v.data, e[1][0], e[1][1]) for v, e in ents], self.device))
+            pb = (key, ops.PackBatch([(v.data, e[1][0], e[1][1], ld) for v, _, e, ld in ents], self.device))
             self._pack_batch = pb
         pb[1].run()
-        for v, e in ents:
-            v.packed["kc_ck"] = (self.store.version, e[1])
+        for v, kind, e, _ in ents:
+            v.packed[kind] = (self.store.version, e[1])
 
     # --- tape ---
     def record(self, fn, produces=()):

@@ -506,6 +506,200 @@ def head_conv_bias(g, feat, names, couts, initializer=None):
     return out, None, None
 
 
+BATCH_HEADS = __import__("os").environ.get("OCR_BATCH_HEADS", "1") == "1"    # one launch per kernel kind over the head sources
+
+
+def head_group(g, feats, names_list, couts, *, mode="bn", is_training=True, relu=True, initializer=None):
+    """The fuse convs of ALL head sources (nets/model_vgg_16.py:160-172: fc7, conv5_3, conv4_3, conv3_3; nets/pixellink.py:
+    58-67; nets/model.py:129-141) with one launch per kernel kind over the sources instead of one per source: per feature map
+    the same merged 1x1 convolution (+ batch-norm statistics | + biases) as head_conv_bn / head_conv_bias, same variables in
+    the same order.  Returns the list of (z SmallAct, scale, shift) triples `fuse` consumes (scale = shift = None for
+    mode="bias").  OCR_BATCH_HEADS=0 (or the f32 verification precision) runs the per-source forms."""
+    if not BATCH_HEADS or g.precision == "f32" or len(feats) > 4:
+        if mode == "bn":
+            return [head_conv_bn(g, f, nm, couts, is_training=is_training, relu=relu) for f, nm in zip(feats, names_list)]
+        return [head_conv_bias(g, f, nm, couts, initializer=initializer) for f, nm in zip(feats, names_list)]
+    C = sum(couts)
+    ws = g.workspace()
+    srcs = []
+    for feat, names in zip(feats, names_list):
+        n, h, w, cin = feat.shape
+        with g.variable_scope("+".join(names)):
+            if mode == "bn":
+                wv = g.get_variable("weights", (cin, C), _merged_init(g, cin, couts), regularized=True)
+                gamma, beta, mm, mv = _bn_vars(g, C)
+                bias = None
+            else:
+                wv = g.get_variable("weights", (cin, C), _merged_init(g, cin, couts, initializer or xavier_uniform),
+                                    regularized=True)
+                bias = g.get_variable("biases", (C,), constant(0.0))
+                gamma = beta = mm = mv = None
+
+        def mk(old, wv=wv, cin=cin):
+            if old is None:
+                old = (g.empty((32, cin)), g.empty((cin, 32)))
+            ops.pack_weights_small(wv.data, old[0], old[1])
+            return old
+        w_kc32, w_ck32 = g.packed(wv, "small", mk)
+        srcs.append(dict(feat=feat, P=n * h * w, cin=cin, wv=wv, bias=bias, gamma=gamma, beta=beta, mm=mm, mv=mv,
+                         w_kc32=w_kc32, w_ck32=w_ck32, z=g.empty((n, h, w, C), F32)))
+    train_bn = mode == "bn" and is_training
+    for s in srcs:
+        if mode == "bn":
+            s["scale"], s["shift"] = g.empty((C,), F32), g.empty((C,), F32)
+            s["mean"], s["invstd"] = g.empty((C,), F32), g.empty((C,), F32)
+        if train_bn:
+            s["T"] = ops.conv1x1_small_batch_rows(s["P"])
+            s["part"] = g.empty((s["T"], 2, C), F32)
+    ops.conv1x1_small_batch([(s["feat"].data, s["w_kc32"], s["bias"].data if s["bias"] is not None else None, s["z"],
+                              s.get("part")) for s in srcs])
+    if train_bn:
+        ops.bn_finalize_batch([(s["part"], s["T"], C, float(s["P"]), s["gamma"].data, s["beta"].data, s["mm"].data,
+                                s["mv"].data, s["scale"], s["shift"], s["mean"], s["invstd"]) for s in srcs],
+                              BN_EPS, BN_DECAY)
+    elif mode == "bn":
+        for s in srcs:
+            ops.bn_inference_params(s["gamma"].data, s["beta"].data, s["mm"].data, s["mv"].data, BN_EPS, s["scale"], s["shift"])
+    for s in srcs:
+        s["out"] = SmallAct(s["z"])          # grad of out = gradient w.r.t. relu(bn(z)) (bn) / z (bias)
+
+    def backward():
+        live = [s for s in srcs if s["out"].grad is not None]
+        if not live:
+            return
+        if mode == "bn":
+            if not is_training:
+                raise NotImplementedError("backward through inference-mode batch norm")
+            items = []
+            for s in live:
+                s["dz"] = g.empty(s["z"].shape, F32)
+                T = ops.sc_num_partials(s["P"], C)
+                items.append((s["z"], s["scale"], s["shift"], s["mean"], s["invstd"], s["out"].grad, s["gamma"].grad,
+                              s["beta"].grad, s["dz"], g.empty((T, 2, C), F32), relu))
+            ops.sc_bn_bwd_batch(items)
+        else:
+            items = []
+            for s in live:
+                s["dz"] = s["out"].grad
+                T = ops.sc_num_partials(s["P"], C)
+                items.append((s["dz"], s["bias"].grad, g.empty((T + 1, 2, C), F32)))
+            ops.sc_colsum_batch(items)
+        wide = [s for s in live if s["cin"] % 128 == 0]        # the batched MFMA kernel's 128-channel blocks
+        if wide:
+            ops.conv1x1_small_wgrad_batch([
+                (s["feat"].data, s["dz"], s["wv"].grad,
+                 g.empty((ops.conv1x1_small_wgrad_batch_slab_bytes(s["P"], s["cin"]),), torch.uint8)) for s in wide])
+        for s in live:
+            if s["cin"] % 128:
+                ops.conv1x1_small_wgrad(s["feat"].data, s["dz"], C, s["wv"].grad, ws)
+        items = []
+        for s in live:
+            feat = s["feat"]
+            if feat.requires_grad:
+                acc = feat.grad is not None
+                if not acc:
+                    feat.grad = g.empty(feat.shape)
+                items.append((s["dz"], s["w_ck32"], feat.grad, acc))
+        if items:
+            ops.conv1x1_small_dgrad_batch(items)
+        for s in live:
+            s["out"].grad = None
+            s["dz"] = None
+    produces = []
+    for s in srcs:
+        produces += [s["wv"]] + ([s["gamma"], s["beta"]] if mode == "bn" else [s["bias"]])
+    g.record(backward, produces)
+    return [(s["out"], s.get("scale") if mode == "bn" else None, s.get("shift") if mode == "bn" else None) for s in srcs]
+
+
+def pointwise_pair(g, x, scopes, *, mode="bn", is_training=True, relu=True, initializer=None):
+    """The two predication convolutions on the fused 18-channel head tensor — pixel (2 -> 2 on channels 0..1) and link
+    (16 -> 16 on channels 2..17): `pointwise_bn` x 2 (nets/model_vgg_16.py:166,173: conv + BN + ReLU) or `pointwise_bias`
+    x 2 (nets/pixellink.py:61,67, nets/model.py:139-141: conv + biases, linear) — as ONE pass over the tensor per
+    direction, same variables in the same order.  Returns (pixel SmallAct [n,h,w,2], link SmallAct [n,h,w,16])."""
+    n, h, w, C = x.data.shape
+    if not BATCH_HEADS or g.precision == "f32" or C != 18:
+        if mode == "bn":
+            return (pointwise_bn(g, x, 0, 2, scopes[0], is_training=is_training, relu=relu),
+                    pointwise_bn(g, x, 2, 16, scopes[1], is_training=is_training, relu=relu))
+        return (pointwise_bias(g, x, 0, 2, scopes[0], initializer=initializer),
+                pointwise_bias(g, x, 2, 16, scopes[1], initializer=initializer))
+    P = n * h * w
+    ws = g.workspace()
+    hd = []
+    for scope, c in zip(scopes, (2, 16)):
+        with g.variable_scope(scope):
+            if mode == "bn":
+                wv = g.get_variable("weights", (1, 1, c, c), variance_scaling(g.rng), regularized=True)
+                gamma, beta, mm, mv = _bn_vars(g, c)
+                bias = None
+            else:
+                wv = g.get_variable("weights", (1, 1, c, c), (initializer or xavier_uniform)(g.rng), regularized=True)
+                bias = g.get_variable("biases", (c,), constant(0.0))
+                gamma = beta = mm = mv = None
+        hd.append(dict(c=c, wv=wv, bias=bias, gamma=gamma, beta=beta, mm=mm, mv=mv, z=g.empty((n, h, w, c), F32)))
+    a, b = hd
+    train_bn = mode == "bn" and is_training
+    if train_bn:
+        T = ops.sc_pointwise_pair_num_partials(P)
+        for d in hd:
+            d["part"] = g.empty((T, 2, d["c"]), F32)
+    ops.sc_pointwise_pair_fwd(x.data, a["wv"].data, a["bias"].data if a["bias"] is not None else None, b["wv"].data,
+                              b["bias"].data if b["bias"] is not None else None, a["z"], b["z"], a.get("part"), b.get("part"))
+    if mode == "bn":
+        for d in hd:
+            d["scale"], d["shift"] = g.empty((d["c"],), F32), g.empty((d["c"],), F32)
+            d["mean"], d["invstd"] = g.empty((d["c"],), F32), g.empty((d["c"],), F32)
+        if train_bn:
+            ops.bn_finalize_batch([(d["part"], T, d["c"], float(P), d["gamma"].data, d["beta"].data, d["mm"].data,
+                                    d["mv"].data, d["scale"], d["shift"], d["mean"], d["invstd"]) for d in hd],
+                                  BN_EPS, BN_DECAY)
+        else:
+            for d in hd:
+                ops.bn_inference_params(d["gamma"].data, d["beta"].data, d["mm"].data, d["mv"].data, BN_EPS, d["scale"], d["shift"])
+        for d in hd:
+            d["out"] = SmallAct(g.empty((n, h, w, d["c"]), F32))
+        ops.sc_act_batch([(d["z"], d["scale"], d["shift"], d["out"].data) for d in hd], relu)
+    else:
+        for d in hd:
+            d["out"] = SmallAct(d["z"])
+
+    def backward():
+        if a["out"].grad is None and b["out"].grad is None:
+            return
+        for d in hd:
+            if d["out"].grad is None:                       # a head the loss did not read: its gradient is zero
+                d["out"].grad = g.empty(d["out"].data.shape, F32)
+                ops.fill_(d["out"].grad, 0.0)
+        if mode == "bn":
+            if not is_training:
+                raise NotImplementedError("backward through inference-mode batch norm")
+            items = []
+            for d in hd:
+                d["dz"] = g.empty(d["z"].shape, F32)
+                Tb = ops.sc_num_partials(P, d["c"])
+                items.append((d["z"], d["scale"], d["shift"], d["mean"], d["invstd"], d["out"].grad, d["gamma"].grad,
+                              d["beta"].grad, d["dz"], g.empty((Tb, 2, d["c"]), F32), relu))
+            ops.sc_bn_bwd_batch(items)
+        else:
+            for d in hd:
+                d["dz"] = d["out"].grad
+        if x.grad is not None:
+            raise RuntimeError("the fused head tensor already carries a gradient (pointwise_pair writes all of it)")
+        x.grad = g.empty(x.data.shape, F32)
+        ops.sc_pointwise_pair_bwd(x.data, a["dz"], b["dz"], a["wv"].data, b["wv"].data, x.grad, a["wv"].grad,
+                                  a["bias"].grad if a["bias"] is not None else None, b["wv"].grad,
+                                  b["bias"].grad if b["bias"] is not None else None, ws)
+        for d in hd:
+            d["out"].grad = None
+            d["dz"] = None
+    produces = []
+    for d in hd:
+        produces += [d["wv"]] + ([d["gamma"], d["beta"]] if mode == "bn" else [d["bias"]])
+    g.record(backward, produces)
+    return a["out"], b["out"]
+
+
 def pointwise_bias(g, x, xo, c, scope, initializer=None):
     """text_predication / link_predication: 1x1 conv with biases and no activation on a channel
     slice of the fused head tensor (nets/pixellink.py:61,67).  Returns contiguous logits."""

@@ -74,16 +74,14 @@ def model_vgg(images, weight_decay=1e-5, is_training=True, graph=None):
         # slim auto-names: pixel convs Conv..Conv_4, link convs Conv_5..Conv_9
         srcs = [('fc7', ('Conv', 'Conv_5')), ('conv5_3', ('Conv_1', 'Conv_6')),
                 ('conv4_3', ('Conv_2', 'Conv_7')), ('conv3_3', ('Conv_3', 'Conv_8'))]
-        heads = {}
-        for k, (key, names) in enumerate(srcs):
-            with g.chain(k):          # four feature maps, four independent chains of small launches (graph.Graph.chain)
-                heads[key] = layers.head_conv_bn(g, end_points[key], names, (2, 16), is_training=is_training)
+        trip = layers.head_group(g, [end_points[key] for key, _ in srcs], [names for _, names in srcs], (2, 16),
+                                 mode="bn", is_training=is_training)
+        heads = {key: t for (key, _), t in zip(srcs, trip)}
         n, h, w, _ = end_points['fc7'].shape
         s1 = layers.fuse(g, (n, h, w, 18), a=heads['fc7'], b=heads['conv5_3'])
         s2 = layers.fuse(g, (n, 2 * h, 2 * w, 18), a=heads['conv4_3'], prev=s1)
         s3 = layers.fuse(g, (n, 4 * h, 4 * w, 18), a=heads['conv3_3'], prev=s2)
-        pixel_cls = layers.pointwise_bn(g, s3, 0, 2, 'Conv_4', is_training=is_training)
-        link_cls = layers.pointwise_bn(g, s3, 2, 16, 'Conv_9', is_training=is_training)
+        pixel_cls, link_cls = layers.pointwise_pair(g, s3, ('Conv_4', 'Conv_9'), mode="bn", is_training=is_training)
     return pixel_cls, link_cls
 
 

@@ -81,17 +81,15 @@ class PixelLinkNet(object):
     def _add_pixellink_layers(self, basenet, end_points):
         g = self.g
         srcs = [('fc7', 'stage_6'), ('conv5_3', 'stage_5'), ('conv4_3', 'stage_4'), ('conv3_3', 'stage_3')]
-        heads = {}
-        for k, (key, st) in enumerate(srcs):
-            with g.chain(k):          # independent chains of small launches (graph.Graph.chain)
-                heads[key] = layers.head_conv_bias(g, end_points[key], (st + '_pixel_fuse', st + '_link_fuse'),
-                                                   (2, 16), initializer=xavier_uniform)
+        trip = layers.head_group(g, [end_points[key] for key, _ in srcs],
+                                 [(st + '_pixel_fuse', st + '_link_fuse') for _, st in srcs], (2, 16), mode="bias",
+                                 initializer=xavier_uniform)
+        heads = {key: t for (key, _), t in zip(srcs, trip)}
         n, h, w, _ = end_points['fc7'].shape
         s1 = layers.fuse(g, (n, h, w, 18), a=heads['fc7'], b=heads['conv5_3'])
         s2 = layers.fuse(g, (n, 2 * h, 2 * w, 18), a=heads['conv4_3'], prev=s1)
         s3 = layers.fuse(g, (n, 4 * h, 4 * w, 18), a=heads['conv3_3'], prev=s2)
-        self.pixel_cls = layers.pointwise_bias(g, s3, 0, 2, 'text_predication')
-        self.link_cls = layers.pointwise_bias(g, s3, 2, 16, 'link_predication')
+        self.pixel_cls, self.link_cls = layers.pointwise_pair(g, s3, ('text_predication', 'link_predication'), mode="bias")
         return self.pixel_cls, self.link_cls
 
     @property

@@ -19,15 +19,11 @@ def model_resnet50_pixellink(images, weight_decay=1e-5, is_training=True, graph=
     f = [end_points['pool5'], end_points['pool4'], end_points['pool3'], end_points['pool2']]
     with g.variable_scope('feature_fusion'):
         names = [('Conv', 'Conv_4'), ('Conv_1', 'Conv_5'), ('Conv_2', 'Conv_6'), ('Conv_3', 'Conv_7')]
-        heads = []
-        for k, (fm, nm) in enumerate(zip(f, names)):
-            with g.chain(k):          # independent chains of small launches (graph.Graph.chain)
-                heads.append(layers.head_conv_bn(g, fm, nm, (2, 16), is_training=is_training))
+        heads = layers.head_group(g, f, names, (2, 16), mode="bn", is_training=is_training)
         n, h, w, _ = f[0].shape
         s0 = layers.fuse(g, (n, h, w, 18), a=heads[0])                          # relu(bn(conv(pool5)))
         s1 = layers.fuse(g, (n, 2 * h, 2 * w, 18), a=heads[1], prev=s0)       # unpool(.) + conv(pool4)
         s2 = layers.fuse(g, (n, 4 * h, 4 * w, 18), a=heads[2], prev=s1)
         s3 = layers.fuse(g, (n, 8 * h, 8 * w, 18), a=heads[3], prev=s2)
-        pixel_4 = layers.pointwise_bias(g, s3, 0, 2, 'Conv_8')
-        link_4 = layers.pointwise_bias(g, s3, 2, 16, 'Conv_9')
+        pixel_4, link_4 = layers.pointwise_pair(g, s3, ('Conv_8', 'Conv_9'), mode="bias")
     return pixel_4, link_4

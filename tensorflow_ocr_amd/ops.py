@@ -347,23 +347,27 @@ def pack_weights(w_hwio, w_kc=None, w_ck=None):
 
 
 class PackBatch:
-    """Device table for ocr_pack_weights_batch_f16: built once for a list of (w_hwio f32, w_kc, w_ck) tensors."""
+    """Device table for ocr_pack_weights_batch_f16: built once for a list of (w_hwio f32, w_kc, w_ck[, ld_ck]) tensors
+    (ld_ck = 32: a fuse head's [32][cin] / [cin][32] zero-padded pair; w then is the [cin][C] master)."""
 
     def __init__(self, entries, device):
         import ctypes
         n = len(entries)
         vp = ctypes.c_void_p * n
         ci = ctypes.c_int * n
-        ws = vp(*[w.data_ptr() for w, _, _ in entries])
-        kc = vp(*[(a.data_ptr() if a is not None else None) for _, a, _ in entries])
-        ck = vp(*[(b.data_ptr() if b is not None else None) for _, _, b in entries])
-        taps = ci(*[w.shape[0] * w.shape[1] for w, _, _ in entries])
-        cin = ci(*[w.shape[2] for w, _, _ in entries])
-        cout = ci(*[w.shape[3] for w, _, _ in entries])
+        ent = [(e + (0,))[:4] for e in entries]
+        shp = [tuple(w.shape) if w.dim() == 4 else (1, 1) + tuple(w.shape) for w, _, _, _ in ent]
+        ws = vp(*[w.data_ptr() for w, _, _, _ in ent])
+        kc = vp(*[(a.data_ptr() if a is not None else None) for _, a, _, _ in ent])
+        ck = vp(*[(b.data_ptr() if b is not None else None) for _, _, b, _ in ent])
+        taps = ci(*[s[0] * s[1] for s in shp])
+        cin = ci(*[s[2] for s in shp])
+        cout = ci(*[s[3] for s in shp])
+        ld = ci(*[l for _, _, _, l in ent])
         nbytes = L.call_size("ocr_pack_weights_batch_table_bytes", c_int(n))
         host = torch.empty(nbytes, dtype=torch.uint8)
         grid = ctypes.c_int(0)
-        L.call("ocr_pack_weights_batch_table", c_int(n), ws, taps, cin, cout, kc, ck, ctypes.c_void_p(host.data_ptr()),
+        L.call("ocr_pack_weights_batch_table", c_int(n), ws, taps, cin, cout, kc, ck, ld, ctypes.c_void_p(host.data_ptr()),
                ctypes.byref(grid))
         self.table = host.to(device)
         self.n, self.grid = n, grid.value
@@ -653,6 +657,110 @@ def softmax_loss_bwd(desc, pixel_logits, link_logits, pixel_labels, link_labels,
                      d_pixel, d_link):
     L.call("ocr_softmax_loss_bwd", byref(desc), ptr(pixel_logits), ptr(link_logits), ptr(pixel_labels),
            ptr(link_labels), ptr(thr), ptr(sums34), c_float(grad_scale), ptr(d_pixel), ptr(d_link), _st())
+
+
+# ------------------------------------------------------------------ heads, batched (one launch per kernel kind)
+def _struct(name, fields):
+    return type(name, (ctypes.Structure,), {"_fields_": fields})
+
+
+_VP, _I32 = ctypes.c_void_p, ctypes.c_int32
+HeadConvItem = _struct("HeadConvItem", [("x", _VP), ("w_kc32", _VP), ("bias", _VP), ("out", _VP), ("stats_partial", _VP),
+                                        ("P", _I32), ("cin", _I32), ("cout", _I32)])
+HeadDgradItem = _struct("HeadDgradItem", [("dz", _VP), ("w_ck32", _VP), ("dx", _VP), ("P", _I32), ("cin", _I32),
+                                          ("cout", _I32), ("accumulate", _I32)])
+HeadWgradItem = _struct("HeadWgradItem", [("x", _VP), ("dz", _VP), ("dw", _VP), ("slab", _VP), ("P", _I32), ("cin", _I32),
+                                          ("cout", _I32)])
+BnFinalizeItem = _struct("BnFinalizeItem", [("partial", _VP), ("T", _I32), ("C", _I32), ("count", c_double), ("gamma", _VP),
+                                            ("beta", _VP), ("moving_mean", _VP), ("moving_var", _VP), ("scale", _VP),
+                                            ("shift", _VP), ("save_mean", _VP), ("save_invstd", _VP)])
+ScBnBwdItem = _struct("ScBnBwdItem", [("z", _VP), ("scale", _VP), ("shift", _VP), ("save_mean", _VP), ("save_invstd", _VP),
+                                      ("dout", _VP), ("dgamma", _VP), ("dbeta", _VP), ("dz", _VP), ("partial", _VP),
+                                      ("P", _I32), ("C", _I32), ("relu", _I32)])
+ScColsumItem = _struct("ScColsumItem", [("x", _VP), ("out", _VP), ("partial", _VP), ("P", _I32), ("C", _I32)])
+ScActItem = _struct("ScActItem", [("z", _VP), ("scale", _VP), ("shift", _VP), ("out", _VP), ("total", c_int64), ("C", _I32)])
+
+
+def _dp(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _arr(cls, rows):
+    return (cls * len(rows))(*[cls(*r) for r in rows])
+
+
+def conv1x1_small_batch_rows(P):
+    return L.call_int("ocr_conv1x1_small_batch_rows", c_int(P))
+
+
+def conv1x1_small_batch(items):
+    """items: [(x f16 [P,cin], w_kc32, bias | None, out f32 [P,cout], stats_partial | None)]"""
+    rows = [(_dp(x), _dp(w), _dp(b), _dp(o), _dp(sp), x.numel() // x.shape[-1], x.shape[-1], o.shape[-1])
+            for x, w, b, o, sp in items]
+    L.call("ocr_conv1x1_small_batch_f16", _arr(HeadConvItem, rows), c_int(len(rows)), _st())
+
+
+def conv1x1_small_dgrad_batch(items, grad_scale=1.0):
+    """items: [(dz f32 [P,cout], w_ck32, dx f16 [P,cin], accumulate)]"""
+    rows = [(_dp(dz), _dp(w), _dp(dx), dx.numel() // dx.shape[-1], dx.shape[-1], dz.shape[-1], int(acc))
+            for dz, w, dx, acc in items]
+    L.call("ocr_conv1x1_small_dgrad_batch_f16", _arr(HeadDgradItem, rows), c_int(len(rows)), c_float(grad_scale), _st())
+
+
+def conv1x1_small_wgrad_batch_slab_bytes(P, cin):
+    return L.call_size("ocr_conv1x1_small_wgrad_batch_slab_bytes", c_int(P), c_int(cin))
+
+
+def conv1x1_small_wgrad_batch(items):
+    """items: [(x f16 [P,cin], dz f32 [P,cout], dw f32 [cin,cout], slab)]"""
+    rows = [(_dp(x), _dp(dz), _dp(dw), _dp(slab), x.numel() // x.shape[-1], x.shape[-1], dz.shape[-1])
+            for x, dz, dw, slab in items]
+    L.call("ocr_conv1x1_small_wgrad_batch_f16", _arr(HeadWgradItem, rows), c_int(len(rows)), _st())
+
+
+def bn_finalize_batch(items, eps, decay):
+    """items: [(partial, T, C, count, gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd)]"""
+    rows = [(_dp(p), T, C, float(cnt), _dp(ga), _dp(be), _dp(mm), _dp(mv), _dp(sc), _dp(sh), _dp(mu), _dp(istd))
+            for p, T, C, cnt, ga, be, mm, mv, sc, sh, mu, istd in items]
+    L.call("ocr_bn_finalize_batch", _arr(BnFinalizeItem, rows), c_int(len(rows)), c_float(eps), c_float(decay), _st())
+
+
+def sc_bn_bwd_batch(items):
+    """items: [(z, scale, shift, save_mean, save_invstd, dout, dgamma, dbeta, dz, partial, relu)] on [P][C] f32 tensors"""
+    rows = [(_dp(z), _dp(sc), _dp(sh), _dp(mu), _dp(istd), _dp(do), _dp(dg), _dp(db), _dp(dz), _dp(part),
+             z.numel() // z.shape[-1], z.shape[-1], int(relu))
+            for z, sc, sh, mu, istd, do, dg, db, dz, part, relu in items]
+    L.call("ocr_sc_bn_bwd_batch", _arr(ScBnBwdItem, rows), c_int(len(rows)), _st())
+
+
+def sc_colsum_batch(items):
+    """items: [(x f32 [P,C], out f32 [C], partial)]"""
+    rows = [(_dp(x), _dp(o), _dp(part), x.numel() // x.shape[-1], x.shape[-1]) for x, o, part in items]
+    L.call("ocr_sc_colsum_batch", _arr(ScColsumItem, rows), c_int(len(rows)), _st())
+
+
+def sc_act_batch(items, relu):
+    """items: [(z, scale, shift, out)]"""
+    rows = [(_dp(z), _dp(sc), _dp(sh), _dp(o), z.numel(), z.shape[-1]) for z, sc, sh, o in items]
+    L.call("ocr_sc_act_batch", _arr(ScActItem, rows), c_int(len(rows)), c_int(int(relu)), _st())
+
+
+def sc_pointwise_pair_num_partials(P):
+    return L.call_int("ocr_sc_pointwise_pair_num_partials", c_int(P))
+
+
+def sc_pointwise_pair_fwd(x18, w_px, b_px, w_lk, b_lk, z_px, z_lk, part_px=None, part_lk=None):
+    P = x18.numel() // 18
+    L.call("ocr_sc_pointwise_pair_fwd", ptr(x18), ptr(w_px), ptr(b_px), ptr(w_lk), ptr(b_lk), c_int(P), ptr(z_px),
+           ptr(z_lk), ptr(part_px), ptr(part_lk), _st())
+
+
+def sc_pointwise_pair_bwd(x18, dz_px, dz_lk, w_px, w_lk, dx18, dw_px, db_px, dw_lk, db_lk, ws):
+    P = x18.numel() // 18
+    nbytes = L.call_size("ocr_sc_pointwise_pair_bwd_workspace")
+    buf = ws.get(nbytes)
+    L.call("ocr_sc_pointwise_pair_bwd", ptr(x18), ptr(dz_px), ptr(dz_lk), ptr(w_px), ptr(w_lk), c_int(P), ptr(dx18),
+           ptr(dw_px), ptr(db_px), ptr(dw_lk), ptr(db_lk), ptr(buf), c_size_t(nbytes), _st())
 
 
 def label_masks(labels, label_rule, pos_u8, neg_u8):
