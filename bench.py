@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs of BASELINE configs[2..4]")
     ap.add_argument("--no-pg", action="store_true", help="N=1: do not run the bucketed exchange through a "
                     "one-rank RCCL communicator (by default it runs, so the line records that RCCL loaded)")
+    ap.add_argument("--proxy-workgroups", type=int, default=24, help="N=1: workgroups of the comm-kernel stand-in (RCCL runs "
+                    "16-32 channels)")
+    ap.add_argument("--proxy-link-gbps", type=float, default=150.0, help="N=1: pace of the stand-in (one xGMI link)")
     ap.add_argument("--loss-scale", type=float, default=1024.0)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); "
                     "gloo lets several ranks share one GPU for a functional check")
@@ -228,8 +231,11 @@ def main():
         f_score, f_geometry = M.model_vgg(im, is_training=True, graph=gr)
         return M.loss(px, f_score, lk, f_geometry, mk, graph=gr)
 
+    # N = 1 with the one-rank exchange recorded: the plan also holds, next to every bucket's all-reduce, a stand-in with
+    # the shape of a multi-rank ring's device code (ocr_comm_proxy) for the `exchange.proxy` leg below
+    proxy_cfg = (args.proxy_workgroups, args.proxy_link_gbps) if (world == 1 and force_reduce and not args.force_pg) else None
     step = TrainStep(g, forward_loss, lambda gr: AdamOptimizer(gr, learning_rate=1e-4), world_size=world,
-                     force_reduce=force_reduce)
+                     force_reduce=force_reduce, comm_proxy=proxy_cfg)
 
     def barrier():
         if td.is_initialized():
@@ -319,6 +325,41 @@ def main():
             comm["comm_exposed_ms"] = round((dt - dt_ab) / args.steps * 1e3, 3)
     elif exchange_error is not None:
         comm = {"backend": None, "error": exchange_error}
+    # One-GPU proxy for the comm / compute overlap: the same K steps (a) without any exchange and (b)
+    # with ocr_comm_proxy on the comm stream in place of every bucket's all-reduce, A/B/A/B interleaved; the end of
+    # backward on the compute stream is marked with an event, so `backward_stretch_ms` is what the stand-in costs the
+    # conv workgroups it shares the chip with and `step_ms_with - step_ms_without` what stays exposed.
+    if comm is not None and red is not None and red.active and red.mode == "abi" and red.proxy is not None and probe_only:
+        res = {False: [[], []], True: [[], []]}
+        for rnd in range(2):
+            for with_proxy in (False, True):
+                red.enabled, red.use_proxy = with_proxy, with_proxy
+                step.backward_end_event = None
+                step(*batch)
+                barrier()
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                t1 = time.perf_counter()
+                for e0, e1 in evs:                       # no host sync inside the loop: the events are read afterwards
+                    e0.record()
+                    step.backward_end_event = e1
+                    step(*batch)
+                barrier()
+                res[with_proxy][0].append((time.perf_counter() - t1) / args.steps * 1e3)
+                res[with_proxy][1].append(float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])))
+        stats = red.proxy_stats.cpu().numpy()
+        red.enabled, red.use_proxy = False, False
+        step.backward_end_event = None
+        nb = len(red.buckets)
+        busy_ms = float(stats[3]) / 1e5 / max(int(stats[4]), 1) * nb          # 100 MHz ticks -> ms, per step
+        paced_ms = 2.0 * comm["grad_bytes"] / (red.proxy[1] * 1e9) * 1e3
+        comm["proxy"] = {
+            "kernel": "ocr_comm_proxy: %d workgroups x 256 threads on the comm stream, one launch per bucket (same events as "
+                      "the all-reduce), 2 x bucket bytes through HBM in 256 KB chunks paced at %.0f GB/s" % red.proxy,
+            "step_ms_without": round(min(res[False][0]), 3), "step_ms_with": round(min(res[True][0]), 3),
+            "backward_ms_without": round(min(res[False][1]), 3), "backward_ms_with": round(min(res[True][1]), 3),
+            "backward_stretch_ms": round(min(res[True][1]) - min(res[False][1]), 3),
+            "proxy_busy_ms_per_step": round(busy_ms, 3), "proxy_paced_ms_per_step": round(paced_ms, 3),
+            "proxy_launches": int(stats[4]), "rounds": "A/B/A/B, best of 2 per arm"}
 
     # dominant kernel: the conv_igemm instantiation with the most accumulated time
     per, fwd = {}, {}

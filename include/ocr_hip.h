@@ -768,6 +768,13 @@ int ocr_event_create(void** event_out);   /* timing disabled */
 int ocr_event_destroy(void* event);
 int ocr_event_record(void* event, void* stream);
 int ocr_stream_wait_event(void* stream, void* event);
+/* MEASUREMENT AID, not part of the exchange: a one-GPU stand-in for the device side of an N-rank ring all-reduce —
+ * `workgroups` persistent 256-thread workgroups that read and re-write `bytes` of `buf` (values unchanged) in 256 KB
+ * chunks paced at one xGMI link's rate (link_gbps; 2 x bytes through HBM in 2 * bytes / rate) — launched on the comm
+ * stream where the step launches ocr_allreduce_bucket (bench.py `exchange.proxy`: what a comm kernel costs the conv
+ * workgroups it shares the chip with).  stats_u64x8 (device; set ONCE by the caller to {~0, 0, 0, 0, 0, 0, 0, 0}; may be NULL): [3] += busy
+ * ticks (100 MHz) of every launch, [4] += 1. */
+int ocr_comm_proxy(void* buf, size_t bytes, int workgroups, float link_gbps, void* stats_u64x8, void* stream);
 
 #ifdef __cplusplus
 }

@@ -166,3 +166,57 @@ extern "C" int ocr_stream_wait_event(void* stream, void* event) {
   if (!event) return OCR_ERR_INVALID_ARG;
   return hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) == hipSuccess ? OCR_OK : OCR_ERR_HIP;
 }
+
+// --- one-GPU stand-in for the device side of a multi-rank ring all-reduce --------------------
+// No 8-GPU node is available to this build, so how RCCL's kernels co-schedule with the step's conv workgroups (one
+// 512-VGPR wave per SIMD: a CU that holds one has no registers left for anything else) has never been observed.  This
+// kernel has the SHAPE of RCCL's device code on the comm stream — a persistent grid of a few dozen 256-thread
+// workgroups with a small register footprint, walking the bucket in 256 KB chunks, every byte read once and written
+// once (2 x bucket bytes through HBM, the values unchanged), chunk k released no earlier than k * (2 * chunk bytes /
+// link rate) after the workgroup started: the pace one xGMI link (~150 GB/s) sets for a ring — and is launched where
+// the recorded step launches ocr_allreduce_bucket, with the same event ordering.  stats (8 x u64, device, set by
+// the caller once to {~0, 0, ...}): [3] accumulates the busy time of every launch (last workgroup's end - first workgroup's start,
+// 100 MHz ticks), [4] counts launches; [0..2] are per-launch scratch that resets itself.
+namespace {
+constexpr size_t kProxyChunk = 256 << 10;
+__global__ __launch_bounds__(256) void comm_proxy_kernel(uint4* __restrict__ buf, size_t bytes, unsigned long long ticks_per_chunk,
+                                                         unsigned long long* __restrict__ stats) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  const size_t nchunks = (bytes + kProxyChunk - 1) / kProxyChunk;
+  for (size_t k = blockIdx.x; k < nchunks; k += gridDim.x) {
+    const unsigned long long due = t0 + k * ticks_per_chunk;
+    while (__builtin_amdgcn_s_memrealtime() < due) __builtin_amdgcn_s_sleep(32);
+    const size_t b0 = k * kProxyChunk, b1 = b0 + kProxyChunk < bytes ? b0 + kProxyChunk : bytes;
+    for (size_t o = b0 + (size_t)threadIdx.x * 16; o + 16 <= b1; o += 256 * 16) {
+      uint4 v = buf[o / 16];
+      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));       // (keep the round trip: same values back)
+      buf[o / 16] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && stats) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    atomicMin(stats + 0, t0);
+    atomicMax(stats + 1, t1);
+    __threadfence();
+    if (atomicAdd(stats + 2, 1ull) == (unsigned long long)gridDim.x - 1) {       // last workgroup out
+      __threadfence();
+      const unsigned long long a = atomicMin(stats + 0, ~0ull), b = atomicMax(stats + 1, 0ull);
+      stats[3] += b - a;
+      stats[4] += 1;
+      stats[0] = ~0ull;
+      stats[1] = 0ull;
+      stats[2] = 0ull;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ocr_comm_proxy(void* buf, size_t bytes, int workgroups, float link_gbps, void* stats_u64x8, void* stream) {
+  if (!buf || bytes < 16 || workgroups < 1 || workgroups > 256 || !(link_gbps > 0.f) || ((uintptr_t)buf & 15)) return OCR_ERR_INVALID_ARG;
+  const double sec_per_chunk = 2.0 * (double)kProxyChunk / ((double)link_gbps * 1e9);
+  const unsigned long long ticks = (unsigned long long)(sec_per_chunk * 1e8 + 0.5);              // s_memrealtime: 100 MHz
+  hipLaunchKernelGGL(comm_proxy_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<uint4*>(buf), bytes, ticks, static_cast<unsigned long long*>(stats_u64x8));
+  return ocr_launch_status();
+}

@@ -165,7 +165,7 @@ def exchange_mode(world, cuda, force=False):
 
 class GradientAllReduce:
     def __init__(self, store, world_size, bucket_bytes=32 << 20, op="mean", group=None, fold_mean=False,
-                 force=False, mode=None, comm=None):
+                 force=False, mode=None, comm=None, proxy=None):
         """op: "mean" = `average_gradients` (multigpu_train.py:70-85); "sum" = `sum_gradients`
         (train_pixellink.py:179-194: the caller has already divided its loss by num_clones).
         fold_mean: leave the SUM in the buffer and let the optimiser apply `grad_scale` (= 1/world)
@@ -177,7 +177,11 @@ class GradientAllReduce:
         `finish` is one stream-wait(compute) per bucket: C-ABI calls only, recorded into the step plan like
         any kernel launch.  In torch mode the hooks are host callbacks (`Recorder.py`).
         `enabled = False` turns every hook into a no-op (bench.py's comm-exposed A/B: the step without
-        its exchange)."""
+        its exchange).
+        proxy=(workgroups, link_gbps): abi mode only, a measurement aid — next to every bucket's all-reduce the step
+        plan also holds an `ocr_comm_proxy` launch (include/ocr_hip.h: a stand-in with the shape of a multi-rank ring's
+        device code) on the comm stream; a replayed step runs ONE of the two, chosen by `self.use_proxy` (bench.py's
+        one-GPU `exchange.proxy` leg)."""
         self.store = store
         self.active = world_size > 1 or force
         self.enabled = True
@@ -207,6 +211,9 @@ class GradientAllReduce:
         self.extra_streams = []       # streams that also produce gradients (side-stream wgrad)
         self.mode = (mode or exchange_mode(world_size, self.cuda, force)) if self.active else "torch"
         self.comm = comm
+        self.proxy = proxy
+        self.use_proxy = False
+        self.proxy_stats = None
         self.ev_ready = self.ev_done = None
         self._replaying = False
         if self.active and self.mode == "abi":
@@ -304,7 +311,12 @@ class GradientAllReduce:
             self._xcall("ocr_event_record", self.ev_ready[bi], cur)
             self._xcall("ocr_stream_wait_event", cs, self.ev_ready[bi])
             self._xcall("ocr_allreduce_bucket", self.comm.handle, L.ptr(buf), ctypes.c_size_t(e - s),
-                        ctypes.c_int(0), ctypes.c_int(0), cs)
+                        ctypes.c_int(0), ctypes.c_int(0), cs, kind="rccl")
+            if self.proxy is not None:
+                if self.proxy_stats is None:     # {min start, max end, tickets | busy ticks, launches}: ocr_comm_proxy
+                    self.proxy_stats = torch.tensor([-1, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int64).to(buf.device)
+                self._xcall("ocr_comm_proxy", L.ptr(buf), ctypes.c_size_t((e - s) * 4), ctypes.c_int(int(self.proxy[0])),
+                            ctypes.c_float(float(self.proxy[1])), L.ptr(self.proxy_stats), cs, kind="proxy")
             self._xcall("ocr_event_record", self.ev_done[bi], cs)
             self.handles.append((bi, buf))
             return
@@ -321,11 +333,13 @@ class GradientAllReduce:
         self.handles.append((h, buf))
 
     @staticmethod
-    def _xcall(name, *args):
+    def _xcall(name, *args, kind=None):
+        """A C-ABI call of the exchange, tagged ("xchg"[, kind]) in a recorded plan: kind "rccl" / "proxy" = the two
+        alternative comm-stream launches of a bucket, "finish" = the compute stream's wait for a bucket."""
         from . import _lib as L
         L.call(name, *args)
         if L.RECORDER is not None:
-            L.RECORDER.tag_last(("xchg",))
+            L.RECORDER.tag_last(("xchg",) if kind is None else ("xchg", kind))
 
     def finish(self):
         """Fire whatever has not been fired (variables without a gradient this step), wait for all
@@ -344,7 +358,7 @@ class GradientAllReduce:
         if self.mode == "abi":
             cur = _lib.stream_ptr()
             for bi, _ in self.handles:
-                self._xcall("ocr_stream_wait_event", cur, self.ev_done[bi])
+                self._xcall("ocr_stream_wait_event", cur, self.ev_done[bi], kind="finish")
         else:
             for h, buf in self.handles:
                 h.wait()          # cuda: makes the current stream wait for the collective

@@ -209,7 +209,7 @@ class TrainStep:
     audit that raises if a torch operator touched device memory inside `forward_loss`."""
 
     def __init__(self, graph, forward_loss, optimizer_factory, world_size=1, bucket_bytes=32 << 20,
-                 replay=True, grad_op="mean", force_reduce=False):
+                 replay=True, grad_op="mean", force_reduce=False, comm_proxy=None):
         """grad_op: "mean" = multigpu_train.py's `average_gradients` (each tower differentiates its own
         loss, the gradients are averaged); "sum" = train_pixellink.py's `sum_gradients`: each clone
         differentiates loss / num_clones (:264) and the gradients are summed (:179-194).
@@ -219,6 +219,8 @@ class TrainStep:
         self.g = graph
         self.grad_op = grad_op
         self.force_reduce = force_reduce
+        self.comm_proxy = comm_proxy      # (workgroups, link GB/s): dist.GradientAllReduce(proxy=...), a measurement aid
+        self.backward_end_event = None    # bench.py: recorded on the compute stream in front of the first wait for a bucket
         if grad_op == "sum":
             graph.loss_div = float(world_size)       # total_clone_loss = sum(losses) / num_clones
         self.forward_loss = forward_loss
@@ -263,7 +265,7 @@ class TrainStep:
             g.store.vars[n].data.copy_(t)
         self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, op=self.grad_op,
                                          fold_mean=True, force=self.force_reduce,
-                                         mode="torch" if self.use_side_stream else None)
+                                         mode="torch" if self.use_side_stream else None, proxy=self.comm_proxy)
         return self
 
     # -- eager / recording path --------------------------------------------------------------
@@ -288,7 +290,7 @@ class TrainStep:
                 self.opt = self.optimizer_factory(g)           # materialises the flat buffers
                 self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, op=self.grad_op,
                                                  fold_mean=True, force=self.force_reduce,
-                                                 mode="torch" if self.use_side_stream else None)
+                                                 mode="torch" if self.use_side_stream else None, proxy=self.comm_proxy)
             g.backward(self.reducer.on_grads_ready if self.reducer.active else None)
             self.reducer.finish()           # records itself: host callback (torch mode) or C-ABI stream waits (abi mode)
         finally:
@@ -334,16 +336,24 @@ class TrainStep:
         side, side_ptr, side_used = self.side_stream, self.side_ptr, False
         chains = self.chain_streams if USE_CHAINS else None
         group_open, forked = False, []
+        bwd_marked = False
         for e in self.plan:
             if e[0] == "c":
                 tag = e[4]
                 if tag is not None and tag[0] == "xchg":
                     # the gradient exchange as C-ABI calls (dist.GradientAllReduce, abi mode)
                     if self.reducer.enabled:
+                        kind = tag[1] if len(tag) > 1 else None
+                        # a bucket's comm-stream launch: the RCCL all-reduce OR its one-GPU stand-in (dist: proxy)
+                        if (kind == "proxy" and not self.reducer.use_proxy) or (kind == "rccl" and self.reducer.use_proxy):
+                            continue
                         if group_open:
                             for k in forked:
                                 main.wait_stream(chains[k][0])
                             group_open, forked = False, []
+                        if kind == "finish" and self.backward_end_event is not None and not bwd_marked:
+                            self.backward_end_event.record(main)      # end of backward on the compute stream
+                            bwd_marked = True
                         rc = e[1](*e[2])
                         if rc != 0:
                             _lib.check(rc, e[3])
@@ -393,6 +403,9 @@ class TrainStep:
                 if side_used and len(e) > 2 and e[2] == "opt":
                     main.wait_stream(side)       # optimiser / end of step: weight gradients done
                     side_used = False
+                if len(e) > 2 and e[2] == "opt" and self.backward_end_event is not None and not bwd_marked:
+                    self.backward_end_event.record(main)          # (no exchange in this step: backward ends here)
+                    bwd_marked = True
                 e[1]()
         for j in forked:
             main.wait_stream(chains[j][0])

@@ -132,7 +132,8 @@ def test_wgrad_batch_vs_float64_and_per_map(device, shapes):
         assert np.abs(got - want).max() <= 2e-5 * scale * max(1.0, np.sqrt(x.shape[0] / 1000.0)), np.abs(got - want).max() / scale
         ref = torch.empty_like(dw)
         ops.conv1x1_small_wgrad(x, dz, C, ref, g.ws)
-        assert np.abs(ref.cpu().numpy() - got).max() <= 1e-4 * scale
+        # (the per-map route for odd pixel counts keeps dz in f32; the batched kernel rounds it to 16 bits like the MFMA route)
+        assert np.abs(ref.cpu().numpy() - got).max() <= 2e-3 * scale
 
 
 def test_sc_bn_bwd_batch_and_colsum_batch(device):
