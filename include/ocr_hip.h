@@ -454,6 +454,29 @@ int ocr_softmax_loss_bwd(const ocr_softmax_loss_desc* d, const void* pixel_logit
                          void* d_pixel_logits, void* d_link_logits, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * f32 INFERENCE PRECISION (round 4; csrc/f32_infer.hip): the forward graph with f32 storage and arithmetic, the
+ * convolutions on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMAs) — Graph(precision="f32"), test.py /
+ * test_pixellink*.py --precision f32 — so that score / link maps are within the north star's 1e-3 of the reference
+ * ON THE PRODUCT LIBRARY (16-bit storage costs ~1e-2 of the logit range after 16 layers).  Forward only.
+ * Tensors NHWC f32; conv weights in the TF HWIO master layout [kh][kw][cin][cout] (no packing).
+ * ------------------------------------------------------------------------- */
+/* flags: OCR_CONV_BIAS, OCR_CONV_RELU, OCR_CONV_ACCUM_F16 (here: y += conv, f32); any kernel size, stride, dilation */
+int ocr_conv2d_f32_mfma(const ocr_conv_desc* d, const void* x, const void* w_hwio, const void* bias, void* y,
+                        void* stream);
+int ocr_channel_stats_f32_num_partials(int64_t npix, int c);
+/* partial [T][2][c] f32 = per-strip (sum, sum of squares): input of ocr_bn_finalize */
+int ocr_channel_stats_f32(const void* x, int64_t npix, int c, void* partial, void* stream);
+int ocr_bn_relu_f32(const void* y, const void* scale, const void* shift, int n, int h, int w, int c, int relu,
+                    int pool, void* a_full, void* a_pool, void* stream);
+int ocr_maxpool_f32(const void* x, int n, int h, int w, int c, int k, int stride, int pad_top, int pad_left,
+                    int oh, int ow, void* y, void* stream);
+int ocr_prep_images_f32(const void* images, int64_t npix, float mean_r, float mean_g, float mean_b, void* out,
+                        void* stream);
+int ocr_bn_add_relu_f32(const void* y, const void* scale, const void* shift, const void* shortcut,
+                        int64_t npix, int c, void* out, void* stream);
+int ocr_unpool_f32(const void* x, int n, int lh, int lw, int c, void* y, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Fuse heads, BATCHED (round 4): one launch per kernel kind over the (up to four) feature maps the heads read
  * (nets/model_vgg_16.py:160-172: fc7, conv5_3, conv4_3, conv3_3; nets/pixellink.py:58-67; nets/model.py:129-141) instead
  * of one per map, and the two predication convolutions (:166,173 / :61,67) as one pass over the fused tensor.  `items` are

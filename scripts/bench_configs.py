@@ -96,6 +96,117 @@ def train_config(name, forward_loss, opt_factory, batch, size, steps, warmup, ex
     return g
 
 
+def make_icdar_dir(root, count=128, h=720, w=1280, quads=16, seed=0):
+    """A synthetic ICDAR-2015-shaped training directory, generated once: `count` 720 x 1280 JPEGs (smooth background +
+    text-like boxes: ~100-200 KB each, the size class of the real set) and their gt_<name>.txt (x1,y1,..,x4,y4,label)."""
+    import os
+    from PIL import Image
+    os.makedirs(root, exist_ok=True)
+    if len([f for f in os.listdir(root) if f.endswith(".jpg")]) >= count:
+        return root
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    bases = []
+    for j in range(4):                        # four smooth backgrounds with sensor-like noise, re-used shifted
+        a, b, c = rng.uniform(0.5, 2.0, 3)
+        bg = np.stack([127 + 100 * np.sin(xx / w * 6.28 * a + k) * np.cos(yy / h * 6.28 * b * (k + 1) / 2 + c) for k in range(3)], -1)
+        bases.append(np.clip(bg + rng.normal(0, 6, bg.shape), 0, 255).astype(np.uint8))
+    for i in range(count):
+        base = np.roll(bases[i % 4], (int(rng.integers(0, h)), int(rng.integers(0, w))), axis=(0, 1)).copy()
+        lines = []
+        for q in range(quads):
+            bw, bh = int(rng.integers(60, 260)), int(rng.integers(18, 60))
+            x0, y0 = int(rng.integers(4, w - bw - 4)), int(rng.integers(4, h - bh - 4))
+            base[y0:y0 + bh, x0:x0 + bw] = rng.integers(0, 255, 3)
+            base[y0 + bh // 4:y0 + 3 * bh // 4:2, x0 + 4:x0 + bw - 4:3] = rng.integers(0, 255, 3)
+            lab = "###" if q % 8 == 7 else "text%d" % q
+            lines.append("%d,%d,%d,%d,%d,%d,%d,%d,%s" % (x0, y0, x0 + bw, y0, x0 + bw, y0 + bh, x0, y0 + bh, lab))
+        Image.fromarray(base).save(os.path.join(root, "img_%d.jpg" % (i + 1)), quality=90)
+        with open(os.path.join(root, "gt_img_%d.txt" % (i + 1)), "w") as f:
+            f.write("\r\n".join(lines) + "\r\n")
+    return root
+
+
+def pipeline_train(steps, warmup, batch=32, size=512, workers=16, root="/tmp/ocr_icdar_synth"):
+    """multigpu_train.py's hot loop (:164-174) WITH its input path — icdar.get_batch (:652-668: files
+    on disk -> decode + parse in `workers` host threads -> pinned slab -> cv2.resize / label-map kernels on the feeder's
+    stream) feeding the recorded model_vgg + dice step — against the same step on a resident batch."""
+    import os
+    from tensorflow_ocr_amd import _lib
+    from tensorflow_ocr_amd.datasets import icdar
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model_vgg_16 as M
+    from tensorflow_ocr_amd.train import AdamOptimizer, TrainStep
+    t0 = time.perf_counter()
+    root = make_icdar_dir(root)
+    gen_s = time.perf_counter() - t0
+    files = icdar.get_images(root)
+    jpg_kb = float(np.mean([os.path.getsize(f) for f in files[:64]])) / 1024.0
+    # host stage alone: decode + annotation parsing + polygon validation in the worker threads, nothing on the GPU
+    from multiprocessing.pool import ThreadPool
+    pool = ThreadPool(workers)
+    jobs = [(f, size) for f in files]
+    list(pool.imap(icdar._load_sample, jobs[:2 * workers], chunksize=4))
+    t0 = time.perf_counter()
+    n_ok = sum(1 for smp in pool.imap(icdar._load_sample, jobs, chunksize=4) if smp is not None)
+    host_rate = n_ok / (time.perf_counter() - t0)
+    pool.terminate()
+    pool.join()
+    dev = torch.device("cuda", 0)
+    g = Graph(dev, loss_scale=1024.0, seed=1)
+
+    def fl(gr, im, sm, gm, tm):
+        a, b = M.model_vgg(im, is_training=True, graph=gr)
+        return M.loss(sm, a, gm, b, tm, graph=gr)
+    step = TrainStep(g, fl, lambda gr: AdamOptimizer(gr, learning_rate=1e-4))
+    feeder = icdar.get_batch(num_workers=workers, training_data_path=root, input_size=size, batch_size=batch, graph=g, seed=1)
+    try:
+        def nxt():
+            images, _, score, geo, mask = next(feeder)
+            return [images, score, geo, mask]
+        first = nxt()
+        for _ in range(3):
+            step(*first)
+        for _ in range(warmup):
+            step(*first)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(*first)
+        torch.cuda.synchronize()
+        resident = (time.perf_counter() - t0) / steps
+        for _ in range(warmup):
+            step(*nxt())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        waits = 0.0
+        for _ in range(steps):
+            tw = time.perf_counter()
+            b = nxt()
+            waits += time.perf_counter() - tw
+            loss = step(*b)
+        torch.cuda.synchronize()
+        fed = (time.perf_counter() - t0) / steps
+    finally:
+        feeder.close()
+    need = batch / resident
+    out = {"config": "multigpu_train hot loop with its input path: %d x 720x1280 JPEG (%.0f KB) + gt_*.txt on disk -> "
+                     "icdar.get_batch (%d decode threads, DeviceFeeder) -> model_vgg + dice + Adam/EMA, batch %d at %d^2"
+                     % (len(files), jpg_kb, workers, batch, size),
+           "batch": batch, "size": size, "steps": steps, "dtype": _lib.STORAGE,
+           "ms_per_step": round(fed * 1e3, 3), "images_per_sec": round(batch / fed, 1),
+           "step_ms_fed": round(fed * 1e3, 3), "step_ms_resident": round(resident * 1e3, 3),
+           "fed_over_resident": round(fed / resident, 4),
+           "host_decode_img_s": round(host_rate, 1), "host_threads": workers, "host_cpus": os.cpu_count(),
+           "host_wait_ms_per_step": round(waits / steps * 1e3, 3),
+           "limiting_stage": ("none: the fed step is within 3 % of the resident step" if fed <= 1.03 * resident else
+                              ("host decode + parse: %.0f images/s on %d threads against the %.0f images/s the resident step takes"
+                               % (host_rate, workers, need) if host_rate < 1.1 * need else
+                               "feeder hand-over (device upload / resize / label kernels sharing the chip with the step)")),
+           "loss": round(float(loss.item()), 5), "dataset_generation_s": round(gen_s, 1)}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="pixellink,resnet,decode")
@@ -106,6 +217,9 @@ def main():
     args = ap.parse_args()
     which = args.which.split(",")
     from tensorflow_ocr_amd.train import AdamOptimizer, MomentumOptimizer
+
+    if "pipeline_train" in which:
+        pipeline_train(max(args.steps, 30), max(args.warmup, 3))
 
     if "pixellink" in which:
         from tensorflow_ocr_amd.nets import pixellink

@@ -208,8 +208,9 @@ class Graph:
 
     def __init__(self, device="cuda:0", loss_scale=1024.0, seed=1, precision="f16"):
         """precision: "f16" = the product path (f16 storage, f32 accumulate, MFMA kernels);
-        "f32" = forward-only VERIFICATION precision (f32 storage and arithmetic, plain kernels;
-        layers_f32.py) used to compare whole-graph outputs with the f32 CPU reference at 1e-3."""
+        "f32" = forward-only f32 INFERENCE precision (f32 storage and arithmetic, the convolutions on the matrix
+        cores with v_mfma_f32_32x32x2_f32: layers_f32.py, csrc/f32_infer.hip): whole-graph outputs within 1e-3 of the
+        f32 reference (the north star's tolerance), ~10x the time of the 16-bit path."""
         if precision not in ("f16", "f32"):
             raise ValueError("precision must be 'f16' or 'f32'")
         self.precision = precision
@@ -348,7 +349,7 @@ class Graph:
         called as soon as a closure has finished a set of parameter gradients — the hook the
         data-parallel all-reduce uses to overlap communication with the rest of backward."""
         if self.precision != "f16":
-            raise NotImplementedError("the f32 verification precision is forward-only")
+            raise NotImplementedError("the f32 inference precision is forward-only")
         for fn, produces in reversed(self.tape):
             fn()
             if on_grads_ready is not None and produces:

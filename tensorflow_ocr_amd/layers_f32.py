@@ -1,9 +1,12 @@
-"""Forward-only f32 VERIFICATION precision of the slim-style layers (Graph(precision="f32")).
+"""Forward-only f32 INFERENCE precision of the slim-style layers (Graph(precision="f32"); test.py / test_pixellink*.py
+--precision f32).
 
-Same variables, scopes, padding rules and batch-norm formulas as layers.py, but activations are f32
-and the kernels are the plain ones of csrc/verify_f32.hip.  Purpose: whole-graph outputs that can be
-compared with the f32 CPU reference at the north star's 1e-3 (tests/test_gpu_f32_verify.py); the f16 MFMA
-kernels themselves are checked layer by layer against that reference's f16-storage mode.  No backward."""
+Same variables, scopes, padding rules and batch-norm formulas as layers.py, but activations are f32, the convolutions
+run on the matrix cores in f32 (ocr_conv2d_f32_mfma: v_mfma_f32_32x32x2_f32, csrc/f32_infer.hip) and the element-wise
+kernels are the f32 ones of the same file — all in the product library.  Purpose: outputs within the north star's 1e-3 of
+the f32 reference (tests/test_gpu_f32_verify.py, test_gpu_f32_mfma.py); the 16-bit MFMA kernels are checked layer by layer
+against that reference's 16-bit-storage mode.  OCR_F32_CONV=direct swaps in the plain direct convolution of
+libocr_verify.so (the independent checker).  No backward."""
 from . import ops
 from .graph import Act, F32, constant, variance_scaling
 from ._lib import CONV_BIAS, CONV_RELU

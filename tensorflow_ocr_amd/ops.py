@@ -948,44 +948,51 @@ def fill_(x, value=0.0):
     L.call("ocr_fill_f32", ptr(x), c_int64(nbytes // 4), c_float(value), _st())
 
 
-# ------------------------------------------------------------------- f32 verification precision
-# (libocr_verify.so / include/ocr_verify.h: test infrastructure, a separate library)
-def conv2d_f32(d, x, w_hwio, y, bias=None):
-    L.call_verify("ocr_conv2d_f32", byref(d), ptr(x), ptr(w_hwio), ptr(bias), ptr(y), _st())
+# ------------------------------------------------------------------- f32 inference precision
+# (product library: matrix-core f32 convolution + element-wise f32 kernels, csrc/f32_infer.hip; the plain direct
+#  convolution of libocr_verify.so / include/ocr_verify.h is its independent checker: F32_CONV = "direct")
+F32_CONV = __import__("os").environ.get("OCR_F32_CONV", "mfma")
+
+
+def conv2d_f32(d, x, w_hwio, y, bias=None, route=None):
+    if (route or F32_CONV) == "direct":
+        L.call_verify("ocr_conv2d_f32", byref(d), ptr(x), ptr(w_hwio), ptr(bias), ptr(y), _st())
+    else:
+        L.call("ocr_conv2d_f32_mfma", byref(d), ptr(x), ptr(w_hwio), ptr(bias), ptr(y), _st())
 
 
 def channel_stats_f32_num_partials(npix, c):
-    return L.call_verify("ocr_channel_stats_f32_num_partials", c_int64(npix), c_int(c))
+    return L.call_int("ocr_channel_stats_f32_num_partials", c_int64(npix), c_int(c))
 
 
 def channel_stats_f32(x, c, partial):
-    L.call_verify("ocr_channel_stats_f32", ptr(x), c_int64(x.numel() // c), c_int(c), ptr(partial), _st())
+    L.call("ocr_channel_stats_f32", ptr(x), c_int64(x.numel() // c), c_int(c), ptr(partial), _st())
 
 
 def bn_relu_f32(y, scale, shift, relu, pool, a_full=None, a_pool=None):
     n, h, w, c = y.shape
-    L.call_verify("ocr_bn_relu_f32", ptr(y), ptr(scale), ptr(shift), c_int(n), c_int(h), c_int(w), c_int(c),
+    L.call("ocr_bn_relu_f32", ptr(y), ptr(scale), ptr(shift), c_int(n), c_int(h), c_int(w), c_int(c),
            c_int(int(relu)), c_int(pool), ptr(a_full), ptr(a_pool), _st())
 
 
 def maxpool_f32(x, k, stride, pad, y):
     n, h, w, c = x.shape
     _, oh, ow, _ = y.shape
-    L.call_verify("ocr_maxpool_f32", ptr(x), c_int(n), c_int(h), c_int(w), c_int(c), c_int(k), c_int(stride),
+    L.call("ocr_maxpool_f32", ptr(x), c_int(n), c_int(h), c_int(w), c_int(c), c_int(k), c_int(stride),
            c_int(pad[0]), c_int(pad[1]), c_int(oh), c_int(ow), ptr(y), _st())
 
 
 def prep_images_f32(images, out, means):
-    L.call_verify("ocr_prep_images_f32", ptr(images), c_int64(images.numel() // 3), c_float(means[0]),
+    L.call("ocr_prep_images_f32", ptr(images), c_int64(images.numel() // 3), c_float(means[0]),
            c_float(means[1]), c_float(means[2]), ptr(out), _st())
 
 
 def bn_add_relu_f32(y, scale, shift, shortcut, out):
     c = y.shape[-1]
-    L.call_verify("ocr_bn_add_relu_f32", ptr(y), ptr(scale), ptr(shift), ptr(shortcut), c_int64(y.numel() // c),
+    L.call("ocr_bn_add_relu_f32", ptr(y), ptr(scale), ptr(shift), ptr(shortcut), c_int64(y.numel() // c),
            c_int(c), ptr(out), _st())
 
 
 def unpool_f32(x, y):
     n, h, w, c = x.shape
-    L.call_verify("ocr_unpool_f32", ptr(x), c_int(n), c_int(h), c_int(w), c_int(c), ptr(y), _st())
+    L.call("ocr_unpool_f32", ptr(x), c_int(n), c_int(h), c_int(w), c_int(c), ptr(y), _st())

@@ -26,6 +26,8 @@ def parse():
     ap.add_argument('--test_data_path', type=str, default='./exhibition')
     ap.add_argument('--checkpoint_path', type=str, default='/tmp/east_icdar2015_resnet_v1_50_rbox/')
     ap.add_argument('--output_dir', type=str, default='/tmp/res/')
+    ap.add_argument('--precision', choices=['f16', 'f32'], default='f16', help="f32: the forward pass in the f32 inference "
+                    "precision (f32 storage, matrix-core f32 convolutions): score maps within 1e-3 of the f32 reference, ~10x the time")
     return ap.parse_args()
 
 
@@ -121,7 +123,7 @@ def main():
     from tensorflow_ocr_amd.nets import model
     from tensorflow_ocr_amd.tool import pixellink_fn
     os.makedirs(FLAGS.output_dir, exist_ok=True)
-    g = Graph('cuda:0')
+    g = Graph('cuda:0', precision=FLAGS.precision)
     restored = False
 
     def network(gr, im):      # sess.run([f_score, f_geometry]) + the two softmaxes: one HIP graph per image shape

@@ -30,6 +30,8 @@ def parse():
     ap.add_argument('--decode_width', type=int, default=1280, help='cv2.resize target (:98), width')
     ap.add_argument('--decode_height', type=int, default=720, help='cv2.resize target (:98), height')
     ap.add_argument('--synthetic', type=int, default=0, help='decode N synthetic images instead of files')
+    ap.add_argument('--precision', choices=['f16', 'f32'], default='f16', help="f32: the forward pass in the f32 inference "
+                    "precision (f32 storage, matrix-core f32 convolutions): score maps within 1e-3 of the f32 reference, ~10x the time")
     return ap.parse_args()
 
 
@@ -50,7 +52,7 @@ def main():
     from tensorflow_ocr_amd.infer import GraphedForward
     from tensorflow_ocr_amd.nets import pixellink
     from tensorflow_ocr_amd.tool import pixellink_fn
-    g = Graph('cuda:0')
+    g = Graph('cuda:0', precision=FLAGS.precision)
     os.makedirs(FLAGS.output_dir, exist_ok=True)
     H, W = FLAGS.eval_image_height, FLAGS.eval_image_width
     if FLAGS.synthetic:

@@ -1,6 +1,6 @@
-"""GPU, whole graph at the north star's tolerance: the f32 VERIFICATION precision
+"""GPU, whole graph at the north star's tolerance: the f32 INFERENCE precision of the product library
 (Graph(precision="f32"): same host graph code, padding rules, BN formulas and head kernels, f32
-storage, plain conv kernels of csrc/verify_f32.hip) against the f32 CPU oracle.
+storage, the convolutions on the matrix cores — ocr_conv2d_f32_mfma, csrc/f32_infer.hip) against the f32 CPU oracle.
 
 Bar: score / link maps L-inf < 1e-3 ("score-map L-inf < 1e-3 vs reference", BASELINE.json
 north_star).  The f16 product kernels cannot meet this end to end (2^-11 storage rounding per layer,

@@ -56,16 +56,22 @@ def test_loader_refuses_a_library_of_another_abi_version(monkeypatch):
 
 
 def test_verification_kernels_live_in_their_own_library():
-    """The f32 verification kernels (include/ocr_verify.h) are test infrastructure: libocr_verify.so
-    exports them, the product libraries export none of them."""
+    """The plain direct f32 convolution (include/ocr_verify.h) is test infrastructure — the independent checker of the
+    product library's matrix-core f32 precision: libocr_verify.so exports it, the product libraries do not; the f32
+    precision itself (ocr_conv2d_f32_mfma + the element-wise ocr_*_f32 kernels) is declared in ocr_hip.h and exported by
+    the product libraries."""
     from tensorflow_ocr_amd import _lib
     names = _declared_symbols("ocr_verify.h")
-    assert len(names) == 8 and all(n.endswith("_f32") or "_f32_" in n for n in names)
+    assert names == ["ocr_conv2d_f32"]
     ver = ctypes.CDLL(_lib.VERIFY_LIB_PATH)
     assert not [n for n in names if not hasattr(ver, n)]
+    prod_f32 = [n for n in _declared_symbols() if n.endswith("_f32_mfma") or n in (
+        "ocr_channel_stats_f32", "ocr_bn_relu_f32", "ocr_maxpool_f32", "ocr_prep_images_f32", "ocr_bn_add_relu_f32", "ocr_unpool_f32")]
+    assert len(prod_f32) == 7
     for path in (_lib.LIB_PATH, os.path.join(os.path.dirname(_lib.LIB_PATH), "libocr_hip_bf16.so")):
         prod = ctypes.CDLL(path)
         assert not [n for n in names if hasattr(prod, n)], path
+        assert not [n for n in prod_f32 if not hasattr(prod, n)], path
     assert not set(names) & set(_declared_symbols())
 
 
