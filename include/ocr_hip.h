@@ -481,8 +481,10 @@ int ocr_unpool_f32(const void* x, int n, int lh, int lw, int c, void* y, void* s
  * (nets/model_vgg_16.py:160-172: fc7, conv5_3, conv4_3, conv3_3; nets/pixellink.py:58-67; nets/model.py:129-141) instead
  * of one per map, and the two predication convolutions (:166,173 / :61,67) as one pass over the fused tensor.  `items` are
  * HOST arrays of the descriptors below (copied into the kernel arguments, like ocr_conv_desc); the pointers INSIDE them
- * are device pointers.  Results equal the per-map entry points' (ocr_conv1x1_small_*, ocr_sc_*) bit for bit, except the
- * forward statistics (another, equally fixed, summation order) and the weight gradient (f32 dz rounded on load).
+ * are device pointers.  Convolution outputs and input gradients equal the per-map entry points' (ocr_conv1x1_small_*)
+ * bit for bit; the forward statistics use another (equally fixed) summation order, the weight gradient rounds f32 dz on
+ * load, the batched finalisations sum partial rows in f64, and the 16 -> 16 predication pass agrees with
+ * ocr_sc_pointwise_* to the last ulp or two (the compiler schedules the 16-term FMA chains of the two kernels differently).
  * ------------------------------------------------------------------------- */
 typedef struct {
   const void* x;             /* f16 [P][cin] feature map */

@@ -516,9 +516,12 @@ def head_group(g, feats, names_list, couts, *, mode="bn", is_training=True, relu
     the same order.  Returns the list of (z SmallAct, scale, shift) triples `fuse` consumes (scale = shift = None for
     mode="bias").  OCR_BATCH_HEADS=0 (or the f32 verification precision) runs the per-source forms."""
     if not BATCH_HEADS or g.precision == "f32" or len(feats) > 4:
-        if mode == "bn":
-            return [head_conv_bn(g, f, nm, couts, is_training=is_training, relu=relu) for f, nm in zip(feats, names_list)]
-        return [head_conv_bias(g, f, nm, couts, initializer=initializer) for f, nm in zip(feats, names_list)]
+        out = []
+        for k, (f, nm) in enumerate(zip(feats, names_list)):
+            with g.chain(k):          # the sources are independent chains of small launches (graph.Graph.chain)
+                out.append(head_conv_bn(g, f, nm, couts, is_training=is_training, relu=relu) if mode == "bn" else
+                           head_conv_bias(g, f, nm, couts, initializer=initializer))
+        return out
     C = sum(couts)
     ws = g.workspace()
     srcs = []

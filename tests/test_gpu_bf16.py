@@ -30,3 +30,14 @@ def test_bf16_build_layers_models_and_train_step(device):
     import re
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 45 and "failed" not in r.stdout, tail
+
+
+def test_bf16_resnet50_east_640_batch64_parity(device):
+    """BASELINE configs[3] as quoted (bf16, batch 64, 640^2): n = 64 replicated == n = 2 in the bf16 library."""
+    env = dict(os.environ, OCR_STORAGE="bf16")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_batch_parity.py"), "-k", "bf16_batch64"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    print("\n".join(l for l in r.stdout.splitlines() if l.startswith("bf16 n=64")))
+    assert r.returncode == 0 and "1 passed" in r.stdout, tail
