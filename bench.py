@@ -334,10 +334,11 @@ def main():
     # backward on the compute stream is marked with an event, so `backward_stretch_ms` is what the stand-in costs the
     # conv workgroups it shares the chip with and `step_ms_with - step_ms_without` what stays exposed.
     if comm is not None and red is not None and red.active and red.mode == "abi" and red.proxy is not None and probe_only:
-        res = {False: [[], []], True: [[], []]}
+        arms = (("without", False, True), ("overlapped", True, True), ("after_backward", True, False))
+        res = {k: [[], []] for k, _, _ in arms}
         for rnd in range(2):
-            for with_proxy in (False, True):
-                red.enabled, red.use_proxy = with_proxy, with_proxy
+            for arm, with_proxy, overlap in arms:
+                red.enabled, red.use_proxy, red.overlap = with_proxy, with_proxy, overlap
                 step.backward_end_event = None
                 step(*batch)
                 barrier()
@@ -348,23 +349,30 @@ def main():
                     step.backward_end_event = e1
                     step(*batch)
                 barrier()
-                res[with_proxy][0].append((time.perf_counter() - t1) / args.steps * 1e3)
-                res[with_proxy][1].append(float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])))
+                res[arm][0].append((time.perf_counter() - t1) / args.steps * 1e3)
+                res[arm][1].append(float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])))
         stats = red.proxy_stats.cpu().numpy()
-        red.enabled, red.use_proxy = False, False
+        red.enabled, red.use_proxy, red.overlap = False, False, True
         step.backward_end_event = None
         nb = len(red.buckets)
         busy_ms = float(stats[3]) / 1e5 / max(int(stats[4]), 1) * nb          # 100 MHz ticks -> ms, per step
         paced_ms = 2.0 * comm["grad_bytes"] / (red.proxy[1] * 1e9) * 1e3
+        best = {k: (min(v[0]), min(v[1])) for k, v in res.items()}
         comm["proxy"] = {
             "kernel": "ocr_comm_proxy: %d workgroups x 256 threads on the comm stream, one launch per bucket (same events as "
                       "the all-reduce), 2 x bucket bytes through HBM in 256 KB chunks paced at %.0f GB/s" % red.proxy,
-            "step_ms_without": round(min(res[False][0]), 3), "step_ms_with": round(min(res[True][0]), 3),
-            "backward_ms_without": round(min(res[False][1]), 3), "backward_ms_with": round(min(res[True][1]), 3),
-            "backward_stretch_ms": round(min(res[True][1]) - min(res[False][1]), 3),
+            "step_ms_without": round(best["without"][0], 3),
+            "step_ms_with": round(best["overlapped"][0], 3),
+            "step_ms_with_after_backward": round(best["after_backward"][0], 3),
+            "backward_ms_without": round(best["without"][1], 3), "backward_ms_with": round(best["overlapped"][1], 3),
+            "backward_ms_with_after_backward": round(best["after_backward"][1], 3),
+            "backward_stretch_ms": round(best["overlapped"][1] - best["without"][1], 3),
+            "exposed_ms_overlapped": round(best["overlapped"][0] - best["without"][0], 3),
+            "exposed_ms_after_backward": round(best["after_backward"][0] - best["without"][0], 3),
             "proxy_busy_ms_per_step": round(busy_ms, 3), "proxy_paced_ms_per_step": round(paced_ms, 3),
-            "proxy_launches": int(stats[4]), "rounds": "A/B/A/B, best of 2 per arm"}
-
+            "proxy_launches": int(stats[4]), "rounds": "three arms interleaved twice, best of 2 per arm",
+            "reading": "overlapped: the buckets' stand-ins run under backward (dist.GradientAllReduce(overlap=True)); "
+                       "after_backward: all of them between backward and the optimiser (overlap=False); DESIGN.md 3.4"}
     # dominant kernel: the conv_igemm instantiation with the most accumulated time
     per, fwd = {}, {}
     for variant, flops, phase, e0, e1 in timing:

@@ -15,5 +15,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_C
 python3 scripts/clock_diag.py > $R/clock_diag.json 2> $R/clock.log && echo clock ok &&
 python3 scripts/step_calls.py > $R/step_calls.json 2> $R/step_calls.txt && echo calls ok &&
 OCR_STORAGE=bf16 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats_resnet -- python3 scripts/bench_configs.py --which resnet --steps 8 --warmup 3 > $R/stats_resnet.log 2>&1 && echo resnet ok &&
+OCR_STORAGE=bf16 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_f_resnet -- python3 scripts/bench_configs.py --which resnet --steps 3 --warmup 1 > $R/pmc_f_resnet.log 2>&1 && echo resnet fetch ok &&
+OCR_STORAGE=bf16 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/pmc_w_resnet -- python3 scripts/bench_configs.py --which resnet --steps 3 --warmup 1 > $R/pmc_w_resnet.log 2>&1 && echo resnet write ok &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats_pl -- python3 scripts/bench_configs.py --which pixellink --steps 8 --warmup 3 > $R/stats_pl.log 2>&1 && echo pixellink ok &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats_dec -- python3 scripts/bench_configs.py --which decode > $R/stats_dec.log 2>&1 && echo decode ok

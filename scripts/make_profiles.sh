@@ -21,6 +21,7 @@ out.update(d)
 json.dump(out, open("profiles/%s_step_calls.json" % N, "w"), indent=1)
 P
 python scripts/steady_stats.py $R/stats_resnet > profiles/${N}_resnet50_east_640_b64_kernel_stats.csv
+OCR_STORAGE=bf16 python scripts/pmc_traffic.py $R/pmc_f_resnet $R/pmc_w_resnet "OCR_STORAGE=bf16 python3 scripts/bench_configs.py --which resnet --steps 3 --warmup 1 (3 engine-build + 1 warm-up + 3 timed + 1 loss step = 8 steps in the pass)" > profiles/${N}_resnet_pmc_traffic.json
 python scripts/steady_stats.py $R/stats_pl --marker momentum_kernel > profiles/${N}_pixellink_vgg_512_b32_kernel_stats.csv
 cp $R/stats_dec/*/*_kernel_stats.csv profiles/${N}_decode_lanms_kernel_stats.csv
 python - <<'P'

@@ -32,6 +32,12 @@ for k, v in out.items():
         continue                                                        # tiny kernels: not worth a row
     res[k] = {"hbm_read_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
               "hbm_bytes_per_launch": round(fetch + write), "launches_profiled": v.get("FETCH_SIZE", {}).get("launches")}
-final = {"_provenance": provenance("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- python3 bench.py")}
+cmd = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py"
+final = {"_provenance": provenance("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- " + cmd)}
+# whole-pass totals (every kernel, tiny ones included): sum over kernels of launches x average bytes
+tot_r = sum(v.get("FETCH_SIZE", {}).get("avg_KiB", 0.0) * 2048 * v.get("FETCH_SIZE", {}).get("launches", 0) for v in out.values())
+tot_w = sum(v.get("WRITE_SIZE", {}).get("avg_KiB", 0.0) * 1024 * v.get("WRITE_SIZE", {}).get("launches", 0) for v in out.values())
+final["_totals"] = {"hbm_read_bytes_profiled_pass": round(tot_r), "hbm_write_bytes_profiled_pass": round(tot_w),
+                    "note": "all launches of the profiled command (engine build + warm-up + timed steps): divide by the pass's step count"}
 final.update(dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * (kv[1]["launches_profiled"] or 1))))
 print(json.dumps(final, indent=1))

@@ -36,49 +36,9 @@ def get_images(training_data_path):
     return files
 
 
-def load_annoataion(p):
-    """icdar.py:43-66: x1,y1,...,x4,y4,label per line; label '*' or '###' = ignored text."""
-    text_polys, text_tags = [], []
-    if not os.path.exists(p):
-        return np.array(text_polys, dtype=np.float32)
-    with open(p, 'r', encoding='utf-8-sig') as f:
-        for line in csv.reader(f):
-            if not line:
-                continue
-            label = line[-1]
-            line = [i.strip('\ufeff').strip('\xef\xbb\xbf') for i in line]
-            x1, y1, x2, y2, x3, y3, x4, y4 = list(map(float, line[:8]))
-            text_polys.append([[x1, y1], [x2, y2], [x3, y3], [x4, y4]])
-            text_tags.append(label == '*' or label == '###')
-    return np.array(text_polys, dtype=np.float32), np.array(text_tags, dtype=bool)
-
-
-def polygon_area(poly):
-    """icdar.py:69-81 (shoelace, sign = orientation)."""
-    edge = [(poly[1][0] - poly[0][0]) * (poly[1][1] + poly[0][1]),
-            (poly[2][0] - poly[1][0]) * (poly[2][1] + poly[1][1]),
-            (poly[3][0] - poly[2][0]) * (poly[3][1] + poly[2][1]),
-            (poly[0][0] - poly[3][0]) * (poly[0][1] + poly[3][1])]
-    return np.sum(edge) / 2.
-
-
-def check_and_validate_polys(polys, tags, size):
-    """icdar.py:108-135: clip to the image, drop |area| < 1, flip clockwise-wrong polygons."""
-    (h, w) = size
-    if polys.shape[0] == 0:
-        return polys
-    polys[:, :, 0] = np.clip(polys[:, :, 0], 0, w - 1)
-    polys[:, :, 1] = np.clip(polys[:, :, 1], 0, h - 1)
-    validated_polys, validated_tags = [], []
-    for poly, tag in zip(polys, tags):
-        p_area = polygon_area(poly)
-        if abs(p_area) < 1:
-            continue
-        if p_area > 0:
-            poly = poly[(0, 3, 2, 1), :]
-        validated_polys.append(poly)
-        validated_tags.append(tag)
-    return np.array(validated_polys), np.array(validated_tags)
+# host side of a sample: datasets/_decode.py (NumPy + PIL only, so that decode WORKER PROCESSES can import it)
+from ._decode import (check_and_validate_polys, load_annoataion, polygon_area, read_image_rgb, txt_name,  # noqa: E402,F401
+                      load_sample as _load_sample)
 
 
 def _ignore_flags(polys, tags, min_text_size):
@@ -144,15 +104,6 @@ def generate_rbox(im_size, polys, tags, min_text_size=MIN_TEXT_SIZE, graph=None)
             m[0, :, :, 0].cpu().numpy().astype(np.uint8))
 
 
-def read_image_rgb(path):
-    """cv2.imread(...)[:, :, ::-1]: uint8 [H,W,3] RGB.  .npy arrays are taken as RGB already."""
-    if path.endswith('.npy'):
-        return np.ascontiguousarray(np.load(path), dtype=np.uint8)
-    from PIL import Image
-    with Image.open(path) as im:
-        return np.array(im.convert("RGB"), dtype=np.uint8)
-
-
 def resize_images(images_u8, input_size, graph=None):
     """`cv2.resize(im, dsize=(input_size, input_size))` + `.astype(np.float32)` (icdar.py:615,630) for a
     list of uint8 [H,W,3] images of any size -> device float32 [n,S,S,3].  The batch crosses PCIe
@@ -178,80 +129,85 @@ def resize_images(images_u8, input_size, graph=None):
     return out
 
 
-def txt_name(im_fn):
-    """icdar.py:564: <dir>/gt_<stem>.txt"""
-    return im_fn[:im_fn.rfind('/') + 1] + 'gt_' + im_fn[im_fn.rfind('/') + 1:im_fn.rfind('.')] + '.txt'
-
-
-def _load_sample(args):
-    """Host side of one sample (icdar.py:559-571,616-619): decode, parse, validate, scale the polygons
-    to the training size.  Runs in the decode workers."""
-    im_fn, input_size = args
-    tf = txt_name(im_fn)
-    if not os.path.exists(tf):
-        return None
-    try:
-        im = read_image_rgb(im_fn)
-        h, w, _ = im.shape
-        text_polys, text_tags = load_annoataion(tf)
-        text_polys, text_tags = check_and_validate_polys(text_polys, text_tags, (h, w))
-        if text_polys.shape[0] == 0:
-            return None
-        text_polys[:, :, 0] *= input_size / float(w)
-        text_polys[:, :, 1] *= input_size / float(h)
-    except Exception:                       # the reference prints the traceback and moves on (:646-649)
-        import traceback
-        traceback.print_exc()
-        return None
-    return im_fn, im, text_polys, text_tags
-
-
 def generator(training_data_path, input_size=512, batch_size=32, graph=None, shuffle=True, seed=None,
-              num_workers=0):
+              num_workers=0, worker_kind=None):
     """icdar.py:542-649 with the branches the reference has live (no random scale / crop: `if (0)`):
     read image + gt, validate polygons, resize to input_size x input_size, scale the polygons,
     labels at 1/4 resolution.  Yields (images [B,S,S,3] float32 RGB, image_fns, score_maps, geo_maps,
     training_masks) as DEVICE tensors (the reference yields lists of NumPy arrays).  num_workers > 0:
-    that many host threads decode and parse ahead (the reference's GeneratorEnqueuer workers)."""
+    that many decode workers run ahead (the reference's GeneratorEnqueuer workers) — worker_kind "process" (default;
+    OCR_DECODE_WORKERS): plain interpreters that import NumPy + PIL only and hand the pixels over through a shared slab
+    (datasets/_decode.py: DecodePool); "thread": threads of this process (their Python parts serialise on the GIL)."""
     image_list = np.array(sorted(get_images(training_data_path)))
     print('{} training images in {}'.format(image_list.shape[0], training_data_path))
     if len(image_list) == 0:
         return
     index = np.arange(0, image_list.shape[0])
     rng = np.random.RandomState(seed)
-    pool = None
-    if num_workers > 0:
-        # decode workers are THREADS: image decoding (PIL / np.load) runs in C with the GIL released, and
-        # a thread pool has none of the fork-after-HIP-init / spawn-teardown hazards of worker processes
+    kind = worker_kind or os.environ.get("OCR_DECODE_WORKERS", "process")
+    if kind not in ("process", "thread"):
+        raise ValueError("worker_kind must be 'process' or 'thread'")
+    pool = dpool = None
+    if num_workers > 0 and kind == "thread":
         from multiprocessing.pool import ThreadPool
         pool = ThreadPool(num_workers)
+    elif num_workers > 0:
+        from ._decode import DecodePool
+        dpool = DecodePool(num_workers, slots=max(2 * batch_size, 2 * num_workers))
+
+    def samples_of(jobs):
+        """The epoch's samples in job order: (im_fn, image, polys, tags, slot | None), None for skipped ones."""
+        if dpool is None:
+            for smp in (pool.imap(_load_sample, jobs, chunksize=4) if pool else map(_load_sample, jobs)):
+                yield None if smp is None else smp + (None,)
+            return
+        from collections import deque
+        pending, it = deque(), iter(jobs)
+        ahead = max(1, dpool.slots - batch_size)           # leave a batch worth of slots to the images being consumed
+        while True:
+            while len(pending) < ahead:
+                j = next(it, None)
+                if j is None:
+                    break
+                pending.append(dpool.submit(*j))
+            if not pending:
+                return
+            yield pending.popleft().result()
     try:
         while True:
             if shuffle:
                 rng.shuffle(index)
             jobs = [(str(image_list[i]), input_size) for i in index]
-            samples = pool.imap(_load_sample, jobs, chunksize=4) if pool else map(_load_sample, jobs)
-            ims, fns, polys_l, tags_l = [], [], [], []
+            ims, fns, polys_l, tags_l, slots = [], [], [], [], []
             produced = False
-            for smp in samples:
+            for smp in samples_of(jobs):
                 if smp is None:
                     continue
                 fns.append(smp[0])
                 ims.append(smp[1])
                 polys_l.append(smp[2])
                 tags_l.append(smp[3])
+                slots.append(smp[4])
                 if len(ims) == batch_size:
-                    images = resize_images(ims, input_size, graph=graph)
+                    images = resize_images(ims, input_size, graph=graph)      # copies the pixels out of their slots
+                    for sl in slots:
+                        if dpool is not None:
+                            dpool.release(sl)
                     score, geo, mask = generate_rbox_batch((input_size, input_size), polys_l, tags_l, graph=graph)
                     produced = True
                     yield images, fns, score, geo, mask
-                    ims, fns, polys_l, tags_l = [], [], [], []
+                    ims, fns, polys_l, tags_l, slots = [], [], [], [], []
+            for sl in slots:                                                  # the epoch's incomplete last batch
+                if dpool is not None:
+                    dpool.release(sl)
             if not produced:
                 return                       # fewer usable samples than one batch: do not spin
     finally:
         if pool is not None:
             pool.terminate()
             pool.join()
+        if dpool is not None:
+            dpool.close()
 
 
 def get_batch(num_workers=0, device_prefetch=2, **kwargs):

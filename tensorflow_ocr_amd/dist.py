@@ -165,7 +165,7 @@ def exchange_mode(world, cuda, force=False):
 
 class GradientAllReduce:
     def __init__(self, store, world_size, bucket_bytes=32 << 20, op="mean", group=None, fold_mean=False,
-                 force=False, mode=None, comm=None, proxy=None):
+                 force=False, mode=None, comm=None, proxy=None, overlap=None):
         """op: "mean" = `average_gradients` (multigpu_train.py:70-85); "sum" = `sum_gradients`
         (train_pixellink.py:179-194: the caller has already divided its loss by num_clones).
         fold_mean: leave the SUM in the buffer and let the optimiser apply `grad_scale` (= 1/world)
@@ -181,7 +181,13 @@ class GradientAllReduce:
         proxy=(workgroups, link_gbps): abi mode only, a measurement aid — next to every bucket's all-reduce the step
         plan also holds an `ocr_comm_proxy` launch (include/ocr_hip.h: a stand-in with the shape of a multi-rank ring's
         device code) on the comm stream; a replayed step runs ONE of the two, chosen by `self.use_proxy` (bench.py's
-        one-GPU `exchange.proxy` leg)."""
+        one-GPU `exchange.proxy` leg).
+        overlap: True = a bucket's all-reduce is issued as soon as its last gradient is written, under the rest of
+        backward; False = every bucket is issued after backward, in front of the optimiser (nothing shares the chip with
+        the conv kernels; the whole exchange is exposed).  Default: OCR_EXCHANGE_OVERLAP (1).  Why the choice exists:
+        DESIGN.md section 3.4 — the weight-gradient, persistent and 256-tile conv launches fill the chip in exactly one
+        round of workgroups, so a comm kernel that holds even a few CUs sends their tiles into a second round.  With
+        `proxy` (world 1, a measurement aid) the plan holds BOTH placements and a replay runs the one `self.overlap` names."""
         self.store = store
         self.active = world_size > 1 or force
         self.enabled = True
@@ -212,6 +218,8 @@ class GradientAllReduce:
         self.mode = (mode or exchange_mode(world_size, self.cuda, force)) if self.active else "torch"
         self.comm = comm
         self.proxy = proxy
+        self.overlap = (__import__("os").environ.get("OCR_EXCHANGE_OVERLAP", "1") == "1") if overlap is None else bool(overlap)
+        self.both_placements = proxy is not None and world_size == 1      # record early AND late launches (one-rank: harmless)
         self.use_proxy = False
         self.proxy_stats = None
         self.ev_ready = self.ev_done = None
@@ -287,8 +295,8 @@ class GradientAllReduce:
             if bi is None:
                 continue
             self.left[bi] -= 1
-            if self.left[bi] == 0 and not self.fired[bi]:
-                self._fire(bi)
+            if self.left[bi] == 0 and not self.fired[bi] and (self.overlap or self.both_placements):
+                self._fire(bi, "early")
 
     def _replayed(self, fn, *args):
         self._replaying = True
@@ -297,7 +305,9 @@ class GradientAllReduce:
         finally:
             self._replaying = False
 
-    def _fire(self, bi):
+    def _fire(self, bi, when=None):
+        """when: "early" / "late" = the bucket's placement (under backward / after it) when a plan records both
+        (`both_placements`); None otherwise."""
         self.fired[bi] = True
         s, e = self.buckets[bi]
         buf = self.store.flat_grad[s:e]
@@ -308,17 +318,19 @@ class GradientAllReduce:
             cs = ctypes.c_void_p(self.comm_stream.cuda_stream)
             for es in self.extra_streams:                  # side-stream weight gradients (off by default)
                 self.comm_stream.wait_stream(es)
-            self._xcall("ocr_event_record", self.ev_ready[bi], cur)
-            self._xcall("ocr_stream_wait_event", cs, self.ev_ready[bi])
+            w = when if self.both_placements else None
+            self._xcall("ocr_event_record", self.ev_ready[bi], cur, when=w)
+            self._xcall("ocr_stream_wait_event", cs, self.ev_ready[bi], when=w)
             self._xcall("ocr_allreduce_bucket", self.comm.handle, L.ptr(buf), ctypes.c_size_t(e - s),
-                        ctypes.c_int(0), ctypes.c_int(0), cs, kind="rccl")
+                        ctypes.c_int(0), ctypes.c_int(0), cs, kind="rccl", when=w)
             if self.proxy is not None:
                 if self.proxy_stats is None:     # {min start, max end, tickets | busy ticks, launches}: ocr_comm_proxy
                     self.proxy_stats = torch.tensor([-1, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int64).to(buf.device)
                 self._xcall("ocr_comm_proxy", L.ptr(buf), ctypes.c_size_t((e - s) * 4), ctypes.c_int(int(self.proxy[0])),
-                            ctypes.c_float(float(self.proxy[1])), L.ptr(self.proxy_stats), cs, kind="proxy")
-            self._xcall("ocr_event_record", self.ev_done[bi], cs)
-            self.handles.append((bi, buf))
+                            ctypes.c_float(float(self.proxy[1])), L.ptr(self.proxy_stats), cs, kind="proxy", when=w)
+            self._xcall("ocr_event_record", self.ev_done[bi], cs, when=w)
+            if not any(h[0] == bi for h in self.handles):
+                self.handles.append((bi, buf))
             return
         if self.cuda:
             ev = torch.cuda.Event()
@@ -333,13 +345,15 @@ class GradientAllReduce:
         self.handles.append((h, buf))
 
     @staticmethod
-    def _xcall(name, *args, kind=None):
-        """A C-ABI call of the exchange, tagged ("xchg"[, kind]) in a recorded plan: kind "rccl" / "proxy" = the two
-        alternative comm-stream launches of a bucket, "finish" = the compute stream's wait for a bucket."""
+    def _xcall(name, *args, kind=None, when=None):
+        """A C-ABI call of the exchange, tagged ("xchg", kind, when) in a recorded plan: kind "rccl" / "proxy" = the two
+        alternative comm-stream launches of a bucket, "finish" = the compute stream's wait for a bucket, None = event
+        plumbing; when "early" / "late" = the placement the entry belongs to when the plan holds both (train.TrainStep.
+        _replay runs the entries of the placement `overlap` names), None = always."""
         from . import _lib as L
         L.call(name, *args)
         if L.RECORDER is not None:
-            L.RECORDER.tag_last(("xchg",) if kind is None else ("xchg", kind))
+            L.RECORDER.tag_last(("xchg", kind, when))
 
     def finish(self):
         """Fire whatever has not been fired (variables without a gradient this step), wait for all
@@ -353,8 +367,8 @@ class GradientAllReduce:
             self.reset()
             return
         for bi in range(len(self.buckets)):
-            if not self.fired[bi]:
-                self._fire(bi)
+            if not self.fired[bi] or self.both_placements:
+                self._fire(bi, "late")
         if self.mode == "abi":
             cur = _lib.stream_ptr()
             for bi, _ in self.handles:

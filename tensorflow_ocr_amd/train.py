@@ -344,14 +344,18 @@ class TrainStep:
                     # the gradient exchange as C-ABI calls (dist.GradientAllReduce, abi mode)
                     if self.reducer.enabled:
                         kind = tag[1] if len(tag) > 1 else None
+                        when = tag[2] if len(tag) > 2 else None
                         # a bucket's comm-stream launch: the RCCL all-reduce OR its one-GPU stand-in (dist: proxy)
                         if (kind == "proxy" and not self.reducer.use_proxy) or (kind == "rccl" and self.reducer.use_proxy):
+                            continue
+                        # a plan that holds both placements of the exchange (under backward / after it) runs one
+                        if when is not None and when != ("early" if self.reducer.overlap else "late"):
                             continue
                         if group_open:
                             for k in forked:
                                 main.wait_stream(chains[k][0])
                             group_open, forked = False, []
-                        if kind == "finish" and self.backward_end_event is not None and not bwd_marked:
+                        if (kind == "finish" or when == "late") and self.backward_end_event is not None and not bwd_marked:
                             self.backward_end_event.record(main)      # end of backward on the compute stream
                             bwd_marked = True
                         rc = e[1](*e[2])
