@@ -108,7 +108,7 @@ def config_legs(steps=5, warmup=2, timeout=240):
                    "dominant_kernel": j.get("dominant_kernel"), "leg_wall_s": round(time.time() - t0, 1)}
             for k in ("loss", "decode_ms_per_batch", "net_forward_ms", "lanms_ms_per_batch", "lanms_boxes_per_sec",
                       "decode_algorithmic_GBps", "components", "peak_hbm_gib", "step_ms_fed", "step_ms_resident",
-                      "fed_over_resident", "host_decode_img_s", "host_threads", "host_cpus", "host_wait_ms_per_step",
+                      "fed_over_resident", "host_decode_img_s", "host_workers", "host_worker_kind", "host_cpus", "host_wait_ms_per_step",
                       "limiting_stage"):
                 if k in j:
                     leg[k] = j[k]

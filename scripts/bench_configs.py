@@ -142,16 +142,40 @@ def pipeline_train(steps, warmup, batch=32, size=512, workers=16, root="/tmp/ocr
     gen_s = time.perf_counter() - t0
     files = icdar.get_images(root)
     jpg_kb = float(np.mean([os.path.getsize(f) for f in files[:64]])) / 1024.0
-    # host stage alone: decode + annotation parsing + polygon validation in the worker threads, nothing on the GPU
-    from multiprocessing.pool import ThreadPool
-    pool = ThreadPool(workers)
-    jobs = [(f, size) for f in files]
-    list(pool.imap(icdar._load_sample, jobs[:2 * workers], chunksize=4))
-    t0 = time.perf_counter()
-    n_ok = sum(1 for smp in pool.imap(icdar._load_sample, jobs, chunksize=4) if smp is not None)
-    host_rate = n_ok / (time.perf_counter() - t0)
-    pool.terminate()
-    pool.join()
+    # host stage alone: decode + annotation parsing + polygon validation in the workers, nothing on the GPU — with the
+    # worker kind the feeder will use (OCR_DECODE_WORKERS: processes by default, threads on request)
+    kind = os.environ.get("OCR_DECODE_WORKERS", "process")
+    jobs = [(f, size) for f in files] * 2
+    if kind == "thread":
+        from multiprocessing.pool import ThreadPool
+        pool = ThreadPool(workers)
+        list(pool.imap(icdar._load_sample, jobs[:2 * workers], chunksize=4))
+        t0 = time.perf_counter()
+        n_ok = sum(1 for smp in pool.imap(icdar._load_sample, jobs, chunksize=4) if smp is not None)
+        host_rate = n_ok / (time.perf_counter() - t0)
+        pool.terminate()
+        pool.join()
+    else:
+        from collections import deque
+        from tensorflow_ocr_amd.datasets._decode import DecodePool
+        dp = DecodePool(workers, slots=4 * workers)
+        for rnd in range(2):                  # round 0 warms the page cache and the workers
+            pend, it, n_ok = deque(), iter(jobs), 0
+            t0 = time.perf_counter()
+            while True:
+                while len(pend) < 3 * workers:
+                    j = next(it, None)
+                    if j is None:
+                        break
+                    pend.append(dp.submit(*j))
+                if not pend:
+                    break
+                r = pend.popleft().result()
+                if r is not None:
+                    n_ok += 1
+                    dp.release(r[4])
+            host_rate = n_ok / (time.perf_counter() - t0)
+        dp.close()
     dev = torch.device("cuda", 0)
     g = Graph(dev, loss_scale=1024.0, seed=1)
 
@@ -191,17 +215,17 @@ def pipeline_train(steps, warmup, batch=32, size=512, workers=16, root="/tmp/ocr
         feeder.close()
     need = batch / resident
     out = {"config": "multigpu_train hot loop with its input path: %d x 720x1280 JPEG (%.0f KB) + gt_*.txt on disk -> "
-                     "icdar.get_batch (%d decode threads, DeviceFeeder) -> model_vgg + dice + Adam/EMA, batch %d at %d^2"
-                     % (len(files), jpg_kb, workers, batch, size),
+                     "icdar.get_batch (%d decode %s workers, DeviceFeeder) -> model_vgg + dice + Adam/EMA, batch %d at %d^2"
+                     % (len(files), jpg_kb, workers, kind, batch, size),
            "batch": batch, "size": size, "steps": steps, "dtype": _lib.STORAGE,
            "ms_per_step": round(fed * 1e3, 3), "images_per_sec": round(batch / fed, 1),
            "step_ms_fed": round(fed * 1e3, 3), "step_ms_resident": round(resident * 1e3, 3),
            "fed_over_resident": round(fed / resident, 4),
-           "host_decode_img_s": round(host_rate, 1), "host_threads": workers, "host_cpus": os.cpu_count(),
+           "host_decode_img_s": round(host_rate, 1), "host_workers": workers, "host_worker_kind": kind, "host_cpus": os.cpu_count(),
            "host_wait_ms_per_step": round(waits / steps * 1e3, 3),
            "limiting_stage": ("none: the fed step is within 3 % of the resident step" if fed <= 1.03 * resident else
-                              ("host decode + parse: %.0f images/s on %d threads against the %.0f images/s the resident step takes"
-                               % (host_rate, workers, need) if host_rate < 1.1 * need else
+                              ("host decode + parse: %.0f images/s on %d %s workers against the %.0f images/s the resident step takes"
+                               % (host_rate, workers, kind, need) if host_rate < 1.1 * need else
                                "feeder hand-over (device upload / resize / label kernels sharing the chip with the step)")),
            "loss": round(float(loss.item()), 5), "dataset_generation_s": round(gen_s, 1)}
     print(json.dumps(out), flush=True)

@@ -236,32 +236,35 @@ struct BnBatchTab {
   BnBatchItem it[8];
 };
 __global__ __launch_bounds__(1024) void bn_finalize_batch_kernel(BnBatchTab tab) {
-  __shared__ double red[16][64];
+  __shared__ double red[1024];
   const BnBatchItem& it = tab.it[blockIdx.x];
-  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int kind = col >> 5, c = col & 31;
+  // thread = one of the 2 C (kind, channel) columns x one of RL = 1024 / (2 C) row lanes (28 lanes for the 18-channel
+  // heads): a lane adds rows lane, lane + RL, ... in row order, eight loads in flight; the lanes are combined in lane order
+  const int cols = 2 * it.C;
+  const int RL = 1024 / cols;
+  const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
   double acc = 0.0;
-  if (c < it.C) {
-    const float* base = it.partial + (size_t)kind * it.C + c;
-    for (int t0 = rl; t0 < it.T; t0 += 16 * 8) {
+  if (rl < RL) {
+    const float* base = it.partial + col;            // row t: partial[t * 2C + kind * C + c] = partial[t * cols + col]
+    for (int t0 = rl; t0 < it.T; t0 += RL * 8) {
       float v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int t = t0 + 16 * k;
-        v[k] = t < it.T ? base[(size_t)t * 2 * it.C] : 0.f;
+        const int t = t0 + RL * k;
+        v[k] = t < it.T ? base[(size_t)t * cols] : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc += (double)v[k];
     }
   }
-  red[rl][col] = acc;
+  red[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x < 32 && c < it.C) {
+  if ((int)threadIdx.x < it.C) {
+    const int c = threadIdx.x;
     double s = 0.0, q = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      s += red[k][c];
-      q += red[k][32 + c];
+    for (int k = 0; k < RL; ++k) {
+      s += red[k * cols + c];
+      q += red[k * cols + it.C + c];
     }
     if (it.mode == 0) bn_fin_apply<BnFin>(it.fin, c, s, q);
     else bn_fin_apply<BnBwdFin>(it.bwd, c, s, q);

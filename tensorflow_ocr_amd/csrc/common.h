@@ -90,6 +90,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // In-place accumulate on an accumulator-file (AGPR) quad.  With all 256 accumulator registers live hipcc's
 // builtin form picks a destination different from the C operand and shuffles quads through
 // v_accvgpr_read/write around every MFMA (968 such moves per 1152 MFMAs in the first build of
