@@ -149,7 +149,7 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 ops.bn_relu(y, scale, shift, relu, 2, full, pooled)
             elif y_pool_e is not None:
                 argmax, y_pool = argmax_e, y_pool_e
-                ops.bn_relu(y_pool, scale, shift, relu, 0, pooled, None)      # the activation of the selected elements
+                ops.bn_relu_selected(y_pool, scale, shift, relu, pooled, argmax)      # the activation of the selected elements
             else:
                 # the pool is the only consumer: keep the first-max position so that the backward routes
                 # the pooled gradient without re-deriving the four candidates' activations

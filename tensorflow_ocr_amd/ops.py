@@ -440,6 +440,14 @@ def bn_relu(y, scale, shift, relu, pool, a_full=None, a_pool=None):
            c_int(int(relu)), c_int(pool), ptr(a_full), ptr(a_pool), _st())
 
 
+def bn_relu_selected(y_pool, scale, shift, relu, a_pool, argmax):
+    """bn + ReLU of a pool selection made by the convolution (conv2d_stats_pool): a_pool = act(y_pool), argmax bytes |= 4
+    where the activation is positive."""
+    c = y_pool.shape[-1]
+    L.call("ocr_bn_relu_selected_f16", ptr(y_pool), ptr(scale), ptr(shift), c_int64(y_pool.numel() // c), c_int(c),
+           c_int(int(relu)), ptr(a_pool), ptr(argmax), _st())
+
+
 def bn_relu_pool_idx(y, scale, shift, relu, a_full, a_pool, argmax, y_pool=None):
     """bn+ReLU+2x2 max-pool that also stores the first-max position (uint8 [n,oh,ow,c]) and, with `y_pool`, the conv
     output AT that position (the BN-backward operand of the pooled positions: bn_relu_pool_bwd_idx_apply)."""
