@@ -38,7 +38,8 @@ struct ConvP {
   BnRed br;       // br.y != nullptr: fused BN-backward reduction (see conv_epilogue.h)
   half_t* pool_out;          // conv_c64_persist_kernel<64, true>: [n][ceil(oh/2)][ceil(ow/2)][cout] pooled output
   unsigned char* pool_idx;   // ... and its first-max positions (ocr_maxpool_f16's argmax format), may be null
-  const float* pool_gamma;   // conv_c64_persist_kernel<64, 2>: the layer's batch-norm gamma (its SIGN picks max or min of y)
+  // (conv_c64_persist_kernel<64, 2> — a statistics launch, br.y == nullptr — takes the layer's batch-norm gamma, whose SIGN
+  // picks max or min of y, in br.scale: the struct keeps its round-3 layout)
 };
 
 
@@ -210,6 +211,13 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
     dma_w(0, cc, wb);
     if (prefetch && cc + 1 < nchunks) halo_load(cc + 1);
     for (int tap = 0; tap < ntaps; ++tap) {
+      // The weight slice of this tap came by LDS-DMA (dma_w, issued one tap ago; at tap 0 just above, with the NH
+      // register loads of the next chunk's halo behind it): retire it EXPLICITLY.  hipcc does not count an LDS-DMA among
+      // the accesses a workgroup barrier has to wait for — whether `s_waitcnt vmcnt(0)` appears in front of the barrier
+      // depended on what else was outstanding (found in round 4: a ConvP field more, and this kernel's <64,64,2,1,8>
+      // instantiation read a weight slice that had not landed).
+      if (tap == 0 && prefetch && cc + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // after this barrier: buf[wb] (this tap, and at tap 0 the halo) is visible and
       // buf[wb^1] is free (its readers finished tap-1)
       __syncthreads();
@@ -433,8 +441,10 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
   dma_stage(0, 0);
   int buf = 0;
   for (int kc = 0; kc < nk; ++kc) {
-    // after this barrier: stage kc has landed (its vmcnt(0)), and stage kc-1's readers are done,
-    // so the other buffer may be overwritten
+    // after this barrier: stage kc has landed (the explicit vmcnt(0): hipcc does not count an LDS-DMA among the accesses
+    // a workgroup barrier waits for — see conv_igemm_kernel), and stage kc-1's readers are done, so the other buffer
+    // may be overwritten
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kc + 1 < nk) dma_stage(kc + 1, buf ^ 1);
     const char* ab = smem + buf * STAGE + a_lane;
@@ -1618,7 +1628,7 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   float psgn[POOL == 2 ? 8 : 1];                           // +1 / -1: which extreme of y the pool will select per channel
   if constexpr (POOL == 2) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) psgn[e] = p.pool_gamma[co0 + c8 * 8 + e] < 0.f ? -1.f : 1.f;
+    for (int e = 0; e < 8; ++e) psgn[e] = p.br.scale[co0 + c8 * 8 + e] < 0.f ? -1.f : 1.f;      // (gamma: see ConvP)
   }
   // this lane's 16 bias values (its accumulator quads' couts are fixed over the tiles)
   float bvv[AI][4];
@@ -2195,7 +2205,6 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
   OCR_CHECK_SHAPE(d->cin % 32 == 0 && d->cout % 32 == 0);
   p->pool_out = nullptr;
   p->pool_idx = nullptr;
-  p->pool_gamma = nullptr;
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
   p->kh = d->kh; p->kw = d->kw; p->stride = d->stride; p->dil = d->dilation;
@@ -2473,7 +2482,7 @@ extern "C" int ocr_conv2d_stats_pool_f16(const ocr_conv_desc* d, const void* x, 
   if (p.pw || cfg.bn != 64 || cfg.ck != 64 || !conv_c64_ok(p)) return OCR_ERR_UNSUPPORTED;
   p.pool_out = static_cast<half_t*>(y_pool);
   p.pool_idx = static_cast<unsigned char*>(argmax_u8);
-  p.pool_gamma = static_cast<const float*>(gamma);
+  p.br.scale = static_cast<const float*>(gamma);     // br.y stays null: not a fused reduction, only the carrier of gamma
   return launch_c64<2>(p, x, w_kc, nullptr, y, stats_partial, static_cast<hipStream_t>(stream));
 }
 

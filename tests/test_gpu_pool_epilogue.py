@@ -107,5 +107,8 @@ def test_model_vgg_step_with_and_without_the_pool_epilogue(device, monkeypatch):
         res[on] = (px.data.clone(), lk.data.clone(), L.item(), g.store.flat_grad.clone())
     a, b = res[True], res[False]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    # where two window elements round to one 16-bit activation the gradient is routed to the larger y (as the f32
+    # reference would) instead of to the first of the two: a handful of relocated gradient elements per map
     ga, gb = a[3].double(), b[3].double()
-    assert float((ga - gb).norm() / gb.norm()) < 1e-3
+    assert float((ga - gb).norm() / gb.norm()) < 1e-2
+    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.9999
