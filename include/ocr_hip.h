@@ -96,19 +96,6 @@ int ocr_conv2d_variant(const ocr_conv_desc* d, char* out, size_t cap);
  * (nets/vgg.py:17-18 under nets/pixellink.py:41-48: conv1_2 -> pool1).  d->flags: OCR_CONV_BIAS | OCR_CONV_RELU. */
 int ocr_conv2d_relu_pool_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, const void* bias, void* pooled,
                              void* argmax_u8, void* stream);
-/* The same kernel for BATCH-NORM layers followed by their 2x2/2 max-pool (nets/vgg.py:17-18 under resnet_arg_scope,
- * nets/model_vgg_16.py:144: conv1_2 -> pool1; d->flags = OCR_CONV_STATS): y and stats_partial as ocr_conv2d_f16, and in
- * addition y_pool [n][ceil(oh/2)][ceil(ow/2)][cout] = the conv output the pool WILL select per window and channel — the
- * window's largest y where gamma >= 0, its smallest where gamma < 0 (relu(bn(y)) is monotone in y whatever the batch
- * statistics turn out to be) — and argmax_u8 = its position (dy*2+dx, first such element).  The bn + ReLU + pool pass then
- * is ocr_bn_relu_selected_f16 on y_pool: a quarter of the elements.  Differs from ocr_bn_relu_pool_idx_f16 only where two window
- * elements have different y but equal 16-bit activations (there the position of the larger y is kept). */
-int ocr_conv2d_stats_pool_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y, void* stats_partial,
-                              const void* gamma, void* y_pool, void* argmax_u8, void* stream);
-/* ... and that pass: a_pool = act(y_pool * scale + shift) over npix pooled pixels, and every byte of argmax_u8 gains bit 2
- * = "the pooled activation is positive" (the format ocr_bn_relu_pool_idx_f16 writes, which its backward reads). */
-int ocr_bn_relu_selected_f16(const void* y_pool, const void* scale, const void* shift, int64_t npix, int c, int relu,
-                             void* a_pool, void* argmax_u8, void* stream);
 
 /* Input-gradient convolution fused with the batch-norm BACKWARD reduction of the layer below:
  * y (= gradient w.r.t. that layer's activation) is written as usual and `partial`

@@ -331,15 +331,6 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const half_t* __restrict__
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (half_t)f[e];
       *reinterpret_cast<half8_t*>(a_full + u * c + ch * 8) = o;
-      if (argmax) {
-        // y is a POOLED selection (ocr_conv2d_stats_pool_f16) and argmax its positions: add the bytes' bit 2 = "the pooled
-        // activation is positive" (the backward's ReLU mask), which only this pass can know
-        unsigned long long am = *reinterpret_cast<const unsigned long long*>(argmax + u * c + ch * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if ((float)o[e] > 0.f) am |= 4ull << (8 * e);
-        *reinterpret_cast<unsigned long long*>(argmax + u * c + ch * 8) = am;
-      }
     } else {
       const int ox = (int)(u % ow);
       const size_t t = u / ow;
@@ -1381,25 +1372,6 @@ extern "C" int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const
                      static_cast<const float*>(dgamma), static_cast<const float*>(dbeta),
                      static_cast<const half_t*>(da_full), (const half_t*)nullptr, (float*)nullptr,
                      static_cast<half_t*>(dy));
-  return ocr_launch_status();
-}
-
-// The bn + ReLU of a layer whose 2x2 pool selection was made by its convolution (ocr_conv2d_stats_pool_f16): y_pool holds
-// the selected conv outputs, argmax_u8 their positions; a_pool = act(y_pool) and the positions gain bit 2 (activation > 0).
-extern "C" int ocr_bn_relu_selected_f16(const void* y_pool, const void* scale, const void* shift, int64_t npix, int c,
-                                        int relu, void* a_pool, void* argmax_u8, void* stream) {
-  OCR_CHECK_ARG(y_pool && scale && shift && a_pool && argmax_u8 && npix > 0);
-  OCR_CHECK_SHAPE(c % 8 == 0 && npix < (1ll << 31));
-  const size_t total = (size_t)npix * (c / 8);
-  dim3 grid(stream_grid(total));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const half_t* yp = static_cast<const half_t*>(y_pool);
-  const float* sc = static_cast<const float*>(scale);
-  const float* sh = static_cast<const float*>(shift);
-  half_t* ap = static_cast<half_t*>(a_pool);
-  unsigned char* am = static_cast<unsigned char*>(argmax_u8);
-  if (relu) hipLaunchKernelGGL((bn_relu_kernel<true, 0>), grid, dim3(256), 0, st, yp, sc, sh, 1, 1, (int)npix, c, ap, (half_t*)nullptr, am, (half_t*)nullptr);
-  else hipLaunchKernelGGL((bn_relu_kernel<false, 0>), grid, dim3(256), 0, st, yp, sc, sh, 1, 1, (int)npix, c, ap, (half_t*)nullptr, am, (half_t*)nullptr);
   return ocr_launch_status();
 }
 

@@ -38,8 +38,6 @@ struct ConvP {
   BnRed br;       // br.y != nullptr: fused BN-backward reduction (see conv_epilogue.h)
   half_t* pool_out;          // conv_c64_persist_kernel<64, true>: [n][ceil(oh/2)][ceil(ow/2)][cout] pooled output
   unsigned char* pool_idx;   // ... and its first-max positions (ocr_maxpool_f16's argmax format), may be null
-  // (conv_c64_persist_kernel<64, 2> — a statistics launch, br.y == nullptr — takes the layer's batch-norm gamma, whose SIGN
-  // picks max or min of y, in br.scale: the struct keeps its round-3 layout)
 };
 
 
@@ -214,8 +212,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
       // The weight slice of this tap came by LDS-DMA (dma_w, issued one tap ago; at tap 0 just above, with the NH
       // register loads of the next chunk's halo behind it): retire it EXPLICITLY.  hipcc does not count an LDS-DMA among
       // the accesses a workgroup barrier has to wait for — whether `s_waitcnt vmcnt(0)` appears in front of the barrier
-      // depended on what else was outstanding (found in round 4: a ConvP field more, and this kernel's <64,64,2,1,8>
-      // instantiation read a weight slice that had not landed).
+      // depended on what else was outstanding (found in round 4: with one more field in ConvP this kernel's
+      // <64,64,2,1,8> instantiation was scheduled differently and read a weight slice that had not landed).
       if (tap == 0 && prefetch && cc + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // after this barrier: buf[wb] (this tap, and at tap 0 the halo) is visible and
@@ -1510,12 +1508,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
 constexpr int C64_NH = 6;                                          // halo DMA rounds of 512 slots (2720 slots used)
 constexpr int C64_LDS = 2 * W4_HBYTES + 9 * 64 * 128;              // 163840 = the whole LDS
 
-// POOL: 0 none; 1 = bias + ReLU + 2x2 max-pool, only the pooled activation leaves the CU (bias nets); 2 = batch-norm layers
-// followed by their 2x2 max-pool: y is stored and summed as usual AND, per window and channel, the conv output that the
-// pool will select — the window's largest y where gamma >= 0, its smallest where gamma < 0 (relu(gamma * x_hat + beta) is
-// monotone in y, whatever the statistics turn out to be) — with its position, so that the bn + ReLU + pool pass over the
-// full-resolution y (1 GiB at 32 x 512^2) becomes a pass over the pooled tensor.
-template <int BN, int POOL = 0, int EPI = 0>   // EPI: the epilogue mode at compile time (see conv3x3_w4_kernel)
+template <int BN, bool POOL = false, int EPI = 0>   // EPI: the epilogue mode at compile time (see conv3x3_w4_kernel)
 __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
@@ -1625,11 +1618,6 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     bsh[e] = has_br ? p.br.shift[co0 + c8 * 8 + e] : 0.f;
   }
 
-  float psgn[POOL == 2 ? 8 : 1];                           // +1 / -1: which extreme of y the pool will select per channel
-  if constexpr (POOL == 2) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) psgn[e] = p.br.scale[co0 + c8 * 8 + e] < 0.f ? -1.f : 1.f;      // (gamma: see ConvP)
-  }
   // this lane's 16 bias values (its accumulator quads' couts are fixed over the tiles)
   float bvv[AI][4];
 #pragma unroll
@@ -1749,7 +1737,7 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if constexpr (POOL == 1) {
+    if constexpr (POOL) {
       // bias + ReLU layers followed by their 2x2/2 max-pool, the full-resolution activation read by nobody else
       // (PixelLink's conv1_2: nets/vgg.py:17-18): the two tile rows of a wave pair are staged side by side, so after a
       // workgroup barrier each lane pools one 2x2 window of 8 channels and ONLY the pooled tile (+ first-max positions,
@@ -1871,46 +1859,6 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
         }
       }
     }
-    }
-    if constexpr (POOL == 2) {
-      // the row pair of two neighbouring waves is staged side by side (16-bit y as stored): behind a workgroup barrier
-      // each lane takes one 2x2 window of 8 channels and keeps, per channel, the y the pool will select and where it sits
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      const char* pair = smem + hb * W4_HBYTES + (wave & ~1) * 4096;
-      const int pp = (wave & 1) * 8 + pg;                     // pooled pixel of the row pair
-      const int oy0 = tyi * TH + (wave & ~1), ox0 = txi * TILE_W + 2 * pp;
-      const int poh = (p.oh + 1) >> 1, pow2 = (p.ow + 1) >> 1;
-      const int poy = oy0 >> 1, pox = ox0 >> 1;
-      if (poy < poh && pox < pow2) {
-        float key[8];
-        half8_t sel;
-        unsigned long long am = 0ull;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { key[e] = -INFINITY; sel[e] = (half_t)0.f; }
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            if (oy0 + dy < p.oh && ox0 + dx < p.ow) {
-              const int px = 2 * pp + dx;
-              const half8_t v = *reinterpret_cast<const half8_t*>(pair + dy * 4096 + px * 128 + ((c8 ^ (px & 7)) << 4));
-              const unsigned long long pos = (unsigned long long)(dy * 2 + dx);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float kv = (float)v[e] * psgn[e];
-                if (kv > key[e]) {
-                  key[e] = kv;
-                  sel[e] = v[e];
-                  am = (am & ~(0xffull << (8 * e))) | (pos << (8 * e));
-                }
-              }
-            }
-          }
-        const size_t off = (((size_t)img * poh + poy) * pow2 + pox) * p.cout + co0 + c8 * 8;
-        *reinterpret_cast<half8_t*>(p.pool_out + off) = sel;
-        *reinterpret_cast<unsigned long long*>(p.pool_idx + off) = am;
-      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own staging reads are done ...
     __builtin_amdgcn_s_barrier();                         // ... and everyone's: the buffer may receive the halo of tile k+2
@@ -2070,17 +2018,16 @@ static int epi_mode(const ConvP& p) {
 }
 typedef void (*ConvKernT)(ConvP, const half_t*, const half_t*, const float*, half_t*, float*);
 
-template <int POOL = 0>
+template <bool POOL = false>
 static int launch_c64(const ConvP& p0, const void* x, const void* w, const void* bias, void* y, void* stats,
                       hipStream_t st) {
-  // (POOL 1 exists for bias + ReLU layers only, POOL 2 for batch-norm statistics launches only: the other slots of their
-  // tables are the generic / the statistics instantiation)
-  constexpr int P = POOL;
-  const int epi = P == 1 ? (epi_mode(p0) != 3 ? 0 : 3) : P == 2 ? 1 : epi_mode(p0);
-  static const ConvKernT kerns[7] = {conv_c64_persist_kernel<64, P, P == 2 ? 1 : 0>, conv_c64_persist_kernel<64, P, P == 1 ? 0 : 1>,
-                                     conv_c64_persist_kernel<64, P, P ? (P == 2 ? 1 : 0) : 2>, conv_c64_persist_kernel<64, P, P == 2 ? 1 : 3>,
-                                     conv_c64_persist_kernel<64, P, P ? (P == 2 ? 1 : 0) : 4>, conv_c64_persist_kernel<64, P, P ? (P == 2 ? 1 : 0) : 5>,
-                                     conv_c64_persist_kernel<64, P, P ? (P == 2 ? 1 : 0) : 6>};
+  // (the pooled variant exists for bias + ReLU layers only: its other modes are the generic instantiation)
+  constexpr bool P = POOL;
+  const int epi = P && epi_mode(p0) != 3 ? 0 : epi_mode(p0);
+  static const ConvKernT kerns[7] = {conv_c64_persist_kernel<64, P, 0>, conv_c64_persist_kernel<64, P, P ? 0 : 1>,
+                                     conv_c64_persist_kernel<64, P, P ? 0 : 2>, conv_c64_persist_kernel<64, P, 3>,
+                                     conv_c64_persist_kernel<64, P, P ? 0 : 4>, conv_c64_persist_kernel<64, P, P ? 0 : 5>,
+                                     conv_c64_persist_kernel<64, P, P ? 0 : 6>};
   const ConvKernT kern = kerns[epi];
   static bool configured[7] = {false, false, false, false, false, false, false};
   if (!configured[epi]) {
@@ -2463,27 +2410,7 @@ extern "C" int ocr_conv2d_relu_pool_f16(const ocr_conv_desc* d, const void* x, c
   if (p.pw || cfg.bn != 64 || cfg.ck != 64 || !conv_c64_ok(p)) return OCR_ERR_UNSUPPORTED;
   p.pool_out = static_cast<half_t*>(pooled);
   p.pool_idx = static_cast<unsigned char*>(argmax_u8);
-  return launch_c64<1>(p, x, w_kc, bias, nullptr, nullptr, static_cast<hipStream_t>(stream));
-}
-
-// conv + batch-norm statistics for a 64 -> 64 channel 3x3 layer followed by its 2x2/2 max-pool (nets/vgg.py:17-18 under
-// resnet_arg_scope: conv1_2 -> pool1): y and the statistics partials as ocr_conv2d_f16 with OCR_CONV_STATS, plus y_pool =
-// the conv output the pool will select per window and channel (largest y where gamma >= 0, smallest where gamma < 0: the
-// activation is monotone in y) and argmax_u8 = its position — so that the bn + ReLU + pool pass runs over the pooled tensor.
-extern "C" int ocr_conv2d_stats_pool_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y,
-                                         void* stats_partial, const void* gamma, void* y_pool, void* argmax_u8,
-                                         void* stream) {
-  ConvP p;
-  TileCfg cfg;
-  int rc = fill_params(d, &p, &cfg);
-  if (rc != OCR_OK) return rc;
-  OCR_CHECK_ARG(x && w_kc && y && stats_partial && gamma && y_pool && argmax_u8);
-  OCR_CHECK_ARG(d->flags == OCR_CONV_STATS);
-  if (p.pw || cfg.bn != 64 || cfg.ck != 64 || !conv_c64_ok(p)) return OCR_ERR_UNSUPPORTED;
-  p.pool_out = static_cast<half_t*>(y_pool);
-  p.pool_idx = static_cast<unsigned char*>(argmax_u8);
-  p.br.scale = static_cast<const float*>(gamma);     // br.y stays null: not a fused reduction, only the carrier of gamma
-  return launch_c64<2>(p, x, w_kc, nullptr, y, stats_partial, static_cast<hipStream_t>(stream));
+  return launch_c64<true>(p, x, w_kc, bias, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 // q = (P * m) >> (31 + l) == P / d for every P < 2^31 (round-up method: m = ceil(2^(31+l) / d), l = ceil(log2 d))

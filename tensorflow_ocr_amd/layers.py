@@ -58,7 +58,6 @@ def _const_vec(g, n, value):
 
 FUSE_BN_W4_MAXHW = int(__import__("os").environ.get("OCR_FUSE_BN_W4_MAXHW", "1000000"))
 FUSE_BN_POOL_REDUCE = __import__("os").environ.get("OCR_FUSE_BN_POOL_REDUCE", "1") == "1"    # measurement switch
-FUSE_BN_POOL_EPI = __import__("os").environ.get("OCR_FUSE_BN_POOL_EPI", "1") == "1"          # conv1_2: the pool's selection in the conv epilogue
 FIRST_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_RECOMPUTE", "1") == "1"            # measurement switch (forward: 439 -> 318 us)
 FIRST_DROP_Y = __import__("os").environ.get("OCR_FIRST_DROP_Y", "1") == "1"                  # conv1_1's y is never stored (ops.LazyFirstY)
 # conv1_1's weight gradient recomputing y even when y IS stored: bit-identical, but no faster by itself (413 vs 402 us at
@@ -117,19 +116,8 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         train_stats = bn_training
         flags = CONV_STATS if train_stats else 0
         part, stage = g.ws_small.two(mt * 2 * cout * 4, ops.bn_reduce_workspace(mt, cout))
-        # conv1_2-shaped layers (64 -> 64 at full resolution) whose only reader is their 2x2 pool: the persistent kernel's
-        # epilogue also picks, per window and channel, the y the pool will select (gamma's sign decides max or min), so
-        # the bn + ReLU + pool pass below runs over the pooled tensor instead of over y
-        pool_epi = (FUSE_BN_POOL_EPI and pool == 2 and not keep_full and train_stats and not first and FUSE_BN_POOL_REDUCE
-                    and ops.conv2d_variant(d) == "conv_c64_persist_kernel<64>")
-        y_pool_e = argmax_e = None
         if first:
             ops.conv2d_first(x.data, w_fwd, None if drop_y else y, flags, None, part if train_stats else None, cout=cout)
-        elif pool_epi:
-            d.flags = flags
-            y_pool_e = g.empty((n, (oh + 1) // 2, (ow + 1) // 2, cout))
-            argmax_e = g.empty(y_pool_e.shape, torch.uint8)
-            ops.conv2d_stats_pool(d, x.data, w_fwd, y, part, gamma.data, y_pool_e, argmax_e)
         else:
             d.flags = flags
             ops.conv2d(d, x.data, w_fwd, y, None, part if train_stats else None)
@@ -147,9 +135,6 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
             if keep_full:
                 full = g.empty((n, oh, ow, cout))
                 ops.bn_relu(y, scale, shift, relu, 2, full, pooled)
-            elif y_pool_e is not None:
-                argmax, y_pool = argmax_e, y_pool_e
-                ops.bn_relu_selected(y_pool, scale, shift, relu, pooled, argmax)      # the activation of the selected elements
             else:
                 # the pool is the only consumer: keep the first-max position so that the backward routes
                 # the pooled gradient without re-deriving the four candidates' activations

@@ -121,24 +121,6 @@ def conv2d_relu_pool(d, x, w_kc, bias, pooled, argmax=None):
         L.RECORDER.tag_last(tag)
 
 
-def conv2d_stats_pool(d, x, w_kc, y, stats, gamma, y_pool, argmax):
-    """conv + batch-norm statistics + the pool's selection of y per 2x2 window (64 -> 64 channel 3x3 layers; include/ocr_hip.h)."""
-    flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
-    tag = (conv2d_variant(d), flops, "fwd")
-    if KERNEL_TIMING is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        L.call("ocr_conv2d_stats_pool_f16", byref(d), ptr(x), ptr(w_kc), ptr(y), ptr(stats), ptr(gamma), ptr(y_pool),
-               ptr(argmax), _st())
-        e1.record()
-        KERNEL_TIMING.append(tag + (e0, e1))
-    else:
-        L.call("ocr_conv2d_stats_pool_f16", byref(d), ptr(x), ptr(w_kc), ptr(y), ptr(stats), ptr(gamma), ptr(y_pool),
-               ptr(argmax), _st())
-    if L.RECORDER is not None:
-        L.RECORDER.tag_last(tag)
-
-
 def conv2d_bnred(d, x, w_kc, y, partial, bn_ctx, store_masked=False):
     """Input-gradient conv fused with the BN-backward reduction of the layer below.  store_masked: y receives the
     gradient PAST that layer's ReLU (bias nets: bn_ctx = (activation, ones, zeros, zeros, ones, True))."""
@@ -438,14 +420,6 @@ def bn_relu(y, scale, shift, relu, pool, a_full=None, a_pool=None):
     n, h, w, c = y.shape
     L.call("ocr_bn_relu_f16", ptr(y), ptr(scale), ptr(shift), c_int(n), c_int(h), c_int(w), c_int(c),
            c_int(int(relu)), c_int(pool), ptr(a_full), ptr(a_pool), _st())
-
-
-def bn_relu_selected(y_pool, scale, shift, relu, a_pool, argmax):
-    """bn + ReLU of a pool selection made by the convolution (conv2d_stats_pool): a_pool = act(y_pool), argmax bytes |= 4
-    where the activation is positive."""
-    c = y_pool.shape[-1]
-    L.call("ocr_bn_relu_selected_f16", ptr(y_pool), ptr(scale), ptr(shift), c_int64(y_pool.numel() // c), c_int(c),
-           c_int(int(relu)), ptr(a_pool), ptr(argmax), _st())
 
 
 def bn_relu_pool_idx(y, scale, shift, relu, a_full, a_pool, argmax, y_pool=None):
