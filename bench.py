@@ -155,7 +155,7 @@ def counters_from_profiles(dom):
     return vals, src
 
 
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def main():
@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs of BASELINE configs[2..4]")
     ap.add_argument("--no-pg", action="store_true", help="N=1: do not run the bucketed exchange through a "
                     "one-rank RCCL communicator (by default it runs, so the line records that RCCL loaded)")
+    ap.add_argument("--no-proxy", action="store_true", help="N=1: skip the comm-kernel stand-in legs (profiling passes: their "
+                    "stretched steps would enter the per-kernel averages)")
     ap.add_argument("--proxy-workgroups", type=int, default=24, help="N=1: workgroups of the comm-kernel stand-in (RCCL runs "
                     "16-32 channels)")
     ap.add_argument("--proxy-link-gbps", type=float, default=150.0, help="N=1: pace of the stand-in (one xGMI link)")
@@ -237,7 +239,7 @@ def main():
 
     # N = 1 with the one-rank exchange recorded: the plan also holds, next to every bucket's all-reduce, a stand-in with
     # the shape of a multi-rank ring's device code (ocr_comm_proxy) for the `exchange.proxy` leg below
-    proxy_cfg = (args.proxy_workgroups, args.proxy_link_gbps) if (world == 1 and force_reduce and not args.force_pg) else None
+    proxy_cfg = (args.proxy_workgroups, args.proxy_link_gbps) if (world == 1 and force_reduce and not args.force_pg and not args.no_proxy) else None
     step = TrainStep(g, forward_loss, lambda gr: AdamOptimizer(gr, learning_rate=1e-4), world_size=world,
                      force_reduce=force_reduce, comm_proxy=proxy_cfg)
 

@@ -7,8 +7,8 @@ set -o pipefail
 R=${1:?output directory under gpurun_out/}
 mkdir -p "$R"
 export TMPDIR=/tmp
-B="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-config-legs"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config-legs > $R/stats.log 2>&1 && echo stats ok &&
+B="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-config-legs --no-proxy"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config-legs --no-proxy > $R/stats.log 2>&1 && echo stats ok &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_f -- $B > $R/pmc_f.log 2>&1 && echo fetch ok &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/pmc_w -- $B > $R/pmc_w.log 2>&1 && echo write ok &&
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/pmc_m -- $B > $R/pmc_m.log 2>&1 && echo sq ok &&
