@@ -214,7 +214,6 @@ int ocr_conv2d_stem_wgrad_f16(int n, int h, int w, int cout, const void* x4, con
 int ocr_conv2d_stem_wgrad_bn_f16(int n, int h, int w, int cout, const void* x4, const void* da, const void* bn_y,
                                  const void* bn_shift, const void* coef_a, const void* coef_b, const void* coef_c,
                                  int relu, void* dw, void* workspace, size_t ws_bytes, void* stream);
-
 /* f32 HWIO master weights -> the f16 operand layouts of the MFMA kernels (done once per optimiser
  * step).  w_kc [taps][cout][cin] feeds ocr_conv2d_f16 forward; w_ck [taps][cin][cout] (a plain
  * cast) feeds the input gradient: call ocr_conv2d_f16 on dy with cin/cout swapped, flip_taps = 1
@@ -304,6 +303,16 @@ int ocr_bn_relu_bwd_reduce_f16(const void* y, const void* scale, const void* shi
                                const void* save_invstd, const void* da_full, int n, int h, int w, int c, int relu,
                                void* dgamma, void* dbeta, void* coef_a, void* coef_b, void* coef_c, void* partial,
                                void* workspace, size_t ws_bytes, void* stream);
+/* The same with the max-pool backward that produces da_full folded in: da_full is GATHERED from the pool's pooled
+ * gradient and first-maximum index (k x k / stride window, pads as ocr_maxpool_f16; da_pooled, argmax: [n,oh,ow,c]) —
+ * the value ocr_maxpool_bwd_f16 stores, bit for bit — summed into the partials while in registers, and written to
+ * da_full_out [n,h,w,c] f16 (nullable) for the reader that applies the coefficients (ocr_conv2d_stem_wgrad_bn_f16):
+ * one pass instead of a gather pass and a reduce pass over the full-resolution tensor.  n*h*w*c < 2^31. */
+int ocr_bn_relu_bwd_reduce_pooled_f16(const void* y, const void* scale, const void* shift, const void* save_mean,
+                                      const void* save_invstd, const void* da_pooled, const void* argmax, int n, int h,
+                                      int w, int c, int k, int stride, int pad_top, int pad_left, int oh, int ow,
+                                      int relu, void* da_full_out, void* dgamma, void* dbeta, void* coef_a, void* coef_b,
+                                      void* coef_c, void* partial, void* workspace, size_t ws_bytes, void* stream);
 int ocr_relu_bwd_f16(const void* out, const void* dout, int64_t n, void* dz, void* stream);
 int ocr_add_inplace_f16(void* a, const void* b, int64_t n, void* stream);
 
@@ -311,6 +320,11 @@ int ocr_add_inplace_f16(void* a, const void* b, int64_t n, void* stream);
  * branch, nets/model_vgg_16.py:15-16,121): x [n,lh,lw,c] -> y [n,2lh,2lw,c]; and its transpose. */
 int ocr_unpool_f16(const void* x, int n, int lh, int lw, int c, void* y, void* stream);
 int ocr_unpool_bwd_f16(const void* dy, int n, int lh, int lw, int c, void* dx, int accumulate, void* stream);
+/* y [n,2lh,2lw,c] += unpool(t_low [n,lh,lw,c]) in place (sampling of ocr_unpool_f16), with the per-channel
+ * (sum, sum of squares) partials [ocr_channel_stats_num_partials(n*4*lh*lw, c)][2][c] of the result (nullable): the
+ * last step of EAST's merge convolution conv1x1(concat(unpool(g), f)) evaluated as unpool(conv_a(g)) + conv_b(f)
+ * (nets/model_vgg_16.py:118-121 — the 1x1 convolution and the resize act on different axes and commute). */
+int ocr_unpool_add_stats_f16(const void* t_low, int n, int lh, int lw, int c, void* y, void* partial, void* stream);
 
 /* Backward of slim.conv2d's bias + ReLU (nets/pixellink.py:41-48): dz = da * [a > 0] (a = stored
  * conv output), dbias [c] = column sums.  partial: f32 [ocr_bias_relu_bwd_num_partials][c]. */
@@ -391,6 +405,12 @@ int ocr_sc_colsum(const void* x, int P, int C, void* out, void* partial, void* s
 /* sigmoid heads (F_score / geo_map, nets/model_vgg_16.py:129-131) and their gradient, f32 */
 int ocr_sc_sigmoid(const void* z, int64_t n, void* out, void* stream);
 int ocr_sc_sigmoid_bwd(const void* out, const void* dout, int64_t n, void* dz, void* stream);
+/* both heads from ONE merged pre-activation map z [P][C] (one pass over the feature for the two convolutions):
+ * out0 [P][c0] = sigmoid(z[:, :c0]), out1 [P][C-c0] = sigmoid(z[:, c0:]); and dz [P][C] from the two activation maps and
+ * their gradients (a null gradient counts as zero). */
+int ocr_sc_sigmoid_split(const void* z, int P, int C, int c0, void* out0, void* out1, void* stream);
+int ocr_sc_sigmoid_split_bwd(const void* out0, const void* dout0, const void* out1, const void* dout1, int P, int C,
+                             int c0, void* dz, void* stream);
 /* pointwise f32 conv on channel slices: out[p][oo+co] = b[co] + sum_ci x[p][xo+ci] w[ci][co] */
 int ocr_sc_pointwise_fwd(const void* x, int ldx, int xo, int cin, const void* w, const void* bias,
                          int P, void* out, int ldo, int oo, int cout, void* stream);

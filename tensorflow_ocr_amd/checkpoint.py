@@ -43,6 +43,8 @@ def internal_to_tf(internal_sd, widths=None):
 def _guess_widths(total, k):
     if k == 2 and total == 18:
         return (2, 16)
+    if k == 2 and total == 9:              # EAST's F_score (1) + geo_map (8) heads on the merge branch's output
+        return (1, 8)
     if total % k:
         raise ValueError("cannot split %d channels over %d scopes" % (total, k))
     return (total // k,) * k

@@ -8,6 +8,7 @@
 // (nets/resnet_utils.py:232-246, nets/model_vgg_16.py:144), slim.max_pool2d SAME
 // (nets/vgg.py:16-32), mean_image_subtraction (nets/model.py:18-31).
 #include "common.h"
+#include "pool_gather.h"
 
 namespace {
 
@@ -519,6 +520,68 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
   }
 }
 
+// The max-pool's backward and the reduce pass of the batch norm below it in ONE pass (ResNet root block: conv1 -> BN ->
+// ReLU -> 3x3/2 pool): the activation's gradient is gathered from the pooled gradient and the forward's first-maximum
+// index (pool_gather.h: what maxpool_bwd_idx_kernel computes), written for the weight gradient that reads it next, and
+// enters the (sum dz, sum dz*xhat) partials while it is in registers — instead of a gather pass that writes it and a
+// reduce pass (MODE 0 of bn_relu_bwd_kernel) that reads it and y back: 839 MB less traffic at 64 x 640^2.  Same unit ->
+// thread map, summation order and 16-bit rounding as those two kernels, so the same numbers bit for bit.
+template <int K, int S>
+__global__ __launch_bounds__(256) void bn_relu_bwd_gather_kernel(
+    BnBwdP p, PoolGather pg, const half_t* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ partial, half_t* __restrict__ da_out) {
+  __shared__ float red[256 * 16];
+  const int c = p.c, chunks = c >> 3;
+  const int lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  const unsigned units = (unsigned)p.n * p.h * p.w;          // (< 2^31: checked by the launcher — 32-bit index arithmetic)
+  float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int cc = ch * 8 + e;
+    sc[e] = scale[cc];
+    sh[e] = shift[cc];
+    mu[e] = mean[cc];
+    is[e] = invstd[cc];
+  }
+  float s_dz[8], s_dzx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s_dz[e] = 0.f; s_dzx[e] = 0.f; }
+  for (unsigned u = blockIdx.x * lanes + ul; u < units; u += gridDim.x * lanes) {
+    const unsigned t = u / (unsigned)p.w;
+    const int ix = (int)(u - t * (unsigned)p.w);
+    const int img = (int)(t / (unsigned)p.h);
+    const int iy = (int)(t - (unsigned)img * (unsigned)p.h);
+    const unsigned off = u * (unsigned)c + (unsigned)ch * 8u;
+    const half8_t v = *reinterpret_cast<const half8_t*>(y + off);
+    const half8_t g = pool_gather8_f16<K, S>(pg, img, iy, ix, c, ch);
+    if (da_out != nullptr) *reinterpret_cast<half8_t*>(da_out + off) = g;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float yv = (float)v[e];
+      const float z = (float)(half_t)(yv * sc[e] + sh[e]);  // the stored f16 activation
+      const float dz = (!p.relu || z > 0.f) ? (float)g[e] : 0.f;
+      const float xh = (yv - mu[e]) * is[e];
+      s_dz[e] += dz;
+      s_dzx[e] += dz * xh;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[(ul * chunks + ch) * 16 + e] = s_dz[e];
+    red[(ul * chunks + ch) * 16 + 8 + e] = s_dzx[e];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * c; j += 256) {
+    const int which = j / c, cc = j % c;
+    const int ch2 = cc >> 3, e = (cc & 7) + which * 8;
+    float tot = 0.f;
+    for (int l = 0; l < lanes; ++l) tot += red[(l * chunks + ch2) * 16 + e];
+    partial[((size_t)blockIdx.x * 2 + which) * c + cc] = tot;
+  }
+}
+
 // Pooled layers whose only consumer is the pool (conv1_2, conv2_2): with the forward's first-max
 // index and the pooled activation at hand the backward needs no recomputation of the four candidate
 // activations — the routed gradient is da_pool where the pooled activation was positive (ReLU; bit 2 of
@@ -830,6 +893,63 @@ __global__ void unpool_bwd_f16_kernel(const half_t* __restrict__ dy, int n, int 
   }
 }
 
+// y += unpool(t) in place, with the per-channel (sum, sum of squares) partials of the result — the tail of EAST's merge
+// step h = conv1x1(concat(unpool(g), f)) evaluated as conv_a(g) upsampled + conv_b(f): a 1x1 convolution acts on the
+// channel axis, the bilinear resize on the spatial axes, so they commute, and the convolution of the upsampled branch
+// runs on a quarter of the pixels and the WIDE upsampled tensor (2048 channels at 1/16 scale) is never written.
+// Sampling as unpool_f16_kernel; thread map and partial layout as channel_stats_kernel.
+__global__ __launch_bounds__(256) void unpool_add_stats_kernel(const half_t* __restrict__ t, int n, int lh, int lw, int c,
+                                                               half_t* __restrict__ y, float* __restrict__ partial) {
+  __shared__ float red[256 * 16];
+  const int chunks = c >> 3, H = 2 * lh, W = 2 * lw;
+  const int lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  const size_t npix = (size_t)n * H * W;
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  for (size_t u = (size_t)blockIdx.x * lanes + ul; u < npix; u += (size_t)gridDim.x * lanes) {
+    const int ox = (int)(u % W);
+    const size_t r = u / W;
+    const int oy = (int)(r % H);
+    const int img = (int)(r / H);
+    const int y0 = oy >> 1, x0 = ox >> 1;
+    const int y1 = (oy & 1) ? (y0 + 1 < lh ? y0 + 1 : lh - 1) : y0;
+    const int x1 = (ox & 1) ? (x0 + 1 < lw ? x0 + 1 : lw - 1) : x0;
+    const float wy = (oy & 1) ? 0.5f : 0.f, wx = (ox & 1) ? 0.5f : 0.f;
+    const half_t* b = t + (size_t)img * lh * lw * c + ch * 8;
+    const half8_t v00 = *reinterpret_cast<const half8_t*>(b + ((size_t)y0 * lw + x0) * c);
+    const half8_t v01 = *reinterpret_cast<const half8_t*>(b + ((size_t)y0 * lw + x1) * c);
+    const half8_t v10 = *reinterpret_cast<const half8_t*>(b + ((size_t)y1 * lw + x0) * c);
+    const half8_t v11 = *reinterpret_cast<const half8_t*>(b + ((size_t)y1 * lw + x1) * c);
+    const half8_t old = *reinterpret_cast<const half8_t*>(y + u * c + ch * 8);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float top = (float)v00[e] + ((float)v01[e] - (float)v00[e]) * wx;
+      const float bot = (float)v10[e] + ((float)v11[e] - (float)v10[e]) * wx;
+      o[e] = (half_t)((float)old[e] + (top + (bot - top) * wy));
+      const float f = (float)o[e];
+      s[e] += f;
+      q[e] += f * f;
+    }
+    *reinterpret_cast<half8_t*>(y + u * c + ch * 8) = o;
+  }
+  if (partial == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[(ul * chunks + ch) * 16 + e] = s[e];
+    red[(ul * chunks + ch) * 16 + 8 + e] = q[e];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * c; j += 256) {
+    const int which = j / c, cc = j % c;
+    float tot = 0.f;
+    for (int l = 0; l < lanes; ++l) tot += red[(l * chunks + (cc >> 3)) * 16 + (cc & 7) + which * 8];
+    partial[((size_t)blockIdx.x * 2 + which) * c + cc] = tot;
+  }
+}
+
 // --------------------------------------------------------- general max-pool
 struct PoolP {
   int n, h, w, c, oh, ow, k, stride, pt, pl;
@@ -898,6 +1018,7 @@ __global__ void maxpool_bwd_idx_kernel(PoolP p, const unsigned char* __restrict_
                                        int accumulate) {
   const int chunks = p.c >> 3;
   const size_t total = (size_t)p.n * p.h * p.w * chunks;
+  const PoolGather pg{argmax, dy, p.oh, p.ow, p.k, p.stride, p.pt, p.pl};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int ch = (int)(i % chunks);
     size_t u = i / chunks;
@@ -906,30 +1027,7 @@ __global__ void maxpool_bwd_idx_kernel(PoolP p, const unsigned char* __restrict_
     const int iy = (int)(u % p.h);
     const int img = (int)(u / p.h);
     float g[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = 0.f;
-    // windows covering (iy, ix): ky = (iy + pt) mod stride, + stride, ... (one division per axis, not
-    // a divisibility test per tap); visited in ascending (ky, kx) like the scan they replace
-    const int ky0 = (iy + p.pt) % p.stride, kx0 = (ix + p.pl) % p.stride;
-    for (int ky = ky0; ky < p.k; ky += p.stride) {
-      const int ny = iy + p.pt - ky;
-      if (ny < 0) break;
-      const int oy = ny / p.stride;
-      if (oy >= p.oh) continue;
-      for (int kx = kx0; kx < p.k; kx += p.stride) {
-        const int nx = ix + p.pl - kx;
-        if (nx < 0) break;
-        const int ox = nx / p.stride;
-        if (ox >= p.ow) continue;
-        const size_t o = (((size_t)img * p.oh + oy) * p.ow + ox) * p.c + ch * 8;
-        const unsigned long long am = *reinterpret_cast<const unsigned long long*>(argmax + o);
-        half8_t d = *reinterpret_cast<const half8_t*>(dy + o);
-        const unsigned pos = (unsigned)(ky * p.k + kx);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (((am >> (8 * e)) & 0xffu) == pos) g[e] += (float)d[e];
-      }
-    }
+    pool_gather8<0, 0>(pg, img, iy, ix, p.c, ch, g);
     if (accumulate) {
       half8_t old = *reinterpret_cast<const half8_t*>(dx + i * 8);
 #pragma unroll
@@ -1183,6 +1281,38 @@ extern "C" int ocr_bn_relu_bwd_reduce_f16(const void* y, const void* scale, cons
   return ocr_launch_status();
 }
 
+extern "C" int ocr_bn_relu_bwd_reduce_pooled_f16(const void* y, const void* scale, const void* shift, const void* save_mean,
+                                                 const void* save_invstd, const void* da_pooled, const void* argmax,
+                                                 int n, int h, int w, int c, int k, int stride, int pad_top, int pad_left,
+                                                 int oh, int ow, int relu, void* da_full_out, void* dgamma, void* dbeta,
+                                                 void* coef_a, void* coef_b, void* coef_c, void* partial,
+                                                 void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(y && scale && shift && save_mean && save_invstd && da_pooled && argmax && dgamma && dbeta);
+  OCR_CHECK_ARG(coef_a && coef_b && coef_c && partial && workspace);
+  OCR_CHECK_ARG(n > 0 && h > 0 && w > 0 && k > 0 && stride > 0 && oh > 0 && ow > 0 && k * k <= 255);
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
+  OCR_CHECK_SHAPE((long long)n * h * w * c < (1ll << 31));        // 32-bit element offsets in the gather
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int T = bwd_blocks(n, h, w, c, 0);
+  if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
+  BnBwdP p{n, h, w, c, relu, 0, (float)(1.0 / ((double)n * h * w))};
+  PoolGather pg{static_cast<const unsigned char*>(argmax), static_cast<const half_t*>(da_pooled), oh, ow, k, stride,
+                pad_top, pad_left};
+  auto kern = (k == 3 && stride == 2) ? bn_relu_bwd_gather_kernel<3, 2> : bn_relu_bwd_gather_kernel<0, 0>;
+  hipLaunchKernelGGL(kern, dim3(T), dim3(256), 0, st, p, pg, static_cast<const half_t*>(y),
+                     static_cast<const float*>(scale), static_cast<const float*>(shift),
+                     static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
+                     static_cast<float*>(partial), static_cast<half_t*>(da_full_out));
+  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
+  OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
+  hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFinC>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,
+                     static_cast<const float*>(partial), static_cast<double*>(workspace), T, c, bn_ticket_slot(), rows,
+                     BnBwdFinC{static_cast<float*>(dgamma), static_cast<float*>(dbeta), static_cast<const float*>(scale),
+                               static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd), p.inv_count,
+                               static_cast<float*>(coef_a), static_cast<float*>(coef_b), static_cast<float*>(coef_c)});
+  return ocr_launch_status();
+}
+
 extern "C" int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k, int stride,
                                int pad_top, int pad_left, int oh, int ow, void* y, void* argmax,
                                void* stream) {
@@ -1334,6 +1464,17 @@ extern "C" int ocr_unpool_f16(const void* x, int n, int lh, int lw, int c, void*
   hipLaunchKernelGGL(unpool_f16_kernel, dim3(stream_grid((size_t)n * lh * lw * 4 * (c / 8))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const half_t*>(x), n, lh, lw, c,
                      static_cast<half_t*>(y));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_unpool_add_stats_f16(const void* t_low, int n, int lh, int lw, int c, void* y, void* partial,
+                                        void* stream) {
+  OCR_CHECK_ARG(t_low && y && n > 0 && lh > 0 && lw > 0);
+  const int T = ocr_channel_stats_num_partials((int64_t)n * lh * lw * 4, c);
+  if (T < 0) return T;
+  hipLaunchKernelGGL(unpool_add_stats_kernel, dim3(T), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const half_t*>(t_low), n, lh, lw, c, static_cast<half_t*>(y),
+                     static_cast<float*>(partial));
   return ocr_launch_status();
 }
 

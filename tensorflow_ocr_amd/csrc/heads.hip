@@ -280,6 +280,60 @@ __global__ __launch_bounds__(256) void conv1x1_small_wgrad_kernel(const half_t* 
   }
 }
 
+// The same for NARROW feature maps (cin = 8 / 16 / 32 / 64: EAST's 32-channel merge output, 1.6 M pixels at 64 x 640^2):
+// thread = one 8-channel chunk of one pixel lane — 16-byte loads of x, dz kept in f32 (the MFMA route pads dz to 64
+// 16-bit columns in a pass of its own and multiplies 64 x 64 tiles for a 32 x 9 result) — 8 x COUT accumulators per
+// thread, the block's pixel lanes combined through LDS in lane order, one partial [cin][COUT] per block.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1x1_small_wgrad_narrow_kernel(const half_t* __restrict__ x,
+                                                                         const float* __restrict__ dz, int P, int cin,
+                                                                         int strip, float* __restrict__ partial) {
+  __shared__ float red[256 * 8];
+  const int Q = cin >> 3, lanes = 256 / Q;
+  const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
+  const int p0 = blockIdx.x * strip;
+  int p1 = p0 + strip;
+  if (p1 > P) p1 = P;
+  float acc[8][COUT];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[e][c] = 0.f;
+  for (int p = p0 + pl; p < p1; p += 2 * lanes) {        // two pixels per trip: both rows' loads ahead of the FMAs
+    const int pb = p + lanes;
+    const bool two = pb < p1;
+    const half8_t xa = *reinterpret_cast<const half8_t*>(x + (size_t)p * cin + q * 8);
+    half8_t xb = xa;
+    if (two) xb = *reinterpret_cast<const half8_t*>(x + (size_t)pb * cin + q * 8);
+    float da[COUT], db[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+      da[c] = dz[(size_t)p * COUT + c];
+      db[c] = two ? dz[(size_t)pb * COUT + c] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float fa = (float)xa[e], fb = (float)xb[e];
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc[e][c] += fa * da[c];
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc[e][c] += fb * db[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[pl * cin + q * 8 + e] = acc[e][c];
+    __syncthreads();
+    if (threadIdx.x < cin) {
+      float tot = 0.f;
+      for (int l = 0; l < lanes; ++l) tot += red[l * cin + threadIdx.x];
+      partial[((size_t)blockIdx.x * cin + threadIdx.x) * COUT + c] = tot;
+    }
+  }
+}
+
 // ---- weight gradient of the head convolutions for up to four feature maps in one launch -------------------------------
 // dw[ci][co] = sum_p x[p][ci] * dz[p][co]: M = ci, N = co (18 padded to 32), K = pixels, both operands K-major in HBM.  The
 // construction of wgrad_pw_kernel (conv_wgrad_pw.hip: 64-pixel stages double-buffered in LDS, fragments by
@@ -1112,7 +1166,13 @@ __global__ void take_cols_kernel(const float* __restrict__ in, int rows, int C, 
 
 // MFMA route: P % 32 == 0 and cin % 64 == 0 (the 1x1 weight gradient with cout padded to 64);
 // otherwise the VALU strip kernel.
-static bool small_wgrad_mfma(int P, int cin) { return P % 32 == 0 && cin % 32 == 0; }
+static bool small_wgrad_narrow(int cin) { return cin == 8 || cin == 16 || cin == 32 || cin == 64; }
+static int small_wgrad_narrow_strips(int P) {
+  int s = ocr_cdiv(P, 1024);
+  if (s > 4096) s = 4096;
+  return s;
+}
+static bool small_wgrad_mfma(int P, int cin) { return !small_wgrad_narrow(cin) && P % 32 == 0 && cin % 32 == 0; }
 
 static ocr_conv_desc small_wgrad_desc(int P, int cin) {
   ocr_conv_desc d = {1, P / 32, 32, cin, P / 32, 32, 64, 1, 1, 1, 1, 0, 0, 0, 0};
@@ -1126,6 +1186,7 @@ extern "C" size_t ocr_conv1x1_small_wgrad_workspace(int P, int cin, int cout) {
     ocr_conv_desc d = small_wgrad_desc(P, cin);
     return al256((size_t)P * 64 * 2) + al256((size_t)cin * 64 * 4) + ocr_conv2d_wgrad_workspace(&d);
   }
+  if (small_wgrad_narrow(cin)) return (size_t)small_wgrad_narrow_strips(P) * cin * cout * sizeof(float);
   return (size_t)small_wgrad_strips(P) * cin * cout * sizeof(float);
 }
 
@@ -1150,12 +1211,29 @@ extern "C" int ocr_conv1x1_small_wgrad_f16(const void* x, const void* dz_f32, in
                        cout, static_cast<float*>(dw_f32));
     return ocr_launch_status();
   }
-  const int S = small_wgrad_strips(P);
-  const int strip = ocr_cdiv(P, S);
-  dim3 grid(S, ocr_cdiv(cin, 256));
   const half_t* xp = static_cast<const half_t*>(x);
   const float* dp = static_cast<const float*>(dz_f32);
   float* ws = static_cast<float*>(workspace);
+  if (small_wgrad_narrow(cin)) {
+    const int S = small_wgrad_narrow_strips(P);
+    const int strip = ocr_cdiv(P, S);
+    switch (cout) {
+      case 1: hipLaunchKernelGGL(conv1x1_small_wgrad_narrow_kernel<1>, dim3(S), dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+      case 2: hipLaunchKernelGGL(conv1x1_small_wgrad_narrow_kernel<2>, dim3(S), dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+      case 8: hipLaunchKernelGGL(conv1x1_small_wgrad_narrow_kernel<8>, dim3(S), dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+      case 9: hipLaunchKernelGGL(conv1x1_small_wgrad_narrow_kernel<9>, dim3(S), dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+      case 16: hipLaunchKernelGGL(conv1x1_small_wgrad_narrow_kernel<16>, dim3(S), dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+      case 18: hipLaunchKernelGGL(conv1x1_small_wgrad_narrow_kernel<18>, dim3(S), dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
+      default: return OCR_ERR_UNSUPPORTED;
+    }
+    const int elems = cin * cout;
+    hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(elems)), dim3(256), 0, st, ws,
+                       static_cast<float*>(dw_f32), elems, S, 1.f);
+    return ocr_launch_status();
+  }
+  const int S = small_wgrad_strips(P);
+  const int strip = ocr_cdiv(P, S);
+  dim3 grid(S, ocr_cdiv(cin, 256));
   switch (cout) {
     case 1: hipLaunchKernelGGL(conv1x1_small_wgrad_kernel<1>, grid, dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
     case 2: hipLaunchKernelGGL(conv1x1_small_wgrad_kernel<2>, grid, dim3(256), 0, st, xp, dp, P, cin, strip, ws); break;
@@ -1341,7 +1419,55 @@ __global__ void sc_sigmoid_bwd_kernel(const float* __restrict__ out, const float
     dz[i] = dout[i] * s * (1.f - s);
   }
 }
+// merged sigmoid heads: one [P][C] pre-activation map -> two activation maps [P][c0], [P][C - c0] (and back)
+__global__ void sc_sigmoid_split_kernel(const float* __restrict__ z, unsigned P, unsigned C, unsigned c0,
+                                        float* __restrict__ out0, float* __restrict__ out1) {
+  const size_t n = (size_t)P * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned p = (unsigned)(i / C), c = (unsigned)(i - (size_t)p * C);
+    const float v = 1.f / (1.f + expf(-z[i]));
+    if (c < c0) out0[(size_t)p * c0 + c] = v;
+    else out1[(size_t)p * (C - c0) + (c - c0)] = v;
+  }
+}
+__global__ void sc_sigmoid_split_bwd_kernel(const float* __restrict__ out0, const float* __restrict__ dout0,
+                                            const float* __restrict__ out1, const float* __restrict__ dout1,
+                                            unsigned P, unsigned C, unsigned c0, float* __restrict__ dz) {
+  const size_t n = (size_t)P * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned p = (unsigned)(i / C), c = (unsigned)(i - (size_t)p * C);
+    float s, d;
+    if (c < c0) {
+      const size_t j = (size_t)p * c0 + c;
+      s = out0[j];
+      d = dout0 ? dout0[j] : 0.f;
+    } else {
+      const size_t j = (size_t)p * (C - c0) + (c - c0);
+      s = out1[j];
+      d = dout1 ? dout1[j] : 0.f;
+    }
+    dz[i] = d * s * (1.f - s);
+  }
+}
 }  // namespace
+
+extern "C" int ocr_sc_sigmoid_split(const void* z, int P, int C, int c0, void* out0, void* out1, void* stream) {
+  OCR_CHECK_ARG(z && out0 && out1 && P > 0 && C > 1 && c0 > 0 && c0 < C);
+  hipLaunchKernelGGL(sc_sigmoid_split_kernel, dim3(sgrid((size_t)P * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(z), (unsigned)P, (unsigned)C, (unsigned)c0, static_cast<float*>(out0),
+                     static_cast<float*>(out1));
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_sc_sigmoid_split_bwd(const void* out0, const void* dout0, const void* out1, const void* dout1, int P,
+                                        int C, int c0, void* dz, void* stream) {
+  OCR_CHECK_ARG(out0 && out1 && dz && P > 0 && C > 1 && c0 > 0 && c0 < C);
+  hipLaunchKernelGGL(sc_sigmoid_split_bwd_kernel, dim3(sgrid((size_t)P * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float*>(out0), static_cast<const float*>(dout0),
+                     static_cast<const float*>(out1), static_cast<const float*>(dout1), (unsigned)P, (unsigned)C,
+                     (unsigned)c0, static_cast<float*>(dz));
+  return ocr_launch_status();
+}
 
 extern "C" int ocr_sc_sigmoid(const void* z, int64_t n, void* out, void* stream) {
   OCR_CHECK_ARG(z && out && n > 0);

@@ -371,6 +371,11 @@ def max_pool2d(g, x, k, stride, scope="pool", bias_relu=None):
             x.bias_done = True
             out.grad = None
             return
+        if x.takes_pool_grad and x.grad is None and x.pool_grad is None and argmax is not None:
+            # the producer gathers this gradient while it loads (resnet_layers.root_block): nothing is written here
+            x.pool_grad = (out.grad, argmax, k, stride, (pt, pl))
+            out.grad = None
+            return
         acc = x.grad is not None
         if not acc:
             x.grad = g.empty(x.shape)

@@ -50,16 +50,12 @@ def model(images, weight_decay=1e-5, is_training=True, graph=None, blocks=None):
     names = iter(['Conv'] + ['Conv_%d' % i for i in range(1, 9)])
     with g.variable_scope('feature_fusion'):
         h = f[0]
-        gi = R.unpool(g, h)
         for i in range(1, 4):
-            c1_1 = R.concat_conv_bn_relu(g, gi, f[i], num_outputs[i], next(names), is_training)
+            # conv1x1(concat(unpool(h), f_i)): the upsampled branch's share of the convolution runs before the resize
+            c1_1 = R.unpool_concat_conv_bn_relu(g, h, f[i], num_outputs[i], next(names), is_training)
             h = R.conv_bn_act(g, c1_1, num_outputs[i], 3, next(names), is_training=is_training)
-            if i <= 2:
-                gi = R.unpool(g, h)
-            else:
-                gi = R.conv_bn_act(g, h, num_outputs[i], 3, next(names), is_training=is_training)
-        F_score = R.sigmoid_head(g, gi, 1, next(names))
-        geo_map = R.sigmoid_head(g, gi, 8, next(names))
+        gi = R.conv_bn_act(g, h, num_outputs[3], 3, next(names), is_training=is_training)
+        F_score, geo_map = R.sigmoid_heads(g, gi, (1, 8), (next(names), next(names)))
     return F_score, geo_map
 
 

@@ -248,6 +248,8 @@ def weights_s2d(w33, w22):
 def weights_s2d_grad(dw22, dw33):
     _, _, cin, cout = dw33.shape
     L.call("ocr_weights_s2d_grad_f32", ptr(dw22), c_int(cin), c_int(cout), ptr(dw33), _st())
+    if L.RECORDER is not None:
+        L.RECORDER.tag_last(("side",))      # reads what the weight-gradient launch before it wrote: same stream
 
 
 def conv2d_first_num_mtiles(n, h, w):
@@ -330,6 +332,20 @@ def bn_relu_bwd_reduce(y, scale, shift, save_mean, save_invstd, da_full, relu, d
     L.call("ocr_bn_relu_bwd_reduce_f16", ptr(y), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(da_full),
            c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(dgamma), ptr(dbeta), ptr(a), ptr(b), ptr(cc),
            ptr(part), ptr(stage), c_size_t(stage.numel()), _st())
+
+
+def bn_relu_bwd_reduce_pooled(y, scale, shift, save_mean, save_invstd, pooled, relu, da_out, dgamma, dbeta, coef, ws):
+    """bn_relu_bwd_reduce with the max-pool backward that produces the activation gradient folded in.
+    pooled = (da_pooled [n,oh,ow,c], argmax u8, k, stride, (pad_top, pad_left)); da_out (nullable): the gathered gradient."""
+    n, h, w, c = y.shape
+    dap, argmax, k, stride, (pt, pl) = pooled
+    T = bn_bwd_num_partials(y.shape, 0)
+    part, stage = ws.two(T * 2 * c * 4, bn_reduce_workspace(T, c))
+    a, b, cc = coef
+    L.call("ocr_bn_relu_bwd_reduce_pooled_f16", ptr(y), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(dap),
+           ptr(argmax), c_int(n), c_int(h), c_int(w), c_int(c), c_int(k), c_int(stride), c_int(pt), c_int(pl),
+           c_int(dap.shape[1]), c_int(dap.shape[2]), c_int(int(relu)), ptr(da_out), ptr(dgamma), ptr(dbeta), ptr(a), ptr(b),
+           ptr(cc), ptr(part), ptr(stage), c_size_t(stage.numel()), _st())
 
 
 def pack_weights_stem(w_hwio, w_stem):
@@ -499,6 +515,23 @@ def unpool_bwd_f16(dy, dx, accumulate):
     n, lh, lw, c = dx.shape
     L.call("ocr_unpool_bwd_f16", ptr(dy), c_int(n), c_int(lh), c_int(lw), c_int(c), ptr(dx),
            c_int(int(accumulate)), _st())
+
+
+def sc_sigmoid_split(z, c0, out0, out1):
+    C = z.shape[-1]
+    L.call("ocr_sc_sigmoid_split", ptr(z), c_int(z.numel() // C), c_int(C), c_int(c0), ptr(out0), ptr(out1), _st())
+
+
+def sc_sigmoid_split_bwd(out0, dout0, out1, dout1, dz):
+    C = dz.shape[-1]
+    L.call("ocr_sc_sigmoid_split_bwd", ptr(out0), ptr(dout0), ptr(out1), ptr(dout1), c_int(dz.numel() // C), c_int(C),
+           c_int(out0.shape[-1]), ptr(dz), _st())
+
+
+def unpool_add_stats(t_low, y, partial):
+    """y += unpool(t_low) in place; partial (nullable): [channel_stats_num_partials(y pixels, c)][2][c] f32."""
+    n, lh, lw, c = t_low.shape
+    L.call("ocr_unpool_add_stats_f16", ptr(t_low), c_int(n), c_int(lh), c_int(lw), c_int(c), ptr(y), ptr(partial), _st())
 
 
 def sc_sigmoid(z, out):

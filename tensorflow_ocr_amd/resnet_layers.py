@@ -23,6 +23,7 @@ FUSE_FWD = __import__("os").environ.get("OCR_RESNET_FUSE_FWD", "1") == "1"     #
 FUSE_BWD = __import__("os").environ.get("OCR_RESNET_FUSE_BWD", "1") == "1"     # conv3's BN-backward apply inside its input-gradient conv
 FUSE_ROOT_POOL = __import__("os").environ.get("OCR_RESNET_FUSE_ROOT_POOL", "1") == "1"   # root conv: BN + ReLU inside the max-pool that follows
 FUSE_ROOT_WGRAD = __import__("os").environ.get("OCR_RESNET_FUSE_ROOT_WGRAD", "1") == "1"   # root conv: BN-backward apply inside its weight gradient
+FUSE_ROOT_GATHER = __import__("os").environ.get("OCR_RESNET_FUSE_ROOT_GATHER", "1") == "1"   # ... and the pool's backward inside that BN's reduction pass
 MASK_BITS = __import__("os").environ.get("OCR_RESNET_MASK_BITS", "0") == "1"   # tail mask as bits instead of the output tensor: measured SLOWER (byte stores +8 % on the writers, byte loads no faster in the latency-bound tail epilogue), off
 
 
@@ -276,10 +277,24 @@ def root_block(g, x4, scope="conv1", cout=64, is_training=True):
         # relu(bn(y)) per window element (layers.max_pool2d) and the 64-channel half-resolution activation is never written
         a.deferred = fill
         a.bn_fwd = (y, scale, shift, True)
+        a.takes_pool_grad = FUSE_ROOT_WGRAD and FUSE_ROOT_GATHER
     else:
         fill()
 
     def backward():
+        if a.pool_grad is not None and a.grad is None:
+            # the pool was the only contributor: its backward (the gather of the routed gradient) and this layer's BN
+            # reduction are one pass — the gradient is summed while it is written for the weight gradient
+            coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
+            da = g.empty(y.shape)
+            ops.bn_relu_bwd_reduce_pooled(y, scale, shift, mean, invstd, a.pool_grad, True, da, gamma.grad, beta.grad, coef, ws)
+            ops.conv2d_stem_wgrad_bn(x4.data, da, y, shift, coef, True, wv.grad, ws)
+            a.pool_grad = None
+            return
+        if a.pool_grad is not None:              # somebody else contributed as well: materialise the pool's share
+            dap, argmax, pk, ps, pads = a.pool_grad
+            ops.maxpool_bwd(a._data, dap, pk, ps, pads, a.grad, True, argmax=argmax, in_shape=a.shape)
+            a.pool_grad = None
         if a.grad is None:
             return
         if FUSE_ROOT_WGRAD:
@@ -521,6 +536,106 @@ def concat_conv_bn_relu(g, xa, xb, cout, scope, is_training=True):
                     flags = CONV_ACCUM_F16
                 dg = ops.ConvDesc(n, h, w, cout, h, w, c, 1, 1, 1, 1, 0, 0, 1, flags)
                 ops.conv2d(dg, dy, w_ck, x.grad, None, None)
+        a.grad = None
+    g.record(backward, (wv, gamma, beta))
+    return a
+
+
+MERGE_HEADS = __import__("os").environ.get("OCR_RESNET_MERGE_HEADS", "1") == "1"   # F_score + geo_map: one pass over the feature
+
+
+def sigmoid_heads(g, feat, couts, scopes):
+    """The two sigmoid heads on the merge branch's output (nets/model_vgg_16.py:129-131: F_score = conv1x1 -> 1,
+    geo_map = conv1x1 -> 8, both sigmoid, biases, no normaliser) as ONE merged 1x1 convolution over the feature
+    (layers.head_conv_bias: variable `<scope0>+<scope1>/weights` [cin, 1+8], split back into the reference's two by
+    checkpoint.internal_to_tf) — one pass over the 105 MB feature for the forward, the weight gradient and the input
+    gradient instead of two each.  Returns the two activation handles."""
+    from .layers import SmallAct, head_conv_bias
+    if g.precision == "f32" or not MERGE_HEADS:
+        return tuple(sigmoid_head(g, feat, c, s) for c, s in zip(couts, scopes))
+    z, _, _ = head_conv_bias(g, feat, tuple(scopes), tuple(couts))
+    n, h, w, _ = z.data.shape
+    o0 = SmallAct(g.empty((n, h, w, couts[0]), F32))
+    o1 = SmallAct(g.empty((n, h, w, couts[1]), F32))
+    ops.sc_sigmoid_split(z.data, couts[0], o0.data, o1.data)
+
+    def backward():
+        if o0.grad is None and o1.grad is None:
+            return
+        z.grad = g.empty(z.data.shape, F32)
+        ops.sc_sigmoid_split_bwd(o0.data, o0.grad, o1.data, o1.grad, z.grad)
+        o0.grad = o1.grad = None
+    g.record(backward)
+    return o0, o1
+
+
+MERGE_REORDER = __import__("os").environ.get("OCR_RESNET_MERGE_REORDER", "1") == "1"   # 1x1 merge conv before the upsample
+
+
+def unpool_concat_conv_bn_relu(g, lo, xb, cout, scope, is_training=True):
+    """slim.conv2d(tf.concat([unpool(lo), xb], axis=-1), cout, 1) + BN + ReLU (nets/model_vgg_16.py:118-121) with the
+    upsampled branch's share of the convolution taken BEFORE the resize: conv(unpool(lo), Wa) = unpool(conv(lo, Wa)) —
+    a 1x1 convolution mixes channels, the bilinear resize mixes positions — so that share runs on a quarter of the pixels
+    and the upsampled tensor (2048 channels at 40^2, 419 MB at 64 x 640^2) and its gradient are never written.
+    y = conv(xb, Wb) + unpool(conv(lo, Wa)); ONE variable `<scope>/weights` [1,1,ca+cb,cout], channel order of the
+    reference's concat (upsampled branch first)."""
+    if g.precision == "f32" or not MERGE_REORDER:
+        return concat_conv_bn_relu(g, unpool(g, lo), xb, cout, scope, is_training=is_training)
+    n, lh, lw, ca = lo.shape
+    _, h, w, cb = xb.shape
+    assert (h, w) == (2 * lh, 2 * lw)
+    with g.variable_scope(scope):
+        wv = g.get_variable("weights", (1, 1, ca + cb, cout), variance_scaling(g.rng), regularized=True)
+        gamma, beta, mm, mv = _bn_vars(g, cout)
+    ws = g.workspace()
+
+    def mk(old):
+        if old is None:
+            old = [g.empty((1, cout, ca)), g.empty((1, ca, cout)), g.empty((1, cout, cb)), g.empty((1, cb, cout))]
+        ops.pack_weights(wv.data[:, :, :ca, :], old[0], old[1])
+        ops.pack_weights(wv.data[:, :, ca:, :], old[2], old[3])
+        return old
+    wa_kc, wa_ck, wb_kc, wb_ck = g.packed(wv, "cat", mk)
+    da = ops.conv_desc((n, lh, lw, ca), cout, 1, 1)
+    db = ops.conv_desc((n, h, w, cb), cout, 1, 1)
+    t = g.empty((n, lh, lw, cout))
+    y = g.empty((n, h, w, cout))
+    da.flags = 0
+    ops.conv2d(da, lo.data, wa_kc, t, None, None)
+    db.flags = 0
+    ops.conv2d(db, xb.data, wb_kc, y, None, None)
+    T = ops.channel_stats_num_partials(n * h * w, cout)
+    part, stage = g.ws_small.two(T * 2 * cout * 4, ops.bn_reduce_workspace(T, cout))
+    ops.unpool_add_stats(t, y, part if is_training else None)
+    scale, shift = g.empty((cout,), F32), g.empty((cout,), F32)
+    mean, invstd = g.empty((cout,), F32), g.empty((cout,), F32)
+    if is_training:
+        ops.bn_finalize(part, T, cout, float(n) * h * w, gamma.data, beta.data, BN_EPS, BN_DECAY, mm.data,
+                        mv.data, scale, shift, mean, invstd, stage)
+    else:
+        ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
+    a = Act(g.empty(y.shape), name=scope)
+    ops.bn_relu(y, scale, shift, True, 0, a.data, None)
+
+    def backward():
+        if a.grad is None:
+            return
+        dy = g.empty(y.shape)
+        ops.bn_relu_bwd(y, scale, shift, mean, invstd, a.grad, None, True, 0, gamma.grad, beta.grad, dy, ws)
+        dt = g.empty(t.shape)
+        ops.unpool_bwd_f16(dy, dt, False)                # gradient of conv(lo, Wa): the resize's transpose on cout channels
+        for x, c, w_ck, sl, d_out, (hh, ww) in ((lo, ca, wa_ck, slice(0, ca), dt, (lh, lw)),
+                                                (xb, cb, wb_ck, slice(ca, ca + cb), dy, (h, w))):
+            dd = ops.conv_desc((n, hh, ww, c), cout, 1, 1)
+            ops.conv2d_wgrad(dd, x.data, d_out, wv.grad[:, :, sl, :], g.ws_wgrad)
+            if x.requires_grad:
+                flags = 0
+                if x.grad is None:
+                    x.grad = g.empty(x.shape)
+                else:
+                    flags = CONV_ACCUM_F16
+                dg = ops.ConvDesc(n, hh, ww, cout, hh, ww, c, 1, 1, 1, 1, 0, 0, 1, flags)
+                ops.conv2d(dg, d_out, w_ck, x.grad, None, None)
         a.grad = None
     g.record(backward, (wv, gamma, beta))
     return a

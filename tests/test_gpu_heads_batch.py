@@ -282,3 +282,123 @@ def test_whole_step_batched_heads_vs_per_map_heads(device, net, monkeypatch):
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
     assert cos > 0.9999, cos
     assert float((ga - gb).norm() / gb.norm()) < 2e-2
+
+
+@pytest.mark.parametrize("P,cin,C", [(1, 32, 9), (77, 32, 9), (4097, 32, 1), (200000, 32, 9), (5000, 64, 18), (3001, 16, 8), (130, 8, 2)])
+def test_small_wgrad_on_narrow_maps(device, P, cin, C):
+    """ocr_conv1x1_small_wgrad_f16 on cin = 8..64 (conv1x1_small_wgrad_narrow_kernel: x in 16-byte chunks, dz in f32)
+    against x^T dz in float64."""
+    from tensorflow_ocr_amd import ops
+    from tensorflow_ocr_amd.graph import F16
+    g = _g(device)
+    g.workspace()
+    rng = np.random.default_rng(P + cin + C)
+    x = _feat(rng, P, cin, device, F16)
+    dz = torch.from_numpy(rng.standard_normal((P, C)).astype(np.float32)).to(device)
+    dw = torch.full((cin, C), float("nan"), dtype=F32, device=device)
+    ops.conv1x1_small_wgrad(x, dz, C, dw, g.ws)
+    torch.cuda.synchronize()
+    want = x.double().cpu().numpy().T @ dz.double().cpu().numpy()
+    got = dw.cpu().numpy()
+    scale = np.abs(want).max() + 1e-30
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-5 * scale * max(1.0, np.sqrt(P / 1000.0)), np.abs(got - want).max() / scale
+
+
+def test_sigmoid_split_and_its_gradient(device):
+    from tensorflow_ocr_amd import ops
+    rng = np.random.default_rng(31)
+    P, C, c0 = 1237, 9, 1
+    z = torch.from_numpy(rng.standard_normal((P, C)).astype(np.float32) * 3).to(device)
+    o0 = torch.empty((P, c0), dtype=F32, device=device)
+    o1 = torch.empty((P, C - c0), dtype=F32, device=device)
+    ops.sc_sigmoid_split(z, c0, o0, o1)
+    ref = torch.empty_like(z)
+    ops.sc_sigmoid(z, ref)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, ref[:, :c0]) and torch.equal(o1, ref[:, c0:])
+    d0 = torch.from_numpy(rng.standard_normal((P, c0)).astype(np.float32)).to(device)
+    d1 = torch.from_numpy(rng.standard_normal((P, C - c0)).astype(np.float32)).to(device)
+    dz = torch.empty_like(z)
+    ops.sc_sigmoid_split_bwd(o0, d0, o1, d1, dz)
+    want = torch.empty_like(z)
+    ops.sc_sigmoid_bwd(ref, torch.cat([d0, d1], 1).contiguous(), want)
+    torch.cuda.synchronize()
+    assert torch.equal(dz, want)
+    ops.sc_sigmoid_split_bwd(o0, None, o1, d1, dz)            # a head nobody differentiated: zero gradient
+    torch.cuda.synchronize()
+    assert float(dz[:, :c0].abs().max()) == 0.0 and torch.equal(dz[:, c0:], want[:, c0:])
+
+
+def test_merged_sigmoid_heads_equal_the_two_heads(device):
+    """resnet_layers.sigmoid_heads (one merged 1x1 convolution for F_score + geo_map) against two sigmoid_head calls with
+    the same weights: activations bit for bit (same kernel, same per-output arithmetic), gradients to f32 summation order."""
+    from tensorflow_ocr_amd import checkpoint, resnet_layers as R
+    from tensorflow_ocr_amd.graph import Act, F16, Graph
+    rng = np.random.default_rng(32)
+    n, h, w, cin = 2, 24, 40, 32
+    feat_v = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    tf_sd = {"a/weights": rng.standard_normal((1, 1, cin, 1)).astype(np.float32) * 0.2, "a/biases": rng.standard_normal(1).astype(np.float32),
+             "b/weights": rng.standard_normal((1, 1, cin, 8)).astype(np.float32) * 0.2, "b/biases": rng.standard_normal(8).astype(np.float32)}
+    d0 = rng.standard_normal((n, h, w, 1)).astype(np.float32)
+    d1 = rng.standard_normal((n, h, w, 8)).astype(np.float32)
+
+    def run(merge):
+        old = R.MERGE_HEADS
+        R.MERGE_HEADS = merge
+        try:
+            g = Graph(device, loss_scale=1.0)
+            mk = lambda: Act(torch.from_numpy(feat_v).to(device).to(F16))
+            R.sigmoid_heads(g, mk(), (1, 8), ("a", "b"))
+            g.reset_tape()
+            g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, tf_sd))
+            feat = mk()
+            o0, o1 = R.sigmoid_heads(g, feat, (1, 8), ("a", "b"))
+            o0.grad = torch.from_numpy(d0).to(device)
+            o1.grad = torch.from_numpy(d1).to(device)
+            g.backward()
+            torch.cuda.synchronize()
+            grads = checkpoint.internal_to_tf({k: v.grad.cpu().numpy() for k, v in g.store.vars.items() if v.trainable})
+            return o0.data.clone(), o1.data.clone(), feat.grad.float().cpu().numpy(), grads
+        finally:
+            R.MERGE_HEADS = old
+    m0, m1, mdx, mg = run(True)
+    s0, s1, sdx, sg = run(False)
+    assert torch.equal(m0, s0) and torch.equal(m1, s1)
+    assert np.abs(mdx - sdx).max() <= 2e-3 * np.abs(sdx).max()
+    assert set(mg) == set(sg) == set(tf_sd)
+    for k in sg:
+        assert mg[k].shape == tf_sd[k].shape               # the merged variable splits back into the reference's two
+        ref = sg[k].reshape(tf_sd[k].shape)
+        assert np.abs(mg[k] - ref).max() <= 2e-3 * (np.abs(ref).max() + 1e-30), k
+
+
+@pytest.mark.parametrize("pc,G,P", [(1, 1, 2 * 37 * 41), (1, 1, 300000), (2, 2, 5000), (2, 1, 777)])
+def test_dice_loss_kernels_against_the_oracle(device, pc, G, P):
+    """ocr_dice_loss_fwd / _bwd (the vector forms for pc = G = 1 and pc = G = 2, the scalar form otherwise) against the
+    oracle's dice loss (nets/model_vgg_16.py:179-225) and its autograd gradient."""
+    from oracle import ocr_oracle as O
+    from tensorflow_ocr_amd import ops
+    g = _g(device)
+    g.workspace()
+    rng = np.random.default_rng(pc * 10 + G + P)
+    ytp = (rng.uniform(size=(1, P, 1, 1)) > 0.7).astype(np.float32)
+    ytl = (rng.uniform(size=(1, P, 1, 8)) > 0.6).astype(np.float32)
+    m = (rng.uniform(size=(1, P, 1, 1)) > 0.1).astype(np.float32)
+    ypp = rng.uniform(size=(1, P, 1, pc)).astype(np.float32)
+    ypl = rng.uniform(size=(1, P, 1, 8 * G)).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(device)
+    sums = torch.zeros(27, dtype=F32, device=device)
+    loss = torch.zeros(10, dtype=F32, device=device)
+    ops.dice_loss_fwd(d(ytp), d(ypp), d(ytl), d(ypl), d(m), sums, loss, g.ws)
+    dpp = torch.full((P, pc), float("nan"), dtype=F32, device=device)
+    dpl = torch.full((P, 8 * G), float("nan"), dtype=F32, device=device)
+    ops.dice_loss_bwd(d(ytp), d(ytl), d(m), sums, 3.0, dpp, dpl)
+    torch.cuda.synchronize()
+    tp_, tl_ = torch.from_numpy(ypp).requires_grad_(), torch.from_numpy(ypl).requires_grad_()
+    want = O.dice_loss(torch.from_numpy(ytp), tp_, torch.from_numpy(ytl), tl_, torch.from_numpy(m))
+    (want * 3.0).backward()
+    assert abs(float(loss[0]) - float(want)) < 2e-5
+    for got, ref in ((dpp, tp_.grad.reshape(P, pc)), (dpl, tl_.grad.reshape(P, 8 * G))):
+        ref = ref.numpy()
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-12

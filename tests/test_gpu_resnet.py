@@ -432,3 +432,118 @@ def test_root_block_and_pool_deferred_activation(device):
     assert torch.equal(of, ou)
     for k in gf:
         assert torch.equal(gf[k], gu[k]), k
+
+
+@pytest.mark.parametrize("k,stride", [(3, 2), (2, 2), (3, 1)])
+def test_root_backward_gathers_the_pool_gradient(device, k, stride):
+    """ocr_bn_relu_bwd_reduce_pooled_f16 (max-pool backward + BN reduction in one pass) against ocr_maxpool_bwd_f16 ->
+    ocr_bn_relu_bwd_reduce_f16: the gathered gradient, dgamma, dbeta and the apply coefficients bit for bit."""
+    from tensorflow_ocr_amd import ops
+    from tensorflow_ocr_amd.graph import F32
+    rng = np.random.default_rng(11)
+    n, oh, ow, c = 2, 23, 37, 64
+    dev = device
+    y = torch.from_numpy(rng.standard_normal((n, oh, ow, c)).astype(np.float32)).to(O.STORAGE).to(dev)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).to(dev)
+    shift = torch.from_numpy(rng.uniform(-0.3, 0.3, c).astype(np.float32)).to(dev)
+    mean = torch.from_numpy(rng.uniform(-0.2, 0.2, c).astype(np.float32)).to(dev)
+    invstd = torch.from_numpy(rng.uniform(0.8, 1.2, c).astype(np.float32)).to(dev)
+    ph, pt = ops.same_pad(oh, k, stride)
+    pw, pl = ops.same_pad(ow, k, stride)
+    pooled = torch.empty((n, ph, pw, c), dtype=O.STORAGE, device=dev)
+    argmax = torch.empty((n, ph, pw, c), dtype=torch.uint8, device=dev)
+    ops.bn_relu_maxpool(y, scale, shift, True, k, stride, (pt, pl), pooled, argmax)
+    dap = torch.from_numpy((rng.standard_normal((n, ph, pw, c)) * 0.1).astype(np.float32)).to(O.STORAGE).to(dev)
+    ws = ops.Workspace(dev, 64 << 20)
+
+    def outs():
+        return ([torch.zeros(c, dtype=F32, device=dev) for _ in range(2)],
+                tuple(torch.zeros(c, dtype=F32, device=dev) for _ in range(3)))
+    (dg0, db0), coef0 = outs()
+    da0 = torch.empty((n, oh, ow, c), dtype=O.STORAGE, device=dev)
+    ops.maxpool_bwd(y, dap, k, stride, (pt, pl), da0, False, argmax=argmax, in_shape=(n, oh, ow, c))
+    ops.bn_relu_bwd_reduce(y, scale, shift, mean, invstd, da0, True, dg0, db0, coef0, ws)
+    (dg1, db1), coef1 = outs()
+    da1 = torch.zeros_like(da0)
+    pg = (dap, argmax, k, stride, (pt, pl))
+    ops.bn_relu_bwd_reduce_pooled(y, scale, shift, mean, invstd, pg, True, da1, dg1, db1, coef1, ws)
+    (dg2, db2), coef2 = outs()
+    ops.bn_relu_bwd_reduce_pooled(y, scale, shift, mean, invstd, pg, True, None, dg2, db2, coef2, ws)    # sums only
+    torch.cuda.synchronize()
+    assert float(da0.float().abs().max()) > 0 and float(dg0.abs().max()) > 0
+    assert torch.equal(da0, da1)
+    for d, b_, cf in ((dg1, db1, coef1), (dg2, db2, coef2)):
+        assert torch.equal(dg0, d) and torch.equal(db0, b_)
+        for a, b in zip(coef0, cf):
+            assert torch.equal(a, b)
+
+
+def test_unpool_add_stats(device):
+    """ocr_unpool_add_stats_f16: y += unpool(t) + per-channel sums, against unpool (f32, unrounded) + add in torch."""
+    from tensorflow_ocr_amd import ops
+    rng = np.random.default_rng(21)
+    n, lh, lw, c = 3, 7, 11, 32
+    t = torch.from_numpy(rng.standard_normal((n, lh, lw, c)).astype(np.float32)).to(O.STORAGE).to(device)
+    y = torch.from_numpy(rng.standard_normal((n, 2 * lh, 2 * lw, c)).astype(np.float32)).to(O.STORAGE).to(device)
+    tf_ = t.float()
+    rows = torch.stack([tf_, 0.5 * (tf_ + torch.cat([tf_[:, 1:], tf_[:, -1:]], 1))], 2).reshape(n, 2 * lh, lw, c)
+    up = torch.stack([rows, 0.5 * (rows + torch.cat([rows[:, :, 1:], rows[:, :, -1:]], 2))], 3).reshape(n, 2 * lh, 2 * lw, c)
+    u16 = torch.empty_like(y)
+    ops.unpool_f16(t, u16)                                    # (the sampling convention itself: the existing kernel)
+    assert float((u16.float() - up).abs().max()) < 4e-3 * TOL
+    ref = (y.float() + up).to(O.STORAGE)
+    T = ops.channel_stats_num_partials(n * 4 * lh * lw, c)
+    part = torch.zeros((T, 2, c), dtype=torch.float32, device=device)
+    out = y.clone()
+    ops.unpool_add_stats(t, out, part)
+    torch.cuda.synchronize()
+    d = (out.float() - ref.float()).abs()
+    assert float(d.max()) <= 8e-3 * TOL and float((d > 0).float().mean()) < 0.02     # one storage ulp, rarely
+    sums = part.sum(0)
+    of = out.float().reshape(-1, c)
+    assert _rel(sums[0].cpu().numpy(), of.sum(0).cpu().numpy()) < 1e-4
+    assert _rel(sums[1].cpu().numpy(), (of * of).sum(0).cpu().numpy()) < 1e-4
+    out2 = y.clone()
+    ops.unpool_add_stats(t, out2, None)                       # inference form: no partials
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+def test_merge_conv_before_the_resize_equals_the_concat_form(device):
+    """resnet_layers.unpool_concat_conv_bn_relu (the upsampled branch's share of the 1x1 merge convolution taken before the
+    resize) against concat_conv_bn_relu(unpool(lo), xb): output and every gradient, to storage rounding."""
+    from tensorflow_ocr_amd import resnet_layers as R
+    from tensorflow_ocr_amd.graph import Act, Graph
+    rng = np.random.default_rng(22)
+    n, lh, lw, ca, cb, cout = 2, 12, 16, 256, 128, 64
+    lo_v = _h(rng.standard_normal((n, lh, lw, ca)))
+    xb_v = _h(rng.standard_normal((n, 2 * lh, 2 * lw, cb)))
+    gout = _h(rng.standard_normal((n, 2 * lh, 2 * lw, cout)) * 0.1)
+    wts = {"m/weights": _h(rng.standard_normal((1, 1, ca + cb, cout)) * 0.05)}
+
+    def run(reorder):
+        old = R.MERGE_REORDER
+        R.MERGE_REORDER = reorder
+        try:
+            g = Graph(device, loss_scale=1.0)
+            mk = lambda v: Act(torch.from_numpy(v).to(O.STORAGE).to(device))
+            R.unpool_concat_conv_bn_relu(g, mk(lo_v), mk(xb_v), cout, "m")
+            g.reset_tape()
+            sd = {k: v.data.cpu().numpy() for k, v in g.store.vars.items()}
+            sd.update(wts)
+            g.store.load_state_dict(sd)
+            lo, xb = mk(lo_v), mk(xb_v)
+            a = R.unpool_concat_conv_bn_relu(g, lo, xb, cout, "m")
+            a.grad = torch.from_numpy(gout).to(O.STORAGE).to(device)
+            g.backward()
+            torch.cuda.synchronize()
+            out = {"a": a.data.float().cpu().numpy(), "dlo": lo.grad.float().cpu().numpy(), "dxb": xb.grad.float().cpu().numpy()}
+            out.update({k: v.grad.cpu().numpy().copy() for k, v in g.store.vars.items() if v.trainable})
+            return out
+        finally:
+            R.MERGE_REORDER = old
+    new, ref = run(True), run(False)
+    assert np.abs(new["a"] - ref["a"]).max() < 2e-2 * TOL
+    for k in new:
+        if k != "a":
+            assert _rel2(new[k], ref[k]) < 1e-2 * TOL, (k, _rel2(new[k], ref[k]))

@@ -551,7 +551,7 @@ def test_counter_provenance_gates_the_reported_fields(tmp_path, monkeypatch):
 
 def test_design_tables_show_the_committed_profiles(tmp_path):
     """DESIGN.md section 5's per-layer table of the dominant kernel and its per-step kernel table are GENERATED from
-    profiles/r03_* (scripts/design_tables.py): regenerating them changes nothing — the text cannot drift from the
+    this round's profiles/rNN_* (scripts/design_tables.py; NN = bench.PROFILE_ROUND): regenerating them changes nothing — the text cannot drift from the
     committed measurements — and the kernel-name folding puts the epilogue-mode instantiations under one name."""
     import importlib.util
     import shutil
@@ -559,12 +559,15 @@ def test_design_tables_show_the_committed_profiles(tmp_path):
     spec = importlib.util.spec_from_file_location("design_tables", os.path.join(root, "scripts", "design_tables.py"))
     dt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(dt)
+    sys.path.insert(0, root)
+    import bench
+    rnd = bench.PROFILE_ROUND
     before = open(os.path.join(root, "DESIGN.md")).read()
-    for name, text in (("w4_per_layer", dt.w4_table("r03")), ("step_kernels", dt.step_table("r03"))):
+    for name, text in (("w4_per_layer", dt.w4_table(rnd)), ("step_kernels", dt.step_table(rnd))):
         start = before.index("<!-- generated: %s -->\n" % name) + len("<!-- generated: %s -->\n" % name)
         end = before.index("\n<!-- end generated -->", start)
         assert before[start:end] == text, name
-    assert "| `conv3x3_w4_kernel` | 17 |" in dt.step_table("r03")
+    assert "| `conv3x3_w4_kernel` | 17 |" in dt.step_table(rnd)
     sys.path.insert(0, os.path.join(root, "scripts"))
     from pmc_mfma import short
     assert short("_ZN12_GLOBAL__N_117conv3x3_w4_kernelILi2EEEvNS_5ConvPEPKDF16_S3_PKfPDF16_Pf") == "conv3x3_w4_kernel"
