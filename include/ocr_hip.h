@@ -154,10 +154,28 @@ int ocr_conv2d_pw_bnaddrelu_f16(const ocr_conv_desc* d, const void* prev_y, cons
                                 const void* prev_shift, const void* shortcut, const void* sc_scale,
                                 const void* sc_shift, void* x_out, void* mask_bits, const void* w_kc, void* y,
                                 void* stats, void* stream);
+/*  - ocr_conv2d_pw_bnrelu_f16: the input is x = relu(prev_y*prev_scale + prev_shift), the batch norm + ReLU of the
+ *    convolution before it (a bottleneck's conv2 -> conv3, nets/resnet_v1.py:99-105), computed on load with
+ *    ocr_bn_relu_f16's arithmetic and written to x_out for the weight gradient — replaces ocr_bn_relu_f16 +
+ *    ocr_conv2d_f16 and one full read of x.  cin >= 128. */
+int ocr_conv2d_pw_bnrelu_f16(const ocr_conv_desc* d, const void* prev_y, const void* prev_scale, const void* prev_shift,
+                             void* x_out, const void* w_kc, void* y, void* stats, void* stream);
 int ocr_conv2d_pw_bnbwd_bnred_f16(const ocr_conv_desc* d, const void* dz, const void* y_above, const void* coef_a,
                                   const void* coef_b, const void* coef_c, void* dy_out, const void* w_kc, void* dx,
                                   void* partial, const void* bn_y, const void* bn_scale, const void* bn_shift,
                                   const void* bn_mean, const void* bn_invstd, int bn_relu, void* stream);
+/* The same loader in front of the pointwise kernel's OTHER epilogues, and for a batch norm that is followed by a ReLU
+ * (a bottleneck's conv1; the projection shortcut's BN has none): relu_shift (nullable) = that BN's shift, dz is then the
+ * ACTIVATION's gradient and dy = A*(dz * [A*y_above + relu_shift > 0]) + B*y_above + C (A is the BN's scale).  Epilogue:
+ * plain store, accumulate into dx (OCR_CONV_ACCUM_F16 in d->flags), or — bn_y ... sub_grad given as for
+ * ocr_conv2d_bnred_tail_f16 — the bottleneck tail (the gradient past the previous unit's output ReLU + that unit's
+ * BN-backward sums in `partial`); all of them null: no tail, `partial` unused.  Replaces the apply pass
+ * ocr_bn_relu_bwd_apply_f16 in front of ocr_conv2d_bnred_tail_f16 / ocr_conv2d_f16.  cout of the convolution >= 128. */
+int ocr_conv2d_pw_bnbwd_tail_f16(const ocr_conv_desc* d, const void* dz, const void* y_above, const void* coef_a,
+                                 const void* coef_b, const void* coef_c, const void* relu_shift, void* dy_out,
+                                 const void* w_kc, void* dx, void* partial, const void* bn_y, const void* bn_mean,
+                                 const void* bn_invstd, const void* tail_out, const void* tail_mask_bits,
+                                 const void* sub_grad, void* stream);
 
 /* First-layer convolution (cin = 3, images [n,h,w,4] f16 with channel 3 zero,
  * produced by ocr_prep_images): 3x3 stride 1, pad 1.

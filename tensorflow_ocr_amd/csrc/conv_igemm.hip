@@ -500,7 +500,11 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
 //                      `out` receives v, `bits` its ReLU mask (one byte per 8 channels)
 //   MODE 2 (backward): v = half(f0*s0 + f1*s1 + f2) = the batch-norm backward apply dy = A*dz + B*y + C
 //                      (ocr_bn_bwd_coefficients), consumed as the input-gradient GEMM's operand; `out` receives dy
-//                      for the weight gradient that follows.
+//                      for the weight gradient that follows.  PROJ here = the batch norm is followed by a ReLU: s0 is
+//                      the ACTIVATION's gradient and dz = s0 * [s1*f0 + f3 > 0] (f0 = A is the BN's scale, f3 its
+//                      shift: the mask of the stored 16-bit activation, as conv_stem_wgrad_kernel evaluates it).
+//   MODE 3 (forward):  v = half(max(s0*f0 + f2, 0)) = relu(bn(conv2)) — bn_relu_kernel's expression — consumed as conv3's
+//                      input (nets/resnet_v1.py:99-105); `out` receives the activation for the weight gradient.
 // Weights still arrive by LDS-DMA; the pixel rows go global -> registers (requested under the previous stage's
 // MFMAs) -> transform -> ds_write into the same swizzled slots the DMA form fills, so the MFMA loop and the
 // epilogues are conv_pw_kernel's.  The VALU work (60-75 operations per 16-byte chunk) equals what the separate
@@ -545,6 +549,7 @@ __global__ __launch_bounds__(512) void conv_pwx_kernel(
   const int nk = p.cin / 64;
   const bool writer = nt == 0;
   constexpr bool proj = MODE == 1 && PROJ;
+  constexpr bool relu2 = MODE == 2 && PROJ;
 
   f32x4 acc[AI][AT];
 #pragma unroll
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(512) void conv_pwx_kernel(
       if (gp < p.npix) {
         const size_t off = (size_t)gp * p.cin + kc * 64 + cs * 8;
         r0[u] = *reinterpret_cast<const half8_t*>(t.s0 + off);
-        r1[u] = *reinterpret_cast<const half8_t*>(t.s1 + off);
+        if (MODE != 3) r1[u] = *reinterpret_cast<const half8_t*>(t.s1 + off);
       }
     }
   };
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(512) void conv_pwx_kernel(
       *reinterpret_cast<f32x4*>(c1) = *reinterpret_cast<const f32x4*>(coef + p.cin + ch);
       *reinterpret_cast<f32x4*>(c1 + 4) = *reinterpret_cast<const f32x4*>(coef + p.cin + ch + 4);
     }
-    if (proj) {
+    if (proj || relu2) {
       *reinterpret_cast<f32x4*>(c3) = *reinterpret_cast<const f32x4*>(coef + 3 * p.cin + ch);
       *reinterpret_cast<f32x4*>(c3 + 4) = *reinterpret_cast<const f32x4*>(coef + 3 * p.cin + ch + 4);
     }
@@ -614,6 +619,13 @@ __global__ __launch_bounds__(512) void conv_pwx_kernel(
             const float f = z + rv;
             v[e] = (half_t)(f > 0.f ? f : 0.f);
             m |= (f > 0.f && (float)v[e] > 0.f ? 1u : 0u) << e;
+          } else if (MODE == 3) {
+            const float f = __builtin_fmaf((float)r0[u][e], c0[e], c2[e]);
+            v[e] = (half_t)(f > 0.f ? f : 0.f);
+          } else if (relu2) {
+            const float yf = (float)r1[u][e];
+            const float dzf = __builtin_fmaf(yf, c0[e], c3[e]) > OCR_RELU_TIE ? (float)r0[u][e] : 0.f;
+            v[e] = (half_t)__builtin_fmaf(c0[e], dzf, __builtin_fmaf(c1[e], yf, c2[e]));
           } else {
             v[e] = (half_t)__builtin_fmaf(c0[e], (float)r0[u][e], __builtin_fmaf(c1[e], (float)r1[u][e], c2[e]));
           }
@@ -1940,10 +1952,11 @@ int launch_pwx(const ConvP& p, const PwX& t, const void* w, void* y, void* stats
 template <int MODE>
 int dispatch_pwx(ConvP& p, const TileCfg& c, const PwX& t, const void* w, void* y, void* stats, hipStream_t st) {
   if (!p.pw || p.cin < 128) return OCR_ERR_UNSUPPORTED;      // (cin = 64: one stage, nothing to overlap the loads with)
-  if (MODE == 1 && t.f1 != nullptr) {            // the shortcut is a projection: its batch norm is applied too
-    if (c.bn == 256) return launch_pwx<256, 4, MODE, MODE == 1>(p, t, w, y, stats, st);
-    if (c.bn == 128) return launch_pwx<128, 2, MODE, MODE == 1>(p, t, w, y, stats, st);
-    return launch_pwx<64, 1, MODE, MODE == 1>(p, t, w, y, stats, st);
+  if ((MODE == 1 && t.f1 != nullptr) ||          // the shortcut is a projection: its batch norm is applied too
+      (MODE == 2 && t.f3 != nullptr)) {          // the batch norm above is followed by a ReLU: its mask is applied too
+    if (c.bn == 256) return launch_pwx<256, 4, MODE, true>(p, t, w, y, stats, st);
+    if (c.bn == 128) return launch_pwx<128, 2, MODE, true>(p, t, w, y, stats, st);
+    return launch_pwx<64, 1, MODE, true>(p, t, w, y, stats, st);
   }
   if (c.bn == 256) return launch_pwx<256, 4, MODE, false>(p, t, w, y, stats, st);
   if (c.bn == 128) return launch_pwx<128, 2, MODE, false>(p, t, w, y, stats, st);
@@ -2370,6 +2383,24 @@ extern "C" int ocr_conv2d_pw_bnaddrelu_f16(const ocr_conv_desc* d, const void* p
   return dispatch_pwx<1>(p, cfg, t, w_kc, y, stats, static_cast<hipStream_t>(stream));
 }
 
+// 1x1 convolution whose input x = relu(prev_y * prev_scale + prev_shift) — the batch norm + ReLU of the layer before it —
+// is computed while it is loaded and written to x_out (the weight gradient reads it): replaces ocr_bn_relu_f16 +
+// ocr_conv2d_f16 and one full read of x.
+extern "C" int ocr_conv2d_pw_bnrelu_f16(const ocr_conv_desc* d, const void* prev_y, const void* prev_scale,
+                                        const void* prev_shift, void* x_out, const void* w_kc, void* y, void* stats,
+                                        void* stream) {
+  ConvP p;
+  TileCfg cfg;
+  int rc = fill_params(d, &p, &cfg);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(prev_y && prev_scale && prev_shift && x_out && w_kc && y);
+  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_BIAS | OCR_CONV_RELU | OCR_CONV_ACCUM_F16)));
+  OCR_CHECK_ARG(!(d->flags & OCR_CONV_STATS) || stats);
+  PwX t{static_cast<const half_t*>(prev_y), nullptr, static_cast<const float*>(prev_scale), nullptr,
+        static_cast<const float*>(prev_shift), nullptr, static_cast<half_t*>(x_out), nullptr};
+  return dispatch_pwx<3>(p, cfg, t, w_kc, y, stats, static_cast<hipStream_t>(stream));
+}
+
 // Input-gradient 1x1 convolution whose operand is the batch-norm backward apply dy = A*dz + B*bn_y_in + C of the
 // layer above (coefficients: ocr_bn_bwd_coefficients), computed while loading; dy_out receives it (the weight
 // gradient reads it next).  The epilogue carries the fused BN-backward reduction of the layer BELOW as
@@ -2444,4 +2475,43 @@ extern "C" int ocr_conv2d_bnred_tail_f16(const ocr_conv_desc* d, const void* x, 
     magic31((unsigned)d->ow, &p.br.sub_m_w, &p.br.sub_l_w);
   }
   return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
+}
+
+// ocr_conv2d_pw_bnbwd_bnred_f16's loader (the BN-backward apply of the layer ABOVE computed on the operand rows, optionally
+// with that layer's ReLU mask) in front of the other epilogues of the pointwise kernel: plain store, accumulate
+// (OCR_CONV_ACCUM_F16 in d->flags), or the bottleneck tail of ocr_conv2d_bnred_tail_f16 (bn_y ... sub_grad as there; all
+// null: no tail, `partial` unused).
+extern "C" int ocr_conv2d_pw_bnbwd_tail_f16(const ocr_conv_desc* d, const void* dz, const void* y_above, const void* coef_a,
+                                            const void* coef_b, const void* coef_c, const void* relu_shift, void* dy_out,
+                                            const void* w_kc, void* dx, void* partial, const void* bn_y,
+                                            const void* bn_mean, const void* bn_invstd, const void* tail_out,
+                                            const void* tail_mask_bits, const void* sub_grad, void* stream) {
+  ConvP p;
+  TileCfg cfg;
+  int rc = fill_params(d, &p, &cfg);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(dz && y_above && coef_a && coef_b && coef_c && dy_out && w_kc && dx);
+  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_BIAS | OCR_CONV_RELU | OCR_CONV_STATS)));
+  const bool tail = bn_y != nullptr;
+  if (tail) {
+    OCR_CHECK_ARG(partial && bn_mean && bn_invstd && (tail_out || tail_mask_bits));
+    p.flags |= OCR_CONV_STATS;
+    p.br = BnRed{static_cast<const half_t*>(bn_y), nullptr, nullptr, static_cast<const float*>(bn_mean),
+                 static_cast<const float*>(bn_invstd), 0, static_cast<const half_t*>(tail_mask_bits ? nullptr : tail_out)};
+    p.br.mask_bits = static_cast<const unsigned char*>(tail_mask_bits);
+    if (sub_grad != nullptr) {
+      OCR_CHECK_SHAPE((long long)d->n * d->oh * d->ow < (1ll << 31));
+      p.br.sub = static_cast<const half_t*>(sub_grad);
+      p.br.sub_h = d->oh;
+      p.br.sub_w = d->ow;
+      magic31((unsigned)(d->oh * d->ow), &p.br.sub_m_hw, &p.br.sub_l_hw);
+      magic31((unsigned)d->ow, &p.br.sub_m_w, &p.br.sub_l_w);
+    }
+  } else {
+    OCR_CHECK_ARG(!bn_mean && !bn_invstd && !tail_out && !tail_mask_bits && !sub_grad);
+  }
+  PwX t{static_cast<const half_t*>(dz), static_cast<const half_t*>(y_above), static_cast<const float*>(coef_a),
+        static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), static_cast<const float*>(relu_shift),
+        static_cast<half_t*>(dy_out), nullptr};
+  return dispatch_pwx<2>(p, cfg, t, w_kc, dx, tail ? partial : nullptr, static_cast<hipStream_t>(stream));
 }

@@ -184,6 +184,15 @@ def conv2d_pw_bnaddrelu(d, prev_y, prev_scale, prev_shift, shortcut, sc_scale, s
         L.RECORDER.tag_last((conv2d_variant(d).replace("conv_pw_kernel", "conv_pwx_kernel"), flops, "fwd"))
 
 
+def conv2d_pw_bnrelu(d, prev_y, prev_scale, prev_shift, x_out, w_kc, y, stats):
+    """1x1 conv whose input x = relu(bn(prev_y)) is computed while it is loaded and written to x_out."""
+    L.call("ocr_conv2d_pw_bnrelu_f16", byref(d), ptr(prev_y), ptr(prev_scale), ptr(prev_shift), ptr(x_out), ptr(w_kc), ptr(y),
+           ptr(stats), _st())
+    if L.RECORDER is not None:
+        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin
+        L.RECORDER.tag_last((conv2d_variant(d).replace("conv_pw_kernel", "conv_pwx_kernel"), flops, "fwd"))
+
+
 def conv2d_pw_bnbwd_bnred(d, dz, y_above, coef, dy_out, w_kc, dx, partial, bn_ctx):
     """1x1 input-gradient conv whose operand dy = A*dz + B*y_above + C is computed while it is loaded and written to
     dy_out; fused BN-backward reduction of the layer below as in conv2d_bnred."""
@@ -193,6 +202,22 @@ def conv2d_pw_bnbwd_bnred(d, dz, y_above, coef, dy_out, w_kc, dx, partial, bn_ct
     a, b, c = coef
     L.call("ocr_conv2d_pw_bnbwd_bnred_f16", byref(d), ptr(dz), ptr(y_above), ptr(a), ptr(b), ptr(c), ptr(dy_out),
            ptr(w_kc), ptr(dx), ptr(partial), ptr(by), ptr(sc), ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), _st())
+    if L.RECORDER is not None:
+        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin
+        L.RECORDER.tag_last((conv2d_variant(d).replace("conv_pw_kernel", "conv_pwx_kernel"), flops, "dgrad"))
+
+
+def conv2d_pw_bnbwd_tail(d, dz, y_above, coef, relu_shift, dy_out, w_kc, dx, partial=None, tail_ctx=None, sub_grad=None):
+    """conv2d_pw_bnbwd_bnred's loader (+ the ReLU mask of the BN above when relu_shift is given) in front of the plain /
+    accumulating (d.flags) / bottleneck-tail epilogue (tail_ctx, sub_grad as conv2d_bnred_tail)."""
+    a, b, c = coef
+    by = mu = istd = out = bits = None
+    if tail_ctx is not None:
+        by, mu, istd, out = tail_ctx[:4]
+        bits = tail_ctx[4] if len(tail_ctx) > 4 else None
+    L.call("ocr_conv2d_pw_bnbwd_tail_f16", byref(d), ptr(dz), ptr(y_above), ptr(a), ptr(b), ptr(c), ptr(relu_shift),
+           ptr(dy_out), ptr(w_kc), ptr(dx), ptr(partial), ptr(by), ptr(mu), ptr(istd), ptr(out), ptr(bits), ptr(sub_grad),
+           _st())
     if L.RECORDER is not None:
         flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin
         L.RECORDER.tag_last((conv2d_variant(d).replace("conv_pw_kernel", "conv_pwx_kernel"), flops, "dgrad"))

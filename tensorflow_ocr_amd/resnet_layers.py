@@ -21,6 +21,11 @@ FUSE_SUB = __import__("os").environ.get("OCR_RESNET_FUSE_SUB", "1") == "1"     #
 # round 3: the element-wise passes around the 1x1 convolutions applied while those convolutions load their operand
 FUSE_FWD = __import__("os").environ.get("OCR_RESNET_FUSE_FWD", "1") == "1"     # relu(bn(conv3) + shortcut) inside the NEXT 1x1 conv
 FUSE_BWD = __import__("os").environ.get("OCR_RESNET_FUSE_BWD", "1") == "1"     # conv3's BN-backward apply inside its input-gradient conv
+# round 4: the same on-load apply for the BN (+ReLU) above conv1 and above a projection shortcut, in front of the tail epilogue
+# relu(bn(conv2)) inside conv3 (ocr_conv2d_pw_bnrelu_f16): measured NEUTRAL at 64 x 640^2 (stage 2 -7 us per unit, stages 3 / 4
+# +6 / +12: the register-staged loader gives back in the 256 -> 1024 GEMM what the removed pass saved), off; path kept under test
+FUSE_FWD_ACT = __import__("os").environ.get("OCR_RESNET_FUSE_FWD_ACT", "0") == "1"
+FUSE_BWD_WIDE = __import__("os").environ.get("OCR_RESNET_FUSE_BWD_WIDE", "1") == "1"
 FUSE_ROOT_POOL = __import__("os").environ.get("OCR_RESNET_FUSE_ROOT_POOL", "1") == "1"   # root conv: BN + ReLU inside the max-pool that follows
 FUSE_ROOT_WGRAD = __import__("os").environ.get("OCR_RESNET_FUSE_ROOT_WGRAD", "1") == "1"   # root conv: BN-backward apply inside its weight gradient
 FUSE_ROOT_GATHER = __import__("os").environ.get("OCR_RESNET_FUSE_ROOT_GATHER", "1") == "1"   # ... and the pool's backward inside that BN's reduction pass
@@ -111,6 +116,12 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             x.deferred = None
             py, psc, psh, short, ssc, ssh, bits = x.tail_fwd
             ops.conv2d_pw_bnaddrelu(d, py, psc, psh, short, ssc, ssh, x._data, bits, w_fwd, y, part)
+        elif (x.deferred is not None and x.bn_fwd is not None and x.bn_fwd[3] and is_training and FUSE_FWD_ACT
+                and _pw_fusable(d)):
+            # x = relu(bn(conv2)) that nobody has computed yet (conv_bn_act(defer=True)): applied to the operand rows
+            x.deferred = None
+            by, bsc, bsh, _ = x.bn_fwd
+            ops.conv2d_pw_bnrelu(d, by, bsc, bsh, x._data, w_fwd, y, part)
         else:
             ops.conv2d(d, x.data, w_fwd, y, None, part if is_training else None)
     c = ConvBN()
@@ -128,13 +139,32 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
         backward apply A*dz + B*y_bn + C, which the input-gradient convolution computes while loading its operand and
         writes into `dy` for the weight gradient (see `can_fuse_bwd`)."""
         if fused is not None:
-            dz_f, ybn_f, coef_f = fused
-            dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, 1, 1, 1, 1, 0, 0, 1, 0)
-            x.grad = g.empty(x.shape)
+            dz_f, ybn_f, coef_f, relu_shift = fused
+            flags = 0
+            if x.grad is None:
+                x.grad = g.empty(x.shape)
+            else:
+                flags |= CONV_ACCUM_F16
+                x.bn_partial = None
+            last = False
+            if x.pending is not None and owner is not None and owner is x.pending_owner:
+                x.pending -= 1
+                assert x.pending >= 0, "more gradient contributions than the owning unit has consumers"
+                last = x.pending == 0
+            dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, 1, 1, 1, 1, 0, 0, 1, flags)
             Tm = ops.conv2d_num_mtiles(dg)
-            partial = g.empty((Tm, 2, d.cin), F32)
-            ops.conv2d_pw_bnbwd_bnred(dg, dz_f, ybn_f, coef_f, dy, w_dg, x.grad, partial, x.bn_ctx)
-            x.bn_partial = (partial, Tm)
+            if last and x.tail_ctx is not None and FUSE_TAIL:
+                # (as the unfused path below: the last contribution to a bottleneck output's gradient)
+                partial = g.empty((Tm, 2, d.cin), F32)
+                ops.conv2d_pw_bnbwd_tail(dg, dz_f, ybn_f, coef_f, relu_shift, dy, w_dg, x.grad, partial, x.tail_ctx, x.sub_grad)
+                x.sub_grad = None
+                x.tail_partial = (partial, Tm)
+            elif x.bn_ctx is not None and not flags and FUSE_BN_REDUCE and relu_shift is None and x.pending is None:
+                partial = g.empty((Tm, 2, d.cin), F32)
+                ops.conv2d_pw_bnbwd_bnred(dg, dz_f, ybn_f, coef_f, dy, w_dg, x.grad, partial, x.bn_ctx)
+                x.bn_partial = (partial, Tm)
+            else:
+                ops.conv2d_pw_bnbwd_tail(dg, dz_f, ybn_f, coef_f, relu_shift, dy, w_dg, x.grad)
             dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, 1, 1, 1, 1, 0, 0, 0, 0)
             ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad)
             return
@@ -196,11 +226,17 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             x.bn_partial = (partial, Tm)
         else:
             ops.conv2d(dg, dy, w_dg, x.grad, None, None)
-    def can_fuse_bwd():
-        """The fused form of `backward_from`: this is a stride-1 1x1 convolution the pointwise kernel takes, its input is
-        a conv+BN(+ReLU) output nobody else has contributed a gradient to (so the epilogue's fused reduction applies)."""
-        if not (FUSE_BWD and FUSE_BN_REDUCE and k == 1 and not strided and x.requires_grad and x.grad is None
-                and x.bn_ctx is not None and x.pending is None and cout >= 128):
+    def can_fuse_bwd(wide=False):
+        """The fused form of `backward_from`: this is a stride-1 1x1 convolution the pointwise kernel takes.  Default: its
+        input is a conv+BN(+ReLU) output nobody else has contributed a gradient to (the epilogue's fused reduction
+        applies: conv3).  wide: any input — the epilogue is whatever the unfused input-gradient launch would use (plain,
+        accumulate, bottleneck tail): conv1 and the projection shortcut."""
+        if not (FUSE_BWD and k == 1 and not strided and x.requires_grad and cout >= 128):
+            return False
+        if wide:
+            if not FUSE_BWD_WIDE:
+                return False
+        elif not (FUSE_BN_REDUCE and x.grad is None and x.bn_ctx is not None and x.pending is None):
             return False
         dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, 1, 1, 1, 1, 0, 0, 1, 0)
         return _pw_fusable(dg)
@@ -209,15 +245,23 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
     return c
 
 
-def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_training=True, owner=None):
-    """conv + batch_norm + (ReLU | identity) -> Act."""
+def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_training=True, owner=None, defer=False):
+    """conv + batch_norm + (ReLU | identity) -> Act.  defer: the activation is left to its first reader (a 1x1 convolution
+    that applies the batch norm + ReLU while loading — conv_bn_raw — or anyone's `.data`, which runs the plain pass)."""
     if g.precision == "f32":
         from . import layers_f32
         return layers_f32.conv_bn_act(g, x, cout, k, scope, stride=stride, rate=rate, relu=relu,
                                       is_training=is_training)
     c = conv_bn_raw(g, x, cout, k, scope, stride=stride, rate=rate, is_training=is_training, owner=owner)
     a = Act(g.empty(c.y.shape), name=scope)
-    ops.bn_relu(c.y, c.scale, c.shift, relu, 0, a.data, None)
+
+    def fill():
+        ops.bn_relu(c.y, c.scale, c.shift, relu, 0, a._data, None)
+    if defer and is_training and FUSE_FWD_ACT:
+        a.deferred = fill
+        a.bn_fwd = (c.y, c.scale, c.shift, relu)
+    else:
+        fill()
     ws = g.workspace()
     if is_training:
         a.bn_ctx = (c.y, c.scale, c.shift, c.mean, c.invstd, relu)
@@ -226,6 +270,18 @@ def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_trainin
         if a.grad is None:
             return
         dy = g.empty(c.y.shape)
+        if a.bn_partial is not None and c.can_fuse_bwd(wide=True):
+            # the sums are reduced already (the consumer's input-gradient epilogue): finalize them into the apply step's
+            # coefficients and let this layer's own input-gradient convolution apply them (and the ReLU mask) on load
+            part_f, T_f = a.bn_partial
+            n_, h_, w_, c_ = c.y.shape
+            coef = (g.empty((c_,), F32), g.empty((c_,), F32), g.empty((c_,), F32))
+            ops.bn_bwd_coefficients(part_f, T_f, c_, float(n_) * h_ * w_, c.scale, c.mean, c.invstd, c.gamma.grad,
+                                    c.beta.grad, coef, ws)
+            a.bn_partial = None
+            c.backward_from(dy, fused=(a.grad, c.y, coef, c.shift if relu else None))
+            a.grad = None
+            return
         if a.bn_partial is not None:
             part_f, T_f = a.bn_partial
             ops.bn_relu_bwd_apply(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, relu, part_f, T_f,
@@ -358,9 +414,17 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
             if dz is None:
                 return
             dy = g.empty(sc.y.shape)
-            ops.bn_relu_bwd(sc.y, sc.scale, sc.shift, sc.mean, sc.invstd, dz, None, False, 0, sc.gamma.grad,
-                            sc.beta.grad, dy, ws)
-            sc.backward_from(dy)
+            if sc.can_fuse_bwd(wide=True):
+                # reduction pass only; the apply step runs inside the projection's input-gradient convolution
+                c_ = sc.y.shape[-1]
+                coef = (g.empty((c_,), F32), g.empty((c_,), F32), g.empty((c_,), F32))
+                ops.bn_relu_bwd_reduce(sc.y, sc.scale, sc.shift, sc.mean, sc.invstd, dz, False, sc.gamma.grad,
+                                       sc.beta.grad, coef, ws)
+                sc.backward_from(dy, fused=(dz, sc.y, coef, None))
+            else:
+                ops.bn_relu_bwd(sc.y, sc.scale, sc.shift, sc.mean, sc.invstd, dz, None, False, 0, sc.gamma.grad,
+                                sc.beta.grad, dy, ws)
+                sc.backward_from(dy)
             sc_hold["dz"] = None
         g.record(sc_backward, (sc.wv, sc.gamma, sc.beta))
         return Act(sc.y, name="shortcut_raw")
@@ -372,7 +436,7 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
             late = depth == depth_in and stride != 1
             shortcut = None if late else make_shortcut()
             r = conv_bn_act(g, x, depth_bottleneck, 1, "conv1", is_training=is_training, owner=owner)
-            r = conv_bn_act(g, r, depth_bottleneck, 3, "conv2", stride=stride, is_training=is_training)
+            r = conv_bn_act(g, r, depth_bottleneck, 3, "conv2", stride=stride, is_training=is_training, defer=True)
             c3 = conv_bn_raw(g, r, depth, 1, "conv3", is_training=is_training)
             if late and fuse_in and FUSE_TAIL and FUSE_SUB and is_training:
                 # the subsample's gradient is not zero-inserted into a full-size tensor: it waits in
@@ -431,7 +495,7 @@ def bottleneck(g, x, depth, depth_bottleneck, stride, scope, is_training=True):
                 coef = (g.empty((c_,), F32), g.empty((c_,), F32), g.empty((c_,), F32))
                 ops.bn_bwd_coefficients(part_f, T_f, c_, float(n_) * h_ * w_, c3.scale, c3.mean, c3.invstd,
                                         c3.gamma.grad, c3.beta.grad, coef, ws)
-                c3.backward_from(dy, fused=(dz, c3.y, coef))
+                c3.backward_from(dy, fused=(dz, c3.y, coef, None))
             else:
                 ops.bn_relu_bwd_apply(c3.y, c3.scale, c3.shift, c3.mean, c3.invstd, dz, False, part_f, T_f,
                                       c3.gamma.grad, c3.beta.grad, dy, ws)

@@ -291,7 +291,11 @@ def test_bottleneck_tail_fusion_equals_separate_passes(device, monkeypatch):
         monkeypatch.setattr(R, "FUSE_TAIL", mode)
         calls = []
         real = R.ops.conv2d_bnred_tail
+        real_x = R.ops.conv2d_pw_bnbwd_tail
         monkeypatch.setattr(R.ops, "conv2d_bnred_tail", lambda *a, _r=real, _c=calls: (_c.append(1), _r(*a))[1])
+        # (round 4: a >= 128-cout projection's tail launch also applies its BN backward on load: same epilogue)
+        monkeypatch.setattr(R.ops, "conv2d_pw_bnbwd_tail",
+                            lambda *a, _r=real_x, _c=calls: (_c.append(1) if len(a) > 9 and a[9] is not None else None, _r(*a))[1])
         g = Graph(device, seed=7, loss_scale=1.0)
         x = Act(torch.from_numpy(xin).to(device).to(R.ops.F16), name="x")
         u1 = R.bottleneck(g, x, 128, 32, 1, "u1")        # projection shortcut (x is not a bottleneck output)
@@ -305,6 +309,7 @@ def test_bottleneck_tail_fusion_equals_separate_passes(device, monkeypatch):
         g.backward()
         torch.cuda.synchronize()
         monkeypatch.setattr(R.ops, "conv2d_bnred_tail", real)
+        monkeypatch.setattr(R.ops, "conv2d_pw_bnbwd_tail", real_x)
         fused_launches[mode] = len(calls)
         out = {"x.grad": x.grad.float().cpu().numpy()}
         for k, v in g.store.vars.items():
@@ -316,6 +321,92 @@ def test_bottleneck_tail_fusion_equals_separate_passes(device, monkeypatch):
         a, b = res[True][k], res[False][k]
         assert np.isfinite(a).all()
         assert _rel2(a, b) < 2e-3 * TOL, (k, _rel2(a, b))
+
+
+def test_wide_backward_fusion_equals_the_apply_pass(device, monkeypatch):
+    """Round 4: the BN-backward apply (+ ReLU mask) above conv1 and above a projection shortcut computed on load by that
+    convolution's own input-gradient launch, in front of the plain / accumulating / bottleneck-tail epilogue
+    (ocr_conv2d_pw_bnbwd_tail_f16) — against the separate apply pass (OCR_RESNET_FUSE_BWD_WIDE=0): dgamma / dbeta of those
+    batch norms bit for bit (the same reduced sums), every other gradient to one 16-bit rounding of dy."""
+    from tensorflow_ocr_amd import resnet_layers as R
+    from tensorflow_ocr_amd.graph import Act, Graph
+    rng = np.random.default_rng(12)
+    n, hw, cin = 2, 24, 128
+    xin = np.abs(rng.standard_normal((n, hw, hw, cin))).astype(np.float32)
+    g_end = (rng.standard_normal((n, 12, 12, 1024)) * 0.1).astype(np.float32)
+    g_mid = (rng.standard_normal((n, hw, hw, 512)) * 0.1).astype(np.float32)
+    res, kinds = {}, {}
+    for mode in (True, False):
+        monkeypatch.setattr(R, "FUSE_BWD_WIDE", mode)
+        calls = []
+        real_x = R.ops.conv2d_pw_bnbwd_tail
+        monkeypatch.setattr(R.ops, "conv2d_pw_bnbwd_tail",
+                            lambda *a, _r=real_x, _c=calls: (_c.append(("tail" if len(a) > 9 and a[9] is not None else "plain",
+                                                                        a[4] is not None, bool(a[0].flags))), _r(*a))[1])
+        g = Graph(device, seed=9, loss_scale=1.0)
+        x = Act(torch.from_numpy(xin).to(device).to(R.ops.F16), name="x")
+        u1 = R.bottleneck(g, x, 512, 128, 1, "u1")       # projection (x is no bottleneck output): plain + accumulate epilogues
+        u2 = R.bottleneck(g, u1, 512, 128, 1, "u2")      # identity: conv1 (ReLU'd BN above it) completes u1's gradient: tail
+        u3 = R.bottleneck(g, u2, 512, 128, 2, "u3")      # subsampling: its strided conv2 leaves no fused sums -> conv1 unfused
+        u4 = R.bottleneck(g, u3, 1024, 256, 1, "u4")     # projection: conv1 accumulates, the shortcut conv completes u3's gradient
+        u2.grad = torch.from_numpy(g_mid).to(device).to(R.ops.F16)
+        u4.grad = torch.from_numpy(g_end).to(device).to(R.ops.F16)
+        g.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(R.ops, "conv2d_pw_bnbwd_tail", real_x)
+        kinds[mode] = calls
+        out = {"x.grad": x.grad.float().cpu().numpy()}
+        for k, v in g.store.vars.items():
+            if v.trainable:
+                out[k] = v.grad.float().cpu().numpy()
+        res[mode] = out
+    assert kinds[False] == []
+    got = kinds[True]
+    # 3 conv1 launches (ReLU'd BN: relu_shift given) + 2 projection shortcuts (no ReLU); tails: u2.conv1, u4.shortcut
+    assert len(got) == 5 and sum(1 for k, relu, acc in got if relu) == 3, got
+    assert sum(1 for k, relu, acc in got if k == "tail") == 2 and any(acc for k, relu, acc in got), got
+    for k in res[True]:
+        a, b = res[True][k], res[False][k]
+        assert np.isfinite(a).all()
+        if k.endswith("BatchNorm/gamma") or k.endswith("BatchNorm/beta"):
+            if "/conv1/" in k or "/shortcut/" in k:
+                # these sums do not depend on how dy is applied — except through upstream units' dz, which do: the LAST
+                # unit's are exact
+                if k.startswith("u4/"):
+                    assert np.array_equal(a, b), k
+        assert _rel2(a, b) < 4e-3 * TOL, (k, _rel2(a, b))
+
+
+def test_conv2_activation_inside_conv3_equals_the_two_pass_form(device, monkeypatch):
+    """Round 4: relu(bn(conv2)) applied by conv3's loader (ocr_conv2d_pw_bnrelu_f16, bottleneck widths >= 128) — the same
+    16-bit activation, the same GEMM: outputs and every gradient bit for bit against the separate ocr_bn_relu_f16 pass."""
+    from tensorflow_ocr_amd import resnet_layers as R
+    from tensorflow_ocr_amd.graph import Act, Graph
+    rng = np.random.default_rng(13)
+    n, hw, cin = 2, 40, 256
+    xin = np.abs(rng.standard_normal((n, hw, hw, cin))).astype(np.float32)
+    g_end = (rng.standard_normal((n, 20, 20, 512)) * 0.1).astype(np.float32)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(R, "FUSE_FWD_ACT", mode)
+        calls = []
+        real = R.ops.conv2d_pw_bnrelu
+        monkeypatch.setattr(R.ops, "conv2d_pw_bnrelu", lambda *a, _r=real, _c=calls: (_c.append(1), _r(*a))[1])
+        g = Graph(device, seed=5, loss_scale=1.0)
+        x = Act(torch.from_numpy(xin).to(device).to(R.ops.F16), name="x")
+        u1 = R.bottleneck(g, x, 512, 128, 1, "u1")
+        u2 = R.bottleneck(g, u1, 512, 128, 2, "u2")          # strided conv2: its activation is deferred all the same
+        u2.grad = torch.from_numpy(g_end).to(device).to(R.ops.F16)
+        g.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(R.ops, "conv2d_pw_bnrelu", real)
+        assert len(calls) == (2 if mode else 0)
+        out = {"out": u2.data.float().cpu().numpy(), "x.grad": x.grad.float().cpu().numpy()}
+        for k, v in g.store.vars.items():
+            out[k] = (v.grad if v.trainable else v.data).float().cpu().numpy()
+        res[mode] = out
+    for k in res[True]:
+        assert np.array_equal(res[True][k], res[False][k]), k
 
 
 def test_block_output_with_a_foreign_consumer(device):
