@@ -390,6 +390,10 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
   const int frow = lane & 15, fkg = lane >> 4;
 
   int bid = blockIdx.x;
+  // XCD-aware order (see conv_igemm_kernel): the cout tiles of one pixel tile run on ONE XCD, whose L2 then serves the
+  // pixel rows to all of them — dealt round-robin, every XCD fetched every pixel tile (PMC: 256 -> 1024 launches read
+  // 1.9x their operand bytes)
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
   const int nt = bid % p.n_tiles;
   const int mt = bid / p.n_tiles;
   const int co0 = nt * BN;
@@ -541,7 +545,8 @@ __global__ __launch_bounds__(512) void conv_pwx_kernel(
   const int wco = wave % WCO, wpx = wave / WCO;
   const int frow = lane & 15, fkg = lane >> 4;
 
-  const int bid = blockIdx.x;
+  int bid = blockIdx.x;
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);      // see conv_pw_kernel
   const int nt = bid % p.n_tiles;
   const int mt = bid / p.n_tiles;
   const int co0 = nt * BN;
@@ -1900,6 +1905,11 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   }
 }
 
+static bool pw_xcd_swizzle() {
+  static const int on = [] { const char* e = getenv("OCR_XCD_PW"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
 template <int BN, int WCO>
 int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
               hipStream_t st) {
@@ -1920,7 +1930,9 @@ int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, vo
     configured[epi_loads] = true;
   }
   const unsigned m_tiles = (unsigned)((p.npix + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(m_tiles * p.n_tiles), dim3(512), lds, st, p, static_cast<const half_t*>(x),
+  ConvP q = p;
+  q.xcd_swizzle = pw_xcd_swizzle() && p.n_tiles > 1 && (m_tiles * p.n_tiles) % 8 == 0;
+  hipLaunchKernelGGL(kern, dim3(m_tiles * p.n_tiles), dim3(512), lds, st, q, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats));
   return ocr_launch_status();
@@ -1944,7 +1956,9 @@ int launch_pwx(const ConvP& p, const PwX& t, const void* w, void* y, void* stats
     configured = true;
   }
   const unsigned m_tiles = (unsigned)((p.npix + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(m_tiles * p.n_tiles), dim3(512), lds, st, p, t, static_cast<const half_t*>(w),
+  ConvP q = p;
+  q.xcd_swizzle = pw_xcd_swizzle() && p.n_tiles > 1 && (m_tiles * p.n_tiles) % 8 == 0;
+  hipLaunchKernelGGL(kern, dim3(m_tiles * p.n_tiles), dim3(512), lds, st, q, t, static_cast<const half_t*>(w),
                      static_cast<half_t*>(y), static_cast<float*>(stats));
   return ocr_launch_status();
 }
@@ -2165,6 +2179,7 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
   OCR_CHECK_SHAPE(d->cin % 32 == 0 && d->cout % 32 == 0);
   p->pool_out = nullptr;
   p->pool_idx = nullptr;
+  p->xcd_swizzle = 0;
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
   p->kh = d->kh; p->kw = d->kw; p->stride = d->stride; p->dil = d->dilation;

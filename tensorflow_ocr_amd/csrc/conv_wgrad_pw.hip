@@ -35,7 +35,7 @@ __device__ __forceinline__ half8_t tr_pair16(const char* base, int second_off) {
 
 struct PwP {
   int n, h, w, cin, oh, ow, cout, stride, pt, pl, kh, kw, dil;
-  int tiles_x, tiles_y, m_tiles, splits, tiles_per_split, nci, nco;
+  int tiles_x, tiles_y, m_tiles, splits, tiles_per_split, nci, nco, xcd_swizzle;
 };
 
 constexpr int PXS = 64;      // pixels per stage: 2 rows x 32 columns of the output map
@@ -64,6 +64,10 @@ __global__ __launch_bounds__(512) void wgrad_pw_kernel(PwP p, const half_t* __re
   // kh*kw > 1 (dilated convs whose halo is too large for the tap-sweeping kernel): every tap is its
   // own pointwise GEMM on a window of x shifted by the tap offset -- one workgroup per (tap, block)
   int bid = blockIdx.x;
+  // XCD-aware order (conv_igemm.hip): the nci x nco blocks of one pixel range (split) run on ONE XCD, whose L2 serves
+  // the x rows to the nco blocks that share them and the dy rows to the nci blocks — dealt round-robin, each of the
+  // eight L2s fetched both (PMC: 1.5-2x the operand bytes on the 256 x 256-tile launches of ResNet's stages 3-4)
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
   const int ntaps = p.kh * p.kw;
   const int tap = bid % ntaps;
   bid /= ntaps;
@@ -188,6 +192,10 @@ bool pw_plan(const ocr_conv_desc* d, PwP* p, PwCfg* c) {
   if (!(d->kh * d->kw == 1 || (d->dilation > 1 && d->kh * d->kw <= 9))) return false;
   c->cib = d->cin % 256 == 0 ? 256 : d->cin % 128 == 0 ? 128 : 64;
   c->cob = d->cout % 256 == 0 ? 256 : d->cout % 128 == 0 ? 128 : 64;
+  static const int max_tile = [] { const char* e = getenv("OCR_WGRAD_PW_TILE"); return e ? atoi(e) : 256; }();   // dev sweep
+  static const int wgs = [] { const char* e = getenv("OCR_WGRAD_PW_WGS"); return e ? atoi(e) : 256; }();
+  if (c->cib > max_tile) c->cib = max_tile;
+  if (c->cob > max_tile) c->cob = max_tile;
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
   p->stride = d->stride; p->pt = d->pad_top; p->pl = d->pad_left;
@@ -200,7 +208,7 @@ bool pw_plan(const ocr_conv_desc* d, PwP* p, PwCfg* c) {
   const int blocks = p->nci * p->nco * d->kh * d->kw;
   // one resident workgroup per CU, and never a few workgroups over a full round of 256 (fc6: 72 blocks x
   // 4 splits = 288 took two rounds; x 3 = 216 takes one)
-  int want = blocks <= 256 ? 256 / blocks : 1;
+  int want = blocks <= wgs ? wgs / blocks : 1;
   if (want > p->m_tiles) want = p->m_tiles;
   if (want < 1) want = 1;
   p->tiles_per_split = ocr_cdiv(p->m_tiles, want);
@@ -219,7 +227,11 @@ int pw_launch(const PwP& p, const void* x, const void* dy, void* slab, hipStream
       return OCR_ERR_HIP;
     configured = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.splits * p.nci * p.nco * p.kh * p.kw)), dim3(512), lds, st, p,
+  PwP q = p;
+  static const int swz = [] { const char* e = getenv("OCR_XCD_PW"); return e ? atoi(e) : 1; }();
+  const unsigned grid = (unsigned)(p.splits * p.nci * p.nco * p.kh * p.kw);
+  q.xcd_swizzle = swz && p.nci * p.nco * p.kh * p.kw > 1 && grid % 8 == 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, q,
                      static_cast<const half_t*>(x), static_cast<const half_t*>(dy), static_cast<float*>(slab));
   return ocr_launch_status();
 }
