@@ -104,16 +104,27 @@ __device__ __forceinline__ void conv_epilogue_store(char* smem, int flags, half_
         ok = oy < oh && ox < ow;
         return (((size_t)img * oh + oy) * ow + ox) * cout + co0 + c * 8;
       };
+      // BRANCH-FREE requests: an operand this launch does not have is read from a dummy row (element 0 of the output /
+      // the partials) and ignored.  With `if (accum) ... if (tail) ... if (stats) ...` around the loads hipcc emitted a
+      // scalar branch per load and — unable to count the outstanding loads across the paths — `s_waitcnt vmcnt(0)` at
+      // every merge: the "batch" went out one load at a time, each behind the previous one's round trip.
+      const bool has_y = do_stats && br != nullptr && br->y != nullptr;
+      const half_t* dummy = y != nullptr ? y : reinterpret_cast<const half_t*>(stats);
+      const half_t* p_old = accum ? y : dummy;
+      const half_t* p_mk = (tail && !tbits) ? br->mask : dummy;
+      const unsigned char* p_mb = tbits ? br->mask_bits : reinterpret_cast<const unsigned char*>(dummy);
+      const half_t* p_yv = has_y ? br->y : dummy;
+      const size_t m_old = accum ? ~(size_t)0 : 0, m_mk = (tail && !tbits) ? ~(size_t)0 : 0, m_mb = tbits ? ~(size_t)0 : 0,
+                   m_yv = has_y ? ~(size_t)0 : 0;
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         bool ok;
-        const size_t off = pixel(u, ok);
-        if (ok) {
-          if (accum) old[u] = *reinterpret_cast<const half8_t*>(y + off);
-          if (tbits) mb[u] = br->mask_bits[off >> 3];
-          else if (tail) mk[u] = *reinterpret_cast<const half8_t*>(br->mask + off);
-          if (do_stats && br != nullptr) yv[u] = *reinterpret_cast<const half8_t*>(br->y + off);
-        }
+        size_t off = pixel(u, ok);
+        off = ok ? off : 0;
+        old[u] = *reinterpret_cast<const half8_t*>(p_old + (off & m_old));
+        mk[u] = *reinterpret_cast<const half8_t*>(p_mk + (off & m_mk));
+        mb[u] = p_mb[(off >> 3) & m_mb];
+        yv[u] = *reinterpret_cast<const half8_t*>(p_yv + (off & m_yv));
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {

@@ -601,13 +601,9 @@ __global__ __launch_bounds__(512) void conv_pwx_kernel(
     *reinterpret_cast<f32x4*>(c0 + 4) = *reinterpret_cast<const f32x4*>(coef + ch + 4);
     *reinterpret_cast<f32x4*>(c2) = *reinterpret_cast<const f32x4*>(coef + 2 * p.cin + ch);
     *reinterpret_cast<f32x4*>(c2 + 4) = *reinterpret_cast<const f32x4*>(coef + 2 * p.cin + ch + 4);
-    if (MODE == 2 || proj) {
+    if (MODE == 2) {
       *reinterpret_cast<f32x4*>(c1) = *reinterpret_cast<const f32x4*>(coef + p.cin + ch);
       *reinterpret_cast<f32x4*>(c1 + 4) = *reinterpret_cast<const f32x4*>(coef + p.cin + ch + 4);
-    }
-    if (proj || relu2) {
-      *reinterpret_cast<f32x4*>(c3) = *reinterpret_cast<const f32x4*>(coef + 3 * p.cin + ch);
-      *reinterpret_cast<f32x4*>(c3 + 4) = *reinterpret_cast<const f32x4*>(coef + 3 * p.cin + ch + 4);
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
@@ -615,6 +611,19 @@ __global__ __launch_bounds__(512) void conv_pwx_kernel(
       half8_t v;
       if (gp < p.npix) {
         unsigned m = 0;
+        if (proj || relu2) {
+          // the fourth coefficient row is re-read from LDS per row group (the index passes through an opaque register, so
+          // the read is not hoisted): held across the loop next to the other three it pushed this instantiation over the
+          // 256-register file, and the spill's reload sat inside the K loop, on the counter the operand loads wait on
+          int c3i = 3 * p.cin + ch;
+          asm volatile("" : "+v"(c3i));
+          *reinterpret_cast<f32x4*>(c3) = *reinterpret_cast<const f32x4*>(coef + c3i);
+          *reinterpret_cast<f32x4*>(c3 + 4) = *reinterpret_cast<const f32x4*>(coef + c3i + 4);
+          if (proj) {                                     // (the 256-cout projection form: the second row as well)
+            *reinterpret_cast<f32x4*>(c1) = *reinterpret_cast<const f32x4*>(coef + c3i - 2 * p.cin);
+            *reinterpret_cast<f32x4*>(c1 + 4) = *reinterpret_cast<const f32x4*>(coef + c3i - 2 * p.cin + 4);
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           if (MODE == 1) {                    // bn_add_relu_kernel's expression, operation for operation
@@ -699,9 +708,13 @@ __global__ __launch_bounds__(512) void conv_pwx_kernel(
   for (int h = 0; h < BN / EBN; ++h) {
     __syncthreads();
     const bool active = EBN == BN || (wco >> 1) == h;
+    // MODE 2: the descriptor is passed as it stands (all-null = no BN operands: every use is guarded by a flag or a field
+    // test).  With `p.br.y ? &p.br : nullptr` hipcc kept a null-descriptor path beside every operand load of the epilogue
+    // and, unable to count the outstanding loads across the two paths, put `s_waitcnt vmcnt(0)` at each merge: the
+    // batch's loads went out one at a time, each behind the previous one's round trip.
+    const BnRed* brp = MODE == 2 ? &p.br : (p.br.y ? &p.br : nullptr);
     conv_epilogue16<EBN, TCO, TPX, EWCO, NT, EPI_LOADS>(acc, smem, p.flags, nullptr, y, stats, 0, mt, 0, mt, co0 + h * EBN,
-                                             rows, 32, p.cout, EBN < BN ? (wco & 1) : wco, wpx, active,
-                                             p.br.y ? &p.br : nullptr);
+                                             rows, 32, p.cout, EBN < BN ? (wco & 1) : wco, wpx, active, brp);
   }
 }
 
