@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
 // page.  Same epilogue (and batch-norm statistics per 256-pixel tile) as the kernel above.
 __device__ const u32x4 ocr_conv_zero_page[4] = {};
 
-template <int BN, int WCO, bool EPI_LOADS>
+template <int BN, int WCO, bool EPI_LOADS, int NBUF = 2>
 __global__ __launch_bounds__(512) void conv_pw_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
@@ -440,15 +440,21 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
     }
   };
 
-  dma_stage(0, 0);
+  if (NBUF == 2) dma_stage(0, 0);
   int buf = 0;
   for (int kc = 0; kc < nk; ++kc) {
+    if (NBUF == 1) {
+      // ONE stage buffer (48 KB with 128-cout tiles: two workgroups per CU — the other one's MFMAs and stores run under
+      // this one's fetch): the previous stage's readers are done, fetch, wait
+      if (kc > 0) __syncthreads();
+      dma_stage(kc, 0);
+    }
     // after this barrier: stage kc has landed (the explicit vmcnt(0): hipcc does not count an LDS-DMA among the accesses
     // a workgroup barrier waits for — see conv_igemm_kernel), and stage kc-1's readers are done, so the other buffer
     // may be overwritten
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kc + 1 < nk) dma_stage(kc + 1, buf ^ 1);
+    if (NBUF == 2 && kc + 1 < nk) dma_stage(kc + 1, buf ^ 1);
     const char* ab = smem + buf * STAGE + a_lane;
     const char* bb = smem + buf * STAGE + ABYTES + b_lane;
 #pragma unroll
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
             acc[i][t0 + t] = OCR_MFMA_16x16x32(a[i], b[t], acc[i][t0 + t], 0, 0, 0);
       }
     }
-    buf ^= 1;
+    if (NBUF == 2) buf ^= 1;
   }
 
   // epilogue on the flat tile: "row" r of the 8x32 layout = pixels px0 + 32r .. +31
@@ -1666,7 +1672,10 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
 #ifndef C64_ABL
 #define C64_ABL 0      // dev ablations: 1 no halo DMA in the loop, 2 no output stores, 4 no MFMAs, 8 no epilogue at all, 16 no MFMA loop at all
 #endif
-    if ((C64_ABL & 1) == 0 && k + 1 < ntile) dma_tile(k + 1, hb ^ 1);        // lands under this tile's MFMAs
+    // (modes 2 / 4 issue it BEHIND their operand requests below: in front of them hipcc waited for it — vmcnt(0) — before
+    // the first request, i.e. the next tile's halo had to land before this tile's MFMAs could start)
+    constexpr bool kDmaLate = !RECOMP && (EPI == 2 || EPI == 4);
+    if (!kDmaLate && (C64_ABL & 1) == 0 && k + 1 < ntile) dma_tile(k + 1, hb ^ 1);        // lands under this tile's MFMAs
     // the epilogue's global operands of THIS tile, requested ahead of the MFMAs
     half8_t yq[4], oq[4];
     const int oy = tyi * TH + wave;
@@ -1674,13 +1683,21 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int ox = txi * TILE_W + kk * 8 + pg;
-        if (oy < p.oh && ox < p.ow) {
+        if constexpr (!RECOMP && (EPI == 2 || EPI == 4)) {
+          // branch-free (a position outside the map reads element 0 and is ignored below): under `if (inside)` hipcc put
+          // `s_waitcnt vmcnt(0)` in front of each of the four requests — each waited for the halo DMA issued just above
+          // and for the request before it, at the head of every tile
+          const bool inside = oy < p.oh && ox < p.ow;
+          const size_t off = inside ? (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c8 * 8 : 0;
+          yq[kk] = *reinterpret_cast<const half8_t*>(p.br.y + off);
+        } else if (oy < p.oh && ox < p.ow) {
           const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c8 * 8;
           if (!RECOMP && do_stats && has_br) yq[kk] = *reinterpret_cast<const half8_t*>(p.br.y + off);
           if (accum) oq[kk] = *reinterpret_cast<const half8_t*>(y + off);
         }
       }
     }
+    if (kDmaLate && (C64_ABL & 1) == 0 && k + 1 < ntile) dma_tile(k + 1, hb ^ 1);
     // mode 6: the image pixels of this wave's row of the first layer instead — per kernel row ky two adjacent pixels
     // (8 bytes each, 4 channels) per lane, exactly the fragment first_mfma reads from its LDS halo; zero outside
     u32x2 fim[RECOMP ? 3 : 1][2];
@@ -1923,18 +1940,18 @@ static bool pw_xcd_swizzle() {
   return on != 0;
 }
 
-template <int BN, int WCO>
+template <int BN, int WCO, int NBUF = 2>
 int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
               hipStream_t st) {
   // one K stage (cin = 64): nothing to double-buffer
-  const size_t main_bytes = (p.cin == 64 ? 1 : 2) * ((size_t)BN * 128 + 256 * 128);
+  const size_t main_bytes = (p.cin == 64 || NBUF == 1 ? 1 : 2) * ((size_t)BN * 128 + 256 * 128);
   const bool epi_loads = (p.flags & OCR_CONV_ACCUM_F16) != 0 || p.br.y != nullptr;
   // the store-only epilogue takes a 256-cout tile in two halves, the one with global operands in one piece
   const size_t epi_bytes = conv_epilogue_lds(epi_loads ? BN : (BN > 128 ? 128 : BN), 512);
   const size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   // two instantiations: the epilogue with global operands (ACCUM / BN-backward / tail) batches its loads
   // ahead of its stores (conv_epilogue.h) and needs ~40 more registers than the store-only one
-  auto kern = epi_loads ? conv_pw_kernel<BN, WCO, true> : conv_pw_kernel<BN, WCO, false>;
+  auto kern = epi_loads ? conv_pw_kernel<BN, WCO, true, NBUF> : conv_pw_kernel<BN, WCO, false, NBUF>;
   static bool configured[2] = {false, false};
   if (!configured[epi_loads]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2307,6 +2324,12 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     if (split_epi && c.bn == 256 && p.cin == 64 && epi_loads) {
       p.n_tiles = p.cout / 128;
       return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
+    }
+    // dev sweep: 128-cout tiles on ONE stage buffer for store-only launches with up to OCR_PW_SINGLE input channels
+    static const int single = [] { const char* e = getenv("OCR_PW_SINGLE"); return e ? atoi(e) : 0; }();
+    if (single && c.bn >= 128 && !epi_loads && p.cin <= single && p.cin > 64) {
+      p.n_tiles = p.cout / 128;
+      return launch_pw<128, 2, 1>(p, x, w_kc, bias, y, stats, st);
     }
     if (c.bn == 256) return launch_pw<256, 4>(p, x, w_kc, bias, y, stats, st);
     if (c.bn == 128) return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
