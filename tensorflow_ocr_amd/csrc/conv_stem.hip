@@ -16,15 +16,26 @@ struct StemP {
   int n, h, w, oh, ow, cout, tiles_x, tiles_y, m_tiles, flags;
 };
 
+// All of a thread's halo pixels are requested before the first is stored (an out-of-image position reads pixel 0 and is
+// replaced by zero): as a load -> ds_write loop hipcc kept one request in flight per thread, six round trips per tile.
+constexpr int kHaloPerThread = (SHH * SHW + 255) / 256;
 __device__ __forceinline__ void load_halo_stem(const half_t* __restrict__ x4, char* halo, int img,
                                                int h, int w, int iy0, int ix0) {
-  for (int i = threadIdx.x; i < SHH * SHW; i += 256) {
+  u32x2 v[kHaloPerThread];
+  bool inside[kHaloPerThread];
+#pragma unroll
+  for (int j = 0; j < kHaloPerThread; ++j) {
+    const int i = threadIdx.x + 256 * j;
     const int hy = i / SHW, hx = i - hy * SHW;
     const int iy = iy0 + hy, ix = ix0 + hx;
-    u32x2 v = {0u, 0u};
-    if (iy >= 0 && iy < h && ix >= 0 && ix < w)
-      v = *reinterpret_cast<const u32x2*>(x4 + (((size_t)img * h + iy) * w + ix) * 4);
-    *reinterpret_cast<u32x2*>(halo + i * 8) = v;
+    inside[j] = i < SHH * SHW && iy >= 0 && iy < h && ix >= 0 && ix < w;
+    const size_t off = inside[j] ? (((size_t)img * h + iy) * w + ix) * 4 : 0;
+    v[j] = *reinterpret_cast<const u32x2*>(x4 + off);
+  }
+#pragma unroll
+  for (int j = 0; j < kHaloPerThread; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    if (i < SHH * SHW) *reinterpret_cast<u32x2*>(halo + i * 8) = inside[j] ? v[j] : u32x2{0u, 0u};
   }
 }
 
@@ -47,6 +58,17 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemP p, const half_t* _
   const int img = tmp / p.tiles_y;
   const int co0 = nt * 64;
 
+  // the 28 weight fragments of this lane (7 kernel rows x 2 halves x 2 cout tiles, 112 registers) are requested FIRST and
+  // land under the halo fetch: loaded where they are used, each MFMA pair waited for its own fragment (L2 latency x 14)
+  half8_t wa[7][2][2];
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        wa[ky][kh][i] = *reinterpret_cast<const half8_t*>(
+            ws + ((size_t)((ky * 2 + kh) * p.cout + co0 + i * 32 + r)) * 16 + 8 * hh);
   load_halo_stem(x4, halo, img, p.h, p.w, tyi * TILE_H * 2 - 3, txi * TILE_W * 2 - 3);
   __syncthreads();
 
@@ -62,11 +84,6 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemP p, const half_t* _
   for (int ky = 0; ky < 7; ++ky) {
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      half8_t a[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a[i] = *reinterpret_cast<const half8_t*>(
-            ws + ((size_t)((ky * 2 + kh) * p.cout + co0 + i * 32 + r)) * 16 + 8 * hh);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int ty = wave * 2 + t;
@@ -76,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemP p, const half_t* _
         half8_t b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[i][t] = OCR_MFMA_32x32x16(a[i], b, acc[i][t], 0, 0, 0);
+          acc[i][t] = OCR_MFMA_32x32x16(wa[ky][kh][i], b, acc[i][t], 0, 0, 0);
       }
     }
   }
@@ -111,7 +128,7 @@ struct StemBn {
 };
 
 template <bool BNAPPLY>
-__global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemP p, const half_t* __restrict__ x4,
+__global__ __launch_bounds__(256, 2) void conv_stem_wgrad_kernel(StemP p, const half_t* __restrict__ x4,
                                                               const half_t* __restrict__ dy, StemBn bn,
                                                               float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) char halo[SHH * SHW * 8];
@@ -144,31 +161,49 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(StemP p, const hal
     const int tyi = tmp % p.tiles_y;
     const int img = tmp / p.tiles_y;
     __syncthreads();
-    load_halo_stem(x4, halo, img, p.h, p.w, tyi * TILE_H * 2 - 3, txi * TILE_W * 2 - 3);
+    // the tile's dy (and y) rows in two batches of four rows per thread, the halo's requests behind the first: every
+    // request of a batch goes out before the first is used (a position outside the map reads element 0 and is stored
+    // as zero) — under `if (inside)` hipcc waited for each dy / y pair before requesting the next: 8 + 6 round trips per
+    // tile, which is what this kernel's time was.  (All sixteen at once cost the second resident workgroup: 276 registers.)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = u * 256 + tid;
-      const int px = idx >> 3, c = idx & 7;
-      const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (oy < p.oh && ox < p.ow) {
-        const size_t off = (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8;
-        v = *reinterpret_cast<const u32x4*>(dy + off);
-        if (BNAPPLY) {
-          const half8_t g8 = __builtin_bit_cast(half8_t, v);
-          const half8_t y8 = *reinterpret_cast<const half8_t*>(bn.y + off);
-          half8_t o;
+    for (int ub = 0; ub < 8; ub += 4) {
+      u32x4 gv[4];
+      half8_t yv8[4];
+      bool okv[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float yf = (float)y8[e];
-            const bool pass = !bn.relu || __builtin_fmaf(yf, cA[e], cS[e]) > OCR_RELU_TIE;
-            const float dz = pass ? (float)g8[e] : 0.f;
-            o[e] = (half_t)__builtin_fmaf(cA[e], dz, __builtin_fmaf(cB[e], yf, cC[e]));
-          }
-          v = __builtin_bit_cast(u32x4, o);
-        }
+      for (int k = 0; k < 4; ++k) {
+        const int idx = (ub + k) * 256 + tid;
+        const int px = idx >> 3, c = idx & 7;
+        const int oy = tyi * TILE_H + (px >> 5), ox = txi * TILE_W + (px & 31);
+        okv[k] = oy < p.oh && ox < p.ow;
+        const size_t off = okv[k] ? (((size_t)img * p.oh + oy) * p.ow + ox) * p.cout + co0 + c * 8 : 0;
+        gv[k] = *reinterpret_cast<const u32x4*>(dy + off);
+        if (BNAPPLY) yv8[k] = *reinterpret_cast<const half8_t*>(bn.y + off);
       }
-      *reinterpret_cast<u32x4*>(dyt + px * DSTRS + c * 16) = v;
+      if (ub == 0) load_halo_stem(x4, halo, img, p.h, p.w, tyi * TILE_H * 2 - 3, txi * TILE_W * 2 - 3);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = (ub + k) * 256 + tid;
+        const int px = idx >> 3, c = idx & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (okv[k]) {
+          v = gv[k];
+          if (BNAPPLY) {
+            const half8_t g8 = __builtin_bit_cast(half8_t, v);
+            const half8_t y8 = yv8[k];
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float yf = (float)y8[e];
+              const bool pass = !bn.relu || __builtin_fmaf(yf, cA[e], cS[e]) > OCR_RELU_TIE;
+              const float dz = pass ? (float)g8[e] : 0.f;
+              o[e] = (half_t)__builtin_fmaf(cA[e], dz, __builtin_fmaf(cB[e], yf, cC[e]));
+            }
+            v = __builtin_bit_cast(u32x4, o);
+          }
+        }
+        *reinterpret_cast<u32x4*>(dyt + px * DSTRS + c * 16) = v;
+      }
     }
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
