@@ -1034,23 +1034,41 @@ __global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, const 
 // row-major window order) of each window that covers it.
 // same gather, but the arg-max comes from the index tensor the forward pass wrote (one byte per
 // output element): no re-scan of x
+// K, S: the window / stride compiled in (pool_gather.h: branch-free, every window slot's operands requested up front;
+// 32-bit element offsets — the launcher checks the sizes) or 0, 0 for the run-time form.
+template <int K, int S>
 __global__ void maxpool_bwd_idx_kernel(PoolP p, const unsigned char* __restrict__ argmax,
                                        const half_t* __restrict__ dy, half_t* __restrict__ dx,
                                        int accumulate) {
   const int chunks = p.c >> 3;
   const size_t total = (size_t)p.n * p.h * p.w * chunks;
   const PoolGather pg{argmax, dy, p.oh, p.ow, p.k, p.stride, p.pt, p.pl};
+  // the old gradient under `accumulate` is requested like the gather's operands — unconditionally (a dummy row otherwise):
+  // behind a flag branch hipcc would wait for the gather's loads first
+  const half_t* p_old = accumulate ? dx : dy;
+  const size_t m_old = accumulate ? ~(size_t)0 : 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ch = (int)(i % chunks);
-    size_t u = i / chunks;
-    const int ix = (int)(u % p.w);
-    u /= p.w;
-    const int iy = (int)(u % p.h);
-    const int img = (int)(u / p.h);
+    int ch, ix, iy, img;
+    if (K != 0) {                                    // (total < 2^31 here)
+      const unsigned iu = (unsigned)i;
+      const unsigned u0 = iu / (unsigned)chunks;
+      ch = (int)(iu - u0 * (unsigned)chunks);
+      const unsigned t = u0 / (unsigned)p.w;
+      ix = (int)(u0 - t * (unsigned)p.w);
+      img = (int)(t / (unsigned)p.h);
+      iy = (int)(t - (unsigned)img * (unsigned)p.h);
+    } else {
+      ch = (int)(i % chunks);
+      size_t u = i / chunks;
+      ix = (int)(u % p.w);
+      u /= p.w;
+      iy = (int)(u % p.h);
+      img = (int)(u / p.h);
+    }
+    const half8_t old = *reinterpret_cast<const half8_t*>(p_old + ((i * 8) & m_old));
     float g[8];
-    pool_gather8<0, 0>(pg, img, iy, ix, p.c, ch, g);
+    pool_gather8<K, S>(pg, img, iy, ix, p.c, ch, g);
     if (accumulate) {
-      half8_t old = *reinterpret_cast<const half8_t*>(dx + i * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] += (float)old[e];
     }
@@ -1371,7 +1389,14 @@ extern "C" int ocr_maxpool_bwd_f16(const void* x, const void* argmax, const void
   PoolP p{n, h, w, c, oh, ow, k, stride, pad_top, pad_left};
   const size_t total = (size_t)n * h * w * (c / 8);
   if (argmax) {
-    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(stream_grid(total)), dim3(256), 0,
+    const bool small = (long long)n * h * w * c < (1ll << 31) && (long long)n * oh * ow * c < (1ll << 31);
+    auto kern = !small ? maxpool_bwd_idx_kernel<0, 0>
+                : (k == 2 && stride == 2) ? maxpool_bwd_idx_kernel<2, 2>
+                : (k == 3 && stride == 2) ? maxpool_bwd_idx_kernel<3, 2>
+                : (k == 3 && stride == 1) ? maxpool_bwd_idx_kernel<3, 1>
+                : (k == 1 && stride == 2) ? maxpool_bwd_idx_kernel<1, 2>
+                                          : maxpool_bwd_idx_kernel<0, 0>;
+    hipLaunchKernelGGL(kern, dim3(stream_grid(total)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), p, static_cast<const unsigned char*>(argmax),
                        static_cast<const half_t*>(dy), static_cast<half_t*>(dx), accumulate);
     return ocr_launch_status();
