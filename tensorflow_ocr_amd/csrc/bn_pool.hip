@@ -958,9 +958,9 @@ struct PoolP {
 // BN: x is a RAW conv output and every window element is relu(x*scale + shift) rounded to 16 bits first — what
 // bn_relu_kernel would have stored (same expression, bn_act8) — so that activation is never written when the pool is its
 // only reader (ResNet root: conv1 -> BN -> ReLU -> 3x3/2 max-pool, nets/resnet_v1.py:193-194).
-// K3: the 3 x 3 window compiled in — its nine rows are requested up front (a tap outside the map reads the image's first
-// row and is skipped) instead of one dependent load per tap behind a bounds branch.
-template <bool BN, bool K3 = false>
+// KK = 2 | 3: the window compiled in — its rows are requested up front (a tap outside the map reads the image's first
+// row and is skipped) instead of one dependent load per tap behind a bounds branch; 0: the run-time window.
+template <bool BN, int KK = 0>
 __global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, const float* __restrict__ scale,
                                    const float* __restrict__ shift, int relu, half_t* __restrict__ y,
                                    unsigned char* __restrict__ argmax) {
@@ -982,18 +982,20 @@ __global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, const 
     unsigned long long am = 0xffffffffffffffffull;   // byte e = window position of the FIRST maximum
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
-    half8_t v9[K3 ? 9 : 1];
-    bool ok9[K3 ? 9 : 1];
+    constexpr bool K3 = KK != 0;
+    constexpr int NT = KK ? KK * KK : 1, KD = KK ? KK : 1;
+    half8_t v9[NT];
+    bool ok9[NT];
     if constexpr (K3) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int iy = oy * p.stride + t / 3 - p.pt, ix = ox * p.stride + t % 3 - p.pl;
+      for (int t = 0; t < NT; ++t) {
+        const int iy = oy * p.stride + t / KD - p.pt, ix = ox * p.stride + t % KD - p.pl;
         ok9[t] = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
         const size_t off = ok9[t] ? (((size_t)img * p.h + iy) * p.w + ix) * p.c : (size_t)img * p.h * p.w * p.c;
         v9[t] = *reinterpret_cast<const half8_t*>(x + off + ch * 8);
       }
     }
-    const int kk = K3 ? 3 : p.k;
+    const int kk = K3 ? KD : p.k;
     auto tap = [&](int ky, int kx, half8_t v) __attribute__((always_inline)) {
       if (BN) {
         float f[8];
@@ -1012,8 +1014,8 @@ __global__ void maxpool_fwd_kernel(PoolP p, const half_t* __restrict__ x, const 
     };
     if constexpr (K3) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
-        if (ok9[t]) tap(t / 3, t % 3, v9[t]);
+      for (int t = 0; t < NT; ++t)
+        if (ok9[t]) tap(t / KD, t % KD, v9[t]);
     } else {
       for (int ky = 0; ky < p.k; ++ky)
         for (int kx = 0; kx < p.k; ++kx) {
@@ -1359,7 +1361,7 @@ extern "C" int ocr_maxpool_f16(const void* x, int n, int h, int w, int c, int k,
   OCR_CHECK_SHAPE(c % 8 == 0);
   PoolP p{n, h, w, c, oh, ow, k, stride, pad_top, pad_left};
   const size_t total = (size_t)n * oh * ow * (c / 8);
-  auto kern = k == 3 ? maxpool_fwd_kernel<false, true> : maxpool_fwd_kernel<false, false>;
+  auto kern = k == 3 ? maxpool_fwd_kernel<false, 3> : k == 2 ? maxpool_fwd_kernel<false, 2> : maxpool_fwd_kernel<false, 0>;
   hipLaunchKernelGGL(kern, dim3(stream_grid(total)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(x), (const float*)nullptr,
                      (const float*)nullptr, 0, static_cast<half_t*>(y), static_cast<unsigned char*>(argmax));
@@ -1373,7 +1375,7 @@ extern "C" int ocr_bn_relu_maxpool_f16(const void* bn_y, const void* scale, cons
   OCR_CHECK_SHAPE(c % 8 == 0);
   PoolP p{n, h, w, c, oh, ow, k, stride, pad_top, pad_left};
   const size_t total = (size_t)n * oh * ow * (c / 8);
-  auto kern = k == 3 ? maxpool_fwd_kernel<true, true> : maxpool_fwd_kernel<true, false>;
+  auto kern = k == 3 ? maxpool_fwd_kernel<true, 3> : k == 2 ? maxpool_fwd_kernel<true, 2> : maxpool_fwd_kernel<true, 0>;
   hipLaunchKernelGGL(kern, dim3(stream_grid(total)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, static_cast<const half_t*>(bn_y),
                      static_cast<const float*>(scale), static_cast<const float*>(shift), relu,
