@@ -194,8 +194,10 @@ bool pw_plan(const ocr_conv_desc* d, PwP* p, PwCfg* c) {
   c->cob = d->cout % 256 == 0 ? 256 : d->cout % 128 == 0 ? 128 : 64;
   static const int max_tile = [] { const char* e = getenv("OCR_WGRAD_PW_TILE"); return e ? atoi(e) : 256; }();   // dev sweep
   static const int wgs = [] { const char* e = getenv("OCR_WGRAD_PW_WGS"); return e ? atoi(e) : 256; }();
+  static const int max_cob = [] { const char* e = getenv("OCR_WGRAD_PW_COB"); return e ? atoi(e) : 256; }();
   if (c->cib > max_tile) c->cib = max_tile;
   if (c->cob > max_tile) c->cob = max_tile;
+  if (c->cob > max_cob) c->cob = max_cob;
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
   p->stride = d->stride; p->pt = d->pad_top; p->pl = d->pad_left;
