@@ -56,7 +56,7 @@ __device__ __forceinline__ int wswz(int row, int ck, bool m16) {
   return ck == 64 ? ((row >> 1) & 7) : m16 ? (((row >> 3) & 1) << 1) : ((row >> 2) & 3);
 }
 
-template <int BN, int CK, int WCO, bool M16, int TH>
+template <int BN, int CK, int WCO, bool M16, int TH, int NW = 2>
 __global__ __launch_bounds__(512) void conv_igemm_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y,
@@ -206,7 +206,12 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
           if (off[u] >= 0) *reinterpret_cast<u32x4*>(halo + off[u]) = v[u];
       }
     }
-    dma_w(0, cc, wb);
+    // NW weight slots: the slices of taps 0 .. NW-2 go out now, tap t+NW-1's at tap t (NW = 2: one tap ahead — 32 MFMAs
+    // per wave on the 256 x 32 tiles, less than an L2 round trip: fc6's 144 tap steps per tile each waited for their
+    // slice; NW = 4 requests it three taps ahead)
+#pragma unroll
+    for (int j = 0; j < NW - 1; ++j)
+      if (j < ntaps) dma_w(j, cc, (wb + j) % NW);
     if (prefetch && cc + 1 < nchunks) halo_load(cc + 1);
     for (int tap = 0; tap < ntaps; ++tap) {
       // The weight slice of this tap came by LDS-DMA (dma_w, issued one tap ago; at tap 0 just above, with the NH
@@ -214,14 +219,31 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
       // the accesses a workgroup barrier has to wait for — whether `s_waitcnt vmcnt(0)` appears in front of the barrier
       // depended on what else was outstanding (found in round 4: with one more field in ConvP this kernel's
       // <64,64,2,1,8> instantiation was scheduled differently and read a weight slice that had not landed).
-      if (tap == 0 && prefetch && cc + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (NW == 2) {
+        if (tap == 0 && prefetch && cc + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        // vector-memory operations issued AFTER this tap's slice (they retire in order): the slices of the taps up to
+        // NW-2 ahead (NWLD requests per thread each: BN * CPP is a multiple of the workgroup here) and, for the first
+        // NW-1 taps of a chunk, the next chunk's NH halo requests issued behind the initial slices
+        int later = tap + NW - 2 < ntaps - 1 ? NW - 2 : ntaps - 1 - tap;
+        const int nh = (tap <= NW - 2 && prefetch && cc + 1 < nchunks) ? NH : 0;
+        switch (later * NWLD + nh) {
+          case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          case NWLD: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWLD) : "memory"); break;
+          case 2 * NWLD: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWLD) : "memory"); break;
+          case NH: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory"); break;
+          case NWLD + NH: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWLD + NH) : "memory"); break;
+          case 2 * NWLD + NH: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NWLD + NH) : "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+      }
       // after this barrier: buf[wb] (this tap, and at tap 0 the halo) is visible and
       // buf[wb^1] is free (its readers finished tap-1)
       __syncthreads();
       auto restage = [&]() {
-        // lands under this tap's MFMAs; the next barrier's vmcnt(0) retires it
-        if (tap + 1 < ntaps) dma_w(tap + 1, cc, wb ^ 1);
+        // lands under this tap's (and the next NW-2 taps') MFMAs; retired by the counted wait above
+        if (tap + NW - 1 < ntaps) dma_w(tap + NW - 1, cc, (wb + NW - 1) % NW);
       };
       if constexpr (BN == 128 && !M16) restage();
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -322,7 +344,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
               acc[i][t] = OCR_MFMA_32x32x16(a[i], b[t], acc[i][t], 0, 0, 0);
         }
       }
-      wb ^= 1;
+      wb = NW == 2 ? (wb ^ 1) : (wb + 1) % NW;
     }
   }
 
@@ -2007,14 +2029,26 @@ int dispatch_pwx(ConvP& p, const TileCfg& c, const PwX& t, const void* w, void* 
   return launch_pwx<64, 1, MODE, false>(p, t, w, y, stats, st);
 }
 
-template <int BN, int CK, int WCO, bool M16, int TH>
+template <int BN, int CK, int WCO, bool M16, int TH, int NW = 2>
 int launch_t(const ConvP& p, const void* x, const void* w, const void* bias, void* y,
              void* stats, hipStream_t st) {
-  size_t main_bytes = (size_t)p.halo_bytes + 2 * BN * conv_wrs(CK);
+  if constexpr (NW == 2 && BN == 256 && M16 && TH == 8) {
+    // dev sweep (OCR_IGEMM_RING=3|4): a deeper weight-slot ring for the 256-cout tiles, the slice requested two or three taps
+    // ahead.  Measured on fc6 (144 tap steps of 32 MFMAs per tile) and the strided ResNet convolutions: headline 19.85 ->
+    // 19.96 ms, ResNet 39.31 -> 39.22 — the tap step's cost is not the slice's fetch; default 2.
+    static const int ring = [] { const char* e = getenv("OCR_IGEMM_RING"); return e ? atoi(e) : 2; }();
+    const int taps = p.kh * p.kw;
+    if (ring >= 4 && taps >= 4 && (size_t)p.halo_bytes + 4 * BN * conv_wrs(CK) <= 160 * 1024)
+      return launch_t<BN, CK, WCO, M16, TH, 4>(p, x, w, bias, y, stats, st);
+    if (ring >= 3 && taps >= 3 && (size_t)p.halo_bytes + 3 * BN * conv_wrs(CK) <= 160 * 1024)
+      return launch_t<BN, CK, WCO, M16, TH, 3>(p, x, w, bias, y, stats, st);
+  }
+  size_t main_bytes = (size_t)p.halo_bytes + NW * BN * conv_wrs(CK);
   size_t epi_bytes = conv_epilogue_lds(BN > 128 ? 128 : BN, 512);
   size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (lds > 160 * 1024) return OCR_ERR_UNSUPPORTED;
-  auto kern = conv_igemm_kernel<BN, CK, WCO, M16, TH>;
+  auto kern = conv_igemm_kernel<BN, CK, WCO, M16, TH, NW>;
+  static_assert(NW == 2 || (BN * (CK / 8)) % 512 == 0, "counted waits: every thread issues the same number of requests");
   static size_t configured = 0;
   if (lds > configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
