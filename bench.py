@@ -148,6 +148,7 @@ def counters_from_profiles(dom):
             vals[field] = (j.get(dom) or {}).get("hbm_bytes_per_launch")
         elif field == "mfma_busy":
             vals[field] = (j.get(dom) or {}).get("mfma_busy_frac")
+            vals["mfma_busy_clock_ghz"] = (j.get(dom) or {}).get("clock_ghz")
         else:
             ck = [v["clock_ghz_median"] for k, v in j.items() if k != "_provenance" and v.get("kernel") == dom
                   and v.get("operands") == "random"]
@@ -403,7 +404,13 @@ def main():
                 "launches_per_step": cnt // args.steps, "avg_launch_ms": round(sec / cnt * 1e3, 4),
                 "share_of_step": round(sec / dt, 3), "achieved_alone": alone,
                 "frac_alone": round(alone / MFMA_F16_PEAK_TFLOPS, 4) if alone else None,
-                "clock_ghz": clock, "mfma_busy": mfma_busy, "counters_from": counters_from}
+                "clock_ghz": clock, "mfma_busy": mfma_busy, "mfma_busy_clock_ghz": vals.get("mfma_busy_clock_ghz"),
+                # which clock goes with which counter: mfma_busy is a CYCLE ratio of the PMC pass and
+                # pairs with that pass's own clock (GRBM_GUI_ACTIVE / launch time: mfma_busy_clock_ghz) — frac ~ mfma_busy x
+                # mfma_busy_clock_ghz / 2.4 x (MFMA issue slots filled while busy); clock_ghz is the diagnostic build's
+                # in-kernel s_memrealtime clock of the main loop alone (no prologue / epilogue), a different run
+                "clock_note": "mfma_busy pairs with mfma_busy_clock_ghz (same PMC pass); clock_ghz = in-kernel main-loop clock of the diagnostic build",
+                "counters_from": counters_from}
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
