@@ -27,6 +27,8 @@ SHAPES = [
     (1, 20, 32, 128, 256, 3, 1),     # 256-cout tile, 2 chunks
     (1, 12, 12, 256, 512, 3, 1),
     (1, 12, 12, 64, 128, 3, 6),      # fc6-style dilation (32-channel chunks)
+    (2, 12, 20, 256, 512, 3, 6),     # ... on 256 x 256 weight-gradient tiles: nine pointwise GEMMs by LDS-DMA, ragged rows
+    (3, 9, 37, 512, 256, 1, 1),      # 256 x 256 tiles, odd height and width, several images per split
     (2, 8, 8, 128, 128, 1, 1),       # 1x1: 32x32x16 MFMA path
     (1, 10, 34, 256, 64, 1, 1),
     (1, 8, 8, 512, 1024, 1, 1),
