@@ -250,9 +250,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_batch_kernel(BnBatchTab tab)
     for (int t0 = rl; t0 < it.T; t0 += RL * 8) {
       float v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 8; ++k) {            // (branch-free: a row past the end re-reads row 0 and counts as zero)
         const int t = t0 + RL * k;
-        v[k] = t < it.T ? base[(size_t)t * cols] : 0.f;
+        const float x = base[(size_t)(t < it.T ? t : 0) * cols];
+        v[k] = t < it.T ? x : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc += (double)v[k];

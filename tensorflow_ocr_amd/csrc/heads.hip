@@ -35,12 +35,16 @@ __device__ __forceinline__ void conv1x1_small_group(const half_t* __restrict__ x
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   u32x4 v[4];
+  bool vok[4];
+  // branch-free requests (a row past the end / a chunk past cin reads element 0; it is replaced by zero where the row is
+  // written to LDS, one K step later — a select here would wait for the load): under `if (inside)` hipcc waited for each
+  // of the four loads before requesting the next
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pp = p0 + lrow + 8 * i;
-      v[i] = u32x4{0u, 0u, 0u, 0u};
-      if (pp < P && k0 + lc * 8 < cin) v[i] = *reinterpret_cast<const u32x4*>(x + (size_t)pp * cin + k0 + lc * 8);
+      vok[i] = pp < P && k0 + lc * 8 < cin;
+      v[i] = *reinterpret_cast<const u32x4*>(x + (vok[i] ? (size_t)pp * cin + k0 + lc * 8 : 0));
     }
   };
   fetch(0);
@@ -48,17 +52,26 @@ __device__ __forceinline__ void conv1x1_small_group(const half_t* __restrict__ x
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                        // the previous tile's fragments have been read
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sx + (lrow + 8 * i) * RS + lc * 16) = v[i];
-    if (k0 + 64 < cin) fetch(k0 + 64);                      // the next tile is in flight under this one's MFMAs
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<u32x4*>(sx + (lrow + 8 * i) * RS + lc * 16) = vok[i] ? v[i] : u32x4{0u, 0u, 0u, 0u};
+    // the four weight fragments of this K step, requested together and BEFORE the next tile's rows (loads retire in
+    // order: a request the MFMAs below wait for must not stand behind the prefetch)
+    half8_t a4[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) a4[kk] = *reinterpret_cast<const half8_t*>(wp + (k0 + kk * 16 < cin ? k0 + kk * 16 : 0));
+    fetch(k0 + 64);                                         // the next tile is in flight under this one's MFMAs (past the
+                                                            // last one: four dummy requests — unconditional, so that the
+                                                            // counted waits below know what is outstanding)
+    __builtin_amdgcn_sched_barrier(0);                      // (pinned here: hipcc sank the requests to the next iteration's
+                                                            // ds_write, i.e. every K step waited out its own fetch)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (k0 + kk * 16 < cin) {
-        half8_t a = *reinterpret_cast<const half8_t*>(wp + k0 + kk * 16);
         half8_t b = *reinterpret_cast<const half8_t*>(sx + r * RS + kk * 32 + hh * 16);
-        acc = OCR_MFMA_32x32x16(a, b, acc, 0, 0, 0);
+        acc = OCR_MFMA_32x32x16(a4[kk], b, acc, 0, 0, 0);
       }
     }
   }
@@ -66,10 +79,17 @@ __device__ __forceinline__ void conv1x1_small_group(const half_t* __restrict__ x
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   float* so = reinterpret_cast<float*>(sx);                 // 32 * cout floats <= 4096 B
+  float bv[16];                                             // (all sixteen requested before the first is used)
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
-    if (co < cout) so[r * cout + co] = acc[e] + (bias ? bias[co] : 0.f);
+    const float* bp = bias ? bias : reinterpret_cast<const float*>(w);
+    bv[e] = bp[co < cout ? co : 0];
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
+    if (co < cout) so[r * cout + co] = acc[e] + (bias ? bv[e] : 0.f);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -171,7 +191,9 @@ __device__ __forceinline__ void conv1x1_small_dgrad_group(const float* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int co = ks * 16 + 8 * hh + j;
-      b[ks][j] = (half_t)((ok && co < cout) ? dz[(size_t)p * cout + co] * gscale : 0.f);
+      const bool in = ok && co < cout;                       // (branch-free: see conv1x1_small_group)
+      const float t = dz[in ? (size_t)p * cout + co : 0];
+      b[ks][j] = (half_t)(in ? t * gscale : 0.f);
     }
   for (int c0 = 0; c0 < cin; c0 += 64) {
 #pragma unroll

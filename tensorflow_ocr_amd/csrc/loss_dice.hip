@@ -121,7 +121,8 @@ __global__ __launch_bounds__(1024) void dice_finalize_kernel(const float* __rest
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int t = t0 + 32 * k;
-        v[k] = t < T ? partial[(size_t)t * 27 + j] : 0.f;
+        const float x = partial[(size_t)(t < T ? t : 0) * 27 + j];
+        v[k] = t < T ? x : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) a += (double)v[k];
