@@ -121,6 +121,16 @@ def test_checkpoint_name_mapping_roundtrip():
     back = checkpoint.internal_to_tf(isd)
     for k, v in tf_sd.items():
         assert np.array_equal(back[k], v), k
+    # EAST's two sigmoid heads on the merge branch's output, merged into one variable (round 4): F_score 1 + geo_map 8
+    east = {"feature_fusion/Conv_7/weights": rng.standard_normal((1, 1, 32, 1)).astype(np.float32),
+            "feature_fusion/Conv_8/weights": rng.standard_normal((1, 1, 32, 8)).astype(np.float32),
+            "feature_fusion/Conv_7/biases": rng.standard_normal(1).astype(np.float32),
+            "feature_fusion/Conv_8/biases": rng.standard_normal(8).astype(np.float32)}
+    isd = checkpoint.tf_to_internal(["feature_fusion/Conv_7+Conv_8/weights", "feature_fusion/Conv_7+Conv_8/biases"], east)
+    assert isd["feature_fusion/Conv_7+Conv_8/weights"].shape == (32, 9) and isd["feature_fusion/Conv_7+Conv_8/biases"].shape == (9,)
+    back = checkpoint.internal_to_tf(isd)
+    for k, v in east.items():
+        assert np.array_equal(back[k], v), k
 
 
 def test_bucket_planner_covers_buffer_on_variable_boundaries():
