@@ -287,16 +287,26 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TCO][TPX], char* sme
   const bool has_bias = (flags & OCR_CONV_BIAS) != 0;
   const bool relu = (flags & OCR_CONV_RELU) != 0;
   if (active) {
+  // the wave's bias values, all requested before the first is used (16-byte loads from a dummy row when there is no
+  // bias): loaded group by group under `if (has_bias)` each group waited out its own round trip
+  f32x4 bvv[TCO][4];
+  {
+    const float* bp = has_bias ? bias + co0 : reinterpret_cast<const float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = wco * TCO * 32 + i * 32 + q * 8 + hh * 4;
+        if (has_bias) bvv[i][q] = *reinterpret_cast<const f32x4*>(bp + col);
+        else bvv[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
 #pragma unroll
   for (int i = 0; i < TCO; ++i) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = wco * TCO * 32 + i * 32 + q * 8 + hh * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (has_bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + col + e];
-      }
+      float bv[4] = {bvv[i][q][0], bvv[i][q][1], bvv[i][q][2], bvv[i][q][3]};
 #pragma unroll
       for (int t = 0; t < TPX; ++t) {
         const int px = (wpx * TPX + t) * 32 + r;
@@ -331,14 +341,17 @@ __device__ __forceinline__ void conv_epilogue16(f32x4 (&acc)[TCO * 2][TPX * 2], 
   const bool has_bias = (flags & OCR_CONV_BIAS) != 0;
   const bool relu = (flags & OCR_CONV_RELU) != 0;
   if (active) {
+    f32x4 bvv[TCO * 2];                           // (all of the wave's bias values requested up front: see conv_epilogue)
 #pragma unroll
     for (int i = 0; i < TCO * 2; ++i) {
       const int col = wco * TCO * 32 + i * 16 + g4 * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (has_bias) {
+      if (has_bias) bvv[i] = *reinterpret_cast<const f32x4*>(bias + co0 + col);
+      else bvv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = bias[co0 + col + e];
-      }
+    for (int i = 0; i < TCO * 2; ++i) {
+      const int col = wco * TCO * 32 + i * 16 + g4 * 4;
+      float bv[4] = {bvv[i][0], bvv[i][1], bvv[i][2], bvv[i][3]};
 #pragma unroll
       for (int t = 0; t < TPX * 2; ++t) {
         const int px = wpx * TPX * 32 + t * 16 + r;
