@@ -24,9 +24,9 @@ extern "C" {
 
 /* Bumped whenever an exported entry point changes its argument list (round 3 added arguments to
  * ocr_conv2d_bnred_f16, ocr_conv2d_bnred_tail_f16, ocr_bn_add_relu_f16, ocr_bn_relu_pool_idx_f16; round 4: the
- * batched head entry points and the seed-rank argument of ocr_link_cc_directed).  The Python host refuses a
+ * batched head entry points and the seed-rank argument of ocr_link_cc_directed; round 5: the guest kernels).  The Python host refuses a
  * library whose ocr_abi_version() differs from the value it was written against (_lib.ABI_VERSION). */
-#define OCR_ABI_VERSION 4
+#define OCR_ABI_VERSION 5
 
 enum {
   OCR_OK = 0,
@@ -194,6 +194,14 @@ int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const void* dy,
                          void* dw_hwio_f32, void* workspace, size_t ws_bytes,
                          void* stream);
 size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d);
+/* The two halves of ocr_conv2d_wgrad_f16 as calls of their own — the split-K slab kernel, and the fixed-order sum of its
+ * slabs into dw — so that the recorded step can issue the first as the host of a guest pass (ocr_bn_relu_bwd_apply_
+ * affine_f16 ...) and the second behind the join: the slab sum is bandwidth- and cache-sensitive (13 us alone, 60-370 us
+ * beside an HBM-streaming guest).  `workspace` (ocr_conv2d_wgrad_workspace bytes) must stay the launch's own until the
+ * reduce has run.  Results are those of ocr_conv2d_wgrad_f16 bit for bit. */
+int ocr_conv2d_wgrad_slabs_f16(const ocr_conv_desc* d, const void* x, const void* dy, void* workspace, size_t ws_bytes,
+                               void* stream);
+int ocr_conv2d_wgrad_reduce_f32(const ocr_conv_desc* d, const void* workspace, void* dw_hwio_f32, void* stream);
 
 /* First-layer weight gradient (cin=3 from the [n,h,w,4] f16 image). dw [3,3,3,cout] f32. */
 int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const void* x4,
@@ -349,6 +357,21 @@ int ocr_unpool_add_stats_f16(const void* t_low, int n, int lh, int lw, int c, vo
 int ocr_bias_relu_bwd_num_partials(int64_t npix, int c);
 int ocr_bias_relu_bwd_f16(const void* a, const void* da, int64_t npix, int c, int relu, void* dz,
                           void* dbias, void* partial, void* stream);
+
+/* GUEST forms of the two apply passes below (csrc/guest_bn.hip): the apply step of the batch-norm (+ReLU) backward of
+ * slim.conv2d under nets/model_vgg_16.py:144 (nets/vgg.py:14-39) as the affine map dy = A*dz + B*y + C with the
+ * coefficients of ocr_bn_bwd_coefficients (A = coef_a = the layer's forward scale), dz = da * [fma(y, A, shift) rounds
+ * to a positive 16-bit value] (relu) — ONE launch, no workspace, <= 56 registers per lane and no LDS, so that its waves
+ * are placed beside a resident weight-gradient workgroup (456 of the 512 registers per lane): the recorded step runs
+ * this pass of layer L-1 on a second stream beside held-back ocr_conv2d_wgrad_slabs_f16 launches.  max_workgroups: 0 =
+ * 4 per CU (the pass alone); 256 = one per CU, what is resident beside such a host (csrc/guest_bn.hip).  Tensors < 2 GiB
+ * (OCR_ERR_UNSUPPORTED otherwise, and for odd h / w in the pooled form: callers keep the general entry points). */
+int ocr_bn_relu_bwd_apply_affine_f16(const void* y, const void* da, const void* scale, const void* shift,
+                                     const void* coef_b, const void* coef_c, int n, int h, int w, int c, int relu,
+                                     void* dy, int max_workgroups, void* stream);
+int ocr_bn_relu_pool_bwd_idx_apply_affine_f16(const void* y, const void* argmax_u8, const void* da_pool,
+                                              const void* coef_a, const void* coef_b, const void* coef_c, int n, int h,
+                                              int w, int c, int relu, void* dy, int max_workgroups, void* stream);
 
 /* ocr_bn_relu_bwd_f16 without its reduction pass (partials [T][2][c] from ocr_conv2d_bnred_f16) */
 int ocr_bn_relu_bwd_apply_f16(const void* y, const void* scale, const void* shift, const void* save_mean,

@@ -808,11 +808,12 @@ static int launch_wg(K kern, const P& p, unsigned grid, size_t lds, const void* 
   return ocr_launch_status();
 }
 
-extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const void* dy,
-                                    void* dw, void* workspace, size_t ws_bytes, void* stream) {
+// The partial slabs [splits][kh][kw][cin][cout] of one weight gradient (every kernel family); *splits_out = their number.
+static int wgrad_slabs(const ocr_conv_desc* d, const void* x, const void* dy, void* workspace, size_t ws_bytes,
+                       void* stream, int* splits_out) {
   OCR_CHECK_ARG(d != nullptr);
   OCR_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0);
-  OCR_CHECK_ARG(x && dy && dw && workspace);
+  OCR_CHECK_ARG(x && dy && workspace);
   const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntaps = d->kh * d->kw;
@@ -853,7 +854,54 @@ extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const
                     : launch_wg(wgrad_kernel<9>, p, grid, lds, x, dy, workspace, st, 512);
   }
   if (rc != OCR_OK) return rc;
-  const size_t elems4 = elems / 4;
-  launch_slab_reduce(static_cast<const float*>(workspace), static_cast<float*>(dw), elems4, splits, st);
+  *splits_out = splits;
+  return ocr_launch_status();
+}
+
+extern "C" int ocr_conv2d_wgrad_f16(const ocr_conv_desc* d, const void* x, const void* dy,
+                                    void* dw, void* workspace, size_t ws_bytes, void* stream) {
+  OCR_CHECK_ARG(dw != nullptr);
+  int splits = 0;
+  const int rc = wgrad_slabs(d, x, dy, workspace, ws_bytes, stream, &splits);
+  if (rc != OCR_OK) return rc;
+  const size_t elems4 = (size_t)d->kh * d->kw * d->cin * d->cout / 4;
+  launch_slab_reduce(static_cast<const float*>(workspace), static_cast<float*>(dw), elems4, splits,
+                     static_cast<hipStream_t>(stream));
+  return ocr_launch_status();
+}
+
+// The two halves of ocr_conv2d_wgrad_f16 as calls of their own: the recorded step issues the slab kernel as the HOST of
+// a guest pass and the (bandwidth- and cache-sensitive: 13 us alone, 60-370 us beside an HBM-streaming guest) slab sum
+// behind the join.  `workspace` must then be the launch's own until the reduce has run.
+extern "C" int ocr_conv2d_wgrad_slabs_f16(const ocr_conv_desc* d, const void* x, const void* dy, void* workspace,
+                                          size_t ws_bytes, void* stream) {
+  int splits = 0;
+  return wgrad_slabs(d, x, dy, workspace, ws_bytes, stream, &splits);
+}
+
+// the number of slabs wgrad_slabs writes for `d` (the same selection, nothing launched); <= 0: unsupported
+static int wgrad_slab_count(const ocr_conv_desc* d) {
+  if (const int s = ocr_detail::wgrad_pw_splits(d)) return s;
+  Wg2P p2;
+  int cob = 0;
+  if (fill2(d, &p2, &cob) == OCR_OK) {
+    static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();
+    const bool small = (size_t)d->n * d->h * d->w * d->cin < (1u << 30) && (size_t)d->n * d->oh * d->ow * d->cout < (1u << 30);
+    const bool use3 = d->kh * d->kw == 9 && v3 && small && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1;
+    return p2.splits * (cob == 64 && !use3 ? 2 : 1);
+  }
+  WgP p;
+  if (fill(d, &p) != OCR_OK) return 0;
+  return p.splits * 2;
+}
+
+extern "C" int ocr_conv2d_wgrad_reduce_f32(const ocr_conv_desc* d, const void* workspace, void* dw, void* stream) {
+  OCR_CHECK_ARG(d && workspace && dw);
+  OCR_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0);
+  const int splits = wgrad_slab_count(d);
+  if (splits <= 0) return OCR_ERR_UNSUPPORTED;
+  const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
+  launch_slab_reduce(static_cast<const float*>(workspace), static_cast<float*>(dw), elems / 4, splits,
+                     static_cast<hipStream_t>(stream));
   return ocr_launch_status();
 }

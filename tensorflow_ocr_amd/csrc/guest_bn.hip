@@ -1,0 +1,222 @@
+// GUEST kernels: the batch-norm backward APPLY passes in a register footprint that fits beside a matrix-core kernel.
+//
+// The weight-gradient kernel wgrad3_kernel<9,128> allocates 200 + 256 = 456 of a SIMD's 512 registers per lane (one wave
+// per SIMD, one workgroup per CU): 56 registers per lane stay free on every SIMD of the chip for its whole launch, and a
+// wave that needs no more than that is placed beside it (measured, scripts/coresidency_probe.hip: an HBM-streaming
+// guest keeps its stand-alone rate beside a synthetic 456-register MFMA host and costs it nothing; beside the real
+// wgrad3 the pair runs at 1.36x the serial rate, profiles/r05_coresidency.json).  The apply pass of layer L-1
+// (reference: the gradient of slim.batch_norm + ReLU, nets/vgg.py:14-39 under nets/model_vgg_16.py:144) depends only on
+// the input gradient of layer L, the weight gradient of layer L on neither: the recorded step runs the two side by
+// side on two streams (train.TrainStep._replay).  bn_relu_bwd_kernel<1> needs 146 registers and could never be such a
+// guest; these need <= 56:
+//   * the apply step as the affine map dy = A*dz + B*y + C per channel (ocr_bn_bwd_coefficients; A = the forward scale),
+//     dz = da * [fma(y, A, shift) rounds to a positive 16-bit value]: four coefficient rows instead of six;
+//   * buffer addressing (one 32-bit offset register; the range check drops the ragged tail, no bounds branches);
+//   * four channels per thread (8-byte accesses), three units (8 B of y + 8 B of da per lane each) in flight.
+// The grid is one workgroup per CU when the pass runs beside hosts (guest_grid below).
+#include "common.h"
+
+namespace {
+
+// Registers: hipcc ignores amdgpu_num_vgpr, so the budget (56 per lane: 512 - the 456 of wgrad3_kernel<9,128>) is met by
+// construction — a thread owns FOUR channels (8-byte accesses: a wave still moves whole 128-byte lines, 512 B per
+// instruction), which halves the coefficient rows a thread keeps (4 x 4 registers), and U units in flight (2 + 2
+// registers each).  tests/test_host_cpu.py::test_guest_kernels_fit_beside_the_weight_gradient compiles this file with
+// -Rpass-analysis=kernel-resource-usage and fails when a kernel here exceeds the budget or touches LDS / scratch.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ half4_t ld8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(half4_t, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void st8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, half4_t v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
+}
+
+// OCR_GUEST_PRIO=1 (measurement switch): the guest's waves at s_setprio 3 — they issue a handful of instructions per
+// hundred of the host's and are otherwise served after the older (host) wave of their SIMD.
+static int guest_prio() {
+  static const int v = [] { const char* e = getenv("OCR_GUEST_PRIO"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+// dy = A*dz + B*y + C, dz = relu ? da * [fma(y, A, S) > tie] : da.  Thread = one 4-channel chunk (fixed for the
+// thread's lifetime: its coefficients stay in registers) x a strided set of pixels, U of them in flight.
+// (A work-queue form — workgroups drawing 96 KB pieces from a counter — was built and measured: 25 % slower alone, the
+// piece boundary drains the loads in flight; with the grid sized to what is RESIDENT, below, the static split is even.)
+template <bool RELU, int U>
+__global__ __launch_bounds__(256) void bn_apply_affine_kernel(
+    const half_t* __restrict__ y, const half_t* __restrict__ da, const float* __restrict__ cA,
+    const float* __restrict__ cS, const float* __restrict__ cB, const float* __restrict__ cC, unsigned units,
+    int c, half_t* __restrict__ dy, int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const int chunks = c >> 2, lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  const size_t bytes = (size_t)units * c * 2;
+  const __amdgpu_buffer_rsrc_t ry = rsrc_of(y, bytes), rg = rsrc_of(da, bytes), ro = rsrc_of(dy, bytes);
+  float A[4], S[4], B[4], C[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    A[e] = cA[ch * 4 + e];
+    S[e] = RELU ? cS[ch * 4 + e] : 0.f;
+    B[e] = cB[ch * 4 + e];
+    C[e] = cC[ch * 4 + e];
+  }
+  const unsigned row = (unsigned)c * 2;
+  const unsigned stride = gridDim.x * (unsigned)lanes;           // units between a thread's successive visits
+  const unsigned sbytes = stride * row;
+  unsigned u = blockIdx.x * (unsigned)lanes + (unsigned)ul;
+  unsigned off = u * row + (unsigned)ch * 8;
+  // offsets past the tensor read zeros and their stores are dropped by the range check: no bounds branches
+  for (; u < units; u += U * stride, off += U * sbytes) {
+    half4_t yv[U], gv[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      yv[k] = ld8(ry, off, k * sbytes);
+      gv[k] = ld8(rg, off, k * sbytes);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      half4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yf = (float)yv[k][e];
+        float dz = (float)gv[k][e];
+        if (RELU) dz = __builtin_fmaf(yf, A[e], S[e]) > OCR_RELU_TIE ? dz : 0.f;
+        o[e] = (half_t)__builtin_fmaf(A[e], dz, __builtin_fmaf(B[e], yf, C[e]));
+      }
+      st8(ro, off, k * sbytes, o);
+    }
+  }
+}
+
+// The same for a layer whose only reader is its 2x2/2 max-pool (conv1_2, conv2_2): the pooled gradient is routed to
+// the window's first maximum (bits 0-1 of the forward's index byte; bit 2 = the pooled activation was positive) and
+// dy = A*dz + B*y + C at all four positions.  Even h and w only (the host keeps the general kernel for ragged maps).
+// Two pooled units (2 x 4 full-resolution loads) in flight per thread.
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_pool_apply_affine_kernel(
+    const half_t* __restrict__ y, const half_t* __restrict__ da_pool, const unsigned char* __restrict__ argmax,
+    const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC, int n, int h, int w,
+    int c, half_t* __restrict__ dy, int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const int chunks = c >> 2, lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  const int oh = h >> 1, ow = w >> 1;
+  const unsigned units = (unsigned)n * oh * ow;
+  const size_t full = (size_t)n * h * w * c * 2, pooled = (size_t)units * c * 2;
+  const __amdgpu_buffer_rsrc_t ry = rsrc_of(y, full), ro = rsrc_of(dy, full), rg = rsrc_of(da_pool, pooled),
+                               ra = rsrc_of(argmax, pooled / 2);
+  float A[4], B[4], C[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    A[e] = cA[ch * 4 + e];
+    B[e] = cB[ch * 4 + e];
+    C[e] = cC[ch * 4 + e];
+  }
+  const unsigned row = (unsigned)c * 2;
+  const unsigned below = (unsigned)w * row;                     // one full-resolution row down
+  const unsigned stride = gridDim.x * (unsigned)lanes;
+  for (unsigned u0 = blockIdx.x * (unsigned)lanes + (unsigned)ul; u0 < units; u0 += 2 * stride) {
+    unsigned foff[2];
+    half4_t gp[2], yv[2][4];
+    unsigned am[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned u = u0 + j * stride;                       // (past the end: every access falls out of range)
+      const unsigned ox = u % (unsigned)ow, t = u / (unsigned)ow;       // t = img * oh + oy
+      const unsigned poff = u < units ? u * row + (unsigned)ch * 8 : 0x80000000u;
+      foff[j] = u < units ? ((t * 2u) * (unsigned)w + ox * 2u) * row + (unsigned)ch * 8 : 0x80000000u;
+      gp[j] = ld8(rg, poff, 0);
+      am[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(poff >> 1), 0, 0);
+      yv[j][0] = ld8(ry, foff[j], 0);
+      yv[j][1] = ld8(ry, foff[j], row);
+      yv[j][2] = ld8(ry, foff[j], below);
+      yv[j][3] = ld8(ry, foff[j], below + row);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (unsigned k = 0; k < 4; ++k) {
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned byte = (am[j] >> (8 * e)) & (RELU ? 7u : 3u);
+          const float dz = byte == (RELU ? (k | 4u) : k) ? (float)gp[j][e] : 0.f;
+          o[e] = (half_t)__builtin_fmaf(A[e], dz, __builtin_fmaf(B[e], (float)yv[j][k][e], C[e]));
+        }
+        st8(ro, foff[j], (k & 1 ? row : 0) + (k & 2 ? below : 0), o);
+      }
+    }
+  }
+}
+
+bool pow2g(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// grid: `max_workgroups` when the caller names one (the recorded step asks for 256 = ONE per CU for a pass it runs
+// beside weight gradients: that is what is resident beside a 456-register host, so the static split stays even, and a
+// second host finds its registers free when the first has gone — more workgroups would fill the CUs the moment a host
+// retires and keep the next host out until the whole pass has finished: measured, 427 -> 735 us for that host);
+// otherwise 4 per CU, which is what the pass needs to reach the HBM rate alone
+unsigned guest_grid(size_t units, size_t per_wg, int max_workgroups) {
+  size_t b = (units + per_wg - 1) / per_wg;
+  static const unsigned cap = [] { const char* e = getenv("OCR_GUEST_GRID"); return e ? (unsigned)atoi(e) : 1024u; }();
+  const size_t lim = max_workgroups > 0 ? (size_t)max_workgroups : (size_t)cap;
+  if (b > lim) b = lim;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+// Apply step of the batch-norm (+ReLU) backward as an affine map of (dz, y): the second half of
+// ocr_bn_relu_bwd_apply_f16 with the coefficients from ocr_bn_bwd_coefficients (coef_a = the forward scale).
+// One launch, <= 56 registers per lane, no LDS: a guest beside the weight-gradient kernels.
+extern "C" int ocr_bn_relu_bwd_apply_affine_f16(const void* y, const void* da, const void* scale, const void* shift,
+                                                const void* coef_b, const void* coef_c, int n, int h, int w, int c,
+                                                int relu, void* dy, int max_workgroups, void* stream) {
+  OCR_CHECK_ARG(y && da && scale && shift && coef_b && coef_c && dy && n > 0 && h > 0 && w > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2g(c / 4) && c / 4 <= 256);
+  const size_t units = (size_t)n * h * w;
+  OCR_CHECK_SHAPE(units * (size_t)c * 2 < (1ull << 31));   // 32-bit buffer offsets, 0x80000000 = out of range
+  const int lanes = 256 / (c / 4);
+  constexpr int U = 3;
+  const unsigned grid = guest_grid(units, (size_t)lanes * U, max_workgroups);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (relu)
+    hipLaunchKernelGGL((bn_apply_affine_kernel<true, U>), dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(y),
+                       static_cast<const half_t*>(da), static_cast<const float*>(scale), static_cast<const float*>(shift),
+                       static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), (unsigned)units, c,
+                       static_cast<half_t*>(dy), guest_prio());
+  else
+    hipLaunchKernelGGL((bn_apply_affine_kernel<false, U>), dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(y),
+                       static_cast<const half_t*>(da), static_cast<const float*>(scale), static_cast<const float*>(shift),
+                       static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), (unsigned)units, c,
+                       static_cast<half_t*>(dy), guest_prio());
+  return ocr_launch_status();
+}
+
+// ... and of ocr_bn_relu_pool_bwd_idx_apply_f16 (pooled layers, stored first-max index).  OCR_ERR_UNSUPPORTED for odd
+// h / w: the caller keeps the general kernel for those.
+extern "C" int ocr_bn_relu_pool_bwd_idx_apply_affine_f16(const void* y, const void* argmax_u8, const void* da_pool,
+                                                         const void* coef_a, const void* coef_b, const void* coef_c,
+                                                         int n, int h, int w, int c, int relu, void* dy, int max_workgroups,
+                                                         void* stream) {
+  OCR_CHECK_ARG(y && argmax_u8 && da_pool && coef_a && coef_b && coef_c && dy && n > 0 && h > 0 && w > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2g(c / 4) && c / 4 <= 256 && h % 2 == 0 && w % 2 == 0);
+  const size_t full = (size_t)n * h * w * c * 2;
+  OCR_CHECK_SHAPE(full < (1ull << 31));
+  const int lanes = 256 / (c / 4);
+  const unsigned grid = guest_grid((size_t)n * (h / 2) * (w / 2), (size_t)lanes * 2, max_workgroups);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (relu)
+    hipLaunchKernelGGL(bn_pool_apply_affine_kernel<true>, dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(y),
+                       static_cast<const half_t*>(da_pool), static_cast<const unsigned char*>(argmax_u8),
+                       static_cast<const float*>(coef_a), static_cast<const float*>(coef_b),
+                       static_cast<const float*>(coef_c), n, h, w, c, static_cast<half_t*>(dy), guest_prio());
+  else
+    hipLaunchKernelGGL(bn_pool_apply_affine_kernel<false>, dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(y),
+                       static_cast<const half_t*>(da_pool), static_cast<const unsigned char*>(argmax_u8),
+                       static_cast<const float*>(coef_a), static_cast<const float*>(coef_b),
+                       static_cast<const float*>(coef_c), n, h, w, c, static_cast<half_t*>(dy), guest_prio());
+  return ocr_launch_status();
+}

@@ -307,8 +307,11 @@ __global__ void label_masks_kernel(const float* __restrict__ lab, size_t total, 
 }
 
 // OHNM_single_image / OHNM_batch on GIVEN scores and masks: per image k = min(n_pos * ratio, #neg), threshold = the k-th
-// smallest score among the negatives (exact: 4-pass 8-bit radix select on the float bits, scores >= 0), selected negatives
-// = neg & score <= threshold (tie-inclusive, like `tf.nn.top_k` + `<=`); nothing when n_pos == 0.
+// smallest score among the negatives (exact: 4-pass 8-bit radix select on an order-preserving key of the float bits —
+// sign bit flipped for non-negative values, all bits for negative ones — so ANY finite scores work, logits included:
+// the reference's top_k(-neg_conf) has no sign restriction, nets/model.py:161-184), selected negatives = neg & score <=
+// threshold (tie-inclusive, like `tf.nn.top_k` + `<=`; -0.0 and +0.0 are one value there as here); nothing when
+// n_pos == 0.  k = min(n_pos * ratio, #neg) in double (exact for every count a map can hold).
 __global__ __launch_bounds__(1024) void ohnm_select_kernel(int hw, float ratio, const float* __restrict__ scores,
                                                            const unsigned char* __restrict__ pos_all,
                                                            const unsigned char* __restrict__ neg_all,
@@ -333,9 +336,10 @@ __global__ __launch_bounds__(1024) void ohnm_select_kernel(int hw, float ratio, 
   atomicAdd(&s_cnt[1], nn);
   __syncthreads();
   const int n_pos = n_pos_in ? n_pos_in[img] : s_cnt[0], n_neg = s_cnt[1];
-  const int k = (int)fminf((float)n_pos * ratio, (float)n_neg);
-  float thr = -1.f;                                   // nothing is selected (scores are >= 0)
-  if (n_pos > 0 && k > 0) {
+  const int k = (int)fmin((double)n_pos * (double)ratio, (double)n_neg);
+  float thr = 0.f;
+  const bool any = n_pos > 0 && k > 0;                // otherwise nothing is selected
+  if (any) {
     if (threadIdx.x == 0) { s_prefix = 0u; s_k = k; }
     for (int pass = 0; pass < 4; ++pass) {
       const int shift = 24 - 8 * pass;
@@ -345,7 +349,8 @@ __global__ __launch_bounds__(1024) void ohnm_select_kernel(int hw, float ratio, 
       const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
       for (int i = threadIdx.x; i < hw; i += 1024) {
         if (!neg[i]) continue;
-        const unsigned u = __float_as_uint(sc[i]);
+        const unsigned b = __float_as_uint(sc[i]);
+        const unsigned u = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);       // unsigned order of u = float order of the score
         if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
       }
       __syncthreads();
@@ -360,10 +365,11 @@ __global__ __launch_bounds__(1024) void ohnm_select_kernel(int hw, float ratio, 
       }
       __syncthreads();
     }
-    thr = __uint_as_float(s_prefix);
+    const unsigned key = s_prefix;
+    thr = __uint_as_float(key ^ ((key >> 31) ? 0x80000000u : 0xffffffffu));
   }
   for (int i = threadIdx.x; i < hw; i += 1024) {
-    const float sn = (neg[i] && sc[i] <= thr) ? 1.f : 0.f;
+    const float sn = (any && neg[i] && sc[i] <= thr) ? 1.f : 0.f;
     if (sel_neg) sel_neg[(size_t)img * hw + i] = sn;
     if (selected) selected[(size_t)img * hw + i] = ((pos && pos[i]) ? 1.f : 0.f) + sn;   // cast(pos_mask) + selected_neg_mask
   }

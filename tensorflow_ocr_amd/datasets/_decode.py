@@ -144,20 +144,59 @@ def _worker_main(path, slots, slot_bytes):
             _send(fout, (fn, tuple(im.shape), im, polys, tags))
 
 
+class SlabUnavailable(RuntimeError):
+    """No directory could hold the decode slab (datasets.icdar.generator then decodes on threads)."""
+
+
+def _reserve_slab(slots, min_slots, slot_bytes, name, dirs=None):
+    """Create the slab file with its pages RESERVED (posix_fallocate), so that a full /dev/shm is an error here and not
+    a SIGBUS at the first touch of a page past the limit (np.memmap(mode="w+") succeeds on a sparse file whatever the
+    file system holds: Docker's default /dev/shm is 64 MB, a batch-32 slab 189 MB).  Tries /dev/shm with `slots`, then
+    with fewer (down to `min_slots`: a batch's images are held at once), then the temp directory (page cache instead
+    of shared memory: same semantics).  Returns (slots, path); raises SlabUnavailable with what was tried."""
+    import errno
+    import tempfile
+    tried = []
+    for d in (dirs if dirs is not None else ("/dev/shm", tempfile.gettempdir())):
+        if not os.path.isdir(d) or not os.access(d, os.W_OK | os.X_OK):
+            tried.append("%s: missing or not writable" % d)
+            continue
+        n = slots
+        while n >= min_slots:
+            path = os.path.join(d, name)
+            try:
+                fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            except OSError as e:
+                tried.append("%s: %s" % (path, e.strerror))
+                break
+            try:
+                os.posix_fallocate(fd, 0, n * slot_bytes)
+                return n, path
+            except OSError as e:
+                os.unlink(path)
+                tried.append("%s: %d slots (%d MB): %s" % (d, n, n * slot_bytes >> 20, e.strerror))
+                if e.errno not in (errno.ENOSPC, errno.EFBIG, errno.EDQUOT) or n == min_slots:
+                    break
+                n = max(min_slots, n // 2)
+            finally:
+                os.close(fd)
+    raise SlabUnavailable("no room for the decode slab: " + "; ".join(tried))
+
+
 class DecodePool:
     """`workers` decode processes + a slab of `slots` image slots shared with them.  submit() returns a Future whose
     result is None (sample skipped) or (im_fn, image, polys, tags) with `image` a uint8 [H,W,3] VIEW of the sample's slot:
     copy it out (datasets.icdar.resize_images does, into the pinned slab) and then release(slot)."""
 
-    def __init__(self, workers, slots=None, slot_bytes=3 * 1280 * 768):
+    def __init__(self, workers, slots=None, slot_bytes=3 * 1280 * 768, min_slots=None):
         import queue
         import subprocess
         import threading
         self.workers = workers
-        self.slots = slots or 4 * workers
         self.slot_bytes = int(slot_bytes)
-        self.path = "/dev/shm/ocr_decode_%d_%x" % (os.getpid(), id(self))
-        self.slab = np.memmap(self.path, dtype=np.uint8, mode="w+", shape=(self.slots, self.slot_bytes))
+        self.slots, self.path = _reserve_slab(slots or 4 * workers, min_slots or min(slots or 4 * workers, 2 * workers),
+                                              self.slot_bytes, "ocr_decode_%d_%x" % (os.getpid(), id(self)))
+        self.slab = np.memmap(self.path, dtype=np.uint8, mode="r+", shape=(self.slots, self.slot_bytes))
         root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         env = dict(os.environ)
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")

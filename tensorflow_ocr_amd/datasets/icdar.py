@@ -152,8 +152,17 @@ def generator(training_data_path, input_size=512, batch_size=32, graph=None, shu
         from multiprocessing.pool import ThreadPool
         pool = ThreadPool(num_workers)
     elif num_workers > 0:
-        from ._decode import DecodePool
-        dpool = DecodePool(num_workers, slots=max(2 * batch_size, 2 * num_workers))
+        from ._decode import DecodePool, SlabUnavailable
+        try:
+            # a batch's images sit in their slots at once: at least batch_size + 1 slots (one ahead), ideally two batches
+            dpool = DecodePool(num_workers, slots=max(2 * batch_size, 2 * num_workers),
+                               min_slots=max(batch_size + 1, num_workers + 1))
+        except SlabUnavailable as e:
+            import warnings
+            warnings.warn("decode worker processes need a shared slab and found no room for it (%s): decoding on %d "
+                          "threads instead (slower: their Python parts share the GIL)" % (e, num_workers))
+            from multiprocessing.pool import ThreadPool
+            pool = ThreadPool(num_workers)
 
     def samples_of(jobs):
         """The epoch's samples in job order: (im_fn, image, polys, tags, slot | None), None for skipped ones."""

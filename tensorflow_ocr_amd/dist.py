@@ -83,6 +83,7 @@ class AbiComm:
     rendezvous is needed at all.  Must be created with the rank's device current."""
 
     _serial = 0
+    ACK_TIMEOUT_S = 120
 
     def __init__(self, rank=0, world=1, store=None):
         import ctypes
@@ -95,17 +96,36 @@ class AbiComm:
         if world > 1:
             if store is None:
                 store = td.distributed_c10d._get_default_store()
-            if rank == 0:
-                rc = L._fn("ocr_comm_unique_id", ctypes.c_int)(ident)
-                # a failure here must reach the other ranks too: they would wait for the key, then for this rank inside
-                # ncclCommInitRank
-                store.set(key, ident.raw if rc == 0 else b"ERR")
-                self._check(rc, "ocr_comm_unique_id")
-            else:
-                raw = bytes(store.get(key))
-                if raw == b"ERR":
-                    raise L.OcrHipError("rank 0 could not create an RCCL unique id")
-                ident = ctypes.create_string_buffer(raw, 128)
+            err = None
+            try:
+                if rank == 0:
+                    rc = L._fn("ocr_comm_unique_id", ctypes.c_int)(ident)
+                    # a failure here must reach the other ranks too: they would wait for the key, then for this rank
+                    # inside ncclCommInitRank
+                    store.set(key, ident.raw if rc == 0 else b"ERR")
+                    self._check(rc, "ocr_comm_unique_id")
+                else:
+                    raw = bytes(store.get(key))
+                    if raw == b"ERR":
+                        raise L.OcrHipError("rank 0 could not create an RCCL unique id")
+                    ident = ctypes.create_string_buffer(raw, 128)
+            except Exception as e:                           # store timeout, refused id, ...
+                err = e
+            # second gate: nobody enters ncclCommInitRank — which blocks until ALL ranks arrive — before every
+            # rank has said that it holds the id; a rank that failed above says so, and all ranks raise together
+            import datetime
+            store.set("%s_ack_%d" % (key, rank), b"OK" if err is None else b"ERR")
+            acks = ["%s_ack_%d" % (key, r) for r in range(world)]
+            try:
+                store.wait(acks, datetime.timedelta(seconds=self.ACK_TIMEOUT_S))
+                bad = [r for r in range(world) if bytes(store.get(acks[r])) != b"OK"]
+            except Exception as e:                           # a rank never answered
+                raise L.OcrHipError("RCCL rendezvous: not every rank acknowledged the unique id within %d s (%s)"
+                                    % (self.ACK_TIMEOUT_S, e)) from err
+            if err is not None:
+                raise err
+            if bad:
+                raise L.OcrHipError("RCCL rendezvous: rank(s) %s could not obtain the unique id" % bad)
         else:
             self._check(L._fn("ocr_comm_unique_id", ctypes.c_int)(ident), "ocr_comm_unique_id")
         self.handle = ctypes.c_void_p()
@@ -220,6 +240,7 @@ class GradientAllReduce:
         self.proxy = proxy
         self.overlap = (__import__("os").environ.get("OCR_EXCHANGE_OVERLAP", "1") == "1") if overlap is None else bool(overlap)
         self.both_placements = proxy is not None and world_size == 1      # record early AND late launches (one-rank: harmless)
+        assert not self.both_placements or world_size == 1     # (running a bucket's all-reduce twice is the identity only on one rank)
         self.use_proxy = False
         self.proxy_stats = None
         self.ev_ready = self.ev_done = None

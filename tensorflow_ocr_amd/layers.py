@@ -195,13 +195,27 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
             dy = g.empty(y_b.shape)
             if not pool and a_full.bn_partial is not None:
                 part_f, T_f = a_full.bn_partial
-                ops.bn_relu_bwd_apply(y_b, scale, shift, mean, invstd, da_full, relu, part_f, T_f,
-                                      gamma.grad, beta.grad, dy, ws)
+                if ops.guest_apply_ok(y_b.shape):
+                    # the apply pass as a GUEST (csrc/guest_bn.hip): dgamma / dbeta / coefficients first, then one slim
+                    # launch that the recorded step runs beside the weight gradient of the layer above
+                    coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
+                    ops.bn_bwd_coefficients_pre(part_f, T_f, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
+                                                beta.grad, coef, ws)
+                    ops.bn_relu_bwd_apply_affine(y_b, da_full, scale, shift, coef[1], coef[2], relu, dy)
+                else:
+                    ops.bn_relu_bwd_apply(y_b, scale, shift, mean, invstd, da_full, relu, part_f, T_f,
+                                          gamma.grad, beta.grad, dy, ws)
                 a_full.bn_partial = None
             elif pool and argmax is not None and da_full is None and a_pool.bn_partial is not None:
                 part_p, T_p = a_pool.bn_partial
-                ops.bn_relu_pool_bwd_idx_apply(y_b, scale, mean, invstd, argmax, da_pool, relu, part_p, T_p,
-                                               gamma.grad, beta.grad, dy, ws)
+                if ops.guest_apply_ok(y_b.shape) and oh % 2 == 0 and ow % 2 == 0:
+                    coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
+                    ops.bn_bwd_coefficients_pre(part_p, T_p, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
+                                                beta.grad, coef, ws)
+                    ops.bn_relu_pool_bwd_idx_apply_affine(y_b, argmax, da_pool, coef, relu, dy)
+                else:
+                    ops.bn_relu_pool_bwd_idx_apply(y_b, scale, mean, invstd, argmax, da_pool, relu, part_p, T_p,
+                                                   gamma.grad, beta.grad, dy, ws)
                 a_pool.bn_partial = None
             elif pool and argmax is not None and da_full is None:
                 ops.bn_relu_pool_bwd_idx(y_b, scale, mean, invstd, a_pool.data, argmax, da_pool, relu,
@@ -292,9 +306,19 @@ def _conv_backward(g, x, wv, w_dg, d, dy, first):
         return
     dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, d.kh, d.kw, d.stride, d.dilation,
                       d.pad_top, d.pad_left, 0, 0)
+    if ops.GUEST_BN and x.requires_grad:
+        # input gradient FIRST: the layer below can then start its backward while this layer's weight gradient runs —
+        # its batch-norm apply pass is a guest beside it (csrc/guest_bn.hip; the recorded step pairs the two)
+        _conv_dgrad(g, x, wv, w_dg, d, dy)
+        ops.conv2d_wgrad(dd, x.data, dy, wv.grad, g.ws_wgrad, alloc=lambda nb: g.empty((nb,), torch.uint8))
+        return
     ops.conv2d_wgrad(dd, x.data, dy, wv.grad, g.ws_wgrad)
     if not x.requires_grad:
         return
+    _conv_dgrad(g, x, wv, w_dg, d, dy)
+
+
+def _conv_dgrad(g, x, wv, w_dg, d, dy):
     if d.stride != 1:
         raise NotImplementedError("strided dgrad")
     # dx = conv(dy, W^T flipped): input = dy [n,oh,ow,cout], output = [n,h,w,cin]
@@ -592,13 +616,17 @@ def head_group(g, feats, names_list, couts, *, mode="bn", is_training=True, relu
                 T = ops.sc_num_partials(s["P"], C)
                 items.append((s["dz"], s["bias"].grad, g.empty((T + 1, 2, C), F32)))
             ops.sc_colsum_batch(items)
-        wide = [s for s in live if s["cin"] % 128 == 0]        # the batched MFMA kernel's 128-channel blocks
+        # the batched MFMA kernel: 128-channel blocks, 32-bit buffer offsets (heads.hip: P * cin * 2 and P * C * 4 below
+        # 2 GiB); anything else — a 256-channel map beyond 4.19 M pixels, say — keeps the per-map kernel, which has no limit
+        def is_wide(s):
+            return s["cin"] % 128 == 0 and s["P"] * s["cin"] * 2 < (1 << 31) and s["P"] * C * 4 < (1 << 31)
+        wide = [s for s in live if is_wide(s)]
         if wide:
             ops.conv1x1_small_wgrad_batch([
                 (s["feat"].data, s["dz"], s["wv"].grad,
                  g.empty((ops.conv1x1_small_wgrad_batch_slab_bytes(s["P"], s["cin"]),), torch.uint8)) for s in wide])
         for s in live:
-            if s["cin"] % 128:
+            if not is_wide(s):
                 ops.conv1x1_small_wgrad(s["feat"].data, s["dz"], C, s["wv"].grad, ws)
         items = []
         for s in live:

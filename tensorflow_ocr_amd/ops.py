@@ -245,14 +245,65 @@ def bn_relu_bwd_apply(y, scale, shift, save_mean, save_invstd, da_full, relu, pa
            ptr(dgamma), ptr(dbeta), ptr(dy), ptr(stage), c_size_t(stage.numel()), _st())
 
 
-def conv2d_wgrad(d, x, dy, dw, ws):
+# --- guest forms (csrc/guest_bn.hip): <= 56 registers per lane, one launch, placed beside a resident weight-gradient
+# workgroup; the recorded step runs them on a second stream (train.TrainStep: tags "pre" / "guest") -------------------
+GUEST_BN = __import__("os").environ.get("OCR_GUEST_BN", "1") == "1"
+
+
+def guest_apply_ok(shape):
+    """The guest kernels address through 32-bit buffer offsets: tensors < 2 GiB, power-of-two channel chunks."""
+    n, h, w, c = shape
+    q = c // 4
+    return GUEST_BN and c % 8 == 0 and q <= 256 and (q & (q - 1)) == 0 and n * h * w * c * 2 < (1 << 31)
+
+
+def bn_bwd_coefficients_pre(partial, T, c, count, scale, save_mean, save_invstd, dgamma, dbeta, coef, ws):
+    """ocr_bn_bwd_coefficients in front of a guest apply pass: tagged so that the recorded step issues it BEFORE the
+    weight gradient the guest runs beside (its finalize workgroups need 72 registers: queued behind a resident
+    weight-gradient grid they would hold the guest back for that grid's whole launch)."""
+    bn_bwd_coefficients(partial, T, c, count, scale, save_mean, save_invstd, dgamma, dbeta, coef, ws)
+    if L.RECORDER is not None:
+        L.RECORDER.tag_last(("pre",))
+
+
+def bn_relu_bwd_apply_affine(y, da, scale, shift, coef_b, coef_c, relu, dy):
+    n, h, w, c = y.shape
+    L.call("ocr_bn_relu_bwd_apply_affine_f16", ptr(y), ptr(da), ptr(scale), ptr(shift), ptr(coef_b), ptr(coef_c),
+           c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(dy), c_int(0), _st())
+    if L.RECORDER is not None:
+        L.RECORDER.tag_last(("guest", 6.0 * n * h * w * c))           # bytes: y + da read, dy written
+
+
+def bn_relu_pool_bwd_idx_apply_affine(y, argmax, da_pool, coef, relu, dy):
+    n, h, w, c = y.shape
+    L.call("ocr_bn_relu_pool_bwd_idx_apply_affine_f16", ptr(y), ptr(argmax), ptr(da_pool), ptr(coef[0]), ptr(coef[1]),
+           ptr(coef[2]), c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(dy), c_int(0), _st())
+    if L.RECORDER is not None:
+        L.RECORDER.tag_last(("guest", 4.75 * n * h * w * c))          # y read + dy written + the pooled gradient and index
+
+
+def conv2d_wgrad(d, x, dy, dw, ws, alloc=None):
+    """alloc (callable: nbytes -> uint8 tensor; layers pass Graph.empty while OCR_GUEST_BN is on): the slabs get a
+    buffer of their own and the call is issued as its two halves — slab kernel ["side", FLOP], slab sum ["reduce"] —
+    so that the recorded step can run the first as the host of a guest pass and the second behind the join
+    (train.schedule_guests).  Same numbers either way."""
     nbytes = L.call_size("ocr_conv2d_wgrad_workspace", byref(d))
+    flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+    if alloc is not None and GUEST_BN:
+        buf = alloc(nbytes)
+        L.call("ocr_conv2d_wgrad_slabs_f16", byref(d), ptr(x), ptr(dy), ptr(buf), c_size_t(nbytes), _st())
+        if L.RECORDER is not None:
+            L.RECORDER.tag_last(("side", flops))
+        L.call("ocr_conv2d_wgrad_reduce_f32", byref(d), ptr(buf), ptr(dw), _st())
+        if L.RECORDER is not None:
+            L.RECORDER.tag_last(("reduce",))
+        return
     buf = ws.get(nbytes)
     L.call("ocr_conv2d_wgrad_f16", byref(d), ptr(x), ptr(dy), ptr(dw), ptr(buf), c_size_t(nbytes), _st())
     if L.RECORDER is not None:
-        # independent of the rest of backward (only the optimiser reads dw): replayed on a side
-        # stream so it overlaps the HBM-bound batch-norm passes of the layers below
-        L.RECORDER.tag_last(("side",))
+        # independent of the rest of backward (only the optimiser and the exchange read dw): the recorded step holds it
+        # back and runs it as the HOST of a later guest pass (train.schedule_guests; FLOP = its estimated cost)
+        L.RECORDER.tag_last(("side", flops))
 
 
 def space_to_depth(x, xs):

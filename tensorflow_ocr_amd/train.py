@@ -191,6 +191,104 @@ def _record_audit():
     return Audit()
 
 
+USE_GUESTS = __import__("os").environ.get("OCR_GUEST_STREAM", "1") == "1"
+
+
+GUEST_COVER = float(__import__("os").environ.get("OCR_GUEST_COVER", "2.1"))
+GUEST_PAIRED_GRID = int(__import__("os").environ.get("OCR_GUEST_PAIRED_GRID", "256"))
+
+
+def schedule_guests(entries, cover=None):
+    """Run the HBM-bound batch-norm backward passes of the recorded step as GUESTS beside its weight gradients
+    (csrc/guest_bn.hip; measured rates: profiles/r05_guest_pairs.json).
+
+    Recorded order (layers._conv_backward, layers.conv2d): ... coefficients(L) ["pre"], apply(L) ["guest", bytes],
+    dgrad(L), wgrad(L) = slab kernel ["side", FLOP] + slab sum ["reduce"], [exchange entries of the bucket that wgrad(L)
+    completed], coefficients(L-1), apply(L-1), ...  The chain apply -> dgrad -> apply is the critical path; a weight
+    gradient depends on its layer's apply pass only, and nothing but the optimiser (and the exchange) waits for it.
+    So weight gradients are HELD BACK and spent as hosts: at every guest the plan forks, the guest goes to the second
+    stream, and held-back slab kernels go to the main stream — chosen, oldest first, so that their estimated time
+    covers `cover` x the guest's stand-alone time without overshooting it by much (beside a host a guest moves ~0.42 of
+    its stand-alone rate, the host keeps ~0.9 of its own: small guests take small hosts, the deep layers' weight
+    gradients — little HBM traffic of their own — are left for the large passes of conv2 / conv1, which come last) —
+    then the plan joins: the next input-gradient kernel owns the whole register file and would only time-slice with a
+    straggler.  The slab sums (and whatever was recorded behind them: a re-layout of the gradient, the exchange entries
+    of the bucket it completed) follow the join: alone they take 13 us, beside a streaming guest 60-370.  A guest's
+    waves (<= 56 registers per lane) are placed beside the weight gradient's resident workgroups (456 of 512).  What is
+    still held back when something needs the gradients (the exchange's closing entries, the optimiser, any host
+    callback) is issued there, in order; a guest with nothing to run beside stays on the main stream.  Exchange entries
+    issued later than recorded are always correct: they order the comm stream behind the compute stream at that
+    point."""
+    cover = GUEST_COVER if cover is None else cover
+    out, pending, i, n = [], [], 0, len(entries)
+
+    def tag(e):
+        return e[4] if (e[0] == "c" and e[4] is not None) else (None,)
+
+    def travels(e):            # an exchange entry that belongs to the weight gradient in front of it
+        t = tag(e)
+        return t[0] == "xchg" and (len(t) < 2 or t[1] != "finish") and (len(t) < 3 or t[2] in (None, "early"))
+
+    def flush():
+        for head, tail, _ in pending:
+            out.append(head)
+            out.extend(tail)
+        del pending[:]
+    while i < n:
+        e = entries[i]
+        t = tag(e)
+        if t[0] == "side":
+            us = (t[1] / 1.3e9) if len(t) > 1 else 0.0            # FLOP at 1.3 PFLOP/s, in us
+            j = i + 1
+            while j < n and (tag(entries[j])[0] == "reduce" or (tag(entries[j])[0] == "side" and len(tag(entries[j])) < 2)
+                             or travels(entries[j])):
+                j += 1
+            pending.append((e, entries[i + 1:j], us))
+            i = j
+            continue
+        if t[0] == "guest":
+            if pending:
+                need = cover * ((t[1] / 5.0e6) if len(t) > 1 else 0.0)     # bytes at 5 TB/s, in us
+                take, acc = [], 0.0
+                for k, (_, _, us) in enumerate(pending):                  # oldest first, no large overshoot
+                    if acc >= 0.85 * need:
+                        break
+                    if acc + us <= 1.3 * need:
+                        take.append(k)
+                        acc += us
+                if not take:
+                    k = min(range(len(pending)), key=lambda q: pending[q][2])
+                    if pending[k][2] <= 3.0 * need:
+                        take = [k]
+                if take:
+                    g = list(e)
+                    g[4] = ("guest", t[1] if len(t) > 1 else 0.0, "paired")
+                    # the guest entry points' `max_workgroups` (second to last argument): one workgroup per CU beside hosts
+                    if len(e[2]) >= 2:
+                        g[2] = tuple(e[2][:-2]) + (__import__("ctypes").c_int(GUEST_PAIRED_GRID),) + (e[2][-1],)
+                    out.append(["fork"])
+                    out.append(g)
+                    hosts = [pending[k] for k in take]
+                    for k in reversed(take):
+                        del pending[k]
+                    for head, _, _ in hosts:
+                        out.append(head)
+                    out.append(["join"])
+                    for _, tail, _ in hosts:
+                        out.extend(tail)
+                    i += 1
+                    continue
+            out.append(e)
+            i += 1
+            continue
+        if e[0] != "c" or (t[0] == "xchg" and not travels(e)):
+            flush()                      # host callbacks (optimiser, torch-mode exchange), the exchange's closing entries
+        out.append(e)
+        i += 1
+    flush()
+    return out
+
+
 class TrainStep:
     """One data-parallel training step of `multigpu_train.py`'s hot loop (:118-142,171-174) for
     this process's tower: forward -> loss -> backward (gradient buckets all-reduced while the rest
@@ -237,6 +335,7 @@ class TrainStep:
         self.side_stream = None
         self.side_ptr = None
         self.chain_streams = {}       # chain id -> (torch stream, its handle): graph.Graph.chain
+        self.guest_stream = self.guest_ptr = self.guest_event = None      # schedule_guests: the paired guest passes' stream
         self.fork_event = None
         self._packed_version = None
         # weight gradients on a second stream: measured neutral-to-negative once the wgrad kernels
@@ -301,7 +400,7 @@ class TrainStep:
             rec.py(lambda: self.opt.apply_gradients(self.reducer.grad_scale))
             rec.entries[-1].append("opt")
             rec.py(self._repack)
-            self.plan = rec.entries
+            self.plan = schedule_guests(rec.entries) if USE_GUESTS else rec.entries
             self.static_batch = list(batch)
             self.keepalive, g.keepalive = g.keepalive, None
             g.reset_tape()
@@ -338,8 +437,25 @@ class TrainStep:
         group_open, forked = False, []
         bwd_marked = False
         for e in self.plan:
+            if e[0] == "fork":
+                # a weight gradient and the guest pass paired with it (schedule_guests): the guest stream starts here
+                if self.guest_stream is None:
+                    self.guest_stream = torch.cuda.Stream()
+                    self.guest_ptr = ctypes.c_void_p(self.guest_stream.cuda_stream)
+                    self.guest_event = torch.cuda.Event()
+                self.guest_event.record(main)
+                self.guest_stream.wait_event(self.guest_event)
+                continue
+            if e[0] == "join":
+                main.wait_stream(self.guest_stream)
+                continue
             if e[0] == "c":
                 tag = e[4]
+                if tag is not None and tag[0] == "guest" and tag[-1] == "paired":
+                    rc = e[1](*(e[2][:-1] + (self.guest_ptr,)))
+                    if rc != 0:
+                        _lib.check(rc, e[3])
+                    continue
                 if tag is not None and tag[0] == "xchg":
                     # the gradient exchange as C-ABI calls (dist.GradientAllReduce, abi mode)
                     if self.reducer.enabled:
@@ -393,7 +509,7 @@ class TrainStep:
                     side.wait_stream(main)
                     rc = e[1](*(e[2][:-1] + (side_ptr,)))
                     side_used = True
-                elif timing is not None and tag is not None and tag[0] != "side":
+                elif timing is not None and tag is not None and len(tag) > 2 and tag[0] not in ("side", "guest", "xchg"):      # (kernel instantiation, FLOP, phase)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     rc = e[1](*e[2])

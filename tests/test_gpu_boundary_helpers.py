@@ -40,6 +40,30 @@ def test_ohnm_single_image_exact(device, hw, n_pos):
         assert got.sum() >= min(3 * n_pos, int(neg.sum()))           # tie-inclusive: at least k
 
 
+@pytest.mark.parametrize("hw,n_pos", [(4096, 100), (1000, 250), (333, 7)])
+def test_ohnm_single_image_on_signed_scores(device, hw, n_pos):
+    """the reference's top_k(-neg_conf) works on any real scores (nets/model.py:161-184); the radix select
+    orders the float bits through a sign-aware key, so logits, mixed signs, -0.0 / +0.0 ties and all-negative maps give
+    the oracle's selection exactly."""
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model as M
+    g = Graph(device)
+    rng = np.random.default_rng(hw * 3 + n_pos)
+    for kind in ("logits", "all_negative", "zeros"):
+        scores = (rng.standard_normal(hw) * 3).astype(np.float32)
+        if kind == "all_negative":
+            scores = -np.abs(scores) - np.float32(0.5)
+        if kind == "zeros":
+            scores[rng.integers(0, hw, hw // 3)] = np.float32(0.0)
+            scores[rng.integers(0, hw, hw // 3)] = np.float32(-0.0)
+        scores[rng.integers(0, hw, hw // 8)] = np.float32(-1.25)     # exact ties below zero
+        neg = rng.random(hw) < 0.7
+        got = M.OHNM_single_image(scores, n_pos, neg, graph=g).cpu().numpy()
+        want = O.ohnm_single_image(scores, n_pos, neg)
+        assert np.array_equal(got, want), kind
+        assert got.sum() >= min(3 * n_pos, int(neg.sum()))
+
+
 def test_ohnm_batch_exact_and_equals_the_loss_kernels_mask(device):
     """OHNM_batch on P(neg) computed with the shared deterministic exp = the mask the fused loss mines."""
     from tensorflow_ocr_amd import layers

@@ -221,6 +221,40 @@ def test_pixellinknet_1024_forward(device):
     assert np.abs(sp - so).max() < 1e-2 * TOL
 
 
+def test_pixellinknet_1024_batch16_replicated_equals_n1(device):
+    """configs[4] AT ITS BATCH: PixelLinkNet inference on 16 x 1024^2.  A bias net in inference has no
+    cross-image term, so 16 copies of one image must give, image by image, the n = 1 result BIT FOR BIT — which drags
+    every tile variant the batch-16 launch selects (the XCD swizzle, the persistent 64-channel kernel on 1024-row maps, 4x
+    the workgroups per layer) through the oracle-checked n = 1 forward of the test above — and two DIFFERENT images in
+    one batch must each equal their own n = 1 result (no leakage across the batch axis)."""
+    from tensorflow_ocr_amd import checkpoint
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import pixellink
+    rng = np.random.default_rng(0)
+    p = O.init_pixellink_params(rng)
+    images, _, _, _ = O.synthetic_batch(rng, 2, 1024)
+    g = Graph(device)
+    pixellink.PixelLinkNet(((images[:1, :64, :64] - np.float32(120.0)) / np.float32(60.0)).astype(np.float32), graph=g)
+    g.reset_tape()
+    g.store.load_state_dict(checkpoint.tf_to_internal(g.store.order, p))
+
+    def fwd(batch):
+        net = pixellink.PixelLinkNet(batch, graph=g, input_norm=(120.0, 60.0))
+        g.reset_tape()
+        torch.cuda.synchronize()
+        return net.pixel_cls.data.clone(), net.link_cls.data.clone()
+    one = [fwd(images[i:i + 1]) for i in range(2)]
+    px16, lk16 = fwd(np.repeat(images[:1], 16, axis=0))
+    assert tuple(px16.shape) == (16, 256, 256, 2) and tuple(lk16.shape) == (16, 256, 256, 16)
+    for i in range(16):
+        assert torch.equal(px16[i], one[0][0][0]) and torch.equal(lk16[i], one[0][1][0]), i
+    mixed = np.concatenate([images[:1], images[1:2]] * 8, axis=0)                 # a b a b ... : distinct neighbours
+    pxm, lkm = fwd(mixed)
+    for i in range(16):
+        assert torch.equal(pxm[i], one[i % 2][0][0]) and torch.equal(lkm[i], one[i % 2][1][0]), i
+    assert not torch.equal(one[0][0], one[1][0])
+
+
 def test_link_cc_decode_16x256_bit_exact(device):
     """configs[4]'s decode at its size: 16 maps of 256x256, labels / counts / component table bit-exact
     against the union-find oracle (NumPy edge set + scipy components, held equal to the loop version on

@@ -1,0 +1,144 @@
+"""The GUEST forms of the batch-norm backward apply passes (csrc/guest_bn.hip; reference: the gradient of slim.batch_norm
++ ReLU under nets/model_vgg_16.py:144, nets/vgg.py:14-39) against the general kernels they stand in for and against a
+float64 restatement, and the recorded step's pairing of each with the weight gradient it runs beside."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ocr_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF16 = O.STORAGE == torch.bfloat16
+ULP = 2.0 ** -7 if BF16 else 2.0 ** -10          # one rounding of the 16-bit result
+
+
+def _inputs(rng, n, h, w, c, device):
+    from tensorflow_ocr_amd.graph import F16
+    y = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(F16).to(device)
+    scale = torch.from_numpy((rng.uniform(0.5, 1.5, c) * rng.choice([-1.0, 1.0], c, p=[0.1, 0.9])).astype(np.float32)).to(device)
+    shift = torch.from_numpy(rng.normal(0, 0.3, c).astype(np.float32)).to(device)
+    mean = torch.from_numpy(rng.normal(0, 0.2, c).astype(np.float32)).to(device)
+    invstd = torch.from_numpy(rng.uniform(0.7, 1.3, c).astype(np.float32)).to(device)
+    T = 37
+    partial = torch.from_numpy((rng.standard_normal((T, 2, c)) * 3).astype(np.float32)).to(device)
+    return y, scale, shift, mean, invstd, partial, T
+
+
+@pytest.mark.parametrize("n,h,w,c,relu", [(2, 16, 24, 64, True), (1, 15, 9, 128, True), (3, 7, 5, 256, True),
+                                          (2, 8, 8, 512, True), (1, 4, 6, 1024, True), (2, 9, 11, 32, False),
+                                          (1, 33, 17, 8, True)])
+def test_apply_affine_guest_equals_the_general_apply_pass(device, n, h, w, c, relu):
+    """ocr_bn_bwd_coefficients + ocr_bn_relu_bwd_apply_affine_f16 against ocr_bn_relu_bwd_apply_f16 on the same partial
+    sums: dgamma / dbeta bit-identical (the same finalisation), dy within one rounding of the 16-bit result (the affine
+    form A*dz + B*y + C and sc*(dz - k_dz - xhat*k_dzx) are two f32 evaluations of one expression), the ReLU mask
+    identical — asserted through a float64 evaluation with the mask taken from the stored activation."""
+    from tensorflow_ocr_amd import ops
+    from tensorflow_ocr_amd.graph import F16
+    rng = np.random.default_rng(c * 7 + h)
+    y, scale, shift, mean, invstd, partial, T = _inputs(rng, n, h, w, c, device)
+    da = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(F16).to(device)
+    ws = ops.Workspace(device, 8 << 20)
+    assert ops.guest_apply_ok(y.shape)
+    dg0, db0, dy0 = torch.zeros(c, device=device), torch.zeros(c, device=device), torch.empty_like(y)
+    ops.bn_relu_bwd_apply(y, scale, shift, mean, invstd, da, relu, partial, T, dg0, db0, dy0, ws)
+    dg1, db1 = torch.zeros(c, device=device), torch.zeros(c, device=device)
+    dy1 = torch.full_like(y, float("nan"))
+    coef = tuple(torch.empty(c, device=device) for _ in range(3))
+    ops.bn_bwd_coefficients_pre(partial, T, c, float(n * h * w), scale, mean, invstd, dg1, db1, coef, ws)
+    ops.bn_relu_bwd_apply_affine(y, da, scale, shift, coef[1], coef[2], relu, dy1)
+    torch.cuda.synchronize()
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert not torch.isnan(dy1.float()).any()
+    # float64 from the same inputs, the mask from the STORED activation (16-bit rounding of fma(y, scale, shift))
+    yf = y.double().cpu().numpy()
+    sc, sh = scale.double().cpu().numpy(), shift.double().cpu().numpy()
+    act = (y.float() * scale + shift).to(F16)                       # (torch evaluates mul + add: ties may differ from the fma ...)
+    act_fma = torch.from_numpy((yf * sc + sh).astype(np.float32)).to(F16)   # ... the exact product rounded once IS the fma
+    mask = (act_fma.float().numpy() > 0) if relu else np.ones_like(yf, bool)
+    dz = da.double().cpu().numpy() * mask
+    N = float(n * h * w)
+    k_dz, k_dzx = db0.double().cpu().numpy() / N, dg0.double().cpu().numpy() / N
+    xh = (yf - mean.double().cpu().numpy()) * invstd.double().cpu().numpy()
+    ref = sc * (dz - k_dz - xh * k_dzx)
+    tol = ULP * np.abs(ref) + 1e-6 + 1e-6 * np.abs(ref).max()
+    for name, dy in (("general", dy0), ("guest", dy1)):
+        err = np.abs(dy.double().cpu().numpy() - ref)
+        assert (err <= tol).all(), (name, float((err / tol).max()))
+    assert float((dy0.float() - dy1.float()).abs().max()) <= 2 * ULP * float(dy0.float().abs().max())
+    assert act.shape == act_fma.shape
+
+
+@pytest.mark.parametrize("n,h,w,c,relu", [(2, 16, 24, 64, True), (1, 14, 10, 128, True), (3, 8, 8, 32, False),
+                                          (1, 6, 4, 512, True)])
+def test_pooled_apply_affine_guest_equals_the_general_pass(device, n, h, w, c, relu):
+    """ocr_bn_relu_pool_bwd_idx_apply_affine_f16 against ocr_bn_relu_pool_bwd_idx_apply_f16 (stored first-max index, even
+    maps): same routing, dy within one rounding; odd maps are refused (the host keeps the general kernel)."""
+    from tensorflow_ocr_amd import _lib as L, ops
+    from tensorflow_ocr_amd.graph import F16
+    rng = np.random.default_rng(c + h)
+    y, scale, shift, mean, invstd, partial, T = _inputs(rng, n, h, w, c, device)
+    y[0, :2, :2, :8] = 0.5                               # ties: the FIRST maximum takes the gradient
+    oh, ow = h // 2, w // 2
+    da = torch.from_numpy(rng.standard_normal((n, oh, ow, c)).astype(np.float32)).to(F16).to(device)
+    ws = ops.Workspace(device, 8 << 20)
+    pooled = torch.empty((n, oh, ow, c), dtype=F16, device=device)
+    am = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=device)
+    ops.bn_relu_pool_idx(y, scale, shift, relu, None, pooled, am)
+    dg0, db0, dy0 = torch.zeros(c, device=device), torch.zeros(c, device=device), torch.empty_like(y)
+    ops.bn_relu_pool_bwd_idx_apply(y, scale, mean, invstd, am, da, relu, partial, T, dg0, db0, dy0, ws)
+    dg1, db1 = torch.zeros(c, device=device), torch.zeros(c, device=device)
+    dy1 = torch.full_like(y, float("nan"))
+    coef = tuple(torch.empty(c, device=device) for _ in range(3))
+    ops.bn_bwd_coefficients_pre(partial, T, c, float(n * h * w), scale, mean, invstd, dg1, db1, coef, ws)
+    ops.bn_relu_pool_bwd_idx_apply_affine(y, am, da, coef, relu, dy1)
+    torch.cuda.synchronize()
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert not torch.isnan(dy1.float()).any()
+    d0, d1 = dy0.float(), dy1.float()
+    assert float((d0 - d1).abs().max()) <= 2 * ULP * float(d0.abs().max())
+    # where the pooled gradient was routed the two agree on WHERE: dz enters with weight A (|A| >= 0.5 here)
+    routed0 = (d0 - (coef[1] * y.float() + coef[2])).abs() > 0.2 * da.float().abs().max()
+    routed1 = (d1 - (coef[1] * y.float() + coef[2])).abs() > 0.2 * da.float().abs().max()
+    assert torch.equal(routed0, routed1)
+    odd = torch.empty((1, 5, 6, 64), dtype=F16, device=device)
+    with pytest.raises(L.OcrHipError):
+        ops.bn_relu_pool_bwd_idx_apply_affine(odd, am, da, coef, relu, torch.empty_like(odd))
+
+
+def test_recorded_step_pairs_every_guest_with_a_weight_gradient(device):
+    """model_vgg's recorded step (train.schedule_guests): each guest apply pass sits between a FORK in front of the
+    weight gradient it runs beside and a JOIN behind it, its coefficient call in front of the fork; the replayed step
+    (two streams) gives the parameters of the eager step (one stream) bit for bit."""
+    from tensorflow_ocr_amd.graph import Graph
+    from tensorflow_ocr_amd.nets import model_vgg_16 as M
+    from tensorflow_ocr_amd.train import AdamOptimizer, TrainStep
+    rng = np.random.default_rng(0)
+    images, pixel, link, mask = O.synthetic_batch(rng, 2, 128)
+    batch = [torch.from_numpy(a).to(device) for a in (images, pixel, link, mask)]
+
+    def fl(g, im, px, lk, mk):
+        p, l = M.model_vgg(im, graph=g)
+        return M.loss(px, p, lk, l, mk, graph=g)
+    outs = []
+    for replay in (True, False):
+        g = Graph(device, loss_scale=1024.0, seed=3)
+        step = TrainStep(g, fl, lambda gg: AdamOptimizer(gg), replay=replay)
+        for _ in range(5):
+            step(*batch)
+        torch.cuda.synchronize()
+        outs.append(g.store.flat.clone())
+        if replay:
+            plan = step.plan
+            kinds = [e[0] if e[0] != "c" else (e[4][0] if e[4] is not None else "c") for e in plan]
+            forks = [i for i, k in enumerate(kinds) if k == "fork"]
+            assert len(forks) >= 8, kinds                        # conv1_2 ... conv5_2 and fc6, minus guests left without a host
+            for i in forks:
+                assert plan[i + 1][4][0] == "guest" and plan[i + 1][4][-1] == "paired" and kinds[i + 2] == "side"
+                j = kinds.index("join", i)
+                assert all(k == "side" for k in kinds[i + 2:j]) and kinds[j + 1] in ("reduce", "side")
+            assert kinds.count("fork") == kinds.count("join")
+            # every weight gradient is issued, and before the optimiser
+            opt = max(i for i, e in enumerate(plan) if e[0] == "py")
+            sides = [i for i, k in enumerate(kinds) if k == "side"]
+            assert len(sides) >= 14 and max(sides) < opt               # fc7, fc6, conv5_3 ... conv1_2
+    assert torch.equal(outs[0], outs[1])

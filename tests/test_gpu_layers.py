@@ -373,8 +373,10 @@ def test_pooled_bn_layer_backward_sums_from_the_consumer_convolution(device):
     gu, dxu = run(False)
     for k in gf:
         ref = np.abs(gu[k]).max()
-        assert ref > 0 and np.abs(gf[k] - gu[k]).max() <= 2e-3 * ref, (k, np.abs(gf[k] - gu[k]).max(), ref)
-    assert np.abs(dxf - dxu).max() <= 2e-3 * np.abs(dxu).max()
+        assert ref > 0 and np.abs(gf[k] - gu[k]).max() <= 2e-3 * TOL * ref, (k, np.abs(gf[k] - gu[k]).max(), ref)
+    # (the fused path's apply step is the guest form dy = A*dz + B*y + C, csrc/guest_bn.hip: one 16-bit rounding of dy
+    # apart from the general kernel's sc*(dz - k_dz - xhat*k_dzx) — 2^-8 relative in the bfloat16 build)
+    assert np.abs(dxf - dxu).max() <= 2e-3 * TOL * np.abs(dxu).max()
 
 
 def test_first_conv_weight_gradient_with_bn_backward_applied_on_load(device):

@@ -584,3 +584,167 @@ def test_design_tables_show_the_committed_profiles(tmp_path):
     assert short("void conv3x3_w4s_kernel<128, 1>(ConvP, bool)") == "conv3x3_w4s_kernel<128>"
     assert short("void conv_c64_persist_kernel<64, false, 6>(ConvP)") == "conv_c64_persist_kernel<64>"
     assert short("void conv_pw_kernel<256, 4, true>(ConvP)") == "conv_pw_kernel<256,4,1>"
+
+
+def test_guest_kernels_fit_beside_the_weight_gradient():
+    """csrc/guest_bn.hip's kernels are placed beside a resident wgrad3_kernel<9,128> workgroup (198 VGPR + 256 AGPR ->
+    200 + 256 = 456 of the 512 registers per lane a SIMD has; allocation granule 8): they must stay within 56 registers
+    per lane, a few bytes of LDS (the work-queue index) and no scratch, in both storage builds — and the host kernel must not have grown."""
+    csrc = os.path.join(ROOT, "tensorflow_ocr_amd", "csrc")
+
+    def usage(src, extra=()):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-DOCR_WPS=1", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+                            "-Rpass-analysis=kernel-resource-usage", *extra, "-c", os.path.join(csrc, src), "-o", os.devnull],
+                           capture_output=True, text=True, cwd=csrc)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = {}
+        for blk in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
+            name = blk.split()[0]
+            f = lambda k: int(re.search(k + r": (\d+)", blk).group(1))
+            out[name] = dict(vgpr=f("VGPRs"), agpr=f("AGPRs"), scratch=f(r"ScratchSize \[bytes/lane\]"), lds=f(r"LDS Size \[bytes/block\]"))
+        return out
+    for extra in ((), ("-DOCR_BF16",)):
+        guests = {k: v for k, v in usage("guest_bn.hip", extra).items() if "affine" in k}
+        assert len(guests) == 4, guests.keys()
+        for k, v in guests.items():
+            alloc = (v["vgpr"] + 7) // 8 * 8
+            assert alloc <= 56 and v["agpr"] == 0 and v["scratch"] == 0 and v["lds"] <= 64, (k, v)
+    host = {k: v for k, v in usage("conv_wgrad.hip").items() if "wgrad3_kernelILi9ELi128" in k}
+    assert len(host) == 1
+    v = next(iter(host.values()))
+    assert (v["vgpr"] + 3) // 4 * 4 + v["agpr"] <= 456 and v["scratch"] == 0, v
+
+
+def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
+    """train.schedule_guests on a synthetic recorded plan: weight gradients wait (with what was recorded behind them);
+    every guest forks, goes to the second stream and takes held-back slab kernels along — oldest first, as many as cover
+    it without a large overshoot; the join sits in front of the next main-stream call and the slab sums / exchange
+    entries of the hosts follow it; whatever is still held back is issued in front of the first entry that needs the
+    gradients; a guest with nothing to run beside stays serial."""
+    from tensorflow_ocr_amd.train import schedule_guests
+
+    def c(name, tag=None):
+        return ["c", None, (), name, tag, None]
+    W = 1.3e9 * 100            # a weight gradient estimated at 100 us
+    G = 5.0e6 * 100            # a guest that takes 100 us alone
+    plan = [c("apply5", ("guest", G)),                                       # nothing held back yet: serial
+            c("dgrad5"), c("wgrad5", ("side", W)), c("red5", ("reduce",)), c("s2d5", ("side",)), c("x5a", ("xchg", None, "early")),
+            c("x5b", ("xchg", "rccl", "early")),
+            c("coef4", ("pre",)), c("apply4", ("guest", G)), c("dgrad4"), c("wgrad4", ("side", W)), c("red4", ("reduce",)),
+            c("coef3", ("pre",)), c("apply3", ("guest", 0.25 * G)), c("dgrad3"), c("wgrad3", ("side", W)), c("wgrad3b", ("side", 5 * W)),
+            c("dgrad2"), c("wgrad2", ("side", W)),
+            c("xl", ("xchg", "rccl", "late")), c("xf", ("xchg", "finish")), ["py", None, "opt"]]
+    out = schedule_guests(plan, cover=2.0)
+    names = [e[3] if e[0] == "c" else e[0] for e in out]
+    assert names == ["apply5", "dgrad5",
+                     "coef4", "fork", "apply4", "wgrad5", "join", "red5", "s2d5", "x5a", "x5b",   # one host is all there is
+                     "dgrad4", "coef3", "fork", "apply3", "wgrad4", "join", "red4",               # 25 us x 2: the smallest host
+                     "dgrad3", "dgrad2", "wgrad3", "wgrad3b", "wgrad2", "xl", "xf", "py"]         # the rest before the exchange closes
+    paired = [e[3] for e in out if e[0] == "c" and e[4] is not None and e[4][0] == "guest" and e[4][-1] == "paired"]
+    assert paired == ["apply4", "apply3"]
+    assert plan[8][4] == ("guest", G)                                        # the input plan is not modified
+    # a long guest takes several hosts along, skips one that would overshoot, and leaves the rest held back
+    plan2 = [c("w0", ("side", W)), c("big", ("side", 4 * W)), c("w1", ("side", W)), c("w2", ("side", W)), c("w3", ("side", W)),
+             c("coef", ("pre",)), c("apply", ("guest", 1.4 * G)), c("dgrad"), ["py", None]]
+    names2 = [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan2, cover=2.0)]
+    assert names2 == ["coef", "fork", "apply", "w0", "w1", "w2", "join", "dgrad", "big", "w3", "py"]
+    # a host far larger than the guest needs is not spent on it
+    plan3 = [c("huge", ("side", 10 * W)), c("coef", ("pre",)), c("apply", ("guest", 0.2 * G)), c("dgrad"), ["py", None]]
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan3, cover=2.0)] == ["coef", "apply", "dgrad", "huge", "py"]
+
+
+def test_decode_slab_is_reserved_not_sparse(tmp_path):
+    """the decode workers' slab must be RESERVED when it is created (a sparse file under a 64 MB /dev/shm maps
+    fine and kills the process with SIGBUS at the first page past the limit).  _reserve_slab: pages allocated, fewer
+    slots when the first size does not fit, the next directory when nothing fits, SlabUnavailable naming what was tried;
+    a pool of decode processes round-trips an image through the reserved slab."""
+    from tensorflow_ocr_amd.datasets import _decode
+    slots, path = _decode._reserve_slab(8, 3, 1 << 16, "slab_a", dirs=(str(tmp_path),))
+    try:
+        st = os.stat(path)
+        assert slots == 8 and st.st_size == 8 << 16 and st.st_blocks * 512 >= st.st_size      # allocated, not sparse
+    finally:
+        os.unlink(path)
+    with pytest.raises(_decode.SlabUnavailable, match="missing or not writable"):
+        _decode._reserve_slab(4, 2, 1 << 16, "slab_b", dirs=(str(tmp_path / "nope"),))
+    # a directory that cannot hold the request: RLIMIT_FSIZE makes posix_fallocate fail with EFBIG in a child process
+    code = r"""
+import os, resource, signal, sys
+sys.path.insert(0, %r)
+from tensorflow_ocr_amd.datasets import _decode
+signal.signal(signal.SIGXFSZ, signal.SIG_IGN)
+resource.setrlimit(resource.RLIMIT_FSIZE, (5 << 16, 5 << 16))
+slots, path = _decode._reserve_slab(16, 3, 1 << 16, "slab_c", dirs=(%r,))
+print(slots, os.stat(path).st_size)
+try:
+    _decode._reserve_slab(16, 9, 1 << 16, "slab_d", dirs=(%r,))
+except _decode.SlabUnavailable as e:
+    print("unavailable", "16 slots" in str(e) and "9 slots" in str(e))
+""" % (ROOT, str(tmp_path), str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.split("\n")
+    assert lines[0] == "4 %d" % (4 << 16) and lines[1] == "unavailable True", r.stdout
+    # end to end: a worker process writes the decoded pixels into the reserved slab
+    from PIL import Image
+    arr = (np.arange(40 * 50 * 3) % 251).astype(np.uint8).reshape(40, 50, 3)
+    Image.fromarray(arr).save(tmp_path / "img_1.png")
+    open(tmp_path / "gt_img_1.txt", "w").write("1,1,20,1,20,10,1,10,text\n")
+    pool = _decode.DecodePool(1, slots=2, slot_bytes=40 * 50 * 3)
+    try:
+        fn, im, polys, tags, slot = pool.submit(str(tmp_path / "img_1.png"), 64).result(timeout=60)
+        assert slot is not None and np.array_equal(np.asarray(im)[..., ::-1] if im.shape == arr.shape and not np.array_equal(im, arr) else im, arr)
+        pool.release(slot)
+    finally:
+        pool.close()
+
+
+_ACK_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch.distributed as td
+from tensorflow_ocr_amd import dist, _lib as L
+rank, world, _ = dist.init_process_group_from_env("gloo")
+store = td.distributed_c10d._get_default_store()
+if rank == 1:
+    class Broken:                                   # rank 1 cannot read the id (a store.get that times out / raises)
+        def __init__(self, s): self.s = s
+        def get(self, k):
+            if k.startswith("ocr_comm_id_") and "_ack_" not in k:
+                raise RuntimeError("simulated store timeout")
+            return self.s.get(k)
+        def set(self, k, v): return self.s.set(k, v)
+        def wait(self, *a): return self.s.wait(*a)
+    store = Broken(store)
+dist.AbiComm.ACK_TIMEOUT_S = 30
+try:
+    dist.AbiComm(rank, world, store=store)
+    print("rank", rank, "entered init")             # must not happen on either rank
+except (L.OcrHipError, RuntimeError) as e:
+    print("rank", rank, "raised:", str(e)[:80])
+td.barrier(); td.destroy_process_group()
+"""
+
+
+def test_rccl_rendezvous_second_gate_keeps_healthy_ranks_out_of_init(tmp_path):
+    """a rank that fails to obtain the unique id AFTER the availability vote must not leave the others
+    blocked inside ncclCommInitRank: every rank acknowledges the id (or its failure) through the store first, and all
+    of them raise — the caller then falls back to the torch exchange collectively.  World 2, gloo, CPU: rank 1's
+    store.get fails; neither rank reaches ocr_comm_init_rank and both return within the timeout."""
+    script = tmp_path / "ack.py"
+    script.write_text(_ACK_WORKER % ROOT)
+    from tensorflow_ocr_amd import launch
+    port = launch.free_port()
+    ps = [subprocess.Popen([sys.executable, str(script)], env=launch.child_env(r, 2, port), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT) for r in range(2)]
+    outs = []
+    for p in ps:
+        try:
+            outs.append(p.communicate(timeout=150)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in ps:
+                q.kill()
+            raise
+    for r, (p, o) in enumerate(zip(ps, outs)):
+        assert p.returncode == 0 and ("rank %d raised" % r) in o and "entered init" not in o, o[-2000:]
+    assert "simulated store timeout" in outs[1] and "could not obtain the unique id" in outs[0]
