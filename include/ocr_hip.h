@@ -202,6 +202,10 @@ size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d);
 int ocr_conv2d_wgrad_slabs_f16(const ocr_conv_desc* d, const void* x, const void* dy, void* workspace, size_t ws_bytes,
                                void* stream);
 int ocr_conv2d_wgrad_reduce_f32(const ocr_conv_desc* d, const void* workspace, void* dw_hwio_f32, void* stream);
+/* Registers per lane that stay free on a SIMD beside the kernel ocr_conv2d_wgrad_slabs_f16 launches for `d` (56 beside
+ * wgrad3_kernel<9,128>, 248 beside <9,64>, 80 beside the 256 x 256 pointwise tile; 0 = none / unknown): whether a guest
+ * pass (<= 56) can be placed beside it.  The recorded step holds back only weight gradients that can host. */
+int ocr_conv2d_wgrad_guest_room(const ocr_conv_desc* d);
 
 /* First-layer weight gradient (cin=3 from the [n,h,w,4] f16 image). dw [3,3,3,cout] f32. */
 int ocr_conv2d_first_wgrad_f16(int n, int h, int w, int cout, const void* x4,

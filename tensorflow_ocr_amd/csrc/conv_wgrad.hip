@@ -895,6 +895,27 @@ static int wgrad_slab_count(const ocr_conv_desc* d) {
   return p.splits * 2;
 }
 
+// Registers per lane a SIMD has LEFT beside the resident workgroup(s) of the kernel ocr_conv2d_wgrad_slabs_f16 selects for
+// `d` — what a guest wave may use (csrc/guest_bn.hip needs 56) — or 0 where the kernel fills the file / is not tabulated.
+// From -Rpass-analysis=kernel-resource-usage (allocation granule 8, AGPRs behind the VGPRs rounded to 4):
+//   wgrad3_kernel<9,128>: 198 + 256 -> 456, one wave per SIMD                       -> 56
+//   wgrad3_kernel<9,64>:  134 + 128 -> 264, one wave per SIMD (106 KB LDS: one WG)   -> 248
+//   wgrad_pw_kernel<256,256,2>: 212 -> 216, two waves per SIMD (one WG of 512)       -> 80
+// tests/test_host_cpu.py::test_guest_kernels_fit_beside_the_weight_gradient re-derives the first from the compiler.
+extern "C" int ocr_conv2d_wgrad_guest_room(const ocr_conv_desc* d) {
+  if (!d || d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh <= 0 || d->ow <= 0) return 0;
+  if (ocr_detail::wgrad_pw_splits(d) > 0)
+    return (d->cin % 256 == 0 && d->cout % 256 == 0 && !getenv("OCR_WGRAD_PW_TILE") && !getenv("OCR_WGRAD_PW_COB")) ? 80 : 0;
+  Wg2P p2;
+  int cob = 0;
+  if (fill2(d, &p2, &cob) != OCR_OK) return 0;
+  static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();
+  const bool small = (size_t)d->n * d->h * d->w * d->cin < (1u << 30) && (size_t)d->n * d->oh * d->ow * d->cout < (1u << 30);
+  const bool use3 = d->kh * d->kw == 9 && v3 && small && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1;
+  if (!use3) return 0;
+  return cob == 128 ? 56 : 248;
+}
+
 extern "C" int ocr_conv2d_wgrad_reduce_f32(const ocr_conv_desc* d, const void* workspace, void* dw, void* stream) {
   OCR_CHECK_ARG(d && workspace && dw);
   OCR_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0);

@@ -248,6 +248,7 @@ def bn_relu_bwd_apply(y, scale, shift, save_mean, save_invstd, da_full, relu, pa
 # --- guest forms (csrc/guest_bn.hip): <= 56 registers per lane, one launch, placed beside a resident weight-gradient
 # workgroup; the recorded step runs them on a second stream (train.TrainStep: tags "pre" / "guest") -------------------
 GUEST_BN = __import__("os").environ.get("OCR_GUEST_BN", "1") == "1"
+GUEST_FIRST = __import__("os").environ.get("OCR_GUEST_FIRST", "0") == "1"
 
 
 def guest_apply_ok(shape):
@@ -293,7 +294,10 @@ def conv2d_wgrad(d, x, dy, dw, ws, alloc=None):
         buf = alloc(nbytes)
         L.call("ocr_conv2d_wgrad_slabs_f16", byref(d), ptr(x), ptr(dy), ptr(buf), c_size_t(nbytes), _st())
         if L.RECORDER is not None:
-            L.RECORDER.tag_last(("side", flops))
+            # a host only if a guest's 56 registers per lane fit beside it (a kernel that fills the file would
+            # time-slice with the guest); otherwise it stays where it was recorded
+            room = L.call_int("ocr_conv2d_wgrad_guest_room", byref(d))
+            L.RECORDER.tag_last(("side", flops) if room >= 56 else ("side",))
         L.call("ocr_conv2d_wgrad_reduce_f32", byref(d), ptr(buf), ptr(dw), _st())
         if L.RECORDER is not None:
             L.RECORDER.tag_last(("reduce",))
@@ -360,6 +364,9 @@ def conv2d_first_wgrad_bn(x4, da, y, shift, coef, relu, dw, ws, w_first=None):
     L.call("ocr_conv2d_first_wgrad_bn_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(da),
            ptr(None if w_first is not None else y), ptr(w_first), ptr(shift), ptr(a), ptr(b), ptr(c), c_int(int(relu)),
            ptr(dw), ptr(buf), c_size_t(nbytes), _st())
+    if L.RECORDER is not None and GUEST_FIRST:
+        # measurement switch: the HBM-bound first-layer weight gradient beside the last held-back weight gradients
+        L.RECORDER.tag_last(("guest", 4.0 * n * h * w * cout, "as_is"))
 
 
 def conv2d_first_bn_relu(x4, w_first, scale, shift, relu, a):

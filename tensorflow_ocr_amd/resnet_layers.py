@@ -9,6 +9,8 @@ sums).  Other strides fall back on the identity the reference's own docstring st
 (resnet_utils.py:85-93): conv2d_same(x, n, 3, stride=s) == subsample(conv2d(x, n, 3, stride=1, SAME), s)
 — 4x the work at stride 2 plus a full-resolution intermediate, which is why it is only the fallback.
 """
+import torch
+
 from . import ops
 from .graph import Act, F32, constant, variance_scaling
 from .layers import BN_DECAY, BN_EPS, FUSE_BN_REDUCE, _bn_vars, _packs
@@ -166,7 +168,7 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             else:
                 ops.conv2d_pw_bnbwd_tail(dg, dz_f, ybn_f, coef_f, relu_shift, dy, w_dg, x.grad)
             dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, 1, 1, 1, 1, 0, 0, 0, 0)
-            ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad)
+            ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad, alloc=_slab_alloc(g))
             return
         if strided and not s2d:
             dy_full = g.empty(y_full.shape)
@@ -174,58 +176,68 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             dy = dy_full
         dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, d.kh, d.kw, 1, d.dilation, d.pad_top,
                           d.pad_left, 0, 0)
-        if s2d:
-            dw22 = g.empty((2, 2, 4 * cin, cout), F32)
-            ops.conv2d_wgrad(dd, x_in, dy, dw22, g.ws_wgrad)
-            ops.weights_s2d_grad(dw22, wv.grad)
-        else:
-            ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad)
-        if not x.requires_grad:
-            return
-        pt = d.dilation * (d.kh - 1) - d.pad_top
-        pl = d.dilation * (d.kw - 1) - d.pad_left
-        if s2d:
-            # input gradient in the shuffled layout, then back to full resolution (added to what is there)
-            dxs = g.empty(x_in.shape)
-            dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, 0)
-            ops.conv2d(dg, dy, w_dg, dxs, None, None)
-            had = x.grad is not None
-            if not had:
+        def weight_gradient():
+            if s2d:
+                dw22 = g.empty((2, 2, 4 * cin, cout), F32)
+                ops.conv2d_wgrad(dd, x_in, dy, dw22, g.ws_wgrad, alloc=_slab_alloc(g))
+                ops.weights_s2d_grad(dw22, wv.grad)
+            else:
+                ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad, alloc=_slab_alloc(g))
+        def input_gradient():
+            pt = d.dilation * (d.kh - 1) - d.pad_top
+            pl = d.dilation * (d.kw - 1) - d.pad_left
+            if s2d:
+                # input gradient in the shuffled layout, then back to full resolution (added to what is there)
+                dxs = g.empty(x_in.shape)
+                dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, 0)
+                ops.conv2d(dg, dy, w_dg, dxs, None, None)
+                had = x.grad is not None
+                if not had:
+                    x.grad = g.empty(x.shape)
+                ops.depth_to_space(dxs, x.grad, had)
+                x.bn_partial = None
+                return
+            flags = 0
+            if x.grad is None:
                 x.grad = g.empty(x.shape)
-            ops.depth_to_space(dxs, x.grad, had)
-            x.bn_partial = None
-            return
-        flags = 0
-        if x.grad is None:
-            x.grad = g.empty(x.shape)
+            else:
+                flags |= CONV_ACCUM_F16
+                x.bn_partial = None     # an earlier consumer's fused BN-backward sums no longer cover the full gradient
+            dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, flags)
+            last = False
+            if x.pending is not None and owner is not None and owner is x.pending_owner:
+                # only the owning unit's two contributions are counted (any other consumer of x was built
+                # later, runs earlier in the backward pass and has already added its share)
+                x.pending -= 1
+                assert x.pending >= 0, "more gradient contributions than the owning unit has consumers"
+                last = x.pending == 0
+            if last and x.tail_ctx is not None and k == 1 and FUSE_TAIL:
+                # x is the previous bottleneck's output and this is the last contribution to its gradient: store
+                # the gradient past its ReLU and emit the BN-backward sums of its last conv (ops.conv2d_bnred_tail)
+                Tm = ops.conv2d_num_mtiles(dg)
+                partial = g.empty((Tm, 2, d.cin), F32)
+                ops.conv2d_bnred_tail(dg, dy, w_dg, x.grad, partial, x.tail_ctx, x.sub_grad)
+                x.sub_grad = None
+                x.tail_partial = (partial, Tm)
+            elif x.bn_ctx is not None and not flags and FUSE_BN_REDUCE:
+                # sole consumer of a conv+BN(+ReLU) output: this input-gradient kernel also emits that
+                # layer's BN-backward sums, so its backward skips the reduction pass (layers.py does the same)
+                Tm = ops.conv2d_num_mtiles(dg)
+                partial = g.empty((Tm, 2, d.cin), F32)
+                ops.conv2d_bnred(dg, dy, w_dg, x.grad, partial, x.bn_ctx)
+                x.bn_partial = (partial, Tm)
+            else:
+                ops.conv2d(dg, dy, w_dg, x.grad, None, None)
+        if ops.GUEST_BN and GUEST_RESNET and x.requires_grad:
+            # input gradient FIRST (layers._conv_backward): the weight gradient is held back by the recorded step and runs
+            # as the host of a later batch-norm apply pass (train.schedule_guests)
+            input_gradient()
+            weight_gradient()
         else:
-            flags |= CONV_ACCUM_F16
-            x.bn_partial = None     # an earlier consumer's fused BN-backward sums no longer cover the full gradient
-        dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, flags)
-        last = False
-        if x.pending is not None and owner is not None and owner is x.pending_owner:
-            # only the owning unit's two contributions are counted (any other consumer of x was built
-            # later, runs earlier in the backward pass and has already added its share)
-            x.pending -= 1
-            assert x.pending >= 0, "more gradient contributions than the owning unit has consumers"
-            last = x.pending == 0
-        if last and x.tail_ctx is not None and k == 1 and FUSE_TAIL:
-            # x is the previous bottleneck's output and this is the last contribution to its gradient: store
-            # the gradient past its ReLU and emit the BN-backward sums of its last conv (ops.conv2d_bnred_tail)
-            Tm = ops.conv2d_num_mtiles(dg)
-            partial = g.empty((Tm, 2, d.cin), F32)
-            ops.conv2d_bnred_tail(dg, dy, w_dg, x.grad, partial, x.tail_ctx, x.sub_grad)
-            x.sub_grad = None
-            x.tail_partial = (partial, Tm)
-        elif x.bn_ctx is not None and not flags and FUSE_BN_REDUCE:
-            # sole consumer of a conv+BN(+ReLU) output: this input-gradient kernel also emits that
-            # layer's BN-backward sums, so its backward skips the reduction pass (layers.py does the same)
-            Tm = ops.conv2d_num_mtiles(dg)
-            partial = g.empty((Tm, 2, d.cin), F32)
-            ops.conv2d_bnred(dg, dy, w_dg, x.grad, partial, x.bn_ctx)
-            x.bn_partial = (partial, Tm)
-        else:
-            ops.conv2d(dg, dy, w_dg, x.grad, None, None)
+            weight_gradient()
+            if x.requires_grad:
+                input_gradient()
+
     def can_fuse_bwd(wide=False):
         """The fused form of `backward_from`: this is a stride-1 1x1 convolution the pointwise kernel takes.  Default: its
         input is a conv+BN(+ReLU) output nobody else has contributed a gradient to (the epilogue's fused reduction
@@ -243,6 +255,18 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
     c.backward_from = backward_from
     c.can_fuse_bwd = can_fuse_bwd
     return c
+
+
+# Guests beside held-back weight gradients (layers.conv2d / train.schedule_guests) for THIS net: measured slower at 64 x 640^2
+# (39.13-39.18 ms/step against 38.77 without, 38.98 with the split weight gradients but one stream): its apply passes are
+# 47 us each — a fork + join costs the main queue ~25 us — and its hosts are the HBM-hungry pointwise weight gradients.
+# Off; the switch keeps the path under test.
+GUEST_RESNET = __import__("os").environ.get("OCR_GUEST_RESNET", "0") == "1"
+
+
+def _slab_alloc(g):
+    """A weight gradient's own slab buffer (ops.conv2d_wgrad: the split form the recorded step can hold back)."""
+    return (lambda nb: g.empty((nb,), torch.uint8)) if GUEST_RESNET else None
 
 
 def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_training=True, owner=None, defer=False):
@@ -284,8 +308,16 @@ def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_trainin
             return
         if a.bn_partial is not None:
             part_f, T_f = a.bn_partial
-            ops.bn_relu_bwd_apply(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, relu, part_f, T_f,
-                                  c.gamma.grad, c.beta.grad, dy, ws)
+            if GUEST_RESNET and ops.guest_apply_ok(c.y.shape):
+                # the apply pass as a guest beside held-back weight gradients (layers.conv2d's backward)
+                n_, h_, w_, c_ = c.y.shape
+                coef = (g.empty((c_,), F32), g.empty((c_,), F32), g.empty((c_,), F32))
+                ops.bn_bwd_coefficients_pre(part_f, T_f, c_, float(n_) * h_ * w_, c.scale, c.mean, c.invstd, c.gamma.grad,
+                                            c.beta.grad, coef, ws)
+                ops.bn_relu_bwd_apply_affine(c.y, a.grad, c.scale, c.shift, coef[1], coef[2], relu, dy)
+            else:
+                ops.bn_relu_bwd_apply(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, relu, part_f, T_f,
+                                      c.gamma.grad, c.beta.grad, dy, ws)
             a.bn_partial = None
         else:
             ops.bn_relu_bwd(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, None, relu, 0, c.gamma.grad,

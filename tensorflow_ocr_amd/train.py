@@ -196,9 +196,10 @@ USE_GUESTS = __import__("os").environ.get("OCR_GUEST_STREAM", "1") == "1"
 
 GUEST_COVER = float(__import__("os").environ.get("OCR_GUEST_COVER", "2.1"))
 GUEST_PAIRED_GRID = int(__import__("os").environ.get("OCR_GUEST_PAIRED_GRID", "256"))
+GUEST_MIN_US = float(__import__("os").environ.get("OCR_GUEST_MIN_US", "40"))
 
 
-def schedule_guests(entries, cover=None):
+def schedule_guests(entries, cover=None, min_us=None):
     """Run the HBM-bound batch-norm backward passes of the recorded step as GUESTS beside its weight gradients
     (csrc/guest_bn.hip; measured rates: profiles/r05_guest_pairs.json).
 
@@ -220,6 +221,7 @@ def schedule_guests(entries, cover=None):
     issued later than recorded are always correct: they order the comm stream behind the compute stream at that
     point."""
     cover = GUEST_COVER if cover is None else cover
+    min_us = GUEST_MIN_US if min_us is None else min_us
     out, pending, i, n = [], [], 0, len(entries)
 
     def tag(e):
@@ -237,8 +239,12 @@ def schedule_guests(entries, cover=None):
     while i < n:
         e = entries[i]
         t = tag(e)
+        if t[0] == "side" and len(t) < 2:
+            out.append(e)                    # a weight gradient that cannot host (ops.conv2d_wgrad): stays in place
+            i += 1
+            continue
         if t[0] == "side":
-            us = (t[1] / 1.3e9) if len(t) > 1 else 0.0            # FLOP at 1.3 PFLOP/s, in us
+            us = t[1] / 1.3e9                                     # FLOP at 1.3 PFLOP/s, in us
             j = i + 1
             while j < n and (tag(entries[j])[0] == "reduce" or (tag(entries[j])[0] == "side" and len(tag(entries[j])) < 2)
                              or travels(entries[j])):
@@ -247,8 +253,9 @@ def schedule_guests(entries, cover=None):
             i = j
             continue
         if t[0] == "guest":
-            if pending:
-                need = cover * ((t[1] / 5.0e6) if len(t) > 1 else 0.0)     # bytes at 5 TB/s, in us
+            alone = (t[1] / 5.0e6) if len(t) > 1 else 0.0                  # bytes at 5 TB/s, in us
+            if pending and alone >= min_us:          # (a fork + join costs the main queue ~25 us of idle time)
+                need = cover * alone
                 take, acc = [], 0.0
                 for k, (_, _, us) in enumerate(pending):                  # oldest first, no large overshoot
                     if acc >= 0.85 * need:
@@ -264,7 +271,7 @@ def schedule_guests(entries, cover=None):
                     g = list(e)
                     g[4] = ("guest", t[1] if len(t) > 1 else 0.0, "paired")
                     # the guest entry points' `max_workgroups` (second to last argument): one workgroup per CU beside hosts
-                    if len(e[2]) >= 2:
+                    if len(e[2]) >= 2 and t[-1] != "as_is":
                         g[2] = tuple(e[2][:-2]) + (__import__("ctypes").c_int(GUEST_PAIRED_GRID),) + (e[2][-1],)
                     out.append(["fork"])
                     out.append(g)

@@ -105,13 +105,15 @@ def test_pooled_apply_affine_guest_equals_the_general_pass(device, n, h, w, c, r
         ops.bn_relu_pool_bwd_idx_apply_affine(odd, am, da, coef, relu, torch.empty_like(odd))
 
 
-def test_recorded_step_pairs_every_guest_with_a_weight_gradient(device):
+def test_recorded_step_pairs_every_guest_with_a_weight_gradient(device, monkeypatch):
     """model_vgg's recorded step (train.schedule_guests): each guest apply pass sits between a FORK in front of the
     weight gradient it runs beside and a JOIN behind it, its coefficient call in front of the fork; the replayed step
     (two streams) gives the parameters of the eager step (one stream) bit for bit."""
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.nets import model_vgg_16 as M
+    from tensorflow_ocr_amd import train
     from tensorflow_ocr_amd.train import AdamOptimizer, TrainStep
+    monkeypatch.setattr(train, "GUEST_MIN_US", 0.0)          # (at this size every pass is shorter than the pairing threshold)
     rng = np.random.default_rng(0)
     images, pixel, link, mask = O.synthetic_batch(rng, 2, 128)
     batch = [torch.from_numpy(a).to(device) for a in (images, pixel, link, mask)]

@@ -634,7 +634,7 @@ def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
             c("coef3", ("pre",)), c("apply3", ("guest", 0.25 * G)), c("dgrad3"), c("wgrad3", ("side", W)), c("wgrad3b", ("side", 5 * W)),
             c("dgrad2"), c("wgrad2", ("side", W)),
             c("xl", ("xchg", "rccl", "late")), c("xf", ("xchg", "finish")), ["py", None, "opt"]]
-    out = schedule_guests(plan, cover=2.0)
+    out = schedule_guests(plan, cover=2.0, min_us=0)
     names = [e[3] if e[0] == "c" else e[0] for e in out]
     assert names == ["apply5", "dgrad5",
                      "coef4", "fork", "apply4", "wgrad5", "join", "red5", "s2d5", "x5a", "x5b",   # one host is all there is
@@ -646,11 +646,16 @@ def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
     # a long guest takes several hosts along, skips one that would overshoot, and leaves the rest held back
     plan2 = [c("w0", ("side", W)), c("big", ("side", 4 * W)), c("w1", ("side", W)), c("w2", ("side", W)), c("w3", ("side", W)),
              c("coef", ("pre",)), c("apply", ("guest", 1.4 * G)), c("dgrad"), ["py", None]]
-    names2 = [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan2, cover=2.0)]
+    names2 = [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan2, cover=2.0, min_us=0)]
     assert names2 == ["coef", "fork", "apply", "w0", "w1", "w2", "join", "dgrad", "big", "w3", "py"]
     # a host far larger than the guest needs is not spent on it
     plan3 = [c("huge", ("side", 10 * W)), c("coef", ("pre",)), c("apply", ("guest", 0.2 * G)), c("dgrad"), ["py", None]]
-    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan3, cover=2.0)] == ["coef", "apply", "dgrad", "huge", "py"]
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan3, cover=2.0, min_us=0)] == ["coef", "apply", "dgrad", "huge", "py"]
+    # a guest shorter than a fork + join costs is left alone; a weight gradient that cannot host stays where it was recorded
+    plan4 = [c("w0", ("side", W)), c("fat", ("side",)), c("redf", ("reduce",)), c("coef", ("pre",)), c("apply", ("guest", 0.3 * G)),
+             c("dgrad"), ["py", None]]
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan4, cover=2.0, min_us=40)] == [
+        "coef", "apply", "dgrad", "w0", "fat", "redf", "py"]
 
 
 def test_decode_slab_is_reserved_not_sparse(tmp_path):
