@@ -327,12 +327,14 @@ int ocr_bn_bwd_coefficients(const void* partial, int T, int c, double count, con
                             void* coef_a, void* coef_b, void* coef_c, void* workspace, size_t ws_bytes,
                             void* stream);
 /* The reduction pass of ocr_bn_relu_bwd_f16 (sum dz, sum dz*xhat over y and da_full) + the same finalize: dgamma, dbeta
- * and (A, B, C), no apply pass — for layers whose dy has a single reader that applies it on load.  partial:
- * [ocr_bn_bwd_num_partials(n,h,w,c,0)][2][c] f32 scratch. */
+ * and (A, B, C), no apply pass — for layers whose dy has a single reader that applies it on load, or whose apply pass
+ * runs as a guest (ocr_bn_relu_bwd_apply_affine_f16 ...).  da_pool (nullable; round 5): the gradient of the layer's
+ * 2x2/2 max-pool [n,ceil(h/2),ceil(w/2),c], routed to each window's first maximum as ocr_bn_relu_bwd_f16(pool = 2) does.
+ * partial: [ocr_bn_bwd_num_partials(n,h,w,c, da_pool ? 2 : 0)][2][c] f32 scratch. */
 int ocr_bn_relu_bwd_reduce_f16(const void* y, const void* scale, const void* shift, const void* save_mean,
-                               const void* save_invstd, const void* da_full, int n, int h, int w, int c, int relu,
-                               void* dgamma, void* dbeta, void* coef_a, void* coef_b, void* coef_c, void* partial,
-                               void* workspace, size_t ws_bytes, void* stream);
+                               const void* save_invstd, const void* da_full, const void* da_pool, int n, int h, int w,
+                               int c, int relu, void* dgamma, void* dbeta, void* coef_a, void* coef_b, void* coef_c,
+                               void* partial, void* workspace, size_t ws_bytes, void* stream);
 /* The same with the max-pool backward that produces da_full folded in: da_full is GATHERED from the pool's pooled
  * gradient and first-maximum index (k x k / stride window, pads as ocr_maxpool_f16; da_pooled, argmax: [n,oh,ow,c]) —
  * the value ocr_maxpool_bwd_f16 stores, bit for bit — summed into the partials while in registers, and written to
@@ -373,6 +375,13 @@ int ocr_bias_relu_bwd_f16(const void* a, const void* da, int64_t npix, int c, in
 int ocr_bn_relu_bwd_apply_affine_f16(const void* y, const void* da, const void* scale, const void* shift,
                                      const void* coef_b, const void* coef_c, int n, int h, int w, int c, int relu,
                                      void* dy, int max_workgroups, void* stream);
+/* pooled END-POINT layers (conv3_3 / conv4_3: the heads read the full-resolution activation, the pool feeds the trunk):
+ * dz = (da_full + [first max] * da_pool) * [ReLU mask of the position]; argmax_u8 from ocr_bn_relu_pool_idx_f16 called
+ * with a_full; coefficients from ocr_bn_relu_bwd_reduce_f16(da_pool).  Even h, w. */
+int ocr_bn_relu_poolfull_bwd_apply_affine_f16(const void* y, const void* da_full, const void* da_pool,
+                                              const void* argmax_u8, const void* scale, const void* shift,
+                                              const void* coef_b, const void* coef_c, int n, int h, int w, int c, int relu,
+                                              void* dy, int max_workgroups, void* stream);
 int ocr_bn_relu_pool_bwd_idx_apply_affine_f16(const void* y, const void* argmax_u8, const void* da_pool,
                                               const void* coef_a, const void* coef_b, const void* coef_c, int n, int h,
                                               int w, int c, int relu, void* dy, int max_workgroups, void* stream);

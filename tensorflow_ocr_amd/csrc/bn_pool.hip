@@ -1298,21 +1298,22 @@ extern "C" int ocr_bn_bwd_sums(const void* partial, int T, int c, void* out0, vo
 // (dy = A*dz + B*y + C): for layers whose dy has a single reader that can apply it on load — the first / root
 // convolutions' weight gradients (ocr_conv2d_first_wgrad_bn_f16, ocr_conv2d_stem_wgrad_bn_f16).
 extern "C" int ocr_bn_relu_bwd_reduce_f16(const void* y, const void* scale, const void* shift, const void* save_mean,
-                                          const void* save_invstd, const void* da_full, int n, int h, int w, int c,
-                                          int relu, void* dgamma, void* dbeta, void* coef_a, void* coef_b, void* coef_c,
-                                          void* partial, void* workspace, size_t ws_bytes, void* stream) {
+                                          const void* save_invstd, const void* da_full, const void* da_pool, int n, int h,
+                                          int w, int c, int relu, void* dgamma, void* dbeta, void* coef_a, void* coef_b,
+                                          void* coef_c, void* partial, void* workspace, size_t ws_bytes, void* stream) {
   OCR_CHECK_ARG(y && scale && shift && save_mean && save_invstd && da_full && dgamma && dbeta);
   OCR_CHECK_ARG(coef_a && coef_b && coef_c && partial && workspace);
   OCR_CHECK_SHAPE(c % 8 == 0 && pow2(c / 8) && c / 8 <= 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int T = bwd_blocks(n, h, w, c, 0);
+  const int pool = da_pool ? 2 : 0;          // da_pool: the gradient of the layer's 2x2/2 max-pool, routed to each window's first maximum
+  const int T = bwd_blocks(n, h, w, c, pool);
   if (ws_bytes < ocr_bn_reduce_workspace(T, c)) return OCR_ERR_WORKSPACE;
-  BnBwdP p{n, h, w, c, relu, 0, (float)(1.0 / ((double)n * h * w))};
+  BnBwdP p{n, h, w, c, relu, pool, (float)(1.0 / ((double)n * h * w))};
   hipLaunchKernelGGL(bn_relu_bwd_kernel<0>, dim3(T), dim3(256), 0, st, p, static_cast<const half_t*>(y),
                      static_cast<const float*>(scale), static_cast<const float*>(shift),
                      static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
                      (const float*)nullptr, (const float*)nullptr, static_cast<const half_t*>(da_full),
-                     (const half_t*)nullptr, static_cast<float*>(partial), (half_t*)nullptr);
+                     static_cast<const half_t*>(da_pool), static_cast<float*>(partial), (half_t*)nullptr);
   const int rows = red_rows(T), R = ocr_cdiv(T, rows);
   OCR_CHECK_SHAPE(ocr_cdiv(c, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
   hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFinC>, dim3(R, ocr_cdiv(c, 64)), dim3(256), 0, st,

@@ -151,6 +151,65 @@ __global__ __launch_bounds__(256) void bn_pool_apply_affine_kernel(
   }
 }
 
+// ... and for a pooled layer that is ALSO an end point (conv3_3 / conv4_3 of nets/vgg.py:22-30: the fuse heads read the
+// full-resolution activation, nets/model_vgg_16.py:160-172): the activation's gradient is the heads' full-resolution
+// contribution plus the pooled gradient routed to each window's first maximum (bits 0-1 of the forward's index byte),
+// masked by the ReLU of the position itself:  dz = (da_full + [first max] * da_pool) * [fma(y, A, S) > tie].
+// One pooled unit (4 positions x (y, da_full) + the pooled gradient + the index) in flight per thread.
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_poolfull_apply_affine_kernel(
+    const half_t* __restrict__ y, const half_t* __restrict__ da_full, const half_t* __restrict__ da_pool,
+    const unsigned char* __restrict__ argmax, const float* __restrict__ cA, const float* __restrict__ cS,
+    const float* __restrict__ cB, const float* __restrict__ cC, int n, int h, int w, int c, half_t* __restrict__ dy,
+    int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const int chunks = c >> 2, lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  const int oh = h >> 1, ow = w >> 1;
+  const unsigned units = (unsigned)n * oh * ow;
+  const size_t full = (size_t)n * h * w * c * 2, pooled = (size_t)units * c * 2;
+  const __amdgpu_buffer_rsrc_t ry = rsrc_of(y, full), rf = rsrc_of(da_full, full), ro = rsrc_of(dy, full),
+                               rg = rsrc_of(da_pool, pooled), ra = rsrc_of(argmax, pooled / 2);
+  float A[4], S[4], B[4], C[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    A[e] = cA[ch * 4 + e];
+    S[e] = RELU ? cS[ch * 4 + e] : 0.f;
+    B[e] = cB[ch * 4 + e];
+    C[e] = cC[ch * 4 + e];
+  }
+  const unsigned row = (unsigned)c * 2;
+  const unsigned below = (unsigned)w * row;
+  const unsigned stride = gridDim.x * (unsigned)lanes;
+  for (unsigned u = blockIdx.x * (unsigned)lanes + (unsigned)ul; u < units; u += stride) {
+    const unsigned ox = u % (unsigned)ow, t = u / (unsigned)ow;
+    const unsigned poff = u * row + (unsigned)ch * 8;
+    const unsigned foff = ((t * 2u) * (unsigned)w + ox * 2u) * row + (unsigned)ch * 8;
+    const half4_t gp = ld8(rg, poff, 0);
+    const unsigned am = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(poff >> 1), 0, 0);
+    half4_t yv[4], gv[4];
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) {
+      const unsigned so = (k & 1 ? row : 0) + (k & 2 ? below : 0);
+      yv[k] = ld8(ry, foff, so);
+      gv[k] = ld8(rf, foff, so);
+    }
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) {
+      half4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yf = (float)yv[k][e];
+        float g = ((am >> (8 * e)) & 3u) == k ? (float)gp[e] : 0.f;       // (the general kernel's order: routed + full)
+        g += (float)gv[k][e];
+        const float dz = RELU ? (__builtin_fmaf(yf, A[e], S[e]) > OCR_RELU_TIE ? g : 0.f) : g;
+        o[e] = (half_t)__builtin_fmaf(A[e], dz, __builtin_fmaf(B[e], yf, C[e]));
+      }
+      st8(ro, foff, (k & 1 ? row : 0) + (k & 2 ? below : 0), o);
+    }
+  }
+}
+
 bool pow2g(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // grid: `max_workgroups` when the caller names one (the recorded step asks for 256 = ONE per CU for a pass it runs
@@ -218,5 +277,27 @@ extern "C" int ocr_bn_relu_pool_bwd_idx_apply_affine_f16(const void* y, const vo
                        static_cast<const half_t*>(da_pool), static_cast<const unsigned char*>(argmax_u8),
                        static_cast<const float*>(coef_a), static_cast<const float*>(coef_b),
                        static_cast<const float*>(coef_c), n, h, w, c, static_cast<half_t*>(dy), guest_prio());
+  return ocr_launch_status();
+}
+
+// ... and of ocr_bn_relu_bwd_f16(pool = 2, da_full given) for pooled end-point layers, with the forward's first-max index
+// (ocr_bn_relu_pool_idx_f16 with a_full): coefficients from ocr_bn_relu_bwd_reduce_f16(da_pool given).  Even h, w.
+extern "C" int ocr_bn_relu_poolfull_bwd_apply_affine_f16(const void* y, const void* da_full, const void* da_pool,
+                                                         const void* argmax_u8, const void* scale, const void* shift,
+                                                         const void* coef_b, const void* coef_c, int n, int h, int w, int c,
+                                                         int relu, void* dy, int max_workgroups, void* stream) {
+  OCR_CHECK_ARG(y && da_full && da_pool && argmax_u8 && scale && shift && coef_b && coef_c && dy && n > 0 && h > 0 && w > 0);
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2g(c / 4) && c / 4 <= 256 && h % 2 == 0 && w % 2 == 0);
+  const size_t full = (size_t)n * h * w * c * 2;
+  OCR_CHECK_SHAPE(full < (1ull << 31));
+  const int lanes = 256 / (c / 4);
+  const unsigned grid = guest_grid((size_t)n * (h / 2) * (w / 2), (size_t)lanes, max_workgroups);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  OCR_CHECK_SHAPE(relu != 0);          // (the ReLU-less instantiation needs 58 registers: no net builds a pooled end point without ReLU)
+  hipLaunchKernelGGL(bn_poolfull_apply_affine_kernel<true>, dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(y),
+                     static_cast<const half_t*>(da_full), static_cast<const half_t*>(da_pool),
+                     static_cast<const unsigned char*>(argmax_u8), static_cast<const float*>(scale),
+                     static_cast<const float*>(shift), static_cast<const float*>(coef_b), static_cast<const float*>(coef_c),
+                     n, h, w, c, static_cast<half_t*>(dy), guest_prio());
   return ocr_launch_status();
 }

@@ -129,12 +129,19 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         else:
             ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
         full = pooled = None
-        argmax = y_pool = None
+        argmax = y_pool = argmax_full = None
         if pool:
             pooled = g.empty((n, (oh + 1) // 2, (ow + 1) // 2, cout))
             if keep_full:
                 full = g.empty((n, oh, ow, cout))
-                ops.bn_relu(y, scale, shift, relu, 2, full, pooled)
+                if train_stats and relu and ops.guest_apply_ok((n, oh, ow, cout)) and oh % 2 == 0 and ow % 2 == 0:
+                    # an end point that is also pooled (conv3_3 / conv4_3): keep the first-max positions, so that the
+                    # backward's apply pass can run as a guest (ops.bn_relu_poolfull_bwd_apply_affine) without
+                    # re-deriving them
+                    argmax_full = g.empty(pooled.shape, torch.uint8)
+                    ops.bn_relu_pool_idx(y, scale, shift, relu, full, pooled, argmax_full, None)
+                else:
+                    ops.bn_relu(y, scale, shift, relu, 2, full, pooled)
             else:
                 # the pool is the only consumer: keep the first-max position so that the backward routes
                 # the pooled gradient without re-deriving the four candidates' activations
@@ -220,6 +227,16 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
             elif pool and argmax is not None and da_full is None:
                 ops.bn_relu_pool_bwd_idx(y_b, scale, mean, invstd, a_pool.data, argmax, da_pool, relu,
                                          gamma.grad, beta.grad, dy, ws)
+            elif (not pool or argmax_full is not None) and da_full is not None and ops.guest_apply_ok(y_b.shape):
+                # no consumer summed this layer's terms (several contributed to its gradient: an end point of the fuse
+                # heads): the reduction pass stays, its finalize emits the coefficients, the apply pass is a guest
+                coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
+                ops.bn_relu_bwd_reduce(y_b, scale, shift, mean, invstd, da_full, relu, gamma.grad, beta.grad, coef, ws,
+                                       da_pool=da_pool if pool else None)
+                if pool:
+                    ops.bn_relu_poolfull_bwd_apply_affine(y_b, da_full, da_pool, argmax_full, scale, shift, coef, relu, dy)
+                else:
+                    ops.bn_relu_bwd_apply_affine(y_b, da_full, scale, shift, coef[1], coef[2], relu, dy)
             else:
                 ops.bn_relu_bwd(y_b, scale, shift, mean, invstd, da_full, da_pool, relu, 2 if pool else 0,
                                 gamma.grad, beta.grad, dy, ws)

@@ -406,15 +406,25 @@ def conv2d_stem_wgrad_bn(x4, da, y, shift, coef, relu, dw, ws):
            ptr(shift), ptr(a), ptr(b), ptr(c), c_int(int(relu)), ptr(dw), ptr(buf), c_size_t(nbytes), _st())
 
 
-def bn_relu_bwd_reduce(y, scale, shift, save_mean, save_invstd, da_full, relu, dgamma, dbeta, coef, ws):
-    """Reduction + finalize of the BN backward, the apply step returned as coefficients (dy = A*dz + B*y + C)."""
+def bn_relu_bwd_reduce(y, scale, shift, save_mean, save_invstd, da_full, relu, dgamma, dbeta, coef, ws, da_pool=None):
+    """Reduction + finalize of the BN backward, the apply step returned as coefficients (dy = A*dz + B*y + C).
+    da_pool: the gradient of the layer's 2x2/2 max-pool, routed to each window's first maximum."""
     n, h, w, c = y.shape
-    T = bn_bwd_num_partials(y.shape, 0)
+    T = bn_bwd_num_partials(y.shape, 2 if da_pool is not None else 0)
     part, stage = ws.two(T * 2 * c * 4, bn_reduce_workspace(T, c))
     a, b, cc = coef
     L.call("ocr_bn_relu_bwd_reduce_f16", ptr(y), ptr(scale), ptr(shift), ptr(save_mean), ptr(save_invstd), ptr(da_full),
-           c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(dgamma), ptr(dbeta), ptr(a), ptr(b), ptr(cc),
-           ptr(part), ptr(stage), c_size_t(stage.numel()), _st())
+           ptr(da_pool), c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(dgamma), ptr(dbeta), ptr(a), ptr(b),
+           ptr(cc), ptr(part), ptr(stage), c_size_t(stage.numel()), _st())
+
+
+def bn_relu_poolfull_bwd_apply_affine(y, da_full, da_pool, argmax, scale, shift, coef, relu, dy):
+    """Guest apply pass of a pooled end-point layer (csrc/guest_bn.hip): dz = (da_full + routed da_pool) * ReLU mask."""
+    n, h, w, c = y.shape
+    L.call("ocr_bn_relu_poolfull_bwd_apply_affine_f16", ptr(y), ptr(da_full), ptr(da_pool), ptr(argmax), ptr(scale), ptr(shift),
+           ptr(coef[1]), ptr(coef[2]), c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(dy), c_int(0), _st())
+    if L.RECORDER is not None:
+        L.RECORDER.tag_last(("guest", 6.75 * n * h * w * c))          # y + da_full read, dy written, pooled gradient + index
 
 
 def bn_relu_bwd_reduce_pooled(y, scale, shift, save_mean, save_invstd, pooled, relu, da_out, dgamma, dbeta, coef, ws):

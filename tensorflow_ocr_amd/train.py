@@ -231,6 +231,16 @@ def schedule_guests(entries, cover=None, min_us=None):
         t = tag(e)
         return t[0] == "xchg" and (len(t) < 2 or t[1] != "finish") and (len(t) < 3 or t[2] in (None, "early"))
 
+    def guest_ahead(i0):             # is there a guest behind entry i0, before anything that needs the gradients?
+        for q in range(i0 + 1, n):
+            eq = entries[q]
+            tq = tag(eq)
+            if tq[0] == "guest":
+                return True
+            if eq[0] != "c" or (tq[0] == "xchg" and not travels(eq)):
+                return False
+        return False
+
     def flush():
         for head, tail, _ in pending:
             out.append(head)
@@ -242,6 +252,10 @@ def schedule_guests(entries, cover=None, min_us=None):
         if t[0] == "side" and len(t) < 2:
             out.append(e)                    # a weight gradient that cannot host (ops.conv2d_wgrad): stays in place
             i += 1
+            continue
+        if t[0] == "side" and not guest_ahead(i):
+            out.append(e)                    # no guest left to host (a net without batch norm: every call stays in place,
+            i += 1                           # and the exchange sees its buckets as early as it was recorded)
             continue
         if t[0] == "side":
             us = t[1] / 1.3e9                                     # FLOP at 1.3 PFLOP/s, in us

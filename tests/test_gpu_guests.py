@@ -105,6 +105,63 @@ def test_pooled_apply_affine_guest_equals_the_general_pass(device, n, h, w, c, r
         ops.bn_relu_pool_bwd_idx_apply_affine(odd, am, da, coef, relu, torch.empty_like(odd))
 
 
+@pytest.mark.parametrize("n,h,w,c,relu", [(2, 16, 24, 64, True), (1, 14, 10, 256, True), (2, 8, 8, 512, True), (3, 6, 4, 32, True)])
+def test_pooled_end_point_guest_equals_the_general_backward(device, n, h, w, c, relu):
+    """A pooled layer that is also an end point (conv3_3 / conv4_3): ocr_bn_relu_bwd_reduce_f16(da_pool) + the guest
+    ocr_bn_relu_poolfull_bwd_apply_affine_f16 (first-max index stored by the forward) against ocr_bn_relu_bwd_f16(pool = 2,
+    da_full): dgamma / dbeta bit-identical (the same reduction kernel and finalisation), dy within one rounding, and the
+    forward with the index gives the activations of the plain pooled forward bit for bit."""
+    from tensorflow_ocr_amd import ops
+    from tensorflow_ocr_amd.graph import F16
+    rng = np.random.default_rng(c + h)
+    y, scale, shift, mean, invstd, _, _ = _inputs(rng, n, h, w, c, device)
+    y[0, :2, :2, :8] = 0.5                               # ties: the FIRST maximum takes the pooled gradient
+    oh, ow = h // 2, w // 2
+    da_full = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(F16).to(device)
+    da_pool = torch.from_numpy(rng.standard_normal((n, oh, ow, c)).astype(np.float32)).to(F16).to(device)
+    ws = ops.Workspace(device, 16 << 20)
+    f0, p0 = torch.empty_like(y), torch.empty((n, oh, ow, c), dtype=F16, device=device)
+    f1, p1 = torch.empty_like(y), torch.empty_like(p0)
+    am = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=device)
+    ops.bn_relu(y, scale, shift, relu, 2, f0, p0)
+    ops.bn_relu_pool_idx(y, scale, shift, relu, f1, p1, am, None)
+    assert torch.equal(f0, f1) and torch.equal(p0, p1)
+    dg0, db0, dy0 = torch.zeros(c, device=device), torch.zeros(c, device=device), torch.empty_like(y)
+    ops.bn_relu_bwd(y, scale, shift, mean, invstd, da_full, da_pool, relu, 2, dg0, db0, dy0, ws)
+    dg1, db1 = torch.zeros(c, device=device), torch.zeros(c, device=device)
+    dy1 = torch.full_like(y, float("nan"))
+    coef = tuple(torch.empty(c, device=device) for _ in range(3))
+    ops.bn_relu_bwd_reduce(y, scale, shift, mean, invstd, da_full, relu, dg1, db1, coef, ws, da_pool=da_pool)
+    ops.bn_relu_poolfull_bwd_apply_affine(y, da_full, da_pool, am, scale, shift, coef, relu, dy1)
+    torch.cuda.synchronize()
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert not torch.isnan(dy1.float()).any()
+    d0, d1 = dy0.float(), dy1.float()
+    assert float((d0 - d1).abs().max()) <= 2 * ULP * float(d0.abs().max())
+    # float64 from the inputs: routing by the first maximum of the STORED activation, mask by the position's own activation
+    yf = y.double().cpu().numpy()
+    sc, sh = scale.double().cpu().numpy(), shift.double().cpu().numpy()
+    act = torch.from_numpy((yf * sc + sh).astype(np.float32)).to(F16).float().numpy()
+    if relu:
+        act = np.maximum(act, 0)
+    win = act.reshape(n, oh, 2, ow, 2, c).transpose(0, 1, 3, 2, 4, 5).reshape(n, oh, ow, 4, c)
+    first = win.argmax(3)                                   # numpy: the first maximum, as TF's gradient routing
+    routed = np.zeros((n, oh, ow, 4, c))
+    np.put_along_axis(routed, first[:, :, :, None, :], da_pool.double().cpu().numpy()[:, :, :, None, :], 3)
+    routed = routed.reshape(n, oh, ow, 2, 2, c).transpose(0, 1, 3, 2, 4, 5).reshape(n, h, w, c)
+    dz = (da_full.double().cpu().numpy() + routed) * ((act > 0) if relu else 1.0)
+    N = float(n * h * w)
+    xh = (yf - mean.double().cpu().numpy()) * invstd.double().cpu().numpy()
+    ref = sc * (dz - db0.double().cpu().numpy() / N - xh * dg0.double().cpu().numpy() / N)
+    tol = ULP * np.abs(ref) + 1e-6 + 1e-6 * np.abs(ref).max()
+    for name, dy in (("general", dy0), ("guest", dy1)):
+        err = np.abs(dy.double().cpu().numpy() - ref)
+        assert (err <= tol).all(), (name, float((err / tol).max()))
+    # dgamma / dbeta themselves
+    assert np.allclose(db0.double().cpu().numpy(), dz.sum((0, 1, 2)), rtol=2e-4, atol=2e-3)
+    assert np.allclose(dg0.double().cpu().numpy(), (dz * xh).sum((0, 1, 2)), rtol=2e-4, atol=2e-3)
+
+
 def test_recorded_step_pairs_every_guest_with_a_weight_gradient(device, monkeypatch):
     """model_vgg's recorded step (train.schedule_guests): each guest apply pass sits between a FORK in front of the
     weight gradient it runs beside and a JOIN behind it, its coefficient call in front of the fork; the replayed step

@@ -605,7 +605,7 @@ def test_guest_kernels_fit_beside_the_weight_gradient():
         return out
     for extra in ((), ("-DOCR_BF16",)):
         guests = {k: v for k, v in usage("guest_bn.hip", extra).items() if "affine" in k}
-        assert len(guests) == 4, guests.keys()
+        assert len(guests) == 5, guests.keys()
         for k, v in guests.items():
             alloc = (v["vgpr"] + 7) // 8 * 8
             assert alloc <= 56 and v["agpr"] == 0 and v["scratch"] == 0 and v["lds"] <= 64, (k, v)
@@ -639,7 +639,7 @@ def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
     assert names == ["apply5", "dgrad5",
                      "coef4", "fork", "apply4", "wgrad5", "join", "red5", "s2d5", "x5a", "x5b",   # one host is all there is
                      "dgrad4", "coef3", "fork", "apply3", "wgrad4", "join", "red4",               # 25 us x 2: the smallest host
-                     "dgrad3", "dgrad2", "wgrad3", "wgrad3b", "wgrad2", "xl", "xf", "py"]         # the rest before the exchange closes
+                     "dgrad3", "wgrad3", "wgrad3b", "dgrad2", "wgrad2", "xl", "xf", "py"]         # no guest ahead: in place
     paired = [e[3] for e in out if e[0] == "c" and e[4] is not None and e[4][0] == "guest" and e[4][-1] == "paired"]
     assert paired == ["apply4", "apply3"]
     assert plan[8][4] == ("guest", G)                                        # the input plan is not modified
@@ -651,6 +651,11 @@ def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
     # a host far larger than the guest needs is not spent on it
     plan3 = [c("huge", ("side", 10 * W)), c("coef", ("pre",)), c("apply", ("guest", 0.2 * G)), c("dgrad"), ["py", None]]
     assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan3, cover=2.0, min_us=0)] == ["coef", "apply", "dgrad", "huge", "py"]
+    # no guest ahead: nothing is held back (a net without batch norm keeps its recorded order, exchange entries included)
+    plan5 = [c("dgrad"), c("w0", ("side", W)), c("r0", ("reduce",)), c("x0", ("xchg", None, "early")), c("dgrad1"), c("w1", ("side", W)),
+             c("xf", ("xchg", "finish")), ["py", None]]
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan5, cover=2.0, min_us=0)] == [
+        "dgrad", "w0", "r0", "x0", "dgrad1", "w1", "xf", "py"]
     # a guest shorter than a fork + join costs is left alone; a weight gradient that cannot host stays where it was recorded
     plan4 = [c("w0", ("side", W)), c("fat", ("side",)), c("redf", ("reduce",)), c("coef", ("pre",)), c("apply", ("guest", 0.3 * G)),
              c("dgrad"), ["py", None]]
