@@ -183,8 +183,8 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 # backward while staging its tiles and dy is never written (ocr_conv2d_first_wgrad_bn_f16)
                 part_f, T_f = a_full.bn_partial
                 coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
-                (ops.bn_bwd_coefficients_pre if ops.GUEST_FIRST else ops.bn_bwd_coefficients)(
-                    part_f, T_f, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad, beta.grad, coef, ws)
+                ops.bn_bwd_coefficients(part_f, T_f, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
+                                        beta.grad, coef, ws)
                 lazy = isinstance(y, ops.LazyFirstY)
                 if lazy and y.t is not None:
                     lazy, y_t = False, y.t                # somebody had it evaluated: read it

@@ -248,7 +248,6 @@ def bn_relu_bwd_apply(y, scale, shift, save_mean, save_invstd, da_full, relu, pa
 # --- guest forms (csrc/guest_bn.hip): <= 56 registers per lane, one launch, placed beside a resident weight-gradient
 # workgroup; the recorded step runs them on a second stream (train.TrainStep: tags "pre" / "guest") -------------------
 GUEST_BN = __import__("os").environ.get("OCR_GUEST_BN", "1") == "1"
-GUEST_FIRST = __import__("os").environ.get("OCR_GUEST_FIRST", "0") == "1"
 
 
 def guest_apply_ok(shape):
@@ -364,9 +363,6 @@ def conv2d_first_wgrad_bn(x4, da, y, shift, coef, relu, dw, ws, w_first=None):
     L.call("ocr_conv2d_first_wgrad_bn_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(da),
            ptr(None if w_first is not None else y), ptr(w_first), ptr(shift), ptr(a), ptr(b), ptr(c), c_int(int(relu)),
            ptr(dw), ptr(buf), c_size_t(nbytes), _st())
-    if L.RECORDER is not None and GUEST_FIRST:
-        # measurement switch: the HBM-bound first-layer weight gradient beside the last held-back weight gradients
-        L.RECORDER.tag_last(("guest", 4.0 * n * h * w * cout, "as_is"))
 
 
 def conv2d_first_bn_relu(x4, w_first, scale, shift, relu, a):
