@@ -378,6 +378,21 @@ def main():
             "proxy_launches": int(stats[4]), "rounds": "three arms interleaved twice, best of 2 per arm",
             "reading": "overlapped: the buckets' stand-ins run under backward (dist.GradientAllReduce(overlap=True)); "
                        "after_backward: all of them between backward and the optimiser (overlap=False); DESIGN.md 3.4"}
+        # the placement this build ships and what each placement projects to at 8 ranks, from THIS run's
+        # numbers (a projection from a one-GPU stand-in paced at one xGMI link: RCCL with more than one rank has never run here)
+        pr = comm["proxy"]
+        w0 = pr["step_ms_without"]
+        comm["plan"] = {
+            "placement": "under_backward" if pr["exposed_ms_overlapped"] <= pr["exposed_ms_after_backward"] else "after_backward",
+            "default_placement": "under_backward (dist.GradientAllReduce(overlap=True); OCR_EXCHANGE_OVERLAP=0 places every bucket after backward)",
+            "buckets": len(red.buckets), "bucket_bytes": comm.get("bucket_bytes"), "rccl_ranks_in_this_run": 1,
+            "projected_step_ms_8_ranks": {"under_backward": round(w0 + pr["exposed_ms_overlapped"], 3),
+                                          "after_backward": round(w0 + pr["exposed_ms_after_backward"], 3)},
+            "projected_scaling_of_8": {"under_backward": round(8.0 * w0 / (w0 + pr["exposed_ms_overlapped"]), 2),
+                                       "after_backward": round(8.0 * w0 / (w0 + pr["exposed_ms_after_backward"]), 2)},
+            "why_the_stand_in_is_not_hidden": "its workgroups (18 registers) are placed beside the weight gradients and the 64-channel "
+                                              "kernel, but a 512-register input-gradient wave cannot share a CU with them: those launches "
+                                              "run one round longer (profiles/r05_coresidency_probe.json; DESIGN.md 3.5a)"}
     # dominant kernel: the conv_igemm instantiation with the most accumulated time
     per, fwd = {}, {}
     for variant, flops, phase, e0, e1 in timing:
@@ -435,6 +450,14 @@ def main():
             out["replicas"] = replicas
         if comm is not None:
             out["exchange"] = comm
+        if getattr(step, "plan", None) is not None:
+            # train.schedule_guests: how much of the recorded step runs as guest / host pairs
+            kinds = [e[0] if e[0] != "c" else (e[4][0] if e[4] is not None else "c") for e in step.plan]
+            paired = [e for e in step.plan if e[0] == "c" and e[4] is not None and e[4][0] == "guest" and e[4][-1] == "paired"]
+            out["guests"] = {"pairs": kinds.count("fork"), "guest_passes": sum(1 for k in kinds if k == "guest"),
+                             "weight_gradients": sum(1 for e in step.plan if e[0] == "c" and e[4] is not None and e[4][0] == "side" and len(e[4]) > 1),
+                             "guest_bytes_per_step_GB": round(sum(e[4][1] for e in paired) / 1e9, 2),
+                             "second_stream": "guest passes (<= 56 registers per lane) beside held-back weight-gradient slab kernels"}
         if world == 1 and not args.no_config_legs:
             # free this process's activations first: the legs are children that need the HBM
             del step, batch

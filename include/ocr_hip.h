@@ -251,6 +251,15 @@ int ocr_conv2d_stem_wgrad_bn_f16(int n, int h, int w, int cout, const void* x4, 
 int ocr_pack_weights_f16(const void* w_hwio_f32, int taps, int cin, int cout, void* w_kc,
                          void* w_ck, void* stream);
 int ocr_pack_weights_first_f16(const void* w_hwio_f32, int cout, void* w_first, void* stream);
+/* conv1_1's batch-norm statistics from the IMAGE's second moments instead of a pass over the 64-channel output (round 5):
+ * sum y_c = w_c . m, sum y_c^2 = w_c^T M w_c with m, M the sums of the 27-value patches and of their outer products —
+ * one MFMA per 16 pixels (csrc/conv_first.hip).  stats_row [2][cout] f32 = what ocr_conv2d_first_f16(y = NULL,
+ * OCR_CONV_STATS) + a sum over its partial rows would give for the f32 convolution outputs (the reference's fused batch
+ * norm sees f32: nets/vgg.py:14), i.e. ocr_bn_finalize's input with T = 1; 1e-7-relative apart from the sums of the 16-bit
+ * roundings the evaluating pass takes. */
+size_t ocr_conv2d_first_moments_workspace(void);
+int ocr_conv2d_first_moments_f16(int n, int h, int w, int cout, const void* x4, const void* w_first, void* stats_row,
+                                 void* workspace, size_t ws_bytes, void* stream);
 /* ocr_pack_weights_f16 for n layers in ONE launch (the re-pack that follows every optimiser step).
  * ocr_pack_weights_batch_table fills a HOST table of ocr_pack_weights_batch_table_bytes(n) bytes from n
  * (weights, taps, cin, cout, w_kc, w_ck) tuples of DEVICE pointers (w_kc[i] or w_ck[i] may be NULL) and returns the

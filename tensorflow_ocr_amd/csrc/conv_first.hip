@@ -324,6 +324,120 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstP p, const h
   }
 }
 
+// ---- batch-norm statistics of conv1_1 WITHOUT evaluating the convolution (round 5) ---------------------------------
+// y_c(p) = w_c . v(p) with v(p) the 27-value patch of pixel p (zero outside the image), so over all pixels
+//   sum y_c = w_c . m,   sum y_c^2 = w_c^T M w_c,   m = sum_p v(p),  M = sum_p v(p) v(p)^T
+// — 28 x 28 numbers that depend on the IMAGES only.  The statistics pass evaluated the 64-channel convolution just to
+// round, sum and square 537 M outputs (VALU-bound: 262 us at 32 x 512^2, plus 30 us to finalise its 32 768 partial
+// rows); M is one 32x32x16 MFMA per 16 pixels with the SAME fragment as both operands (the im2col rows the weight
+// gradient builds, column 27 = 1: row 27 of M is m, M[27][27] the pixel count).  f32 accumulation over a workgroup's
+// ~8 K pixels, f64 across workgroups and in the quadratic form; the sums are those of the f32 conv outputs (the reference's
+// fused batch norm: nets/vgg.py:14 under slim.batch_norm), not of their 16-bit roundings: mean and variance move by
+// ~1e-7 relative (rounding to nearest is unbiased), far inside every bar, but NOT bit-identical to the evaluating pass.
+constexpr int FM_WGS = 1024;
+__global__ __launch_bounds__(256) void first_moments_kernel(FirstP p, const half_t* __restrict__ x4,
+                                                            float* __restrict__ slab) {
+  __shared__ __attribute__((aligned(16))) char halo[10 * HW * 8];
+  __shared__ __attribute__((aligned(16))) char patch[256 * PSTRF];
+  __shared__ float red[4][1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int q = li >> 2, pp = li & 3, hh = g >> 1, gc = g & 1;
+  const int a_lane = (8 * hh + q) * PSTRF + (16 * gc + 4 * pp) * 2;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int mt = blockIdx.x; mt < p.m_tiles; mt += gridDim.x) {
+    const int txi = mt % p.tiles_x;
+    const int tmp = mt / p.tiles_x;
+    const int tyi = tmp % p.tiles_y;
+    const int img = tmp / p.tiles_y;
+    __syncthreads();
+    load_halo4(x4, halo, img, p.h, p.w, tyi * TILE_H - 1, txi * TILE_W - 1);
+    __syncthreads();
+    {  // im2col row of this thread's pixel: 27 values, k = (ky*3+kx)*3 + c, then the constant 1; all zero outside the image
+      const int ty = tid >> 5, tx = tid & 31;
+      const bool inside = tyi * TILE_H + ty < p.h && txi * TILE_W + tx < p.w;
+      half_t row[32];
+#pragma unroll
+      for (int k = 27; k < 32; ++k) row[k] = (half_t)0.f;
+      row[27] = inside ? (half_t)1.f : (half_t)0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          half4_t xv = *reinterpret_cast<const half4_t*>(halo + ((ty + ky) * HW + tx + kx) * 8);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) row[(ky * 3 + kx) * 3 + c] = inside ? xv[c] : (half_t)0.f;
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        half8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = row[k * 8 + e];
+        *reinterpret_cast<half8_t*>(patch + tid * PSTRF + k * 16) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k0 = (wave * 4 + s) * 16;   // this wave's 16-pixel k-step
+      half8_t a = tr_pair_f(patch + a_lane + k0 * PSTRF, 4 * PSTRF);
+      acc = OCR_MFMA_32x32x16(a, a, acc, 0, 0, 0);
+    }
+  }
+  // the four waves' quarters meet in LDS (fixed order), one [32][32] block per workgroup
+  const int r = lane & 31, h2 = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * h2) * 32 + r] = acc[e];
+  __syncthreads();
+  for (int i = tid; i < 1024; i += 256)
+    slab[(size_t)blockIdx.x * 1024 + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// slab [blocks][1024] -> stage [32][1024] f64 (fixed order)
+__global__ __launch_bounds__(256) void first_moments_stage_kernel(const float* __restrict__ slab, int blocks,
+                                                                  double* __restrict__ stage) {
+  const int per = (blocks + 31) / 32;
+  const int b0 = blockIdx.x * per, b1 = b0 + per < blocks ? b0 + per : blocks;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    double a = 0.0;
+    for (int b = b0; b < b1; ++b) a += (double)slab[(size_t)b * 1024 + i];
+    stage[(size_t)blockIdx.x * 1024 + i] = a;
+  }
+}
+// stage -> M; per channel (sum y, sum y^2) with the PACKED (16-bit) weights the convolution multiplies by -> one partial
+// row [2][cout] for ocr_bn_finalize (T = 1)
+__global__ __launch_bounds__(256) void first_moments_finish_kernel(const double* __restrict__ stage,
+                                                                   const half_t* __restrict__ wf, int cout,
+                                                                   float* __restrict__ row) {
+  __shared__ double M[32 * 32];
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    double a = 0.0;
+    for (int b = 0; b < 32; ++b) a += stage[(size_t)b * 1024 + i];
+    M[i] = a;
+  }
+  __syncthreads();
+  for (int co = threadIdx.x; co < cout; co += 256) {
+    double wv[27];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wv[(ky * 3 + kx) * 3 + c] = (double)(float)wf[((size_t)(ky * cout + co)) * 16 + kx * 4 + c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < 27; ++i) {
+      s1 += wv[i] * M[27 * 32 + i];
+      double t = 0.0;
+      for (int j = 0; j < 27; ++j) t += M[i * 32 + j] * wv[j];
+      s2 += wv[i] * t;
+    }
+    row[co] = (float)s1;
+    row[cout + co] = (float)s2;
+  }
+}
+
 __global__ void first_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                     int elems, int blocks) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -454,5 +568,26 @@ extern "C" int ocr_conv2d_first_wgrad_bn_f16(int n, int h, int w, int cout, cons
   const int elems = 27 * cout;
   hipLaunchKernelGGL(ocr_sum_rows_kernel, dim3(sum_rows_grid(elems)), dim3(256), 0, st,
                      static_cast<const float*>(workspace), static_cast<float*>(dw), elems, blocks * 2, 1.f);
+  return ocr_launch_status();
+}
+
+// Batch-norm statistics of conv1_1 from the image moments (first_moments_kernel above): row [2][cout] = (sum y, sum y^2)
+// over the n*h*w outputs, for ocr_bn_finalize with T = 1.  workspace: ocr_conv2d_first_moments_workspace() bytes.
+extern "C" size_t ocr_conv2d_first_moments_workspace(void) { return (size_t)FM_WGS * 1024 * sizeof(float) + 32 * 1024 * sizeof(double); }
+extern "C" int ocr_conv2d_first_moments_f16(int n, int h, int w, int cout, const void* x4, const void* w_first,
+                                            void* stats_row, void* workspace, size_t ws_bytes, void* stream) {
+  FirstP p;
+  int rc = fill(&p, n, h, w, cout, 0);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x4 && w_first && stats_row && workspace);
+  if (ws_bytes < ocr_conv2d_first_moments_workspace() || ((uintptr_t)workspace & 7)) return OCR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int blocks = p.m_tiles < FM_WGS ? p.m_tiles : FM_WGS;
+  float* slab = static_cast<float*>(workspace);
+  double* stage = reinterpret_cast<double*>(static_cast<char*>(workspace) + (size_t)FM_WGS * 1024 * sizeof(float));
+  hipLaunchKernelGGL(first_moments_kernel, dim3(blocks), dim3(256), 0, st, p, static_cast<const half_t*>(x4), slab);
+  hipLaunchKernelGGL(first_moments_stage_kernel, dim3(32), dim3(256), 0, st, slab, blocks, stage);
+  hipLaunchKernelGGL(first_moments_finish_kernel, dim3(1), dim3(256), 0, st, stage, static_cast<const half_t*>(w_first),
+                     cout, static_cast<float*>(stats_row));
   return ocr_launch_status();
 }

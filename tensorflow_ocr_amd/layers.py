@@ -60,6 +60,7 @@ FUSE_BN_W4_MAXHW = int(__import__("os").environ.get("OCR_FUSE_BN_W4_MAXHW", "100
 FUSE_BN_POOL_REDUCE = __import__("os").environ.get("OCR_FUSE_BN_POOL_REDUCE", "1") == "1"    # measurement switch
 FIRST_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_RECOMPUTE", "1") == "1"            # measurement switch (forward: 439 -> 318 us)
 FIRST_DROP_Y = __import__("os").environ.get("OCR_FIRST_DROP_Y", "1") == "1"                  # conv1_1's y is never stored (ops.LazyFirstY)
+FIRST_MOMENTS = __import__("os").environ.get("OCR_FIRST_MOMENTS", "1") == "1"                # ... and its statistics come from the image's moments
 # conv1_1's weight gradient recomputing y even when y IS stored: bit-identical, but no faster by itself (413 vs 402 us at
 # 32 x 512^2: with one stream instead of two the kernel is bound by its per-tile LDS work, not by HBM).  With
 # FIRST_DROP_Y (y never stored) the recomputing form is what runs regardless of this switch.
@@ -116,7 +117,13 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         train_stats = bn_training
         flags = CONV_STATS if train_stats else 0
         part, stage = g.ws_small.two(mt * 2 * cout * 4, ops.bn_reduce_workspace(mt, cout))
-        if first:
+        mt_fin = mt
+        if first and drop_y and train_stats and FIRST_MOMENTS:
+            # the statistics from the image's second moments (csrc/conv_first.hip: first_moments_kernel): no pass over the
+            # 64-channel output at all; one partial row
+            ops.conv2d_first_moments(x.data, w_fwd, part, cout, ws)
+            mt_fin = 1
+        elif first:
             ops.conv2d_first(x.data, w_fwd, None if drop_y else y, flags, None, part if train_stats else None, cout=cout)
         else:
             d.flags = flags
@@ -124,7 +131,7 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         scale, shift = g.empty((cout,), F32), g.empty((cout,), F32)
         mean, invstd = g.empty((cout,), F32), g.empty((cout,), F32)
         if train_stats:
-            ops.bn_finalize(part, mt, cout, float(n) * oh * ow, gamma.data, beta.data, BN_EPS, BN_DECAY,
+            ops.bn_finalize(part, mt_fin, cout, float(n) * oh * ow, gamma.data, beta.data, BN_EPS, BN_DECAY,
                             mm.data, mv.data, scale, shift, mean, invstd, stage)
         else:
             ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)

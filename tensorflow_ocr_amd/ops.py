@@ -304,9 +304,9 @@ def conv2d_wgrad(d, x, dy, dw, ws, alloc=None):
     buf = ws.get(nbytes)
     L.call("ocr_conv2d_wgrad_f16", byref(d), ptr(x), ptr(dy), ptr(dw), ptr(buf), c_size_t(nbytes), _st())
     if L.RECORDER is not None:
-        # independent of the rest of backward (only the optimiser and the exchange read dw): the recorded step holds it
-        # back and runs it as the HOST of a later guest pass (train.schedule_guests; FLOP = its estimated cost)
-        L.RECORDER.tag_last(("side", flops))
+        # (the one-call form shares the tower's slab workspace with the next weight gradient: it stays where it was
+        # recorded — train.schedule_guests holds back only the split form above)
+        L.RECORDER.tag_last(("side",))
 
 
 def space_to_depth(x, xs):
@@ -341,6 +341,16 @@ def conv2d_first(x4, w_first, y, flags=0, bias=None, stats=None, cout=None):
     cout = y.shape[-1] if y is not None else cout
     L.call("ocr_conv2d_first_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(w_first),
            ptr(bias), c_int(flags), ptr(y), ptr(stats), _st())
+
+
+def conv2d_first_moments(x4, w_first, row, cout, ws):
+    """conv1_1's batch-norm statistics (sum y, sum y^2 per channel -> row [1][2][cout] f32, any byte buffer) from the
+    image's second moments."""
+    n, h, w, _ = x4.shape
+    nbytes = L.call_size("ocr_conv2d_first_moments_workspace")
+    buf = ws.get(nbytes)
+    L.call("ocr_conv2d_first_moments_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(w_first), ptr(row),
+           ptr(buf), c_size_t(nbytes), _st())
 
 
 def conv2d_first_wgrad(x4, dy, dw, ws):

@@ -316,8 +316,9 @@ def test_first_conv_y_not_stored_and_the_fallback_that_evaluates_it(device, cb):
     seen = {}
 
     def run(drop):
-        old = layers.FIRST_DROP_Y
+        old = layers.FIRST_DROP_Y, layers.FIRST_MOMENTS
         layers.FIRST_DROP_Y = drop
+        layers.FIRST_MOMENTS = False           # (this test is about the recomputed y: both runs take the evaluating statistics pass)
         try:
             g = Graph(device, loss_scale=1.0, seed=9)
             x4 = layers.prep_images(g, torch.from_numpy(img).to(device))
@@ -332,11 +333,81 @@ def test_first_conv_y_not_stored_and_the_fallback_that_evaluates_it(device, cb):
                 seen["materialised"] = lazy.t is not None
             return {k: v.grad.cpu().numpy().copy() for k, v in g.store.vars.items() if v.trainable}
         finally:
-            layers.FIRST_DROP_Y = old
+            layers.FIRST_DROP_Y, layers.FIRST_MOMENTS = old
     gd, gs = run(True), run(False)
     assert seen["materialised"] == (cb != 64)
     for k in gs:
         assert np.abs(gs[k]).max() > 0 and np.array_equal(gd[k], gs[k]), (k, np.abs(gd[k] - gs[k]).max())
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 100, 130), (1, 64, 96), (3, 37, 45)])
+def test_first_conv_statistics_from_the_image_moments(device, n, h, w):
+    """conv1_1's batch-norm statistics without evaluating the convolution (ocr_conv2d_first_moments_f16): sum y_c = w_c . m,
+    sum y_c^2 = w_c^T M w_c from the 28 x 28 second moments of the image patches.  Against float64 on the same 16-bit
+    operands (ragged tiles, image borders: zero padding enters the patches), against the evaluating pass (which sums the
+    16-bit ROUNDINGS of y: equal to ~1e-4 of a standard deviation / 1e-6 relative in the variance), and through the
+    layer: activations and gradients within the layer test's bars of the run that evaluates."""
+    from tensorflow_ocr_amd import layers, ops
+    from tensorflow_ocr_amd.graph import F16, Graph
+    rng = np.random.default_rng(n * 100 + h)
+    img = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    g = Graph(device, loss_scale=1.0, seed=4)
+    x4 = layers.prep_images(g, torch.from_numpy(img).to(device))
+    wt = _h(rng.standard_normal((3, 3, 3, 64)) * 0.02)
+    wdev = torch.from_numpy(wt).to(device)
+    wf = torch.empty((3, 64, 16), dtype=F16, device=device)
+    ops.pack_weights_first(wdev, wf)
+    ws = ops.Workspace(device, 16 << 20)
+    row = torch.zeros((1, 2, 64), dtype=torch.float32, device=device)
+    ops.conv2d_first_moments(x4.data, wf, row, 64, ws)
+    mt = ops.conv2d_first_num_mtiles(n, h, w)
+    part = torch.zeros((mt, 2, 64), dtype=torch.float32, device=device)
+    from tensorflow_ocr_amd._lib import CONV_STATS
+    ops.conv2d_first(x4.data, wf, None, CONV_STATS, None, part, cout=64)
+    torch.cuda.synchronize()
+    # float64 convolution of the 16-bit operands
+    x = x4.data[..., :3].double().cpu().numpy()
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    y = np.zeros((n, h, w, 64))
+    for ky in range(3):
+        for kx in range(3):
+            y += xp[:, ky:ky + h, kx:kx + w, :] @ wt[ky, kx].astype(np.float64)
+    s1, s2 = y.sum((0, 1, 2)), (y * y).sum((0, 1, 2))
+    got = row.double().cpu().numpy()[0]
+    N = n * h * w
+    mean, var = s1 / N, s2 / N - (s1 / N) ** 2
+    gmean, gvar = got[0] / N, got[1] / N - (got[0] / N) ** 2
+    assert np.abs(gmean - mean).max() <= 1e-5 * np.sqrt(var).max() and np.abs(gvar / var - 1).max() <= 1e-5
+    ev = part.double().sum(0).cpu().numpy()
+    emean, evar = ev[0] / N, ev[1] / N - (ev[0] / N) ** 2
+    tol = 16.0 if O.STORAGE == torch.bfloat16 else 1.0
+    assert np.abs(gmean - emean).max() <= 1e-3 * tol * np.sqrt(var).max() and np.abs(gvar / evar - 1).max() <= 1e-4 * tol * tol
+    # through the layer
+    gout = _h(rng.standard_normal((n, h, w, 64)) * 0.1)
+
+    def run(moments):
+        old = layers.FIRST_MOMENTS
+        layers.FIRST_MOMENTS = moments
+        try:
+            gg = Graph(device, loss_scale=1.0, seed=9)
+            xx = layers.prep_images(gg, torch.from_numpy(img).to(device))
+            a, _ = layers.conv2d(gg, xx, 64, 3, "a", first=True)
+            b, _ = layers.conv2d(gg, a, 64, 3, "b")
+            b.grad = torch.from_numpy(gout).to(O.STORAGE).to(device)
+            gg.backward()
+            torch.cuda.synchronize()
+            return a.data.float().cpu().numpy(), {k: v.grad.cpu().numpy().copy() for k, v in gg.store.vars.items() if v.trainable}
+        finally:
+            layers.FIRST_MOMENTS = old
+    a1, g1 = run(True)
+    a0, g0 = run(False)
+    assert np.abs(a1 - a0).max() <= 2e-3 * TOL * max(1.0, np.abs(a0).max())
+    # (two 16-bit evaluations of one graph: a 1e-7 change of the statistics flips the last bit of some activations and with
+    # it a few ReLU decisions of layer b — sparse differences of a percent of the tensor maximum, DESIGN section 4)
+    for k in g0:
+        a_, b_ = g1[k].ravel().astype(np.float64), g0[k].ravel().astype(np.float64)
+        assert np.linalg.norm(a_ - b_) <= 2e-2 * TOL * np.linalg.norm(b_), k
+        assert a_ @ b_ / (np.linalg.norm(a_) * np.linalg.norm(b_) + 1e-30) >= (0.99 if O.STORAGE == torch.bfloat16 else 0.9995), k
 
 
 def test_pooled_bn_layer_backward_sums_from_the_consumer_convolution(device):
@@ -398,8 +469,9 @@ def test_first_conv_weight_gradient_with_bn_backward_applied_on_load(device):
     gout = _h(rng.standard_normal((n, h, w, cout)) * 0.1)
 
     def run(fused):
-        old = layers.FUSE_FIRST_WGRAD
+        old = layers.FUSE_FIRST_WGRAD, layers.FIRST_MOMENTS
         layers.FUSE_FIRST_WGRAD = fused
+        layers.FIRST_MOMENTS = False       # (both runs on the evaluating statistics pass: the test is about the weight gradient)
         try:
             g = Graph(device, loss_scale=1.0)
             x4 = layers.prep_images(g, torch.from_numpy(img).to(device))
@@ -417,7 +489,7 @@ def test_first_conv_weight_gradient_with_bn_backward_applied_on_load(device):
             torch.cuda.synchronize()
             return {k: v.grad.cpu().numpy().copy() for k, v in g.store.vars.items() if v.trainable}
         finally:
-            layers.FUSE_FIRST_WGRAD = old
+            layers.FUSE_FIRST_WGRAD, layers.FIRST_MOMENTS = old
     gf, gu = run(True), run(False)
     tp = O.to_torch_params(p)
     xm = O.q(O.mean_image_subtraction(torch.from_numpy(img)), True)
