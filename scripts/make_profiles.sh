@@ -33,4 +33,8 @@ for f in ("pmc_mfma", "pmc_traffic", "clock_diag", "w4_per_layer", "step_calls")
     for p in sorted(glob.glob("profiles/*_%s.json" % f))[-1:]:
         print(p, json.load(open(p))["_provenance"]["csrc_sha16"], "current" if json.load(open(p))["_provenance"]["csrc_sha16"] == now else "STALE (sources changed since)")
 P
+# round 5: co-residency probe, real-kernel guest probe, the recorded step's guest / host pairs, serial-vs-guests trace diff
+for f in coresidency_probe.json guest_probe.json guest_pairs.json guest_pairs_trace.txt trace_diff_serial_vs_guests.txt; do
+  [ -f $R/$f ] && cp $R/$f profiles/${N}_$f
+done
 python scripts/design_tables.py $N

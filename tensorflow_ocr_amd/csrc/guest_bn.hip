@@ -4,7 +4,7 @@
 // per SIMD, one workgroup per CU): 56 registers per lane stay free on every SIMD of the chip for its whole launch, and a
 // wave that needs no more than that is placed beside it (measured, scripts/coresidency_probe.hip: an HBM-streaming
 // guest keeps its stand-alone rate beside a synthetic 456-register MFMA host and costs it nothing; beside the real
-// wgrad3 the pair runs at 1.36x the serial rate, profiles/r05_coresidency.json).  The apply pass of layer L-1
+// wgrad3 the pair runs at 1.36x the serial rate, profiles/r05_coresidency_probe.json, r05_guest_probe.json).  The apply pass of layer L-1
 // (reference: the gradient of slim.batch_norm + ReLU, nets/vgg.py:14-39 under nets/model_vgg_16.py:144) depends only on
 // the input gradient of layer L, the weight gradient of layer L on neither: the recorded step runs the two side by
 // side on two streams (train.TrainStep._replay).  bn_relu_bwd_kernel<1> needs 146 registers and could never be such a

@@ -270,15 +270,22 @@ def schedule_guests(entries, cover=None, min_us=None):
             alone = (t[1] / 5.0e6) if len(t) > 1 else 0.0                  # bytes at 5 TB/s, in us
             if pending and alone >= min_us:          # (a fork + join costs the main queue ~25 us of idle time)
                 need = cover * alone
-                take, acc = [], 0.0
+                # a host that carries exchange entries (its weight gradient completed a bucket) may only go once every
+                # weight gradient recorded before it has gone: the bucket's all-reduce reads all of them
+                def closes_bucket(k):
+                    return any(tag(x)[0] == "xchg" for x in pending[k][1])
+                take, acc, skipped = [], 0.0, False
                 for k, (_, _, us) in enumerate(pending):                  # oldest first, no large overshoot
                     if acc >= 0.85 * need:
                         break
-                    if acc + us <= 1.3 * need:
+                    if acc + us <= 1.3 * need and not (skipped and closes_bucket(k)):
                         take.append(k)
                         acc += us
+                    else:
+                        skipped = True
                 if not take:
-                    k = min(range(len(pending)), key=lambda q: pending[q][2])
+                    ok = [q for q in range(len(pending)) if q == 0 or not closes_bucket(q)]
+                    k = min(ok, key=lambda q: pending[q][2])
                     if pending[k][2] <= 3.0 * need:
                         take = [k]
                 if take:

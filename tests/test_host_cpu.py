@@ -651,6 +651,15 @@ def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
     # a host far larger than the guest needs is not spent on it
     plan3 = [c("huge", ("side", 10 * W)), c("coef", ("pre",)), c("apply", ("guest", 0.2 * G)), c("dgrad"), ["py", None]]
     assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan3, cover=2.0, min_us=0)] == ["coef", "apply", "dgrad", "huge", "py"]
+    # a host whose weight gradient completed an exchange bucket never overtakes an older held-back weight gradient (the
+    # bucket's all-reduce reads both): the small one stays behind the big one it was recorded after
+    plan6 = [c("big", ("side", 4 * W)), c("small", ("side", W)), c("xs", ("xchg", "rccl", "early")), c("coef", ("pre",)),
+             c("apply", ("guest", 0.5 * G)), c("dgrad"), ["py", None]]
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan6, cover=2.0, min_us=0)] == [
+        "coef", "apply", "dgrad", "big", "small", "xs", "py"]
+    plan7 = [c("big", ("side", 4 * W)), c("small", ("side", W)), c("coef", ("pre",)), c("apply", ("guest", 0.5 * G)), c("dgrad"), ["py", None]]
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan7, cover=2.0, min_us=0)] == [
+        "coef", "fork", "apply", "small", "join", "dgrad", "big", "py"]
     # no guest ahead: nothing is held back (a net without batch norm keeps its recorded order, exchange entries included)
     plan5 = [c("dgrad"), c("w0", ("side", W)), c("r0", ("reduce",)), c("x0", ("xchg", None, "early")), c("dgrad1"), c("w1", ("side", W)),
              c("xf", ("xchg", "finish")), ["py", None]]
