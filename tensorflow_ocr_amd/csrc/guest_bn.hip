@@ -26,11 +26,18 @@ namespace {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
 }
+// Non-temporal policy (aux = 2) on the guests' loads (bit 0) and stores (bit 1): every byte is touched once, and the host
+// beside them lives on what its L2 keeps.  Measured per variant inside one gpurun call (libraries built with
+// -DOCR_GUEST_NT=0/1/2/3): 19.14-19.20 / 19.10-19.14 / 19.13 / 19.06-19.11 ms per step; on another box 18.87-18.90 -> 18.79-18.82.
+#ifndef OCR_GUEST_NT
+#define OCR_GUEST_NT 3
+#endif
+constexpr int kGuestAuxLd = (OCR_GUEST_NT & 1) ? 2 : 0, kGuestAuxSt = (OCR_GUEST_NT & 2) ? 2 : 0;
 __device__ __forceinline__ half4_t ld8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(half4_t, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+  return __builtin_bit_cast(half4_t, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, kGuestAuxLd));
 }
 __device__ __forceinline__ void st8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, half4_t v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, kGuestAuxSt);
 }
 
 // OCR_GUEST_PRIO=1 (measurement switch): the guest's waves at s_setprio 3 — they issue a handful of instructions per
