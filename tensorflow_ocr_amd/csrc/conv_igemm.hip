@@ -769,6 +769,17 @@ __global__ __launch_bounds__(512) void conv_pwx_kernel(
 //     vmcnt arithmetic is the same in every step.
 // Same tile geometry (8 x 32 pixels x 256 couts), weight pack, epilogue and batch-norm partials as
 // conv_igemm_kernel<256,64,4,true,8>: a drop-in for that instantiation.
+// Cache policy of the output stores of the wave-private epilogues (measurement switch, -DOCR_CONV_NT_STORE=mask: 1 = the
+// persistent 64-channel kernel, 2 = conv3x3_w4s, 4 = conv3x3_w4): a conv output is written once; non-temporal stores keep it
+// from evicting the halo rows and weight slices the neighbouring workgroups are about to read.
+#ifndef OCR_CONV_NT_STORE
+#define OCR_CONV_NT_STORE 7          // A/B in one gpurun call, ms per step: 0 -> 18.67 / 18.67, 1 -> 18.59 / 18.67, 3 -> 18.59 / 18.62, 7 -> 18.53 / 18.57
+#endif
+#define OCR_EPI_STORE(bit, ptr, val)                                                   \
+  do {                                                                                 \
+    if constexpr ((OCR_CONV_NT_STORE & (bit)) != 0) __builtin_nontemporal_store(val, ptr); \
+    else *(ptr) = (val);                                                               \
+  } while (0)
 template <int N> struct IC { static constexpr int value = N; };
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -1108,7 +1119,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
               for (int e = 0; e < 8; ++e)
                 if (!((float)yv[e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
             }
-            *reinterpret_cast<half8_t*>(y + off) = v;
+            OCR_EPI_STORE(4, reinterpret_cast<half8_t*>(y + off), v);
             if (do_stats) {
               if (has_br) {
 #pragma unroll
@@ -1475,7 +1486,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
               for (int e = 0; e < 8; ++e)
                 if (!((float)yv[e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
             }
-            *reinterpret_cast<half8_t*>(y + off) = v;
+            OCR_EPI_STORE(2, reinterpret_cast<half8_t*>(y + off), v);
             if (do_stats) {
               if (has_br) {
 #pragma unroll
@@ -1907,7 +1918,7 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
           for (int e = 0; e < 8; ++e)
             if (!((float)yq[kk][e] * bsc[e] + bsh[e] > relu_thr)) v[e] = (half_t)0.f;
         }
-        if ((C64_ABL & 2) == 0 || v[0] == (half_t)12345.f) *reinterpret_cast<half8_t*>(y + off) = v;
+        if ((C64_ABL & 2) == 0 || v[0] == (half_t)12345.f) OCR_EPI_STORE(1, reinterpret_cast<half8_t*>(y + off), v);
         if (do_stats) {
           if (has_br) {
 #pragma unroll
