@@ -26,7 +26,7 @@ extern "C" {
  * ocr_conv2d_bnred_f16, ocr_conv2d_bnred_tail_f16, ocr_bn_add_relu_f16, ocr_bn_relu_pool_idx_f16; round 4: the
  * batched head entry points and the seed-rank argument of ocr_link_cc_directed; round 5: the guest kernels).  The Python host refuses a
  * library whose ocr_abi_version() differs from the value it was written against (_lib.ABI_VERSION). */
-#define OCR_ABI_VERSION 5
+#define OCR_ABI_VERSION 6
 
 enum {
   OCR_OK = 0,
@@ -117,6 +117,23 @@ int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc
 int ocr_conv2d_bnred_first_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y, void* partial,
                                const void* x4, const void* w_first, const void* bn_scale, const void* bn_shift,
                                const void* bn_mean, const void* bn_invstd, int bn_relu, void* stream);
+/* ... and WITHOUT storing the gradient at all (round 5): conv1_1's weight gradient is the only other reader of conv1_2's
+ * input gradient (conv1_1 has no input gradient of its own: nets/vgg.py:14-17), and with the batch-norm backward apply
+ * dy = A dz + B y + C per channel, V the 27-value image patches and y = V W,
+ *     dW = V^T dy = A .* (V^T dz) + B .* (M W) + C .* m,     M = V^T V, m = V^T 1  (ocr_conv2d_first_moments_keep_f16)
+ * so the launch only has to leave S1 = V^T dz: s1_blocks [ocr_conv2d_bnred_first_wgrad_blocks(d)][32][64] f32, one block
+ * per workgroup (slot ky*10 + kx*3 + c of the 32), accumulated on the matrix cores in the epilogue; `partial` as above.
+ * ocr_bn_bwd_coefficients then turns `partial` into (A, B, C) and ocr_conv2d_first_wgrad_sums_f32 finishes dW — the
+ * 1 GiB gradient tensor (32 x 512^2 x 64) is neither written nor read, and ocr_conv2d_first_wgrad_bn_f16's pass over it
+ * disappears.  ocr_conv2d_bnred_first_wgrad_blocks: -1 where the launch is unsupported. */
+int ocr_conv2d_bnred_first_wgrad_blocks(const ocr_conv_desc* d);
+int ocr_conv2d_bnred_first_wgrad_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* partial,
+                                     const void* x4, const void* w_first, const void* bn_scale, const void* bn_shift,
+                                     const void* bn_mean, const void* bn_invstd, int bn_relu, void* s1_blocks,
+                                     void* stream);
+int ocr_conv2d_first_wgrad_sums_f32(const void* s1_blocks, int blocks, const void* moments_f64, const void* w_first,
+                                    int cout, const void* coef_a, const void* coef_b, const void* coef_c,
+                                    void* dw_hwio_f32, void* stream);
 /* Column sums of such partial rows [T][2][c] -> out0 (kind 0), out1 (kind 1); fixed order, one launch. */
 int ocr_bn_bwd_sums(const void* partial, int T, int c, void* out0, void* out1, void* workspace, size_t ws_bytes,
                     void* stream);
@@ -260,6 +277,10 @@ int ocr_pack_weights_first_f16(const void* w_hwio_f32, int cout, void* w_first, 
 size_t ocr_conv2d_first_moments_workspace(void);
 int ocr_conv2d_first_moments_f16(int n, int h, int w, int cout, const void* x4, const void* w_first, void* stats_row,
                                  void* workspace, size_t ws_bytes, void* stream);
+/* ... keeping the moments: moments_f64 [32][32] doubles (rows / columns k = (ky*3+kx)*3 + c; row 27 = the patch sums m,
+ * [27][27] = the pixel count) for ocr_conv2d_first_wgrad_sums_f32; NULL = ocr_conv2d_first_moments_f16. */
+int ocr_conv2d_first_moments_keep_f16(int n, int h, int w, int cout, const void* x4, const void* w_first,
+                                      void* stats_row, void* moments_f64, void* workspace, size_t ws_bytes, void* stream);
 /* ocr_pack_weights_f16 for n layers in ONE launch (the re-pack that follows every optimiser step).
  * ocr_pack_weights_batch_table fills a HOST table of ocr_pack_weights_batch_table_bytes(n) bytes from n
  * (weights, taps, cin, cout, w_kc, w_ck) tuples of DEVICE pointers (w_kc[i] or w_ck[i] may be NULL) and returns the

@@ -50,6 +50,10 @@ struct BnRed {
   // by the forward's own MFMA sequence (conv_first.hip: first_mfma), hence the same 16-bit values
   const half_t* first_x4;
   const half_t* first_wf;
+  // ... epilogue mode 7: the gradient is NOT stored; S1 = V^T dz (V: the image patches, dz: the gradient past conv1_1's
+  // ReLU) leaves as one [32 slots][64 channels] f32 block per workgroup — all conv1_1's weight gradient needs
+  // (ocr_conv2d_bnred_first_wgrad_f16)
+  float* first_s1;
 };
 
 // LDS needed by the epilogue for a BN-wide tile.

@@ -410,12 +410,13 @@ __global__ __launch_bounds__(256) void first_moments_stage_kernel(const float* _
 // row [2][cout] for ocr_bn_finalize (T = 1)
 __global__ __launch_bounds__(256) void first_moments_finish_kernel(const double* __restrict__ stage,
                                                                    const half_t* __restrict__ wf, int cout,
-                                                                   float* __restrict__ row) {
+                                                                   float* __restrict__ row, double* __restrict__ m_out) {
   __shared__ double M[32 * 32];
   for (int i = threadIdx.x; i < 1024; i += 256) {
     double a = 0.0;
     for (int b = 0; b < 32; ++b) a += stage[(size_t)b * 1024 + i];
     M[i] = a;
+    if (m_out != nullptr) m_out[i] = a;       // kept for the weight gradient (first_wgrad_sums_kernel)
   }
   __syncthreads();
   for (int co = threadIdx.x; co < cout; co += 256) {
@@ -435,6 +436,47 @@ __global__ __launch_bounds__(256) void first_moments_finish_kernel(const double*
     }
     row[co] = (float)s1;
     row[cout + co] = (float)s2;
+  }
+}
+
+// conv1_1's weight gradient from sums (round 5, second half).  With dy = A dz + B y + C per channel (the batch-norm
+// backward apply: ocr_bn_bwd_coefficients), V the 27-value patches, y = V W:
+//   dW = V^T dy = A .* (V^T dz) + B .* (V^T V) W + C .* (V^T 1) = A .* S1 + B .* (M W) + C .* m
+// S1 arrives as one [32 slots][64] block per workgroup of conv1_2's input-gradient launch (conv_c64_persist_kernel,
+// epilogue mode 7; slot ky*10 + kx*3 + c), M (rows / columns k = (ky*3+kx)*3 + c, row 27 = m) from
+// first_moments_finish_kernel; W = the packed 16-bit weights the forward multiplies by.  One block per k: thread =
+// (one of 4 block lanes, channel), blocks summed in index order per lane (eight loads in flight), lanes in lane order.
+__global__ __launch_bounds__(256) void first_wgrad_sums_kernel(const float* __restrict__ s1, int blocks,
+                                                               const double* __restrict__ M,
+                                                               const half_t* __restrict__ wf,
+                                                               const float* __restrict__ A, const float* __restrict__ B,
+                                                               const float* __restrict__ C, float* __restrict__ dw) {
+  __shared__ double red[4][64];
+  const int k = blockIdx.x;                      // (ky*3 + kx)*3 + c
+  const int ky = k / 9, kx = (k / 3) % 3, ch = k % 3;
+  const int slot = ky * 10 + kx * 3 + ch;
+  const int c = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (int b0 = bl; b0 < blocks; b0 += 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 4 * u;
+      v[u] = b < blocks ? s1[((size_t)b * 32 + slot) * 64 + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (double)v[u];
+  }
+  red[bl][c] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const double S1 = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    double mw = 0.0;
+    for (int j = 0; j < 27; ++j) {
+      const int jy = j / 9, jx = (j / 3) % 3, jc = j % 3;
+      mw += M[k * 32 + j] * (double)(float)wf[((size_t)(jy * 64 + c)) * 16 + jx * 4 + jc];
+    }
+    dw[k * 64 + c] = (float)((double)A[c] * S1 + (double)B[c] * mw + (double)C[c] * M[27 * 32 + k]);
   }
 }
 
@@ -574,8 +616,18 @@ extern "C" int ocr_conv2d_first_wgrad_bn_f16(int n, int h, int w, int cout, cons
 // Batch-norm statistics of conv1_1 from the image moments (first_moments_kernel above): row [2][cout] = (sum y, sum y^2)
 // over the n*h*w outputs, for ocr_bn_finalize with T = 1.  workspace: ocr_conv2d_first_moments_workspace() bytes.
 extern "C" size_t ocr_conv2d_first_moments_workspace(void) { return (size_t)FM_WGS * 1024 * sizeof(float) + 32 * 1024 * sizeof(double); }
+extern "C" int ocr_conv2d_first_moments_keep_f16(int n, int h, int w, int cout, const void* x4, const void* w_first,
+                                                 void* stats_row, void* moments_f64, void* workspace, size_t ws_bytes,
+                                                 void* stream);
 extern "C" int ocr_conv2d_first_moments_f16(int n, int h, int w, int cout, const void* x4, const void* w_first,
                                             void* stats_row, void* workspace, size_t ws_bytes, void* stream) {
+  return ocr_conv2d_first_moments_keep_f16(n, h, w, cout, x4, w_first, stats_row, nullptr, workspace, ws_bytes, stream);
+}
+// ... and with the moments themselves kept: moments_f64 [32][32] doubles (rows / columns k = (ky*3+kx)*3 + c, row 27 =
+// the patch sums, [27][27] = the pixel count), what ocr_conv2d_first_wgrad_sums_f32 needs in the backward pass.
+extern "C" int ocr_conv2d_first_moments_keep_f16(int n, int h, int w, int cout, const void* x4, const void* w_first,
+                                                 void* stats_row, void* moments_f64, void* workspace, size_t ws_bytes,
+                                                 void* stream) {
   FirstP p;
   int rc = fill(&p, n, h, w, cout, 0);
   if (rc != OCR_OK) return rc;
@@ -587,7 +639,22 @@ extern "C" int ocr_conv2d_first_moments_f16(int n, int h, int w, int cout, const
   double* stage = reinterpret_cast<double*>(static_cast<char*>(workspace) + (size_t)FM_WGS * 1024 * sizeof(float));
   hipLaunchKernelGGL(first_moments_kernel, dim3(blocks), dim3(256), 0, st, p, static_cast<const half_t*>(x4), slab);
   hipLaunchKernelGGL(first_moments_stage_kernel, dim3(32), dim3(256), 0, st, slab, blocks, stage);
+  OCR_CHECK_ARG(((uintptr_t)moments_f64 & 7) == 0);
   hipLaunchKernelGGL(first_moments_finish_kernel, dim3(1), dim3(256), 0, st, stage, static_cast<const half_t*>(w_first),
-                     cout, static_cast<float*>(stats_row));
+                     cout, static_cast<float*>(stats_row), static_cast<double*>(moments_f64));
+  return ocr_launch_status();
+}
+
+// conv1_1's weight gradient dw [3,3,3,64] f32 from the S1 blocks of ocr_conv2d_bnred_first_wgrad_f16 ([blocks][32][64]
+// f32), the kept moments and the batch-norm backward coefficients (ocr_bn_bwd_coefficients): first_wgrad_sums_kernel.
+extern "C" int ocr_conv2d_first_wgrad_sums_f32(const void* s1_blocks, int blocks, const void* moments_f64,
+                                               const void* w_first, int cout, const void* coef_a, const void* coef_b,
+                                               const void* coef_c, void* dw, void* stream) {
+  OCR_CHECK_ARG(s1_blocks && blocks > 0 && moments_f64 && w_first && coef_a && coef_b && coef_c && dw);
+  OCR_CHECK_SHAPE(cout == 64);
+  hipLaunchKernelGGL(first_wgrad_sums_kernel, dim3(27), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(s1_blocks), blocks, static_cast<const double*>(moments_f64),
+                     static_cast<const half_t*>(w_first), static_cast<const float*>(coef_a),
+                     static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), static_cast<float*>(dw));
   return ocr_launch_status();
 }

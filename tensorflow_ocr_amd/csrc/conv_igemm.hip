@@ -1574,6 +1574,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
 // Per tile: DMA(k+1) | MFMAs(k) | wait for DMA(k+1) + barrier (every wave is done reading halo k, halo k+1 is
 // visible) | epilogue(k) | barrier (staging reads done: the buffer may receive DMA(k+2)).  The wait sits BEFORE
 // the epilogue's stores are issued, so it never waits for them.
+typedef short c64_short4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) c64_short4v* c64_lds_s4_ptr;
+__device__ __forceinline__ half8_t c64_tr_pair(const char* base, int second_off) {
+  c64_short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c64_lds_s4_ptr)(base));
+  c64_short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c64_lds_s4_ptr)(base + second_off));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  short8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(half8_t, v);
+}
 constexpr int C64_NH = 6;                                          // halo DMA rounds of 512 slots (2720 slots used)
 constexpr int C64_LDS = 2 * W4_HBYTES + 9 * 64 * 128;              // 163840 = the whole LDS
 
@@ -1598,10 +1607,22 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   const bool has_bias = EPI == 0 ? (p.flags & OCR_CONV_BIAS) != 0 : EPI == 3;
   const bool relu = EPI == 0 ? (p.flags & OCR_CONV_RELU) != 0 : EPI == 3;
   const bool accum = EPI == 0 ? (p.flags & OCR_CONV_ACCUM_F16) != 0 : false;
-  const bool do_stats = EPI == 0 ? (p.flags & OCR_CONV_STATS) != 0 : (EPI == 1 || EPI == 2 || EPI == 4 || EPI == 6);
-  const bool has_br = EPI == 0 ? p.br.y != nullptr : (EPI == 2 || EPI == 4 || EPI == 6);              // (fields read by value: a pointer to p.br would pin the arguments in scratch)
+  const bool do_stats = EPI == 0 ? (p.flags & OCR_CONV_STATS) != 0 : (EPI == 1 || EPI == 2 || EPI == 4 || EPI == 6 || EPI == 7);
+  const bool has_br = EPI == 0 ? p.br.y != nullptr : (EPI == 2 || EPI == 4 || EPI == 6 || EPI == 7);  // (fields read by value: a pointer to p.br would pin the arguments in scratch)
   // mode 6 = mode 2 with the producing layer's y RECOMPUTED (BnRed::first_x4): conv1_1 under conv1_2's input gradient
-  constexpr bool RECOMP = EPI == 6;
+  // mode 7 = mode 6 that does NOT store the gradient: conv1_1's weight gradient is its only other reader, and
+  //   dW = A .* (V^T dz) + B .* (M W) + C .* m        (dy = A dz + B y + C per channel; V = the 27-value image patches,
+  //   M = V^T V and m = sum V: ocr_conv2d_first_moments_f16 has them) needs only S1 = V^T dz, which this epilogue
+  //   accumulates per wave on the matrix cores (BnRed::first_s1) — the 1 GiB gradient is neither written nor read again
+  constexpr bool RECOMP = EPI == 6 || EPI == 7;
+  constexpr bool FWG = EPI == 7;
+  f32x16 s1acc[FWG ? 2 : 1];
+  if constexpr (FWG) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s1acc[i][e] = 0.f;
+  }
   const int r32 = lane & 31, h32 = lane >> 5;         // the 32x32x16 MFMA's lane -> (row / pixel, k half) map
   half8_t fw[RECOMP ? 3 : 1][2];                      // first-layer weights: the same for every tile
   if constexpr (RECOMP) {
@@ -1859,6 +1880,7 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
       }
     } else {
     half8_t vq[RECOMP ? 4 : 1];
+    half8_t dzq[FWG ? 4 : 1];
     if constexpr (RECOMP) {
       // the gradient chunks out of the staging rows first, then the same rows carry this wave's row of y: six MFMAs on
       // the fragments fetched above (first_mfma's sequence for one tile row), rounded to the storage type as the
@@ -1904,6 +1926,10 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
     for (int kk = 0; kk < 4; ++kk) {
       const int px = kk * 8 + pg;
       const int ox = txi * TILE_W + px;
+      if constexpr (FWG) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dzq[kk][e] = (half_t)0.f;       // outside the map: no contribution
+      }
       if (oy < p.oh && ox < p.ow) {
         half8_t v;
         if constexpr (RECOMP) v = vq[kk];
@@ -1918,13 +1944,17 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
           for (int e = 0; e < 8; ++e)
             if (!((float)yq[kk][e] * bsc[e] + bsh[e] > relu_thr)) v[e] = (half_t)0.f;
         }
-        if ((C64_ABL & 2) == 0 || v[0] == (half_t)12345.f) OCR_EPI_STORE(1, reinterpret_cast<half8_t*>(y + off), v);
+        if constexpr (!FWG) {
+          if ((C64_ABL & 2) == 0 || v[0] == (half_t)12345.f) OCR_EPI_STORE(1, reinterpret_cast<half8_t*>(y + off), v);
+        }
         if (do_stats) {
           if (has_br) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float yf = (float)yq[kk][e];
-              const float dz = yf * bsc[e] + bsh[e] > relu_thr ? (float)v[e] : 0.f;   // mask of the stored activation
+              const bool pass = yf * bsc[e] + bsh[e] > relu_thr;                      // mask of the stored activation
+              const float dz = pass ? (float)v[e] : 0.f;
+              if constexpr (FWG) dzq[kk][e] = pass ? v[e] : (half_t)0.f;
               s[e] += dz;
               q2[e] += dz * yf;
             }
@@ -1939,9 +1969,75 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
         }
       }
     }
+    if constexpr (FWG) {
+      // S1 += V^T dz over this wave's 32 pixels: M = 32 patch slots, N = 64 channels (two halves), K = pixels.  The 4 KB
+      // staging rows are dead (every lane holds its chunks); they now carry the dz half tile [32 px][32 ch] (64-byte
+      // rows) and, behind it, the patch rows [32 px][32 slots]: slot ky*10 + kx*3 + c (30 used, slot ky*10 + 9 is the
+      // image's zero 4th channel) — both MFMA operands come out of transposing reads (conv_first.hip's weight gradient)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      char* const dzt = stage;
+      char* const pat = stage + 2048;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        // lanes h32 = 0 hold the pixels kx = 0, 1 (6 values -> 3 dwords at slot ky*10), lanes h32 = 1 the pixel kx = 2
+        // (+ the zero-weight kx = 3): 2 dwords at slot ky*10 + 6 (the second one written twice: one code path)
+        const unsigned a0 = fim[ky][0][0], a1 = fim[ky][0][1], b0 = fim[ky][1][0], b1 = fim[ky][1][1];
+        const unsigned w1 = h32 ? a1 : ((a1 & 0xffffu) | (b0 << 16));
+        const unsigned w2 = h32 ? a1 : ((b0 >> 16) | (b1 << 16));
+        char* const row = pat + r32 * 64 + ky * 20 + h32 * 12;
+        *reinterpret_cast<unsigned*>(row) = a0;
+        *reinterpret_cast<unsigned*>(row + 4) = w1;
+        *reinterpret_cast<unsigned*>(row + (h32 ? 4 : 8)) = w2;
+      }
+      const int li = lane & 15, g4 = lane >> 4;
+      const int tr_lane = (8 * (g4 >> 1) + (li >> 2)) * 64 + (16 * (g4 & 1) + 4 * (li & 3)) * 2;
+      half8_t pf[2];
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        if ((c8 >> 2) == nh) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            *reinterpret_cast<half8_t*>(dzt + (kk * 8 + pg) * 64 + (c8 & 3) * 16) = dzq[kk];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (nh == 0) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) pf[ks] = c64_tr_pair(pat + tr_lane + ks * 16 * 64, 4 * 64);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const half8_t df = c64_tr_pair(dzt + tr_lane + ks * 16 * 64, 4 * 64);
+          s1acc[nh] = OCR_MFMA_32x32x16(pf[ks], df, s1acc[nh], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                  // the second half overwrites the rows just read
+      }
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own staging reads are done ...
     __builtin_amdgcn_s_barrier();                         // ... and everyone's: the buffer may receive the halo of tile k+2
+  }
+  if constexpr (FWG) {
+    // the eight waves' S1 blocks meet in LDS (dead by now: every wave is behind the last tile's closing barrier) and
+    // leave as ONE [32][64] block per workgroup, summed in wave order
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        red[wave * 2048 + ((e & 3) + 8 * (e >> 2) + 4 * h32) * 64 + nh * 32 + r32] = s1acc[nh][e];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = u * 512 + tid;
+      float a = red[i];
+#pragma unroll
+      for (int w8 = 1; w8 < 8; ++w8) a += red[w8 * 2048 + i];
+      p.br.first_s1[(size_t)blockIdx.x * 2048 + i] = a;
+    }
   }
   if (do_stats) {
     if (has_br) {
@@ -2111,7 +2207,7 @@ static int epi_mode(const ConvP& p) {
   if (force_generic) return 0;
   const bool br = p.br.y != nullptr;
   const int fl = p.flags;
-  if (p.br.first_x4 != nullptr) return 6;      // (conv_c64_persist_kernel only: the entry point checks the variant)
+  if (p.br.first_x4 != nullptr) return p.br.first_s1 != nullptr ? 7 : 6;      // (conv_c64_persist_kernel only: the entry point checks the variant)
   if (fl == OCR_CONV_STATS && !br) return 1;
   if (fl == OCR_CONV_STATS && br && p.br.mask == nullptr && p.br.mask_bits == nullptr) return p.br.store_dz ? 4 : 2;
   if (fl == (OCR_CONV_BIAS | OCR_CONV_RELU) && !br) return 3;
@@ -2126,12 +2222,12 @@ static int launch_c64(const ConvP& p0, const void* x, const void* w, const void*
   // (the pooled variant exists for bias + ReLU layers only: its other modes are the generic instantiation)
   constexpr bool P = POOL;
   const int epi = P && epi_mode(p0) != 3 ? 0 : epi_mode(p0);
-  static const ConvKernT kerns[7] = {conv_c64_persist_kernel<64, P, 0>, conv_c64_persist_kernel<64, P, P ? 0 : 1>,
+  static const ConvKernT kerns[8] = {conv_c64_persist_kernel<64, P, 0>, conv_c64_persist_kernel<64, P, P ? 0 : 1>,
                                      conv_c64_persist_kernel<64, P, P ? 0 : 2>, conv_c64_persist_kernel<64, P, 3>,
                                      conv_c64_persist_kernel<64, P, P ? 0 : 4>, conv_c64_persist_kernel<64, P, P ? 0 : 5>,
-                                     conv_c64_persist_kernel<64, P, P ? 0 : 6>};
+                                     conv_c64_persist_kernel<64, P, P ? 0 : 6>, conv_c64_persist_kernel<64, P, P ? 0 : 7>};
   const ConvKernT kern = kerns[epi];
-  static bool configured[7] = {false, false, false, false, false, false, false};
+  static bool configured[8] = {false, false, false, false, false, false, false, false};
   if (!configured[epi]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(160 * 1024)) != hipSuccess)
@@ -2456,6 +2552,37 @@ extern "C" int ocr_conv2d_bnred_first_f16(const ocr_conv_desc* d, const void* x,
   p.br.first_x4 = static_cast<const half_t*>(x4);
   p.br.first_wf = static_cast<const half_t*>(w_first);
   return launch_c64<false>(p, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
+}
+
+// ocr_conv2d_bnred_first_f16 that does not store the gradient but the sums conv1_1's weight gradient is made of
+// (epilogue mode 7 of conv_c64_persist_kernel; the finishing step is ocr_conv2d_first_wgrad_sums_f32, conv_first.hip).
+extern "C" int ocr_conv2d_bnred_first_wgrad_blocks(const ocr_conv_desc* d) {
+  ConvP p;
+  TileCfg cfg;
+  if (fill_params(d, &p, &cfg) != OCR_OK) return -1;
+  if (!uses_c64(p, cfg) || p.cout != 64) return -1;
+  p.tiles_y = ocr_cdiv(p.oh, 8);
+  return c64_per(p) * p.n_tiles;
+}
+
+extern "C" int ocr_conv2d_bnred_first_wgrad_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* partial,
+                                                const void* x4, const void* w_first, const void* bn_scale,
+                                                const void* bn_shift, const void* bn_mean, const void* bn_invstd,
+                                                int bn_relu, void* s1_blocks, void* stream) {
+  ConvP p;
+  TileCfg cfg;
+  int rc = fill_params(d, &p, &cfg);
+  if (rc != OCR_OK) return rc;
+  OCR_CHECK_ARG(x && w_kc && partial && x4 && w_first && bn_scale && bn_shift && bn_mean && bn_invstd && s1_blocks);
+  OCR_CHECK_ARG(!(d->flags & (OCR_CONV_BIAS | OCR_CONV_RELU | OCR_CONV_ACCUM_F16)));
+  if (!uses_c64(p, cfg) || p.cout != 64) return OCR_ERR_UNSUPPORTED;
+  p.flags |= OCR_CONV_STATS;
+  p.br = BnRed{nullptr, static_cast<const float*>(bn_scale), static_cast<const float*>(bn_shift),
+               static_cast<const float*>(bn_mean), static_cast<const float*>(bn_invstd), bn_relu};
+  p.br.first_x4 = static_cast<const half_t*>(x4);
+  p.br.first_wf = static_cast<const half_t*>(w_first);
+  p.br.first_s1 = static_cast<float*>(s1_blocks);
+  return launch_c64<false>(p, x, w_kc, nullptr, nullptr, partial, static_cast<hipStream_t>(stream));
 }
 
 // 1x1 convolution whose input is the previous bottleneck's output relu(bn(conv3) + shortcut), computed while the

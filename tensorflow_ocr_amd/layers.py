@@ -66,6 +66,9 @@ FIRST_MOMENTS = __import__("os").environ.get("OCR_FIRST_MOMENTS", "1") == "1"   
 # FIRST_DROP_Y (y never stored) the recomputing form is what runs regardless of this switch.
 FIRST_WGRAD_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_WGRAD_RECOMPUTE", "0") == "1"
 FUSE_FIRST_WGRAD = __import__("os").environ.get("OCR_FUSE_FIRST_WGRAD", "1") == "1"    # measurement switch
+# conv1_1's weight gradient from SUMS (csrc/conv_first.hip: first_wgrad_sums_kernel): conv1_2's input-gradient launch
+# leaves S1 = V^T dz instead of the 1 GiB gradient, dW = A .* S1 + B .* (M W) + C .* m
+FIRST_WGRAD_SUMS = __import__("os").environ.get("OCR_FIRST_WGRAD_SUMS", "1") == "1"
 
 
 def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True, pool=0,
@@ -121,7 +124,9 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         if first and drop_y and train_stats and FIRST_MOMENTS:
             # the statistics from the image's second moments (csrc/conv_first.hip: first_moments_kernel): no pass over the
             # 64-channel output at all; one partial row
-            ops.conv2d_first_moments(x.data, w_fwd, part, cout, ws)
+            if FIRST_WGRAD_SUMS:
+                y.moments = g.empty((32 * 32,), torch.float64)      # kept for the backward (ops.conv2d_first_wgrad_sums)
+            ops.conv2d_first_moments(x.data, w_fwd, part, cout, ws, moments=y.moments)
             mt_fin = 1
         elif first:
             ops.conv2d_first(x.data, w_fwd, None if drop_y else y, flags, None, part if train_stats else None, cout=cout)
@@ -178,6 +183,18 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 raise NotImplementedError("backward through inference-mode batch norm")
             da_full = a_full.grad if a_full is not None else None
             da_pool = a_pool.grad if a_pool is not None else None
+            if first and a_full is not None and a_full.first_s1 is not None:
+                # conv1_1 whose sole consumer left the sums instead of the gradient (_conv_dgrad): dgamma / dbeta and the
+                # apply coefficients from the partial rows, then dW = A .* S1 + B .* (M W) + C .* m — no pass over a
+                # 64-channel tensor at all
+                part_f, T_f = a_full.bn_partial
+                coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
+                ops.bn_bwd_coefficients(part_f, T_f, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
+                                        beta.grad, coef, ws)
+                ops.conv2d_first_wgrad_sums(a_full.first_s1, y.moments, w_fwd, coef, wv.grad)
+                a_full.bn_partial = None
+                a_full.first_s1 = None
+                return
             if da_full is None and da_pool is None:
                 return
             if pool and da_pool is None:
@@ -349,6 +366,21 @@ def _conv_dgrad(g, x, wv, w_dg, d, dy):
     pt = d.dilation * (d.kh - 1) - d.pad_top
     pl = d.dilation * (d.kw - 1) - d.pad_left
     flags = 0
+    by0 = x.bn_ctx[0] if x.bn_ctx is not None else None
+    if (x.grad is None and x.sole_consumer and FIRST_WGRAD_SUMS and FUSE_BN_REDUCE and isinstance(by0, ops.LazyFirstY)
+            and by0.t is None and by0.moments is not None and d.cin == 64):
+        # conv1_1's activation, read by this convolution only: its gradient has one more reader — conv1_1's weight
+        # gradient — which needs sums of it, not the tensor; the launch leaves those (epilogue mode 7) and nothing else
+        dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1, 0)
+        blocks = ops.conv2d_bnred_first_wgrad_blocks(dg)
+        if blocks > 0:
+            T = ops.conv2d_num_mtiles(dg)
+            partial = g.empty((T, 2, d.cin), F32)
+            s1 = g.empty((blocks, 32, 64), F32)
+            ops.conv2d_bnred_first_wgrad(dg, dy, w_dg, partial, (by0.x4, by0.w_first) + tuple(x.bn_ctx[1:]), s1)
+            x.bn_partial = (partial, T)
+            x.first_s1 = s1
+            return
     if x.grad is None:
         x.grad = g.empty(x.shape)
     else:

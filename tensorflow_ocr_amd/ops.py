@@ -142,6 +142,7 @@ class LazyFirstY:
     def __init__(self, alloc, x4, w_first, shape):
         self.alloc, self.x4, self.w_first, self.shape = alloc, x4, w_first, shape
         self.t = None
+        self.moments = None       # f64 [32*32]: the image's patch moments, when the statistics came from them (kept for the backward)
 
     def tensor(self):
         if self.t is None:
@@ -159,6 +160,29 @@ def conv2d_bnred_first(d, x, w_kc, y, partial, first_ctx):
     if L.RECORDER is not None:
         flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
         L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
+
+
+def conv2d_bnred_first_wgrad_blocks(d):
+    """Number of S1 blocks conv2d_bnred_first_wgrad leaves (one per workgroup); -1 where that launch is unsupported."""
+    return int(L._fn("ocr_conv2d_bnred_first_wgrad_blocks", ctypes.c_int)(byref(d)))
+
+
+def conv2d_bnred_first_wgrad(d, x, w_kc, partial, first_ctx, s1):
+    """conv2d_bnred_first that does not store the gradient: `s1` [blocks][32][64] f32 receives the sums conv1_1's weight
+    gradient is finished from (conv2d_first_wgrad_sums)."""
+    x4, wf, sc, sh, mu, istd, relu = first_ctx
+    L.call("ocr_conv2d_bnred_first_wgrad_f16", byref(d), ptr(x), ptr(w_kc), ptr(partial), ptr(x4), ptr(wf), ptr(sc),
+           ptr(sh), ptr(mu), ptr(istd), c_int(int(relu)), ptr(s1), _st())
+    if L.RECORDER is not None:
+        flops = 2.0 * d.n * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+        L.RECORDER.tag_last((conv2d_variant(d), flops, "dgrad"))
+
+
+def conv2d_first_wgrad_sums(s1, moments, w_first, coef, dw):
+    """dW of conv1_1 = A .* S1 + B .* (M W) + C .* m (csrc/conv_first.hip: first_wgrad_sums_kernel)."""
+    a, b, c = coef
+    L.call("ocr_conv2d_first_wgrad_sums_f32", ptr(s1), c_int(s1.shape[0]), ptr(moments), ptr(w_first),
+           c_int(dw.shape[-1]), ptr(a), ptr(b), ptr(c), ptr(dw), _st())
 
 
 def conv2d_bnred_tail(d, x, w_kc, y, partial, tail_ctx, sub_grad=None):
@@ -343,14 +367,14 @@ def conv2d_first(x4, w_first, y, flags=0, bias=None, stats=None, cout=None):
            ptr(bias), c_int(flags), ptr(y), ptr(stats), _st())
 
 
-def conv2d_first_moments(x4, w_first, row, cout, ws):
+def conv2d_first_moments(x4, w_first, row, cout, ws, moments=None):
     """conv1_1's batch-norm statistics (sum y, sum y^2 per channel -> row [1][2][cout] f32, any byte buffer) from the
-    image's second moments."""
+    image's second moments; `moments` (f64 [32][32]) keeps them for conv2d_first_wgrad_sums."""
     n, h, w, _ = x4.shape
     nbytes = L.call_size("ocr_conv2d_first_moments_workspace")
     buf = ws.get(nbytes)
-    L.call("ocr_conv2d_first_moments_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(w_first), ptr(row),
-           ptr(buf), c_size_t(nbytes), _st())
+    L.call("ocr_conv2d_first_moments_keep_f16", c_int(n), c_int(h), c_int(w), c_int(cout), ptr(x4), ptr(w_first),
+           ptr(row), ptr(moments), ptr(buf), c_size_t(nbytes), _st())
 
 
 def conv2d_first_wgrad(x4, dy, dw, ws):

@@ -205,6 +205,92 @@ def test_fused_reduction_with_conv1_1_recomputed_equals_reading_it(device, n, h,
         ops.conv2d_bnred_first(d128, dy, w_ck, dx_f, part_f, (x4, wf) + ctx + (True,))
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 100, 130), (9, 64, 64), (2, 129, 97), (4, 256, 256)])
+def test_first_layer_weight_gradient_from_sums_equals_the_pass_over_the_gradient(device, n, h, w):
+    """ocr_conv2d_bnred_first_wgrad_f16 (epilogue mode 7: conv1_2's input gradient is NOT stored, the launch leaves
+    S1 = V^T dz) + ocr_conv2d_first_moments_keep_f16 + ocr_conv2d_first_wgrad_sums_f32 against the pass-by-pass form
+    (ocr_conv2d_bnred_first_f16 stores the gradient, ocr_conv2d_first_wgrad_bn_f16 reads it): the partial rows are
+    bit-identical; dW agrees within the 16-bit rounding of dy that only the pass-by-pass form applies, and with float64
+    on the host from the stored gradient.  Ragged tiles, image borders and a negative scale included."""
+    from tensorflow_ocr_amd import layers, ops
+    from tensorflow_ocr_amd.graph import Graph
+    rng = np.random.default_rng(h + n)
+    c = 64
+    g = Graph(device, loss_scale=1.0)
+    img = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    x4 = layers.prep_images(g, torch.from_numpy(img).to(device)).data
+    wt1 = torch.from_numpy((rng.standard_normal((3, 3, 3, c)) * 0.05).astype(np.float32)).to(device)
+    wf = torch.empty((3, c, 16), dtype=O.STORAGE, device=device)
+    ops.pack_weights_first(wt1, wf)
+    dy = torch.from_numpy(_h(rng.standard_normal((n, h, w, c)) * 0.1)).to(O.STORAGE).to(device)
+    w2 = torch.from_numpy(_h(rng.standard_normal((3, 3, c, c)) * np.sqrt(2.0 / (9 * c)))).to(device)
+    w_kc = torch.empty((9, c, c), dtype=O.STORAGE, device=device)
+    w_ck = torch.empty((9, c, c), dtype=O.STORAGE, device=device)
+    ops.pack_weights(w2, w_kc, w_ck)
+    dg = ops.ConvDesc(n, h, w, c, h, w, c, 3, 3, 1, 1, 1, 1, 1, 0)
+    T = ops.conv2d_num_mtiles(dg)
+    # conv1_1's batch norm: its real statistics (so that the mask cuts about half) with a negative gamma in one channel
+    ws = ops.Workspace(device, 16 << 20)
+    row = torch.zeros((1, 2, c), dtype=torch.float32, device=device)
+    moments = torch.zeros((32 * 32,), dtype=torch.float64, device=device)
+    ops.conv2d_first_moments(x4, wf, row, c, ws, moments=moments)
+    cnt = float(n * h * w)
+    r = row.cpu().numpy().astype(np.float64)[0]
+    mean = r[0] / cnt
+    var = np.maximum(r[1] / cnt - mean * mean, 0.0)
+    invstd = 1.0 / np.sqrt(var + 1e-5)
+    gamma = rng.uniform(0.5, 1.5, c)
+    gamma[5] = -0.8
+    beta = rng.normal(0, 0.2, c)
+    f = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(device)
+    scale, shift, mu, istd = f(gamma * invstd), f(beta - mean * gamma * invstd), f(mean), f(invstd)
+    ctx = (scale, shift, mu, istd)
+    dx = torch.empty((n, h, w, c), dtype=O.STORAGE, device=device)
+    part_r = torch.zeros((T, 2, c), dtype=torch.float32, device=device)
+    part_s = torch.zeros_like(part_r)
+    ops.conv2d_bnred_first(dg, dy, w_ck, dx, part_r, (x4, wf) + ctx + (True,))
+    blocks = ops.conv2d_bnred_first_wgrad_blocks(dg)
+    assert blocks > 0
+    s1 = torch.full((blocks, 32, 64), float("nan"), dtype=torch.float32, device=device)
+    ops.conv2d_bnred_first_wgrad(dg, dy, w_ck, part_s, (x4, wf) + ctx + (True,), s1)
+    torch.cuda.synchronize()
+    assert float(part_r.abs().sum()) > 0 and torch.equal(part_r, part_s)
+    # coefficients (any values: the identity is linear in them; A = the layer's scale, which the mask reads)
+    coef = (scale, f(rng.normal(0, 0.05, c)), f(rng.normal(0, 0.05, c)))
+    dw_p = torch.zeros((3, 3, 3, c), dtype=torch.float32, device=device)
+    dw_s = torch.full_like(dw_p, float("nan"))
+    ops.conv2d_first_wgrad_bn(x4, dx, None, shift, coef, True, dw_p, ws, w_first=wf)
+    ops.conv2d_first_wgrad_sums(s1, moments, wf, coef, dw_s)
+    torch.cuda.synchronize()
+    # float64 on the host from the stored gradient and the stored-precision y
+    y1 = torch.empty((n, h, w, c), dtype=O.STORAGE, device=device)
+    ops.conv2d_first(x4, wf, y1)
+    yv = y1.float().cpu().numpy().astype(np.float64)
+    dxv = dx.float().cpu().numpy().astype(np.float64)
+    A, B, C = (t.cpu().numpy().astype(np.float64) for t in coef)
+    sh = shift.cpu().numpy().astype(np.float64)
+    dzv = np.where(yv * A + sh > 0, dxv, 0.0)       # (elements within a rounding of the threshold carry no weight here)
+    dyv = A * dzv + B * yv + C
+    xi = x4.float().cpu().numpy().astype(np.float64)[..., :3]
+    xp = np.pad(xi, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    ref = np.zeros((3, 3, 3, c))
+    for ky in range(3):
+        for kx in range(3):
+            ref[ky, kx] = np.einsum("nhwc,nhwd->cd", xp[:, ky:ky + h, kx:kx + w], dyv)
+    got_s = dw_s.cpu().numpy().astype(np.float64)
+    got_p = dw_p.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got_s).all()
+    tol = 2e-3 * np.abs(ref).max()
+    assert np.abs(got_s - ref).max() <= tol, (np.abs(got_s - ref).max(), np.abs(ref).max())
+    assert np.abs(got_p - ref).max() <= tol, (np.abs(got_p - ref).max(), np.abs(ref).max())
+    # a shape another kernel would run is refused
+    d128 = ops.ConvDesc(n, h, w, 128, h, w, 64, 3, 3, 1, 1, 1, 1, 1, 0)
+    assert ops.conv2d_bnred_first_wgrad_blocks(d128) < 0
+    from tensorflow_ocr_amd._lib import OcrHipError
+    with pytest.raises(OcrHipError):
+        ops.conv2d_bnred_first_wgrad(d128, dy, w_ck, part_s, (x4, wf) + ctx + (True,), s1)
+
+
 def test_batched_weight_repack_equals_per_layer(device):
     """ocr_pack_weights_batch_f16 (every conv layer's two operand layouts in one launch, after the optimiser step)
     writes exactly what ocr_pack_weights_f16 writes layer by layer — including ragged 32-tiles and a NULL layout."""
