@@ -808,6 +808,28 @@ constexpr int W4_LDS = 2 * W4_HBYTES + W4_RING * W4_WSTEP;           // 155648
 // libocr_hip_diag.so) — 16 rounds x 2 k cycles on a single wave per SIMD, where every issued instruction is serial time.
 //   0 generic (run-time flags: ACCUM and anything else)   1 STATS (forward, BN nets)        2 STATS + fused BN-backward sums
 //   3 BIAS + RELU (forward, bias nets)                     4 as 2, storing dz (store_dz)    5 plain store
+// [z > thr] as 1.f / 0.f WITHOUT a compare and a select: v_cmp writes a lane mask to an SGPR pair, the v_cndmask that
+// reads it needs wait states behind it (296 s_nop in the fused-sum epilogue of conv3x3_w4_kernel) and neither packs.
+// clamp((z - thr) * 2^60) is exact for the f16 build: z and thr = 2^-25 are f32, so z > thr means z - thr >= 2^-48 and the
+// product is >= 2^12 (clamped to 1), z <= thr gives <= 0 (clamped to 0); thr = -inf (no ReLU) gives +inf -> 1.  The bf16
+// build's threshold (2^-134) sits among the f32 subnormals, where no scale separates the two sides: it keeps the compare.
+__device__ __forceinline__ float epi_step(float z, float thr, float nthr_h) {
+#ifdef OCR_BF16
+  (void)nthr_h;
+  return z > thr ? 1.f : 0.f;
+#else
+  (void)thr;
+  return __builtin_amdgcn_fmed3f(__builtin_fmaf(z, 0x1p60f, nthr_h), 0.f, 1.f);
+#endif
+}
+// four f32 -> four 16-bit values by TWO packed converts (round to nearest even: v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32).
+// Element by element hipcc built a quad from two scalar converts, one packed convert, a pack and an alignbit: five
+// instructions where two do, on the one wave a SIMD holds in these epilogues (every issued instruction is serial time).
+__device__ __forceinline__ half4_t epi_pack4(float a, float b, float c, float d) {
+  const half2_t lo = __builtin_convertvector(f32x2{a, b}, half2_t);
+  const half2_t hi = __builtin_convertvector(f32x2{c, d}, half2_t);
+  return half4_t{lo[0], lo[1], hi[0], hi[1]};
+}
 template <int EPI>
 __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
@@ -1027,6 +1049,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[2][8], bsh[2][8];
     const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;   // no ReLU: every element passes
+    const float nthr_h = -relu_thr * 0x1p60f;                      // (epi_step)
     const bool sdz = EPI == 0 ? (has_br && p.br.store_dz != 0) : EPI == 4;
     if (has_br) {
 #pragma unroll
@@ -1070,81 +1093,99 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
               (((t >> 1) * p.ow + (t & 1) * 16 + k * 8) * p.cout + hf * 64) * 2, 0, 0);
         }
     }
+    // Software-pipelined over the 16 rounds (round 5): the rounds were a serial chain on the one wave a SIMD holds — stage,
+    // read back (an LDS round trip), then ~60 instructions of sums and stores that wait for it: ~880 cycles a round, 14 k
+    // per tile and the same on a single workgroup as on a full chip (scripts/epilogue_probe.py), i.e. latency, not
+    // bandwidth.  Now round r's read-back is issued FIRST, round r+1 is converted and staged into the second staging
+    // buffer while it is in flight, and only then is round r consumed.
+    char* const stage2 = smem + 147456 + wave * 2048;    // behind the operand tile: W4_LDS leaves 8 KB there
+    auto stage_round = [&](auto IT) __attribute__((always_inline)) {
+      constexpr int it = decltype(IT)::value;
+      constexpr int t = it >> 1, hf = it & 1;
+      char* const st = (it & 1) ? stage2 : stage;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = hf * 4 + ii;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (has_bias) bv = *reinterpret_cast<const f32x4*>(lbias + (wco * 128 + i * 16 + g4 * 4));   // one LDS read, not four loads
+        float vq4[4];
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int it = t * 2 + hf;
-        if (accum) {                                  // old gradient of this round: in flight under the staging
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            bool ok;
-            const size_t off = round_off(it, k, ok);
-            if (ok) oq[k] = *reinterpret_cast<const half8_t*>(y + off);
-          }
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][t][e];
+          if (has_bias) v += bv[e];        // (an unconditional "+ 0.f" is not folded away: -0.f + 0.f = +0.f)
+          if (relu) v = v > 0.f ? v : 0.f;
+          vq4[e] = v;
         }
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const int i = hf * 4 + ii;
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (has_bias) bv = *reinterpret_cast<const f32x4*>(lbias + (wco * 128 + i * 16 + g4 * 4));   // one LDS read, not four loads
-          half4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[i][t][e] + bv[e];
-            if (relu) v = v > 0.f ? v : 0.f;
-            o[e] = (half_t)v;
-          }
-          *reinterpret_cast<half4_t*>(stage + L * 128 + (((ii * 2 + (g4 >> 1)) ^ (L & 7)) << 4) + (g4 & 1) * 8) = o;
-        }
-        if (it == 0 && has_br) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the operand tile has landed (behind round 0's staging)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const half4_t o = epi_pack4(vq4[0], vq4[1], vq4[2], vq4[3]);
+        *reinterpret_cast<half4_t*>(st + L * 128 + (((ii * 2 + (g4 >> 1)) ^ (L & 7)) << 4) + (g4 & 1) * 8) = o;
+      }
+    };
+    stage_round(IC<0>{});
+    if (has_br) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the operand tile has landed (behind round 0's staging)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    static_for<0, 16>([&](auto IT) {
+      constexpr int it = decltype(IT)::value;
+      constexpr int hf = it & 1;
+      const char* const st = (it & 1) ? stage2 : stage;
+      if (accum) {                                  // old gradient of this round
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           bool ok;
           const size_t off = round_off(it, k, ok);
-          const int px = k * 8 + pg;
-          if (ok) {
-            half8_t v = *reinterpret_cast<const half8_t*>(stage + px * 128 + ((c8 ^ (px & 7)) << 4));
-            half8_t yv;
-            if (has_br) yv = *reinterpret_cast<const half8_t*>(ylds + (it * 2 + k) * 1024 + lane * 16);
-            if (accum) {
+          if (ok) oq[k] = *reinterpret_cast<const half8_t*>(y + off);
+        }
+      }
+      half8_t vv[2], yv2[2];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
-            }
-            if (sdz) {                                // store the gradient PAST the ReLU (BnRed::store_dz)
+      for (int k = 0; k < 2; ++k) {
+        const int px = k * 8 + pg;
+        vv[k] = *reinterpret_cast<const half8_t*>(st + px * 128 + ((c8 ^ (px & 7)) << 4));
+        if (has_br) yv2[k] = *reinterpret_cast<const half8_t*>(ylds + (it * 2 + k) * 1024 + lane * 16);
+      }
+      if constexpr (it + 1 < 16) stage_round(IC<it + 1>{});      // into the OTHER buffer, while the reads above are in flight
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (!((float)yv[e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
-            }
-            OCR_EPI_STORE(4, reinterpret_cast<half8_t*>(y + off), v);
-            if (do_stats) {
-              if (has_br) {
+      for (int k = 0; k < 2; ++k) {
+        bool ok;
+        const size_t off = round_off(it, k, ok);
+        if (ok) {
+          half8_t v = vv[k];
+          const half8_t yv = yv2[k];
+          if (accum) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  const float yf = (float)yv[e];
-                  const float dz = yf * bsc[hf][e] + bsh[hf][e] > relu_thr ? (float)v[e] : 0.f;   // mask of the stored activation
-                  s[hf][e] += dz;
-                  q2[hf][e] += dz * yf;
-                }
-              } else {
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)oq[k][e]);
+          }
+          if (sdz) {                                // store the gradient PAST the ReLU (BnRed::store_dz)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  const float f = (float)v[e];
-                  s[hf][e] += f;
-                  q2[hf][e] += f * f;
-                }
+            for (int e = 0; e < 8; ++e)
+              if (!((float)yv[e] * bsc[hf][e] + bsh[hf][e] > relu_thr)) v[e] = (half_t)0.f;
+          }
+          OCR_EPI_STORE(4, reinterpret_cast<half8_t*>(y + off), v);
+          if (do_stats) {
+            if (has_br) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float yf = (float)yv[e];
+                const float dz = epi_step(yf * bsc[hf][e] + bsh[hf][e], relu_thr, nthr_h) * (float)v[e];   // mask of the stored activation
+                s[hf][e] += dz;
+                q2[hf][e] += dz * yf;
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s[hf][e] += f;
+                q2[hf][e] += f * f;
               }
             }
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();          // the next round's writes come after these reads (in-order LDS)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-    }
+    });
     if (do_stats) {
       if (has_br) {
 #pragma unroll
@@ -1397,6 +1438,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
     // sums at the end: sum dz*xhat = invstd * (sum dz*y - mean * sum dz))
     float bsc[NW][8], bsh[NW][8];
     const float relu_thr = p.br.relu ? OCR_RELU_TIE : -INFINITY;   // no ReLU: every element passes
+    const float nthr_h = -relu_thr * 0x1p60f;                      // (epi_step)
     const bool sdz = EPI == 0 ? (has_br && p.br.store_dz != 0) : EPI == 4;
     if (has_br) {
 #pragma unroll
@@ -1455,13 +1497,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
           const int i = hf * 4 + ii;
           f32x4 bv = {0.f, 0.f, 0.f, 0.f};
           if (has_bias) bv = *reinterpret_cast<const f32x4*>(lbias + (i * 16 + g4 * 4));   // one LDS read, not four loads
-          half4_t o;
+          float vq4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float v = acc[i][t][e] + bv[e];
+            float v = acc[i][t][e];
+            if (has_bias) v += bv[e];        // (an unconditional "+ 0.f" is not folded away: -0.f + 0.f = +0.f)
             if (relu) v = v > 0.f ? v : 0.f;
-            o[e] = (half_t)v;
+            vq4[e] = v;
           }
+          const half4_t o = epi_pack4(vq4[0], vq4[1], vq4[2], vq4[3]);
           *reinterpret_cast<half4_t*>(stage + L * 128 + (((ii * 2 + (g4 >> 1)) ^ (L & 7)) << 4) + (g4 & 1) * 8) = o;
         }
         if (it == 0 && has_br) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the operand tile has landed (behind round 0's staging)
@@ -1492,7 +1536,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   const float yf = (float)yv[e];
-                  const float dz = yf * bsc[hf][e] + bsh[hf][e] > relu_thr ? (float)v[e] : 0.f;   // mask of the stored activation
+                  const float dz = epi_step(yf * bsc[hf][e] + bsh[hf][e], relu_thr, nthr_h) * (float)v[e];   // mask of the stored activation
                   s[hf][e] += dz;
                   q2[hf][e] += dz * yf;
                 }
@@ -1824,13 +1868,15 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
 #pragma unroll
         for (int t = 0; t < AT; ++t) {
           const int px = t * 16 + L;
-          half4_t o;
+          float vq4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float v = acc[i][t][e] + bvv[i][e];
+            float v = acc[i][t][e];
+            if (has_bias) v += bvv[i][e];        // (an unconditional "+ 0.f" is not folded away: -0.f + 0.f = +0.f)
             if (relu) v = v > 0.f ? v : 0.f;
-            o[e] = (half_t)v;
+            vq4[e] = v;
           }
+          const half4_t o = epi_pack4(vq4[0], vq4[1], vq4[2], vq4[3]);
           *reinterpret_cast<half4_t*>(stage + px * 128 + (((i * 2 + (g4 >> 1)) ^ (px & 7)) << 4) + (g4 & 1) * 8) = o;
         }
       }
