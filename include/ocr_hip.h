@@ -405,6 +405,17 @@ int ocr_bias_relu_bwd_f16(const void* a, const void* da, int64_t npix, int c, in
 int ocr_bn_relu_bwd_apply_affine_f16(const void* y, const void* da, const void* scale, const void* shift,
                                      const void* coef_b, const void* coef_c, int n, int h, int w, int c, int relu,
                                      void* dy, int max_workgroups, void* stream);
+/* The REDUCTION pass of an end-point layer's batch-norm backward (several consumers contributed to the activation's
+ * gradient, so no convolution's epilogue summed it: conv3_3 / conv4_3 / conv5_3 / fc7 of nets/vgg.py under
+ * nets/model_vgg_16.py:160-172) as a guest as well: partial rows [ocr_bn_relu_bwd_reduce_rows_count(...)][2][c] f32 of
+ * (sum dz, sum dz*xhat), dz = (da_full + [first max] * da_pool) * [fma(y, scale, shift) rounds to a positive value], for
+ * ocr_bn_bwd_coefficients.  da_pool / argmax_u8: both (a pooled end point: even h, w, relu) or neither.  The grid is at
+ * most one workgroup per CU (max_workgroups: 0 = 256; a smaller value must be given to the row count too), so the rows do
+ * not depend on where the recorded step places the launch.  <= 56 registers per lane, no LDS. */
+int ocr_bn_relu_bwd_reduce_rows_count(int n, int h, int w, int c, int pooled, int max_workgroups);
+int ocr_bn_relu_bwd_reduce_rows_f16(const void* y, const void* da_full, const void* da_pool, const void* argmax_u8,
+                                    const void* scale, const void* shift, const void* save_mean, const void* save_invstd,
+                                    int n, int h, int w, int c, int relu, void* partial, int max_workgroups, void* stream);
 /* pooled END-POINT layers (conv3_3 / conv4_3: the heads read the full-resolution activation, the pool feeds the trunk):
  * dz = (da_full + [first max] * da_pool) * [ReLU mask of the position]; argmax_u8 from ocr_bn_relu_pool_idx_f16 called
  * with a_full; coefficients from ocr_bn_relu_bwd_reduce_f16(da_pool).  Even h, w. */

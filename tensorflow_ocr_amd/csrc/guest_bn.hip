@@ -217,6 +217,141 @@ __global__ __launch_bounds__(256) void bn_poolfull_apply_affine_kernel(
   }
 }
 
+// The REDUCTION pass of an end-point layer's batch-norm backward (conv3_3 / conv4_3 / conv5_3 / fc7: several consumers
+// contributed to the activation's gradient, so no convolution's epilogue could sum it) in the same footprint: per thread
+// (sum dz, sum dz*y) of its four channels over its pixels, converted to (sum dz, sum dz*xhat) at the end and written as the
+// thread's own partial row — no LDS, no cross-lane step; ocr_bn_bwd_coefficients folds the rows in a fixed order.
+// bn_relu_bwd_kernel<0> (166 registers, one 16-byte load in flight, an LDS fold) ran these passes at 1.8-3.3 TB/s on
+// the critical path between two input-gradient convolutions; this one runs beside held-back weight gradients.
+template <bool RELU, int U>
+__global__ __launch_bounds__(256) void bn_reduce_rows_kernel(
+    const half_t* __restrict__ y, const half_t* __restrict__ da, const float* __restrict__ cA,
+    const float* __restrict__ cS, const float* __restrict__ cMu, const float* __restrict__ cIs, unsigned units, int c,
+    float* __restrict__ partial, int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const int chunks = c >> 2, lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  const size_t bytes = (size_t)units * c * 2;
+  const __amdgpu_buffer_rsrc_t ry = rsrc_of(y, bytes), rg = rsrc_of(da, bytes);
+  float A[4], S[4], s[4], q[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    A[e] = cA[ch * 4 + e];
+    S[e] = RELU ? cS[ch * 4 + e] : 0.f;
+    s[e] = 0.f;
+    q[e] = 0.f;
+  }
+  const unsigned row = (unsigned)c * 2;
+  const unsigned stride = gridDim.x * (unsigned)lanes;
+  const unsigned sbytes = stride * row;
+  unsigned u = blockIdx.x * (unsigned)lanes + (unsigned)ul;
+  unsigned off = u * row + (unsigned)ch * 8;
+  for (; u < units; u += U * stride, off += U * sbytes) {       // (offsets past the tensor read zeros: dz = 0)
+    half4_t yv[U], gv[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      yv[k] = ld8(ry, off, k * sbytes);
+      gv[k] = ld8(rg, off, k * sbytes);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      // unit by unit: hipcc converts every unit's eight values up front otherwise (24 more registers live: 64 in all);
+      // the empty asm statements keep their order, so unit k's values are not touched before unit k-1's sums exist
+      u32x2 ry2 = __builtin_bit_cast(u32x2, yv[k]), rg2 = __builtin_bit_cast(u32x2, gv[k]);
+      asm volatile("" : "+v"(ry2), "+v"(rg2));
+      const half4_t y4 = __builtin_bit_cast(half4_t, ry2), g4 = __builtin_bit_cast(half4_t, rg2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yf = (float)y4[e];
+        float dz = (float)g4[e];
+        if (RELU) dz = __builtin_fmaf(yf, A[e], S[e]) > OCR_RELU_TIE ? dz : 0.f;
+        s[e] += dz;
+        q[e] = __builtin_fmaf(dz, yf, q[e]);
+      }
+      asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    }
+  }
+  float* const out = partial + ((size_t)(blockIdx.x * (unsigned)lanes + (unsigned)ul) * 2) * c + ch * 4;
+  f32x4 so, qo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    so[e] = s[e];
+    qo[e] = (q[e] - cMu[ch * 4 + e] * s[e]) * cIs[ch * 4 + e];      // sum dz*xhat = invstd * (sum dz*y - mean * sum dz)
+  }
+  *reinterpret_cast<f32x4*>(out) = so;
+  *reinterpret_cast<f32x4*>(out + c) = qo;
+}
+
+// ... of a pooled end point (conv3_3 / conv4_3): dz = (da_full + [first max] * da_pool) * [ReLU mask of the position],
+// the forward's index byte as in bn_poolfull_apply_affine_kernel.  One pooled unit in flight per thread.
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_poolfull_reduce_rows_kernel(
+    const half_t* __restrict__ y, const half_t* __restrict__ da_full, const half_t* __restrict__ da_pool,
+    const unsigned char* __restrict__ argmax, const float* __restrict__ cA, const float* __restrict__ cS,
+    const float* __restrict__ cMu, const float* __restrict__ cIs, int n, int h, int w, int c,
+    float* __restrict__ partial, int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const int chunks = c >> 2, lanes = 256 / chunks;
+  const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+  const int oh = h >> 1, ow = w >> 1;
+  const unsigned units = (unsigned)n * oh * ow;
+  const size_t full = (size_t)n * h * w * c * 2, pooled = (size_t)units * c * 2;
+  const __amdgpu_buffer_rsrc_t ry = rsrc_of(y, full), rf = rsrc_of(da_full, full), rg = rsrc_of(da_pool, pooled),
+                               ra = rsrc_of(argmax, pooled / 2);
+  float A[4], S[4], s[4], q[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    A[e] = cA[ch * 4 + e];
+    S[e] = RELU ? cS[ch * 4 + e] : 0.f;
+    s[e] = 0.f;
+    q[e] = 0.f;
+  }
+  const unsigned row = (unsigned)c * 2;
+  const unsigned below = (unsigned)w * row;
+  const unsigned stride = gridDim.x * (unsigned)lanes;
+  for (unsigned u = blockIdx.x * (unsigned)lanes + (unsigned)ul; u < units; u += stride) {
+    const unsigned ox = u % (unsigned)ow, t = u / (unsigned)ow;
+    const unsigned poff = u * row + (unsigned)ch * 8;
+    const unsigned foff = ((t * 2u) * (unsigned)w + ox * 2u) * row + (unsigned)ch * 8;
+    const half4_t gp = ld8(rg, poff, 0);
+    const unsigned am = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(poff >> 1), 0, 0);
+    half4_t yv[4], gv[4];
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) {
+      const unsigned so = (k & 1 ? row : 0) + (k & 2 ? below : 0);
+      yv[k] = ld8(ry, foff, so);
+      gv[k] = ld8(rf, foff, so);
+    }
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) {
+      // position by position (see bn_reduce_rows_kernel; the index word too: its sixteen selections would all be made up front)
+      u32x2 ry2 = __builtin_bit_cast(u32x2, yv[k]), rg2 = __builtin_bit_cast(u32x2, gv[k]);
+      unsigned amk = am;
+      asm volatile("" : "+v"(ry2), "+v"(rg2), "+v"(amk));
+      const half4_t y4 = __builtin_bit_cast(half4_t, ry2), g4 = __builtin_bit_cast(half4_t, rg2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yf = (float)y4[e];
+        float g = ((amk >> (8 * e)) & 3u) == k ? (float)gp[e] : 0.f;      // (the general kernel's order: routed + full)
+        g += (float)g4[e];
+        const float dz = RELU ? (__builtin_fmaf(yf, A[e], S[e]) > OCR_RELU_TIE ? g : 0.f) : g;
+        s[e] += dz;
+        q[e] = __builtin_fmaf(dz, yf, q[e]);
+      }
+      asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    }
+  }
+  float* const out = partial + ((size_t)(blockIdx.x * (unsigned)lanes + (unsigned)ul) * 2) * c + ch * 4;
+  f32x4 so, qo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    so[e] = s[e];
+    qo[e] = (q[e] - cMu[ch * 4 + e] * s[e]) * cIs[ch * 4 + e];
+  }
+  *reinterpret_cast<f32x4*>(out) = so;
+  *reinterpret_cast<f32x4*>(out + c) = qo;
+}
+
 bool pow2g(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // grid: `max_workgroups` when the caller names one (the recorded step asks for 256 = ONE per CU for a pass it runs
@@ -306,5 +441,55 @@ extern "C" int ocr_bn_relu_poolfull_bwd_apply_affine_f16(const void* y, const vo
                      static_cast<const unsigned char*>(argmax_u8), static_cast<const float*>(scale),
                      static_cast<const float*>(shift), static_cast<const float*>(coef_b), static_cast<const float*>(coef_c),
                      n, h, w, c, static_cast<half_t*>(dy), guest_prio());
+  return ocr_launch_status();
+}
+
+// Reduction pass of an end-point layer's batch-norm backward as a guest (bn_reduce_rows_kernel): partial rows
+// [ocr_bn_relu_bwd_reduce_rows_count(...)][2][c] f32 = (sum dz, sum dz*xhat) per thread lane, for
+// ocr_bn_bwd_coefficients.  dz = (da_full + [first max] * da_pool) * [fma(y, scale, shift) rounds to a positive value];
+// da_pool / argmax_u8 (both or neither): the layer's 2x2/2 max-pool gradient and the forward's index
+// (ocr_bn_relu_pool_idx_f16 with a_full), even h and w.  The grid never exceeds one workgroup per CU (what is resident
+// beside a weight-gradient host), so the row count does not depend on where the recorded step places the launch;
+// max_workgroups (0 = 256) can only lower it and must then be passed to the row count too.
+static unsigned reduce_rows_grid(int n, int h, int w, int c, int pooled, int max_workgroups, int* lanes_out) {
+  const int lanes = 256 / (c / 4);
+  const size_t units = pooled ? (size_t)n * (h / 2) * (w / 2) : (size_t)n * h * w;
+  const int cap = max_workgroups > 0 && max_workgroups < 256 ? max_workgroups : 256;
+  *lanes_out = lanes;
+  return guest_grid(units, (size_t)lanes * (pooled ? 1 : 4), cap);
+}
+extern "C" int ocr_bn_relu_bwd_reduce_rows_count(int n, int h, int w, int c, int pooled, int max_workgroups) {
+  if (n <= 0 || h <= 0 || w <= 0 || c % 8 != 0 || !pow2g(c / 4) || c / 4 > 256) return -1;
+  int lanes;
+  return (int)reduce_rows_grid(n, h, w, c, pooled, max_workgroups, &lanes) * lanes;
+}
+extern "C" int ocr_bn_relu_bwd_reduce_rows_f16(const void* y, const void* da_full, const void* da_pool, const void* argmax_u8,
+                                               const void* scale, const void* shift, const void* save_mean,
+                                               const void* save_invstd, int n, int h, int w, int c, int relu, void* partial,
+                                               int max_workgroups, void* stream) {
+  OCR_CHECK_ARG(y && da_full && scale && shift && save_mean && save_invstd && partial && n > 0 && h > 0 && w > 0);
+  OCR_CHECK_ARG((da_pool == nullptr) == (argmax_u8 == nullptr));
+  OCR_CHECK_SHAPE(c % 8 == 0 && pow2g(c / 4) && c / 4 <= 256);
+  OCR_CHECK_SHAPE((size_t)n * h * w * c * 2 < (1ull << 31));
+  const int pooled = da_pool != nullptr;
+  OCR_CHECK_SHAPE(!pooled || (h % 2 == 0 && w % 2 == 0 && relu != 0));
+  int lanes;
+  const unsigned grid = reduce_rows_grid(n, h, w, c, pooled, max_workgroups, &lanes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const half_t* yp = static_cast<const half_t*>(y);
+  const half_t* gf = static_cast<const half_t*>(da_full);
+  const float *sc = static_cast<const float*>(scale), *sh = static_cast<const float*>(shift),
+              *mu = static_cast<const float*>(save_mean), *is = static_cast<const float*>(save_invstd);
+  float* out = static_cast<float*>(partial);
+  if (pooled)
+    hipLaunchKernelGGL(bn_poolfull_reduce_rows_kernel<true>, dim3(grid), dim3(256), 0, st, yp, gf,
+                       static_cast<const half_t*>(da_pool), static_cast<const unsigned char*>(argmax_u8), sc, sh, mu, is,
+                       n, h, w, c, out, guest_prio());
+  else if (relu)
+    hipLaunchKernelGGL((bn_reduce_rows_kernel<true, 4>), dim3(grid), dim3(256), 0, st, yp, gf, sc, sh, mu, is,
+                       (unsigned)((size_t)n * h * w), c, out, guest_prio());
+  else
+    hipLaunchKernelGGL((bn_reduce_rows_kernel<false, 4>), dim3(grid), dim3(256), 0, st, yp, gf, sc, sh, mu, is,
+                       (unsigned)((size_t)n * h * w), c, out, guest_prio());
   return ocr_launch_status();
 }

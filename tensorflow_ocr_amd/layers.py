@@ -65,6 +65,7 @@ FIRST_MOMENTS = __import__("os").environ.get("OCR_FIRST_MOMENTS", "1") == "1"   
 # 32 x 512^2: with one stream instead of two the kernel is bound by its per-tile LDS work, not by HBM).  With
 # FIRST_DROP_Y (y never stored) the recomputing form is what runs regardless of this switch.
 FIRST_WGRAD_RECOMPUTE = __import__("os").environ.get("OCR_FIRST_WGRAD_RECOMPUTE", "0") == "1"
+GUEST_REDUCE = __import__("os").environ.get("OCR_GUEST_REDUCE", "1") == "1"            # end-point layers' BN-backward reduction as a guest pass
 FUSE_FIRST_WGRAD = __import__("os").environ.get("OCR_FUSE_FIRST_WGRAD", "1") == "1"    # measurement switch
 # conv1_1's weight gradient from SUMS (csrc/conv_first.hip: first_wgrad_sums_kernel): conv1_2's input-gradient launch
 # leaves S1 = V^T dz instead of the 1 GiB gradient, dW = A .* S1 + B .* (M W) + C .* m
@@ -255,8 +256,16 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 # no consumer summed this layer's terms (several contributed to its gradient: an end point of the fuse
                 # heads): the reduction pass stays, its finalize emits the coefficients, the apply pass is a guest
                 coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
-                ops.bn_relu_bwd_reduce(y_b, scale, shift, mean, invstd, da_full, relu, gamma.grad, beta.grad, coef, ws,
-                                       da_pool=da_pool if pool else None)
+                if GUEST_REDUCE and (relu or not pool):
+                    # ... as a guest as well (beside weight gradients still held back), its rows folded on the main stream
+                    part_e, T_e = ops.bn_relu_bwd_reduce_rows(y_b, da_full, scale, shift, mean, invstd, relu, g.empty,
+                                                              da_pool=da_pool if pool else None,
+                                                              argmax=argmax_full if pool else None)
+                    ops.bn_bwd_coefficients_pre(part_e, T_e, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
+                                                beta.grad, coef, ws)
+                else:
+                    ops.bn_relu_bwd_reduce(y_b, scale, shift, mean, invstd, da_full, relu, gamma.grad, beta.grad, coef, ws,
+                                           da_pool=da_pool if pool else None)
                 if pool:
                     ops.bn_relu_poolfull_bwd_apply_affine(y_b, da_full, da_pool, argmax_full, scale, shift, coef, relu, dy)
                 else:

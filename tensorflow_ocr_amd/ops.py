@@ -448,6 +448,23 @@ def bn_relu_bwd_reduce(y, scale, shift, save_mean, save_invstd, da_full, relu, d
            ptr(cc), ptr(part), ptr(stage), c_size_t(stage.numel()), _st())
 
 
+def bn_relu_bwd_reduce_rows(y, da_full, scale, shift, save_mean, save_invstd, relu, alloc, da_pool=None, argmax=None):
+    """Guest reduction pass of an end-point layer's BN backward (csrc/guest_bn.hip): returns (partial rows, T) for
+    bn_bwd_coefficients_pre.  alloc: shape, dtype -> tensor (the rows outlive the call: the recorded step runs the
+    finalize later)."""
+    n, h, w, c = y.shape
+    pooled = int(da_pool is not None)
+    T = L.call_int("ocr_bn_relu_bwd_reduce_rows_count", c_int(n), c_int(h), c_int(w), c_int(c), c_int(pooled), c_int(0))
+    part = alloc((T, 2, c), torch.float32)
+    L.call("ocr_bn_relu_bwd_reduce_rows_f16", ptr(y), ptr(da_full), ptr(da_pool), ptr(argmax), ptr(scale), ptr(shift),
+           ptr(save_mean), ptr(save_invstd), c_int(n), c_int(h), c_int(w), c_int(c), c_int(int(relu)), ptr(part), c_int(0),
+           _st())
+    if L.RECORDER is not None:
+        # (its grid is one workgroup per CU wherever it runs: the row count must not depend on the placement)
+        L.RECORDER.tag_last(("guest", (4.0 if not pooled else 4.75) * n * h * w * c, "as_is"))
+    return part, T
+
+
 def bn_relu_poolfull_bwd_apply_affine(y, da_full, da_pool, argmax, scale, shift, coef, relu, dy):
     """Guest apply pass of a pooled end-point layer (csrc/guest_bn.hip): dz = (da_full + routed da_pool) * ReLU mask."""
     n, h, w, c = y.shape

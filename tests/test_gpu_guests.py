@@ -162,6 +162,64 @@ def test_pooled_end_point_guest_equals_the_general_backward(device, n, h, w, c, 
     assert np.allclose(dg0.double().cpu().numpy(), (dz * xh).sum((0, 1, 2)), rtol=2e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("n,h,w,c,relu,pooled", [(2, 16, 24, 64, True, False), (1, 15, 9, 128, True, False),
+                                                 (3, 7, 5, 256, False, False), (1, 4, 6, 1024, True, False),
+                                                 (32, 32, 32, 512, True, False), (2, 16, 24, 64, True, True),
+                                                 (1, 14, 10, 256, True, True), (8, 64, 64, 512, True, True)])
+def test_reduce_rows_guest_equals_the_general_reduction(device, n, h, w, c, relu, pooled):
+    """ocr_bn_relu_bwd_reduce_rows_f16 (the end-point layers' reduction pass as a guest: per-thread partial rows, no LDS) +
+    ocr_bn_bwd_coefficients against ocr_bn_relu_bwd_reduce_f16 on the same tensors: dgamma, dbeta and the three
+    coefficient rows agree to f32 summation accuracy (another order of the same sums) and with float64 on the host."""
+    from tensorflow_ocr_amd import ops
+    from tensorflow_ocr_amd.graph import F16
+    rng = np.random.default_rng(c + h + n)
+    y, scale, shift, mean, invstd, _, _ = _inputs(rng, n, h, w, c, device)
+    da_full = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(F16).to(device)
+    ws = ops.Workspace(device, 64 << 20)
+    da_pool = am = None
+    if pooled:
+        oh, ow = h // 2, w // 2
+        y[0, :2, :2, :8] = 0.5
+        da_pool = torch.from_numpy(rng.standard_normal((n, oh, ow, c)).astype(np.float32)).to(F16).to(device)
+        am = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=device)
+        ops.bn_relu_pool_idx(y, scale, shift, relu, torch.empty_like(y), torch.empty((n, oh, ow, c), dtype=F16, device=device),
+                             am, None)
+    dg0, db0 = torch.zeros(c, device=device), torch.zeros(c, device=device)
+    coef0 = tuple(torch.empty(c, device=device) for _ in range(3))
+    ops.bn_relu_bwd_reduce(y, scale, shift, mean, invstd, da_full, relu, dg0, db0, coef0, ws, da_pool=da_pool)
+    dg1, db1 = torch.full((c,), float("nan"), device=device), torch.full((c,), float("nan"), device=device)
+    coef1 = tuple(torch.full((c,), float("nan"), device=device) for _ in range(3))
+    part, T = ops.bn_relu_bwd_reduce_rows(y, da_full, scale, shift, mean, invstd, relu,
+                                          lambda shp, dt: torch.full(shp, float("nan"), dtype=dt, device=device),
+                                          da_pool=da_pool, argmax=am)
+    assert T <= 256 * (256 // (c // 4)) and not torch.isnan(part).any()
+    ops.bn_bwd_coefficients_pre(part, T, c, float(n * h * w), scale, mean, invstd, dg1, db1, coef1, ws)
+    torch.cuda.synchronize()
+    # float64 on the host
+    yf = y.double().cpu().numpy()
+    sc, sh = scale.double().cpu().numpy(), shift.double().cpu().numpy()
+    act = torch.from_numpy((yf * sc + sh).astype(np.float32)).to(F16).float().numpy()
+    g = da_full.double().cpu().numpy()
+    if pooled:
+        a2 = np.maximum(act, 0) if relu else act
+        oh, ow = h // 2, w // 2
+        win = a2.reshape(n, oh, 2, ow, 2, c).transpose(0, 1, 3, 2, 4, 5).reshape(n, oh, ow, 4, c)
+        first = win.argmax(3)
+        routed = np.zeros((n, oh, ow, 4, c))
+        np.put_along_axis(routed, first[:, :, :, None, :], da_pool.double().cpu().numpy()[:, :, :, None, :], 3)
+        g = g + routed.reshape(n, oh, ow, 2, 2, c).transpose(0, 1, 3, 2, 4, 5).reshape(n, h, w, c)
+    dz = g * ((act > 0) if relu else 1.0)
+    xh = (yf - mean.double().cpu().numpy()) * invstd.double().cpu().numpy()
+    ref_b, ref_g = dz.sum((0, 1, 2)), (dz * xh).sum((0, 1, 2))
+    scale_b = np.abs(dz).sum((0, 1, 2)).max()
+    for name, db, dg in (("general", db0, dg0), ("guest", db1, dg1)):
+        assert np.abs(db.double().cpu().numpy() - ref_b).max() <= 2e-6 * scale_b + 1e-4, name
+        assert np.abs(dg.double().cpu().numpy() - ref_g).max() <= 4e-6 * scale_b + 1e-4, name
+    for a0, a1 in zip(coef0, coef1):
+        d = (a0 - a1).abs().max().item()
+        assert d <= 1e-5 * max(1.0, a0.abs().max().item()), d
+
+
 def test_recorded_step_pairs_every_guest_with_a_weight_gradient(device, monkeypatch):
     """model_vgg's recorded step (train.schedule_guests): each guest apply pass sits between a FORK in front of the
     weight gradient it runs beside and a JOIN behind it, its coefficient call in front of the fork; the replayed step
