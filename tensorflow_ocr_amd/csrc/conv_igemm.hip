@@ -1995,14 +1995,26 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
         }
         if (do_stats) {
           if (has_br) {
+            float dzf[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float yf = (float)yq[kk][e];
               const bool pass = yf * bsc[e] + bsh[e] > relu_thr;                      // mask of the stored activation
               const float dz = pass ? (float)v[e] : 0.f;
-              if constexpr (FWG) dzq[kk][e] = pass ? v[e] : (half_t)0.f;
+              dzf[e] = dz;
               s[e] += dz;
               q2[e] += dz * yf;
+            }
+            if constexpr (FWG) {
+              // the masked gradient back to 16 bits (exact: it came from there) by packed converts of the f32 values the
+              // sums use — a select per 16-bit element and the re-packing were 50 instructions a tile on a kernel that is
+              // bound by instruction issue
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                const half2_t h2 = __builtin_convertvector(f32x2{dzf[e], dzf[e + 1]}, half2_t);
+                dzq[kk][e] = h2[0];
+                dzq[kk][e + 1] = h2[1];
+              }
             }
           } else {
 #pragma unroll
