@@ -419,23 +419,37 @@ __global__ __launch_bounds__(256) void first_moments_finish_kernel(const double*
     if (m_out != nullptr) m_out[i] = a;       // kept for the weight gradient (first_wgrad_sums_kernel)
   }
   __syncthreads();
-  for (int co = threadIdx.x; co < cout; co += 256) {
-    double wv[27];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) wv[(ky * 3 + kx) * 3 + c] = (double)(float)wf[((size_t)(ky * cout + co)) * 16 + kx * 4 + c];
+  // thread = (channel of a group of 64, one of four row lanes): rows i = lane, lane + 4, ... of the quadratic form, the
+  // lanes' parts added in lane order (one thread per channel walked all 27 x 27 products alone: 39 us on one workgroup)
+  __shared__ double part[2][4][64];
+  for (int c0 = 0; c0 < cout; c0 += 64) {
+    const int co = c0 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < 27; ++i) {
-      s1 += wv[i] * M[27 * 32 + i];
-      double t = 0.0;
-      for (int j = 0; j < 27; ++j) t += M[i * 32 + j] * wv[j];
-      s2 += wv[i] * t;
+    if (co < cout) {
+      double wv[27];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) wv[(ky * 3 + kx) * 3 + c] = (double)(float)wf[((size_t)(ky * cout + co)) * 16 + kx * 4 + c];
+      for (int i = rl; i < 27; i += 4) {
+        s1 += wv[i] * M[27 * 32 + i];
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 27; ++j) t += M[i * 32 + j] * wv[j];
+        s2 += wv[i] * t;
+      }
     }
-    row[co] = (float)s1;
-    row[cout + co] = (float)s2;
+    part[0][rl][threadIdx.x & 63] = s1;
+    part[1][rl][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int k = threadIdx.x >> 6, cc = threadIdx.x & 63;
+      if (c0 + cc < cout)
+        row[k * cout + c0 + cc] = (float)(((part[k][0][cc] + part[k][1][cc]) + part[k][2][cc]) + part[k][3][cc]);
+    }
+    __syncthreads();
   }
 }
 
@@ -451,32 +465,46 @@ __global__ __launch_bounds__(256) void first_wgrad_sums_kernel(const float* __re
                                                                const half_t* __restrict__ wf,
                                                                const float* __restrict__ A, const float* __restrict__ B,
                                                                const float* __restrict__ C, float* __restrict__ dw) {
-  __shared__ double red[4][64];
+  __shared__ double red[2][4][64];
+  __shared__ double Mrow[32];
   const int k = blockIdx.x;                      // (ky*3 + kx)*3 + c
   const int ky = k / 9, kx = (k / 3) % 3, ch = k % 3;
   const int slot = ky * 10 + kx * 3 + ch;
   const int c = threadIdx.x & 63, bl = threadIdx.x >> 6;
-  double acc = 0.0;
-  for (int b0 = bl; b0 < blocks; b0 += 32) {
-    float v[8];
+  if (threadIdx.x < 32) Mrow[threadIdx.x] = M[k * 32 + threadIdx.x];
+  // this lane's share of (M W)[k][c]: columns j = bl, bl + 4, ... (the loads go out before the block sums')
+  float wj[7];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+  for (int u = 0; u < 7; ++u) {
+    const int j = bl + 4 * u;
+    const int jy = j / 9, jx = (j / 3) % 3, jc = j % 3;
+    wj[u] = j < 27 ? (float)wf[((size_t)(jy * 64 + c)) * 16 + jx * 4 + jc] : 0.f;
+  }
+  double acc = 0.0;
+  for (int b0 = bl; b0 < blocks; b0 += 64) {     // sixteen loads in flight, added in block order
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
       const int b = b0 + 4 * u;
       v[u] = b < blocks ? s1[((size_t)b * 32 + slot) * 64 + c] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    for (int u = 0; u < 16; ++u) acc += (double)v[u];
   }
-  red[bl][c] = acc;
+  __syncthreads();
+  double mw = 0.0;
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    const int j = bl + 4 * u;
+    if (j < 27) mw += Mrow[j] * (double)wj[u];
+  }
+  red[0][bl][c] = acc;
+  red[1][bl][c] = mw;
   __syncthreads();
   if (threadIdx.x < 64) {
-    const double S1 = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    double mw = 0.0;
-    for (int j = 0; j < 27; ++j) {
-      const int jy = j / 9, jx = (j / 3) % 3, jc = j % 3;
-      mw += M[k * 32 + j] * (double)(float)wf[((size_t)(jy * 64 + c)) * 16 + jx * 4 + jc];
-    }
-    dw[k * 64 + c] = (float)((double)A[c] * S1 + (double)B[c] * mw + (double)C[c] * M[27 * 32 + k]);
+    const double S1 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    const double MW = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    dw[k * 64 + c] = (float)((double)A[c] * S1 + (double)B[c] * MW + (double)C[c] * M[27 * 32 + k]);
   }
 }
 
