@@ -158,7 +158,7 @@ def counters_from_profiles(dom):
     return vals, src
 
 
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def main():
