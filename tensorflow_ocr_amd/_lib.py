@@ -107,8 +107,7 @@ class Recorder:
     long as every tensor they point to is kept alive (graph.Graph.keepalive)."""
 
     def __init__(self):
-        self.entries = []     # ("c", fn, args, name, tag, chain) | ("py", callable)
-        self.chain = None     # graph.Graph.chain: the independent chain the calls being recorded belong to
+        self.entries = []     # ["c", fn, args, name, tag] | ["py", callable]
         # only the thread that created the recorder is recorded (the feeder thread launches its own
         # resize / label kernels concurrently); the owner is part of the object, so it is set before
         # the recorder can be seen through `RECORDER`
@@ -118,7 +117,7 @@ class Recorder:
         return self.owner == threading.get_ident()
 
     def c(self, fn, args, name):
-        self.entries.append(["c", fn, args, name, None, self.chain])
+        self.entries.append(["c", fn, args, name, None])
 
     def py(self, fn):
         if self.mine():

@@ -234,7 +234,6 @@ class GradientAllReduce:
                     break
         self.cuda = store.flat.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
-        self.extra_streams = []       # streams that also produce gradients (side-stream wgrad)
         self.mode = (mode or exchange_mode(world_size, self.cuda, force)) if self.active else "torch"
         self.comm = comm
         self.proxy = proxy
@@ -337,8 +336,6 @@ class GradientAllReduce:
             from . import _lib as L
             cur = L.stream_ptr()
             cs = ctypes.c_void_p(self.comm_stream.cuda_stream)
-            for es in self.extra_streams:                  # side-stream weight gradients (off by default)
-                self.comm_stream.wait_stream(es)
             w = when if self.both_placements else None
             self._xcall("ocr_event_record", self.ev_ready[bi], cur, when=w)
             self._xcall("ocr_stream_wait_event", cs, self.ev_ready[bi], when=w)
@@ -358,8 +355,6 @@ class GradientAllReduce:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                for es in self.extra_streams:
-                    self.comm_stream.wait_stream(es)
                 h = td.all_reduce(buf, op=td.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             h = td.all_reduce(buf, op=td.ReduceOp.SUM, group=self.group, async_op=True)

@@ -230,8 +230,6 @@ class Graph:
         self.ws_wgrad = None
         self.collections = {"losses": [], "update_ops": []}
         self.keepalive = None        # list while a step is being recorded (train.TrainStep)
-        self.current_chain = None    # see chain()
-        self._chain_ws = {}
 
     # --- scopes / variables (tf.variable_scope, tf.get_variable) ---
     @contextlib.contextmanager
@@ -262,37 +260,6 @@ class Graph:
             self.ws_small = ops.Workspace(self.device, 8 << 20)
             self.ws_wgrad = ops.Workspace(self.device, 160 << 20)   # weight-gradient slabs (side stream)
         return self.ws
-
-    @contextlib.contextmanager
-    def chain(self, k):
-        """Marks the calls issued inside as chain `k` of a group of mutually INDEPENDENT chains (the 1x1 fuse convs the
-        heads apply to four different feature maps, nets/model_vgg_16.py:160-172: 24 small launches that each leave
-        most of the chip idle).  Consecutive chained calls form a group; eagerly they simply run in program order on
-        the one stream, a replayed step plan (train.TrainStep._replay) runs chain k > 0 on its own stream between a
-        fork after the last unchained call and a join before the next one.  A chain must take its scratch from
-        chain_workspaces(): the shared arenas are stream-ordered."""
-        from . import _lib
-        prev = self.current_chain
-        self.current_chain = k
-        rec = _lib.RECORDER
-        mine = rec is not None and rec.mine()
-        if mine:
-            prev_r, rec.chain = rec.chain, k
-        try:
-            yield
-        finally:
-            self.current_chain = prev
-            if mine:
-                rec.chain = prev_r
-
-    def chain_workspaces(self):
-        """(workspace, small workspace) of the current chain: the tower's own outside a chain."""
-        k = self.current_chain
-        if k is None:
-            return self.workspace(), self.ws_small
-        if k not in self._chain_ws:
-            self._chain_ws[k] = (ops.Workspace(self.device, 32 << 20), ops.Workspace(self.device, 2 << 20))
-        return self._chain_ws[k]
 
     def empty(self, shape, dtype=F16):
         t = torch.empty(shape, dtype=dtype, device=self.device)

@@ -508,8 +508,7 @@ def head_conv_bn(g, feat, names, couts, is_training=True, relu=True):
     Returns (z, scale, shift, ctx): z = raw conv output [n,h,w,sum(couts)] f32."""
     n, h, w, cin = feat.shape
     C = sum(couts)
-    chain = g.current_chain                 # (graph.Graph.chain: the net runs the four sources as independent chains)
-    ws, ws_small = g.chain_workspaces()
+    ws, ws_small = g.workspace(), g.ws_small
     # one merged parameter per source; columns map onto the reference variables `names`
     with g.variable_scope("+".join(names)):
         wv = g.get_variable("weights", (cin, C), _merged_init(g, cin, couts), regularized=True)
@@ -543,15 +542,14 @@ def head_conv_bn(g, feat, names, couts, is_training=True, relu=True):
     def backward():
         if out.grad is None:
             return
-        with g.chain(chain):
-            dz = g.empty(z.shape, F32)
-            ops.sc_bn_bwd(z, scale, shift, mean, invstd, out.grad, relu, gamma.grad, beta.grad, dz, ws)
-            ops.conv1x1_small_wgrad(feat.data, dz, C, wv.grad, ws)
-            if feat.requires_grad:
-                acc = feat.grad is not None
-                if not acc:
-                    feat.grad = g.empty(feat.shape)
-                ops.conv1x1_small_dgrad(dz, w_ck32, C, feat.grad, acc)
+        dz = g.empty(z.shape, F32)
+        ops.sc_bn_bwd(z, scale, shift, mean, invstd, out.grad, relu, gamma.grad, beta.grad, dz, ws)
+        ops.conv1x1_small_wgrad(feat.data, dz, C, wv.grad, ws)
+        if feat.requires_grad:
+            acc = feat.grad is not None
+            if not acc:
+                feat.grad = g.empty(feat.shape)
+            ops.conv1x1_small_dgrad(dz, w_ck32, C, feat.grad, acc)
         out.grad = None
     g.record(backward, (wv, gamma, beta))
     return out, scale, shift
@@ -563,8 +561,7 @@ def head_conv_bias(g, feat, names, couts, initializer=None):
     Returns (z, None, None) in the triple form `fuse` consumes."""
     n, h, w, cin = feat.shape
     C = sum(couts)
-    chain = g.current_chain
-    ws, _ = g.chain_workspaces()
+    ws = g.workspace()
     with g.variable_scope("+".join(names)):
         init = _merged_init(g, cin, couts, initializer or xavier_uniform)
         wv = g.get_variable("weights", (cin, C), init, regularized=True)
@@ -587,14 +584,13 @@ def head_conv_bias(g, feat, names, couts, initializer=None):
     def backward():
         if out.grad is None:
             return
-        with g.chain(chain):
-            ops.sc_colsum(out.grad, C, bias.grad, ws)
-            ops.conv1x1_small_wgrad(feat.data, out.grad, C, wv.grad, ws)
-            if feat.requires_grad:
-                acc = feat.grad is not None
-                if not acc:
-                    feat.grad = g.empty(feat.shape)
-                ops.conv1x1_small_dgrad(out.grad, w_ck32, C, feat.grad, acc)
+        ops.sc_colsum(out.grad, C, bias.grad, ws)
+        ops.conv1x1_small_wgrad(feat.data, out.grad, C, wv.grad, ws)
+        if feat.requires_grad:
+            acc = feat.grad is not None
+            if not acc:
+                feat.grad = g.empty(feat.shape)
+            ops.conv1x1_small_dgrad(out.grad, w_ck32, C, feat.grad, acc)
         out.grad = None
     g.record(backward, (wv, bias))
     return out, None, None
@@ -611,10 +607,9 @@ def head_group(g, feats, names_list, couts, *, mode="bn", is_training=True, relu
     mode="bias").  OCR_BATCH_HEADS=0 (or the f32 verification precision) runs the per-source forms."""
     if not BATCH_HEADS or g.precision == "f32" or len(feats) > 4:
         out = []
-        for k, (f, nm) in enumerate(zip(feats, names_list)):
-            with g.chain(k):          # the sources are independent chains of small launches (graph.Graph.chain)
-                out.append(head_conv_bn(g, f, nm, couts, is_training=is_training, relu=relu) if mode == "bn" else
-                           head_conv_bias(g, f, nm, couts, initializer=initializer))
+        for f, nm in zip(feats, names_list):
+            out.append(head_conv_bn(g, f, nm, couts, is_training=is_training, relu=relu) if mode == "bn" else
+                       head_conv_bias(g, f, nm, couts, initializer=initializer))
         return out
     C = sum(couts)
     ws = g.workspace()

@@ -14,12 +14,6 @@ import torch
 from . import ops
 from .graph import F32
 
-# independent chains (graph.Graph.chain) on streams of their own: measured SLOWER than the one-stream order (headline step
-# 20.37 vs 20.03 ms, PixelLink 16.87 vs 16.44: the cross-queue fork / join signals cost more than the overlap of ~24 small
-# launches gains), so off by default; the path stays tested (tests/test_gpu_train_step.py)
-USE_CHAINS = __import__("os").environ.get("OCR_CHAINS", "0") == "1"
-
-
 def exponential_decay(learning_rate, global_step, decay_steps=5000, decay_rate=0.94, staircase=True):
     """tf.train.exponential_decay (multigpu_train.py:104)."""
     e = global_step // decay_steps if staircase else global_step / decay_steps
@@ -309,8 +303,11 @@ def schedule_guests(entries, cover=None, min_us=None):
             out.append(e)
             i += 1
             continue
-        if e[0] != "c" or (t[0] == "xchg" and not travels(e)):
-            flush()                      # host callbacks (optimiser, torch-mode exchange), the exchange's closing entries
+        if e[0] != "c" or t[0] == "xchg":
+            # host callbacks (optimiser, torch-mode exchange), the exchange's closing entries — and an exchange entry that
+            # TRAVELS behind a weight gradient which stayed in place (one that cannot host, or conv1_1's sums form): its
+            # bucket's all-reduce reads every weight gradient recorded before it, the held-back ones included
+            flush()
         out.append(e)
         i += 1
     flush()
@@ -360,16 +357,8 @@ class TrainStep:
         self.plan = None
         self.static_batch = None
         self.loss = None
-        self.side_stream = None
-        self.side_ptr = None
-        self.chain_streams = {}       # chain id -> (torch stream, its handle): graph.Graph.chain
         self.guest_stream = self.guest_ptr = self.guest_event = None      # schedule_guests: the paired guest passes' stream
-        self.fork_event = None
         self._packed_version = None
-        # weight gradients on a second stream: measured neutral-to-negative once the wgrad kernels
-        # reached the conv kernels' efficiency (both saturate the VGPR file, so they time-slice rather
-        # than overlap, and every overlapped launch is stretched); off by default, kept as a switch
-        self.use_side_stream = __import__("os").environ.get("OCR_SIDE_STREAM", "0") == "1"
 
     def build(self, *batch):
         """Create the variables, the flat buffers, the optimiser and the reducer WITHOUT taking a
@@ -391,8 +380,7 @@ class TrainStep:
         for n, t in before.items():
             g.store.vars[n].data.copy_(t)
         self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, op=self.grad_op,
-                                         fold_mean=True, force=self.force_reduce,
-                                         mode="torch" if self.use_side_stream else None, proxy=self.comm_proxy)
+                                         fold_mean=True, force=self.force_reduce, proxy=self.comm_proxy)
         return self
 
     # -- eager / recording path --------------------------------------------------------------
@@ -416,8 +404,7 @@ class TrainStep:
                 from .dist import GradientAllReduce
                 self.opt = self.optimizer_factory(g)           # materialises the flat buffers
                 self.reducer = GradientAllReduce(g.store, self.world, self.bucket_bytes, op=self.grad_op,
-                                                 fold_mean=True, force=self.force_reduce,
-                                                 mode="torch" if self.use_side_stream else None, proxy=self.comm_proxy)
+                                                 fold_mean=True, force=self.force_reduce, proxy=self.comm_proxy)
             g.backward(self.reducer.on_grads_ready if self.reducer.active else None)
             self.reducer.finish()           # records itself: host callback (torch mode) or C-ABI stream waits (abi mode)
         finally:
@@ -453,16 +440,6 @@ class TrainStep:
                 dst.copy_(src, non_blocking=True)
         timing = ops.KERNEL_TIMING
         main = torch.cuda.current_stream()
-        if self.fork_event is None:
-            self.fork_event = torch.cuda.Event()
-        if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream()
-            self.side_ptr = ctypes.c_void_p(self.side_stream.cuda_stream)
-            if self.reducer is not None:
-                self.reducer.extra_streams = [self.side_stream]
-        side, side_ptr, side_used = self.side_stream, self.side_ptr, False
-        chains = self.chain_streams if USE_CHAINS else None
-        group_open, forked = False, []
         bwd_marked = False
         for e in self.plan:
             if e[0] == "fork":
@@ -495,10 +472,6 @@ class TrainStep:
                         # a plan that holds both placements of the exchange (under backward / after it) runs one
                         if when is not None and when != ("early" if self.reducer.overlap else "late"):
                             continue
-                        if group_open:
-                            for k in forked:
-                                main.wait_stream(chains[k][0])
-                            group_open, forked = False, []
                         if (kind == "finish" or when == "late") and self.backward_end_event is not None and not bwd_marked:
                             self.backward_end_event.record(main)      # end of backward on the compute stream
                             bwd_marked = True
@@ -506,38 +479,9 @@ class TrainStep:
                         if rc != 0:
                             _lib.check(rc, e[3])
                     continue
-            # independent chains (graph.Graph.chain): chain k > 0 on its own stream, forked from the main stream where the
-            # group begins (the first chained call after an unchained one), joined before the next unchained entry
-            k = e[5] if (chains is not None and e[0] == "c") else None
-            if k is None:
-                if group_open:
-                    for j in forked:
-                        main.wait_stream(chains[j][0])
-                    group_open, forked = False, []
-            else:
-                if not group_open:
-                    group_open = True
-                    self.fork_event.record(main)
-                if k > 0:
-                    if k not in chains:
-                        st = torch.cuda.Stream()
-                        chains[k] = (st, ctypes.c_void_p(st.cuda_stream))
-                    st, st_ptr = chains[k]
-                    if k not in forked:
-                        st.wait_event(self.fork_event)
-                        forked.append(k)
-                    rc = e[1](*(e[2][:-1] + (st_ptr,)))
-                    if rc != 0:
-                        _lib.check(rc, e[3])
-                    continue
             if e[0] == "c":
                 tag = e[4]
-                if tag is not None and tag[0] == "side" and self.use_side_stream:
-                    # weight gradient: only the optimiser (and the all-reduce) consumes it
-                    side.wait_stream(main)
-                    rc = e[1](*(e[2][:-1] + (side_ptr,)))
-                    side_used = True
-                elif timing is not None and tag is not None and len(tag) > 2 and tag[0] not in ("side", "guest", "xchg"):      # (kernel instantiation, FLOP, phase)
+                if timing is not None and tag is not None and len(tag) > 2 and tag[0] not in ("side", "guest", "xchg"):      # (kernel instantiation, FLOP, phase)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     rc = e[1](*e[2])
@@ -548,17 +492,10 @@ class TrainStep:
                 if rc != 0:
                     _lib.check(rc, e[3])
             else:
-                if side_used and len(e) > 2 and e[2] == "opt":
-                    main.wait_stream(side)       # optimiser / end of step: weight gradients done
-                    side_used = False
                 if len(e) > 2 and e[2] == "opt" and self.backward_end_event is not None and not bwd_marked:
                     self.backward_end_event.record(main)          # (no exchange in this step: backward ends here)
                     bwd_marked = True
                 e[1]()
-        for j in forked:
-            main.wait_stream(chains[j][0])
-        if side_used:
-            main.wait_stream(side)
         return self.loss
 
     def __call__(self, *batch):

@@ -25,13 +25,12 @@ def _make(device, replay):
     return g, batch, TrainStep(g, fl, lambda gr: AdamOptimizer(gr, learning_rate=1e-3), replay=replay)
 
 
-@pytest.mark.parametrize("chains", [False, True])
-def test_replay_equals_eager_bitwise(device, chains, monkeypatch):
-    from tensorflow_ocr_amd import layers, train
-    monkeypatch.setattr(train, "USE_CHAINS", chains)
-    # the independent-chain machinery belongs to the per-source heads (layers.head_conv_bn); the default since round 4 is
-    # one launch per kernel kind over the sources (layers.head_group), which has no chains to fork
-    monkeypatch.setattr(layers, "BATCH_HEADS", not chains)
+@pytest.mark.parametrize("batch_heads", [True, False])
+def test_replay_equals_eager_bitwise(device, batch_heads, monkeypatch):
+    from tensorflow_ocr_amd import layers
+    # both head forms: one launch per kernel kind over the sources (layers.head_group, the default) and the per-source
+    # convolutions (layers.head_conv_bn)
+    monkeypatch.setattr(layers, "BATCH_HEADS", batch_heads)
     ge, be, se = _make(device, False)
     gr, br, sr = _make(device, True)
     le, lr = [], []
@@ -41,10 +40,6 @@ def test_replay_equals_eager_bitwise(device, chains, monkeypatch):
     assert sr.plan is not None and se.plan is None
     assert le == lr, (le, lr)
     assert le[-1] < le[0]
-    # the four head sources are independent chains (graph.Graph.chain): with train.USE_CHAINS the replayed plan runs three
-    # of them on streams of their own, forward and backward, and still agrees with the one-stream eager run bit for bit
-    assert sorted({e[5] for e in sr.plan if e[0] == "c" and e[5] is not None}) == ([0, 1, 2, 3] if chains else [])
-    assert sorted(sr.chain_streams) == ([1, 2, 3] if chains else [])
     assert torch.equal(ge.store.flat, gr.store.flat)
     assert torch.equal(ge.store.flat_aux, gr.store.flat_aux)
     # fresh data goes through the recorded input buffers

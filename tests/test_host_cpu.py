@@ -624,7 +624,7 @@ def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
     from tensorflow_ocr_amd.train import schedule_guests
 
     def c(name, tag=None):
-        return ["c", None, (), name, tag, None]
+        return ["c", None, (), name, tag]
     W = 1.3e9 * 100            # a weight gradient estimated at 100 us
     G = 5.0e6 * 100            # a guest that takes 100 us alone
     plan = [c("apply5", ("guest", G)),                                       # nothing held back yet: serial
@@ -670,6 +670,54 @@ def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
              c("dgrad"), ["py", None]]
     assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan4, cover=2.0, min_us=40)] == [
         "coef", "apply", "dgrad", "w0", "fat", "redf", "py"]
+
+
+def test_schedule_guests_never_fires_a_bucket_before_its_held_back_weight_gradients():
+    """an exchange entry that travels behind a weight gradient which stays IN PLACE (one that cannot
+    host: ("side",) without a FLOP count, an untagged one such as conv1_1's sums form, or one with no guest ahead) used to
+    be issued while older weight gradients of the same bucket were still held back, so the bucket's all-reduce read
+    gradients that had not been written.  Property checked on several plans: in the scheduled order every weight-gradient
+    entry recorded BEFORE an exchange entry is still in front of it, and the multiset of entries is unchanged."""
+    from tensorflow_ocr_amd.train import schedule_guests
+
+    def c(name, tag=None):
+        return ["c", None, (), name, tag]
+    W, G = 1.3e9 * 100, 5.0e6 * 100
+
+    def check(plan, **kw):
+        out = schedule_guests(plan, **kw)
+        names = [e[3] if e[0] == "c" else e[0] for e in out]
+        rec = [e[3] if e[0] == "c" else e[0] for e in plan]
+        assert sorted(n for n in names if n not in ("fork", "join")) == sorted(rec)
+        for xi, e in enumerate(plan):
+            if e[0] == "c" and e[4] is not None and e[4][0] == "xchg":
+                for w in plan[:xi]:
+                    if w[0] == "c" and (w[3].startswith("w") or w[3].startswith("red")):
+                        assert names.index(w[3]) < names.index(e[3]), (w[3], e[3], names)
+        return names
+    # the advisor's plan: wA is held back (a small guest follows that takes nothing), wB cannot host and stays in place
+    # with the bucket's early all-reduce behind it
+    plan = [c("wA", ("side", W)), c("redA", ("reduce",)), c("coef", ("pre",)), c("apply", ("guest", 0.1 * G)), c("dgrad"),
+            c("wB", ("side",)), c("redB", ("reduce",)), c("xAB", ("xchg", "rccl", "early")), c("xf", ("xchg", "finish")), ["py", None, "opt"]]
+    names = check(plan, cover=2.0, min_us=40)
+    assert names == ["coef", "apply", "dgrad", "wB", "redB", "wA", "redA", "xAB", "xf", "py"]
+    # every guest below the minimum: all weight gradients are held back until something needs them — here the bucket that
+    # conv1_1's untagged sums-form weight gradient completes
+    plan = [c("w3", ("side", W)), c("red3", ("reduce",)), c("coef2", ("pre",)), c("apply2", ("guest", 0.1 * G)), c("dgrad2"),
+            c("w2", ("side", W)), c("red2", ("reduce",)), c("coef1", ("pre",)), c("apply1", ("guest", 0.1 * G)),
+            c("w1sums"), c("x0a", ("xchg", None, "early")), c("x0b", ("xchg", "rccl", "early")), c("xf", ("xchg", "finish")), ["py", None, "opt"]]
+    names = check(plan, cover=2.0, min_us=40)
+    assert names.index("w3") < names.index("x0a") and names.index("w2") < names.index("x0a")
+    # a weight gradient with no guest ahead stays in place; the early entries behind it still wait for the held-back ones
+    plan = [c("w5", ("side", W)), c("red5", ("reduce",)), c("coef4", ("pre",)), c("apply4", ("guest", 0.1 * G)), c("dgrad4"),
+            c("w4", ("side", W)), c("red4", ("reduce",)), c("x45", ("xchg", "rccl", "early")), c("dgrad3"), c("xf", ("xchg", "finish")), ["py", None]]
+    check(plan, cover=2.0, min_us=40)
+    # pairing still happens where it is safe, and a paired host's own exchange entries follow the join
+    plan = [c("w5", ("side", W)), c("red5", ("reduce",)), c("x5", ("xchg", "rccl", "early")), c("coef4", ("pre",)),
+            c("apply4", ("guest", G)), c("dgrad4"), c("w4", ("side",)), c("red4", ("reduce",)), c("x4", ("xchg", "rccl", "early")),
+            c("xf", ("xchg", "finish")), ["py", None]]
+    names = check(plan, cover=1.0, min_us=0)
+    assert names[:6] == ["coef4", "fork", "apply4", "w5", "join", "red5"]
 
 
 def test_decode_slab_is_reserved_not_sparse(tmp_path):
