@@ -26,7 +26,7 @@ extern "C" {
  * ocr_conv2d_bnred_f16, ocr_conv2d_bnred_tail_f16, ocr_bn_add_relu_f16, ocr_bn_relu_pool_idx_f16; round 4: the
  * batched head entry points and the seed-rank argument of ocr_link_cc_directed; round 5: the guest kernels).  The Python host refuses a
  * library whose ocr_abi_version() differs from the value it was written against (_lib.ABI_VERSION). */
-#define OCR_ABI_VERSION 7
+#define OCR_ABI_VERSION 6
 
 enum {
   OCR_OK = 0,
@@ -322,26 +322,6 @@ int ocr_bn_finalize(const void* partial, int T, int C, double count, const void*
                     const void* beta, float eps, float decay, void* moving_mean, void* moving_var,
                     void* scale, void* shift, void* save_mean, void* save_invstd, void* workspace,
                     size_t ws_bytes, void* stream);
-/* The same finalisations CHAINED to the launch that produces the partial rows (round 6; csrc/bn_reduce.h).  These two
- * calls launch nothing: they arm the finalisation, on the calling host thread, for the NEXT convolution entry point
- * (ocr_conv2d_f16 with OCR_CONV_STATS, ocr_conv2d_bnred_f16, the ocr_conv2d_pw_* forms ...) whose `stats` / `partial`
- * argument is exactly `partial` with T rows of C channels.  A kernel that writes one partial row per workgroup
- * (conv3x3_w4, conv3x3_w4s, conv_igemm, conv_pw, conv_pwx) appends the reduction's workgroups to its own grid — they
- * wait for the producers' arrival counter instead of for a kernel boundary, which saves the dependent launch (~5 us of
- * queue time + the reduction's own latency, 30 times per VGG step) — any other kernel is followed by the separate
- * launch ocr_bn_finalize / ocr_bn_bwd_coefficients would have been.  Same code, same order: bit-identical results.
- * Arming twice without a consuming launch, or a consuming launch with other rows, returns OCR_ERR_INVALID_ARG and
- * disarms.  OCR_BN_CHAIN=0 in the environment keeps every finalisation a separate launch (measurement switch).
- * Replaces, on the reference's side, nothing visible: slim.batch_norm's moments + moving-average update
- * (nets/resnet_utils.py:232-246) and its gradient are single graph ops there. */
-int ocr_bn_finalize_arm(const void* partial, int T, int C, double count, const void* gamma, const void* beta,
-                        float eps, float decay, void* moving_mean, void* moving_var, void* scale, void* shift,
-                        void* save_mean, void* save_invstd, void* workspace, size_t ws_bytes);
-int ocr_bn_bwd_coefficients_arm(const void* partial, int T, int c, double count, const void* scale,
-                                const void* save_mean, const void* save_invstd, void* dgamma, void* dbeta,
-                                void* coef_a, void* coef_b, void* coef_c, void* workspace, size_t ws_bytes);
-/* 1 while a finalisation is armed on the calling host thread */
-int ocr_bn_armed(void);
 int ocr_bn_inference_params(const void* gamma, const void* beta, const void* moving_mean,
                             const void* moving_var, float eps, int C, void* scale, void* shift,
                             void* stream);

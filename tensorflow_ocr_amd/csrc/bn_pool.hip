@@ -8,10 +8,7 @@
 // (nets/resnet_utils.py:232-246, nets/model_vgg_16.py:144), slim.max_pool2d SAME
 // (nets/vgg.py:16-32), mean_image_subtraction (nets/model.py:18-31).
 #include "common.h"
-#include "bn_reduce.h"
 #include "pool_gather.h"
-
-using namespace ocr_bn;
 
 namespace {
 
@@ -28,16 +25,202 @@ __global__ void prep_images_kernel(const float* __restrict__ img, half_t* __rest
 }
 
 // ------------------------------------------------- per-channel partial reduce
-// (bn_reduce.h: the reduction's body, shared with the chained form inside the convolution kernels)
-__device__ unsigned ocr_bn_tickets[kTicketWords];
-__device__ unsigned ocr_bn_arrive[16 * 2];            // bn_reduce.h BnChain::arrive, one pair per slot
+// partial [T][2][C] f32 -> stage [R][2][C] f64 (R = ceil(T/256)) -> final per-channel sums, in ONE
+// launch: every block reduces its 256 rows, publishes them and takes a ticket; the block that draws
+// the last ticket of its 64-channel group sums the R stage rows IN ROW ORDER (so the result does not
+// depend on which block happens to be last: bitwise reproducible) and runs the finalisation.  No
+// block ever waits for another one (no spinning), the ticket counter resets itself.
+struct BnFin {            // MODE 0: batch-norm forward statistics -> scale/shift (+ moving stats)
+  double count;
+  const float *gamma, *beta;
+  float eps, decay;
+  float *moving_mean, *moving_var, *scale, *shift, *save_mean, *save_invstd;
+};
+struct BnBwdFin {         // MODE 1: batch-norm backward sums -> dbeta, dgamma
+  float *dgamma, *dbeta;
+};
+struct BnBwdFinC {        // MODE 2: ... and the coefficients of dy = A*dz + B*y + C (the apply step as an affine map of
+  float *dgamma, *dbeta;  //         (dz, y), for a consumer that applies it while loading: conv_pwx_kernel)
+  const float *scale, *mean, *invstd;
+  float inv_count;
+  float *A, *B, *C;
+};
+
+// Arrival counters, zero at load, self-resetting.  Two levels: blocks take a ticket of their group of 32
+// row blocks, the last of a group takes a ticket of the channel group — R same-address atomics in a
+// row cost ~0.1 us each (63 us for the 512 row blocks of conv1_2), 32 + R/32 do not.
+constexpr int kTicketGroup = 32, kTicketGroups = 128;            // R <= 4096 row blocks
+__device__ unsigned ocr_bn_tickets[16 * 32 * (1 + kTicketGroups)];   // [slot][channel group][0: level 2 | 1 + g: level 1]
+
+template <typename FIN>
+__device__ __forceinline__ void bn_fin_apply(const FIN& f, int c, double s, double q);
+
+template <>
+__device__ __forceinline__ void bn_fin_apply<BnFin>(const BnFin& f, int c, double s, double q) {
+  double mean = s / f.count;
+  double var = q / f.count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+  float g = f.gamma ? f.gamma[c] : 1.f;
+  float b = f.beta ? f.beta[c] : 0.f;
+  float sc = g * invstd;
+  f.scale[c] = sc;
+  f.shift[c] = b - (float)mean * sc;
+  if (f.save_mean) f.save_mean[c] = (float)mean;
+  if (f.save_invstd) f.save_invstd[c] = invstd;
+  if (f.moving_mean) {
+    // fused batch norm feeds the unbiased variance to the moving average
+    double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+    f.moving_mean[c] = f.moving_mean[c] * f.decay + (float)mean * (1.f - f.decay);
+    f.moving_var[c] = f.moving_var[c] * f.decay + (float)unbiased * (1.f - f.decay);
+  }
+}
+
+template <>
+__device__ __forceinline__ void bn_fin_apply<BnBwdFin>(const BnBwdFin& f, int c, double s, double q) {
+  f.dbeta[c] = (float)s;
+  f.dgamma[c] = (float)q;
+}
+
+template <>
+__device__ __forceinline__ void bn_fin_apply<BnBwdFinC>(const BnBwdFinC& f, int c, double s, double q) {
+  f.dbeta[c] = (float)s;
+  f.dgamma[c] = (float)q;
+  // bn_relu_bwd_kernel<1>: dy = sc * (dz - k_dz - (y - mu) * is * k_dzx),  k_dz = dbeta / N, k_dzx = dgamma / N
+  const float sc = f.scale[c], mu = f.mean[c], is = f.invstd[c];
+  const float k_dz = (float)s * f.inv_count, k_dzx = (float)q * f.inv_count;
+  f.A[c] = sc;
+  f.B[c] = -sc * is * k_dzx;
+  f.C[c] = sc * (mu * is * k_dzx - k_dz);
+}
+
+// Partial rows per block.  The launch is a latency chain: first phase (rows / 64 batches of 8 loads per thread),
+// tickets, then the last arriver of a channel group sums the R = T / rows stage rows (R / 16 batches of
+// agent-scope loads) — and every block costs ~0.1 us of dispatch.  Measured (MI355X, us per launch, rows =
+// 64 | 256 | 512): T x C = 6400 x 256: 38.6 | 14.7 | 13.1; 8192 x 128: 28.6 | 11.9 | 11.4; 2048 x 256: 14.9 | 10.1 |
+// 10.7; 400 x 1024: 13.9 | 9.9 | 9.0 (one block per channel group: 8.7).  So: up to 1024 rows one block per channel
+// group finalises directly; beyond that T / 16 rows per block, at least 256.
+static inline int red_rows(int T) {
+  static const int forced = [] { const char* e = getenv("OCR_BN_ROWS"); return e ? atoi(e) : 0; }();   // dev sweep
+  if (forced > 0) return forced;
+  if (T <= 1024) return (T + 63) / 64 * 64;
+  int rows = ((T + 15) / 16 + 31) / 32 * 32;
+  if (rows < 256) rows = 256;
+  if (rows > 2048) rows = 2048;
+  return rows;
+}
 
 template <typename FIN>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ partial,
                                                               double* __restrict__ stage, int T, int C, int slot,
                                                               int rows, FIN fin) {
-  __shared__ __attribute__((aligned(16))) char lds[16 * 2 * 64 * 8 + 16];
-  reduce_finalize_body<FIN>(partial, stage, T, C, slot, rows, fin, ocr_bn_tickets, lds, blockIdx.x, blockIdx.y, gridDim.x);
+  // a block = one 64-channel group x `rows` partial rows; thread = 4 channels (one 16-byte load per
+  // row and sum) x one of 16 row lanes
+  __shared__ double red[16][2][64];
+  __shared__ unsigned s_ticket;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c4 = blockIdx.y * 64 + cl * 4;        // first of this thread's 4 channels
+  const int t0 = blockIdx.x * rows;
+  const int R = gridDim.x;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+  const bool live = c4 < C;
+  const bool vec = (C & 3) == 0;
+  if (live) {
+    const int t1 = min(t0 + rows, T);
+    for (int t = t0 + rl; t < t1; t += 64) {      // rows rl, rl+16, ...: four rows (8 loads) in flight, added in row order
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int tt = t + 16 * k;
+        const bool ok = tt < t1;
+        a[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        b[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const float* pa = partial + ((size_t)tt * 2 + 0) * C + c4;
+          const float* pb = partial + ((size_t)tt * 2 + 1) * C + c4;
+          if (vec) {
+            a[k] = *reinterpret_cast<const f32x4*>(pa);
+            b[k] = *reinterpret_cast<const f32x4*>(pb);
+          } else {                                 // C not a multiple of 4 (the 18-channel heads): scalar, bounded
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c4 + e < C) { a[k][e] = pa[e]; b[k][e] = pb[e]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[e] += (double)a[k][e];
+          q[e] += (double)b[k][e];
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[rl][0][cl * 4 + e] = s[e];
+    red[rl][1][cl * 4 + e] = q[e];
+  }
+  __syncthreads();
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int which = threadIdx.x >> 6;             // threads 0..63: sums, 64..127: second sums
+  double tot = 0.0;
+  if (which < 2) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += red[k][which][threadIdx.x & 63];
+    if (R > 1 && c < C) stage[((size_t)blockIdx.x * 2 + which) * C + c] = tot;
+  }
+  if (R == 1) {                                   // single block per channel group: finalise directly
+    if (which == 1) red[0][1][threadIdx.x & 63] = tot;
+    __syncthreads();
+    if (which == 0 && c < C) bn_fin_apply(fin, c, tot, red[0][1][threadIdx.x & 63]);
+    return;
+  }
+  __threadfence();                                // publish this block's stage rows
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* tk = &ocr_bn_tickets[(size_t)(slot * 32 + blockIdx.y) * (1 + kTicketGroups)];
+    const int g = blockIdx.x / kTicketGroup, ng = (R + kTicketGroup - 1) / kTicketGroup;
+    const int gsize = min(kTicketGroup, R - g * kTicketGroup);
+    unsigned last = 0u;
+    if (atomicAdd(tk + 1 + g, 1u) == (unsigned)(gsize - 1)) {     // last of its group: everyone else of the group is done
+      tk[1 + g] = 0u;                                             // ready for the next launch that uses this slot
+      __threadfence();
+      if (atomicAdd(tk, 1u) == (unsigned)(ng - 1)) {
+        tk[0] = 0u;
+        last = 1u;
+      }
+    }
+    s_ticket = last;
+  }
+  __syncthreads();
+  if (!s_ticket) return;                          // not the last block of this channel group
+  __threadfence();
+  // the last arriver sums the R stage rows: thread = (sum kind, channel) x one of two row lanes... keep
+  // it simple and wide: 128 (kind, channel) columns x 2 row lanes, eight rows in flight, fixed order
+  {
+    const int col = threadIdx.x & 127, lane2 = threadIdx.x >> 7;      // col: kind = col >> 6, channel = col & 63
+    const int cc = blockIdx.y * 64 + (col & 63);
+    double acc = 0.0;
+    if (cc < C) {
+      const unsigned long long* st = reinterpret_cast<const unsigned long long*>(stage);
+      for (int r0 = lane2; r0 < R; r0 += 16) {   // agent-scope loads (other CUs wrote these)
+        unsigned long long u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = r0 + 2 * k;
+          u[k] = r < R ? __hip_atomic_load(st + ((size_t)r * 2 + (col >> 6)) * C + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += __builtin_bit_cast(double, u[k]);
+      }
+    }
+    red[lane2][col >> 6][col & 63] = acc;         // (every reader of the first use passed the barriers above)
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C)
+    bn_fin_apply(fin, c, red[0][0][threadIdx.x] + red[1][0][threadIdx.x], red[0][1][threadIdx.x] + red[1][1][threadIdx.x]);
 }
 
 // Up to eight SMALL reductions (T <= 2048 partial rows, C <= 32 channels: the fuse heads' batch norms) finalised in one
@@ -1029,134 +1212,6 @@ extern "C" int ocr_bn_finalize(const void* partial, int T, int C, double count, 
                      rows, fin);
   return ocr_launch_status();
 }
-
-// ---------------------------------------------------------------------------------- chained finalisation (bn_reduce.h)
-// ocr_bn_finalize_arm / ocr_bn_bwd_coefficients_arm do NOT launch: they arm the finalisation for the NEXT launch on this
-// host thread that produces exactly these partial rows.  A producer that can carry it (conv3x3_w4 / conv3x3_w4s /
-// conv_igemm / conv_pw / conv_pwx with one partial row per workgroup) appends the reduction's workgroups to its own grid;
-// any other producer entry point runs it as the separate launch it always was, right behind its kernel — so arming is
-// always correct, and the result is bit-identical either way.  A finalisation armed for other rows than the producer
-// writes is an error (OCR_ERR_INVALID_ARG) and is dropped.
-namespace {
-struct BnArmed {
-  int kind = 0;            // 0: nothing armed
-  bool taken = false;
-  const float* partial = nullptr;
-  double* stage = nullptr;
-  int T = 0, C = 0;
-  BnFin fin{};
-  BnBwdFinC finc{};
-};
-thread_local BnArmed g_armed;
-
-unsigned* bn_device_words(int which) {           // 0: ticket table, 1: arrival counters
-  static unsigned* ptrs[2] = {nullptr, nullptr};
-  if (ptrs[0] == nullptr) {
-    void *a = nullptr, *b = nullptr;
-    if (hipGetSymbolAddress(&a, HIP_SYMBOL(ocr_bn_tickets)) != hipSuccess ||
-        hipGetSymbolAddress(&b, HIP_SYMBOL(ocr_bn_arrive)) != hipSuccess)
-      return nullptr;
-    ptrs[0] = static_cast<unsigned*>(a);
-    ptrs[1] = static_cast<unsigned*>(b);
-  }
-  return ptrs[which];
-}
-
-int bn_arm_common(int kind, const void* partial, int T, int C, void* workspace, size_t ws_bytes) {
-  OCR_CHECK_ARG(partial && workspace && T > 0 && C > 0);
-  if (ws_bytes < ocr_bn_reduce_workspace(T, C)) return OCR_ERR_WORKSPACE;
-  const int rows = red_rows(T), R = ocr_cdiv(T, rows);
-  OCR_CHECK_SHAPE(ocr_cdiv(C, 64) <= 32 && R <= kTicketGroup * kTicketGroups);
-  if (g_armed.kind != 0) {                     // the previous one was never consumed: a host-logic error, not a race
-    g_armed = BnArmed{};
-    return OCR_ERR_INVALID_ARG;
-  }
-  g_armed.kind = kind;
-  g_armed.taken = false;
-  g_armed.partial = static_cast<const float*>(partial);
-  g_armed.stage = static_cast<double*>(workspace);
-  g_armed.T = T;
-  g_armed.C = C;
-  return OCR_OK;
-}
-}  // namespace
-
-extern "C" int ocr_bn_finalize_arm(const void* partial, int T, int C, double count, const void* gamma, const void* beta,
-                                   float eps, float decay, void* moving_mean, void* moving_var, void* scale, void* shift,
-                                   void* save_mean, void* save_invstd, void* workspace, size_t ws_bytes) {
-  OCR_CHECK_ARG(scale && shift && count > 0);
-  OCR_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
-  int rc = bn_arm_common(1, partial, T, C, workspace, ws_bytes);
-  if (rc != OCR_OK) return rc;
-  g_armed.fin = BnFin{count, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, decay,
-                      static_cast<float*>(moving_mean), static_cast<float*>(moving_var), static_cast<float*>(scale),
-                      static_cast<float*>(shift), static_cast<float*>(save_mean), static_cast<float*>(save_invstd)};
-  return OCR_OK;
-}
-
-extern "C" int ocr_bn_bwd_coefficients_arm(const void* partial, int T, int c, double count, const void* scale,
-                                           const void* save_mean, const void* save_invstd, void* dgamma, void* dbeta,
-                                           void* coef_a, void* coef_b, void* coef_c, void* workspace, size_t ws_bytes) {
-  OCR_CHECK_ARG(scale && save_mean && save_invstd && dgamma && dbeta && coef_a && coef_b && coef_c && count > 0);
-  int rc = bn_arm_common(2, partial, T, c, workspace, ws_bytes);
-  if (rc != OCR_OK) return rc;
-  g_armed.finc = BnBwdFinC{static_cast<float*>(dgamma), static_cast<float*>(dbeta), static_cast<const float*>(scale),
-                           static_cast<const float*>(save_mean), static_cast<const float*>(save_invstd),
-                           (float)(1.0 / count), static_cast<float*>(coef_a), static_cast<float*>(coef_b),
-                           static_cast<float*>(coef_c)};
-  return OCR_OK;
-}
-
-// 1 while a finalisation is armed on this host thread (tests)
-extern "C" int ocr_bn_armed(void) { return g_armed.kind != 0; }
-
-namespace ocr_detail {
-
-bool bn_chain_take(const void* partial, int T, int C, BnChain* out) {
-  static const int on = [] { const char* e = getenv("OCR_BN_CHAIN"); return e ? atoi(e) : 1; }();   // 0: always the separate launch (A/B)
-  out->kind = 0;
-  if (!on || g_armed.kind == 0 || g_armed.taken || g_armed.partial != partial || g_armed.T != T || g_armed.C != C)
-    return false;
-  unsigned* tickets = bn_device_words(0);
-  unsigned* arrive = bn_device_words(1);
-  if (tickets == nullptr || arrive == nullptr) return false;
-  const int slot = bn_ticket_slot();
-  out->kind = g_armed.kind;
-  out->nprod = 0;                              // (the launcher knows its grid)
-  out->T = T;
-  out->C = C;
-  out->rows = red_rows(T);
-  out->R = ocr_cdiv(T, out->rows);
-  out->ncg = ocr_cdiv(C, 64);
-  out->slot = slot;
-  out->partial = g_armed.partial;
-  out->stage = g_armed.stage;
-  out->tickets = tickets;
-  out->arrive = arrive + 2 * slot;
-  out->fin = g_armed.fin;
-  out->finc = g_armed.finc;
-  g_armed.taken = true;
-  return true;
-}
-
-int bn_chain_flush(int rc, const void* partial, hipStream_t st) {
-  if (g_armed.kind == 0) return rc;
-  const BnArmed a = g_armed;
-  g_armed = BnArmed{};
-  if (rc != OCR_OK) return rc;
-  if (a.taken) return rc;
-  if (a.partial != partial) return OCR_ERR_INVALID_ARG;     // armed for rows this launch does not produce
-  const int rows = red_rows(a.T), R = ocr_cdiv(a.T, rows);
-  if (a.kind == 1)
-    hipLaunchKernelGGL(reduce_finalize_kernel<BnFin>, dim3(R, ocr_cdiv(a.C, 64)), dim3(256), 0, st, a.partial, a.stage,
-                       a.T, a.C, bn_ticket_slot(), rows, a.fin);
-  else
-    hipLaunchKernelGGL(reduce_finalize_kernel<BnBwdFinC>, dim3(R, ocr_cdiv(a.C, 64)), dim3(256), 0, st, a.partial,
-                       a.stage, a.T, a.C, bn_ticket_slot(), rows, a.finc);
-  return ocr_launch_status();
-}
-
-}  // namespace ocr_detail
 
 extern "C" int ocr_bn_inference_params(const void* gamma, const void* beta, const void* moving_mean,
                                        const void* moving_var, float eps, int C, void* scale,

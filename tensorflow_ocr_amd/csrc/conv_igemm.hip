@@ -21,7 +21,6 @@
 //     per-tile per-cout sum and sum of squares of the stored (f16-rounded) values for training-mode
 //     batch norm (or, in the input-gradient form, the producing layer's BN-backward sums).
 #include "common.h"
-#include "bn_reduce.h"
 #include "conv_epilogue.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -39,17 +38,7 @@ struct ConvP {
   BnRed br;       // br.y != nullptr: fused BN-backward reduction (see conv_epilogue.h)
   half_t* pool_out;          // conv_c64_persist_kernel<64, true>: [n][ceil(oh/2)][ceil(ow/2)][cout] pooled output
   unsigned char* pool_idx;   // ... and its first-max positions (ocr_maxpool_f16's argmax format), may be null
-  ocr_bn::BnChain chain;     // chain.kind != 0: the launch carries the finalisation of its own partial rows (bn_reduce.h)
 };
-
-// The head of a kernel that can carry a chained finalisation: the workgroups behind the producers run the reduction and
-// leave; `bid` is the producer's index and `nwg` the producer count (what the XCD-aware order divides by eight).
-#define OCR_CHAIN_HEAD(p, smem, bid, nwg)                                           \
-  if ((p).chain.kind != 0 && (bid) >= (p).chain.nprod) {                            \
-    ocr_bn::bn_chain_finalize((p).chain, (smem), (bid) - (p).chain.nprod);          \
-    return;                                                                         \
-  }                                                                                 \
-  const int nwg = (p).chain.kind != 0 ? (p).chain.nprod : (int)gridDim.x;
 
 
 // LDS pixel / weight-row stride: CK f16 + padding that makes the 16-byte fragment reads
@@ -857,8 +846,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
   const int L = lane & 15, kg = lane >> 4;
 
   int bid = blockIdx.x;
-  OCR_CHAIN_HEAD(p, smem, bid, nwg)
-  if (p.xcd_swizzle) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
   const int nt = bid % p.n_tiles;
   int mt = bid / p.n_tiles;
   const int txi = mt % p.tiles_x;
@@ -1232,8 +1220,7 @@ __global__ __launch_bounds__(256) void conv3x3_w4_kernel(
       }
       __syncthreads();
       for (int i = tid; i < 512; i += 256)
-        ocr_bn::bn_chain_store(&stats[((size_t)mt8 * 2 + (i >> 8)) * p.cout + co0 + (i & 255)], red[i] + red[512 + i]);
-      if (p.chain.kind != 0) ocr_bn::bn_chain_signal(p.chain);
+        stats[((size_t)mt8 * 2 + (i >> 8)) * p.cout + co0 + (i & 255)] = red[i] + red[512 + i];
     }
   }
   OCR_DIAG_WG_END(ocr_diag_conv)
@@ -1281,8 +1268,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
   const int L = lane & 15, kg = lane >> 4;
 
   int bid = blockIdx.x;
-  OCR_CHAIN_HEAD(p, smem, bid, nwg)
-  if (p.xcd_swizzle) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+  if (p.xcd_swizzle) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
   const int nt = bid % p.n_tiles;
   int mt = bid / p.n_tiles;
   const int txi = mt % p.tiles_x;
@@ -1604,9 +1590,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w4s_kernel(
       }
       __syncthreads();
       if (tid < 2 * BN)
-        ocr_bn::bn_chain_store(&stats[((size_t)mt8 * 2 + tid / BN) * p.cout + co0 + tid % BN],
-                               ((red[tid] + red[2 * BN + tid]) + red[4 * BN + tid]) + red[6 * BN + tid]);
-      if (p.chain.kind != 0) ocr_bn::bn_chain_signal(p.chain);
+        stats[((size_t)mt8 * 2 + tid / BN) * p.cout + co0 + tid % BN] =
+            ((red[tid] + red[2 * BN + tid]) + red[4 * BN + tid]) + red[6 * BN + tid];
     }
   }
   OCR_DIAG_WG_END(ocr_diag_conv)
@@ -2317,16 +2302,6 @@ static int launch_c64(const ConvP& p0, const void* x, const void* w, const void*
   return ocr_launch_status();
 }
 
-// A finalisation armed for this launch's partial rows (bn_reduce.h): `rows` of them, one per producer workgroup and cout
-// tile; the reduction's workgroups go behind the producers' in the same grid.
-static void chain_attach(ConvP& q, const void* stats, int rows, dim3* grid) {
-  q.chain.kind = 0;
-  if (stats == nullptr || !(q.flags & OCR_CONV_STATS)) return;
-  if (!ocr_detail::bn_chain_take(stats, rows, q.cout, &q.chain)) return;
-  q.chain.nprod = (int)grid->x;
-  grid->x += (unsigned)(q.chain.R * q.chain.ncg);
-}
-
 // 4-wave kernel: 3x3 / stride 1 / dilation 1, 64-channel chunks, 256-cout tiles, 16x16x32 MFMA
 static bool conv_w4_ok(const ConvP& p) {
   static const int on = [] { const char* e = getenv("OCR_CONV_W4"); return e ? atoi(e) : 1; }();
@@ -2352,7 +2327,6 @@ static int launch_w4(const ConvP& p, const void* x, const void* w, const void* b
   static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 3; }();
   ConvP q = p;
   q.xcd_swizzle = (swz & 1) && grid.x % 8 == 0;
-  chain_attach(q, stats, m_tiles, &grid);
   hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)W4_LDS, st, q, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats));
@@ -2398,7 +2372,6 @@ static int launch_w4s(const ConvP& p0, const void* x, const void* w, const void*
   dim3 grid((unsigned)(m_tiles * p.n_tiles));
   static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 3; }();
   p.xcd_swizzle = (swz & 1) && grid.x % 8 == 0;
-  chain_attach(p, stats, m_tiles, &grid);
   // OCR_W4S_SOLO=1 (measurement switch): ask for the whole LDS, so that ONE workgroup fits a CU — what a wave of this
   // kernel does without a partner on its SIMD (scripts/clock_diag.py)
   static const int solo = [] { const char* e = getenv("OCR_W4S_SOLO"); return e ? atoi(e) : 0; }();
@@ -2436,7 +2409,6 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
   p->pool_out = nullptr;
   p->pool_idx = nullptr;
   p->xcd_swizzle = 0;
-  p->chain = ocr_bn::BnChain{};
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
   p->kh = d->kh; p->kw = d->kw; p->stride = d->stride; p->dil = d->dilation;
@@ -2597,7 +2569,7 @@ extern "C" int ocr_conv2d_f16(const ocr_conv_desc* d, const void* x, const void*
   OCR_CHECK_ARG(x && w_kc && y);
   OCR_CHECK_ARG(!(d->flags & OCR_CONV_BIAS) || bias);
   OCR_CHECK_ARG(!(d->flags & OCR_CONV_STATS) || stats);
-  return ocr_detail::bn_chain_flush(dispatch(p, cfg, x, w_kc, bias, y, stats, static_cast<hipStream_t>(stream)), stats, static_cast<hipStream_t>(stream));
+  return dispatch(p, cfg, x, w_kc, bias, y, stats, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const void* w_kc, void* y,
@@ -2615,7 +2587,7 @@ extern "C" int ocr_conv2d_bnred_f16(const ocr_conv_desc* d, const void* x, const
                static_cast<const float*>(bn_shift), static_cast<const float*>(bn_mean),
                static_cast<const float*>(bn_invstd), bn_relu};
   p.br.store_dz = store_masked;
-  return ocr_detail::bn_chain_flush(dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream)), partial, static_cast<hipStream_t>(stream));
+  return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }
 
 // ocr_conv2d_bnred_f16 for the convolution that consumes conv1_1's activation (conv1_2 of nets/vgg.py:17): the fused
@@ -2637,7 +2609,7 @@ extern "C" int ocr_conv2d_bnred_first_f16(const ocr_conv_desc* d, const void* x,
                static_cast<const float*>(bn_mean), static_cast<const float*>(bn_invstd), bn_relu};
   p.br.first_x4 = static_cast<const half_t*>(x4);
   p.br.first_wf = static_cast<const half_t*>(w_first);
-  return ocr_detail::bn_chain_flush(launch_c64<false>(p, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream)), partial, static_cast<hipStream_t>(stream));
+  return launch_c64<false>(p, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }
 
 // ocr_conv2d_bnred_first_f16 that does not store the gradient but the sums conv1_1's weight gradient is made of
@@ -2668,7 +2640,7 @@ extern "C" int ocr_conv2d_bnred_first_wgrad_f16(const ocr_conv_desc* d, const vo
   p.br.first_x4 = static_cast<const half_t*>(x4);
   p.br.first_wf = static_cast<const half_t*>(w_first);
   p.br.first_s1 = static_cast<float*>(s1_blocks);
-  return ocr_detail::bn_chain_flush(launch_c64<false>(p, x, w_kc, nullptr, nullptr, partial, static_cast<hipStream_t>(stream)), partial, static_cast<hipStream_t>(stream));
+  return launch_c64<false>(p, x, w_kc, nullptr, nullptr, partial, static_cast<hipStream_t>(stream));
 }
 
 // 1x1 convolution whose input is the previous bottleneck's output relu(bn(conv3) + shortcut), computed while the
@@ -2689,7 +2661,7 @@ extern "C" int ocr_conv2d_pw_bnaddrelu_f16(const ocr_conv_desc* d, const void* p
   PwX t{static_cast<const half_t*>(prev_y), static_cast<const half_t*>(shortcut), static_cast<const float*>(prev_scale),
         static_cast<const float*>(sc_scale), static_cast<const float*>(prev_shift), static_cast<const float*>(sc_shift),
         static_cast<half_t*>(x_out), static_cast<unsigned char*>(mask_bits)};
-  return ocr_detail::bn_chain_flush(dispatch_pwx<1>(p, cfg, t, w_kc, y, stats, static_cast<hipStream_t>(stream)), stats, static_cast<hipStream_t>(stream));
+  return dispatch_pwx<1>(p, cfg, t, w_kc, y, stats, static_cast<hipStream_t>(stream));
 }
 
 // 1x1 convolution whose input x = relu(prev_y * prev_scale + prev_shift) — the batch norm + ReLU of the layer before it —
@@ -2707,7 +2679,7 @@ extern "C" int ocr_conv2d_pw_bnrelu_f16(const ocr_conv_desc* d, const void* prev
   OCR_CHECK_ARG(!(d->flags & OCR_CONV_STATS) || stats);
   PwX t{static_cast<const half_t*>(prev_y), nullptr, static_cast<const float*>(prev_scale), nullptr,
         static_cast<const float*>(prev_shift), nullptr, static_cast<half_t*>(x_out), nullptr};
-  return ocr_detail::bn_chain_flush(dispatch_pwx<3>(p, cfg, t, w_kc, y, stats, static_cast<hipStream_t>(stream)), stats, static_cast<hipStream_t>(stream));
+  return dispatch_pwx<3>(p, cfg, t, w_kc, y, stats, static_cast<hipStream_t>(stream));
 }
 
 // Input-gradient 1x1 convolution whose operand is the batch-norm backward apply dy = A*dz + B*bn_y_in + C of the
@@ -2733,7 +2705,7 @@ extern "C" int ocr_conv2d_pw_bnbwd_bnred_f16(const ocr_conv_desc* d, const void*
   PwX t{static_cast<const half_t*>(dz), static_cast<const half_t*>(y_above), static_cast<const float*>(coef_a),
         static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), nullptr, static_cast<half_t*>(dy_out),
         nullptr};
-  return ocr_detail::bn_chain_flush(dispatch_pwx<2>(p, cfg, t, w_kc, dx, partial, static_cast<hipStream_t>(stream)), partial, static_cast<hipStream_t>(stream));
+  return dispatch_pwx<2>(p, cfg, t, w_kc, dx, partial, static_cast<hipStream_t>(stream));
 }
 
 // conv + bias + ReLU + 2x2/2 max-pool in one kernel for 64 -> 64 channel 3x3 layers (PixelLink's conv1_2 and the same
@@ -2750,7 +2722,7 @@ extern "C" int ocr_conv2d_relu_pool_f16(const ocr_conv_desc* d, const void* x, c
   if (p.pw || cfg.bn != 64 || cfg.ck != 64 || !conv_c64_ok(p)) return OCR_ERR_UNSUPPORTED;
   p.pool_out = static_cast<half_t*>(pooled);
   p.pool_idx = static_cast<unsigned char*>(argmax_u8);
-  return ocr_detail::bn_chain_flush(launch_c64<true>(p, x, w_kc, bias, nullptr, nullptr, static_cast<hipStream_t>(stream)), nullptr, static_cast<hipStream_t>(stream));
+  return launch_c64<true>(p, x, w_kc, bias, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 // q = (P * m) >> (31 + l) == P / d for every P < 2^31 (round-up method: m = ceil(2^(31+l) / d), l = ceil(log2 d))
@@ -2783,7 +2755,7 @@ extern "C" int ocr_conv2d_bnred_tail_f16(const ocr_conv_desc* d, const void* x, 
     magic31((unsigned)(d->oh * d->ow), &p.br.sub_m_hw, &p.br.sub_l_hw);
     magic31((unsigned)d->ow, &p.br.sub_m_w, &p.br.sub_l_w);
   }
-  return ocr_detail::bn_chain_flush(dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream)), partial, static_cast<hipStream_t>(stream));
+  return dispatch(p, cfg, x, w_kc, nullptr, y, partial, static_cast<hipStream_t>(stream));
 }
 
 // ocr_conv2d_pw_bnbwd_bnred_f16's loader (the BN-backward apply of the layer ABOVE computed on the operand rows, optionally
@@ -2822,5 +2794,5 @@ extern "C" int ocr_conv2d_pw_bnbwd_tail_f16(const ocr_conv_desc* d, const void* 
   PwX t{static_cast<const half_t*>(dz), static_cast<const half_t*>(y_above), static_cast<const float*>(coef_a),
         static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), static_cast<const float*>(relu_shift),
         static_cast<half_t*>(dy_out), nullptr};
-  return ocr_detail::bn_chain_flush(dispatch_pwx<2>(p, cfg, t, w_kc, dx, tail ? partial : nullptr, static_cast<hipStream_t>(stream)), tail ? partial : nullptr, static_cast<hipStream_t>(stream));
+  return dispatch_pwx<2>(p, cfg, t, w_kc, dx, tail ? partial : nullptr, static_cast<hipStream_t>(stream));
 }

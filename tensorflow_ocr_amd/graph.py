@@ -159,7 +159,7 @@ class Act:
 
     __slots__ = ("_data", "grad", "requires_grad", "name", "bn_ctx", "bn_partial", "tail_ctx", "tail_partial",
                  "pending", "sub_grad", "deferred", "tail_fwd", "pending_owner", "consumed", "bn_fwd", "bias_ctx",
-                 "bias_partial", "sole_consumer", "bias_done", "pool_grad", "takes_pool_grad", "first_s1", "bn_arm", "bn_coef")
+                 "bias_partial", "sole_consumer", "bias_done", "pool_grad", "takes_pool_grad", "first_s1")
 
     def __init__(self, data, requires_grad=True, name=""):
         self._data = data
@@ -187,9 +187,6 @@ class Act:
         self.pool_grad = None     # ... which that pool's backward then leaves here: (pooled grad, argmax, k, stride, (pt, pl))
         self.first_s1 = None      # conv1_1's activation: the sums its weight gradient is finished from, left by the sole consumer's
                                   # input-gradient launch INSTEAD of the gradient (layers._conv_dgrad; `grad` then stays None)
-        self.bn_arm = None        # callable (partial, T) -> coefficients: arms the producing layer's BN-backward finalisation for the
-                                  # input-gradient launch that sums `partial` (ops.bn_bwd_coefficients_arm); result in bn_coef
-        self.bn_coef = None
         self.bn_fwd = None        # (y, scale, shift, relu): a deferred relu(bn(y)) a fusing consumer (max-pool) can evaluate itself
         self.tail_fwd = None      # (y3, scale, shift, shortcut tensor, sc_scale, sc_shift, bits): what a fusing consumer needs
 

@@ -70,9 +70,6 @@ FUSE_FIRST_WGRAD = __import__("os").environ.get("OCR_FUSE_FIRST_WGRAD", "1") == 
 # conv1_1's weight gradient from SUMS (csrc/conv_first.hip: first_wgrad_sums_kernel): conv1_2's input-gradient launch
 # leaves S1 = V^T dz instead of the 1 GiB gradient, dW = A .* S1 + B .* (M W) + C .* m
 FIRST_WGRAD_SUMS = __import__("os").environ.get("OCR_FIRST_WGRAD_SUMS", "1") == "1"
-# batch-norm finalisations as the closing workgroups of the launch that produces their partial rows (csrc/bn_reduce.h);
-# 0: the separate launches (bit-identical; A/B)
-CHAIN_BN = __import__("os").environ.get("OCR_CHAIN_BN", "1") == "1"
 
 
 def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True, pool=0,
@@ -125,9 +122,6 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
         flags = CONV_STATS if train_stats else 0
         part, stage = g.ws_small.two(mt * 2 * cout * 4, ops.bn_reduce_workspace(mt, cout))
         mt_fin = mt
-        scale, shift = g.empty((cout,), F32), g.empty((cout,), F32)
-        mean, invstd = g.empty((cout,), F32), g.empty((cout,), F32)
-        chained = False
         if first and drop_y and train_stats and FIRST_MOMENTS:
             # the statistics from the image's second moments (csrc/conv_first.hip: first_moments_kernel): no pass over the
             # 64-channel output at all; one partial row
@@ -139,16 +133,12 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
             ops.conv2d_first(x.data, w_fwd, None if drop_y else y, flags, None, part if train_stats else None, cout=cout)
         else:
             d.flags = flags
-            if train_stats and CHAIN_BN:
-                # the finalisation rides in the convolution's own launch (ops.bn_finalize_arm)
-                chained = True
-                ops.bn_finalize_arm(part, mt_fin, cout, float(n) * oh * ow, gamma.data, beta.data, BN_EPS, BN_DECAY,
-                                    mm.data, mv.data, scale, shift, mean, invstd, stage)
             ops.conv2d(d, x.data, w_fwd, y, None, part if train_stats else None)
+        scale, shift = g.empty((cout,), F32), g.empty((cout,), F32)
+        mean, invstd = g.empty((cout,), F32), g.empty((cout,), F32)
         if train_stats:
-            if not chained:
-                ops.bn_finalize(part, mt_fin, cout, float(n) * oh * ow, gamma.data, beta.data, BN_EPS, BN_DECAY,
-                                mm.data, mv.data, scale, shift, mean, invstd, stage)
+            ops.bn_finalize(part, mt_fin, cout, float(n) * oh * ow, gamma.data, beta.data, BN_EPS, BN_DECAY,
+                            mm.data, mv.data, scale, shift, mean, invstd, stage)
         else:
             ops.bn_inference_params(gamma.data, beta.data, mm.data, mv.data, BN_EPS, scale, shift)
         full = pooled = None
@@ -183,24 +173,11 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 ops.bn_relu(y.tensor() if isinstance(y, ops.LazyFirstY) else y, scale, shift, relu, 0, full, None)
         a_full = Act(full, name=scope) if full is not None else None
         a_pool = Act(pooled, name=scope + "/pool") if pooled is not None else None
-        def arm_bwd(part_b, T_b):
-            # this layer's BN-backward finalisation (dgamma, dbeta, the apply pass's coefficients) as the closing
-            # workgroups of the consumer's input-gradient launch, whose epilogue sums `part_b` (_conv_dgrad)
-            coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
-            stage_b = g.empty((ops.bn_reduce_workspace(T_b, cout),), torch.uint8)
-            ops.bn_bwd_coefficients_arm(part_b, T_b, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad, beta.grad,
-                                        coef, stage_b)
-            return coef
-        guest_bwd = CHAIN_BN and train_stats and not first and ops.guest_apply_ok((n, oh, ow, cout))
         if not pool and train_stats:
             # lets the consumer conv's input-gradient kernel do this layer's BN-backward reduction
             a_full.bn_ctx = (y, scale, shift, mean, invstd, relu)
-            if guest_bwd:
-                a_full.bn_arm = arm_bwd
         if pool and argmax is not None and y_pool is not None:
             a_pool.bn_ctx = (y_pool, scale, shift, mean, invstd, relu)
-            if guest_bwd and oh % 2 == 0 and ow % 2 == 0:
-                a_pool.bn_arm = arm_bwd
 
         def backward():
             if not train_stats:
@@ -253,11 +230,9 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
                 if ops.guest_apply_ok(y_b.shape):
                     # the apply pass as a GUEST (csrc/guest_bn.hip): dgamma / dbeta / coefficients first, then one slim
                     # launch that the recorded step runs beside the weight gradient of the layer above
-                    coef, a_full.bn_coef = a_full.bn_coef, None      # (left by the consumer's chained finalisation: arm_bwd)
-                    if coef is None:
-                        coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
-                        ops.bn_bwd_coefficients_pre(part_f, T_f, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
-                                                    beta.grad, coef, ws)
+                    coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
+                    ops.bn_bwd_coefficients_pre(part_f, T_f, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
+                                                beta.grad, coef, ws)
                     ops.bn_relu_bwd_apply_affine(y_b, da_full, scale, shift, coef[1], coef[2], relu, dy)
                 else:
                     ops.bn_relu_bwd_apply(y_b, scale, shift, mean, invstd, da_full, relu, part_f, T_f,
@@ -266,11 +241,9 @@ def conv2d(g, x, cout, k, scope, *, stride=1, rate=1, normalizer="bn", relu=True
             elif pool and argmax is not None and da_full is None and a_pool.bn_partial is not None:
                 part_p, T_p = a_pool.bn_partial
                 if ops.guest_apply_ok(y_b.shape) and oh % 2 == 0 and ow % 2 == 0:
-                    coef, a_pool.bn_coef = a_pool.bn_coef, None
-                    if coef is None:
-                        coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
-                        ops.bn_bwd_coefficients_pre(part_p, T_p, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
-                                                    beta.grad, coef, ws)
+                    coef = (g.empty((cout,), F32), g.empty((cout,), F32), g.empty((cout,), F32))
+                    ops.bn_bwd_coefficients_pre(part_p, T_p, cout, float(n) * oh * ow, scale, mean, invstd, gamma.grad,
+                                                beta.grad, coef, ws)
                     ops.bn_relu_pool_bwd_idx_apply_affine(y_b, argmax, da_pool, coef, relu, dy)
                 else:
                     ops.bn_relu_pool_bwd_idx_apply(y_b, scale, mean, invstd, argmax, da_pool, relu, part_p, T_p,
@@ -422,7 +395,6 @@ def _conv_dgrad(g, x, wv, w_dg, d, dy):
     else:
         flags |= CONV_ACCUM_F16
         x.bn_partial = None     # an earlier consumer's fused BN-backward sums no longer cover the full gradient
-        x.bn_coef = None        # ... nor do the coefficients its chained finalisation made of them
         x.bias_partial = None   # ... nor its masked store (backward_bias then masks the whole sum again: idempotent)
     dg = ops.ConvDesc(d.n, d.oh, d.ow, d.cout, d.h, d.w, d.cin, d.kh, d.kw, 1, d.dilation, pt, pl, 1,
                       flags)
@@ -446,8 +418,6 @@ def _conv_dgrad(g, x, wv, w_dg, d, dy):
             # the consumer of conv1_1's activation (conv1_2): conv1_1's y is recomputed in the epilogue, not read
             ops.conv2d_bnred_first(dg, dy, w_dg, x.grad, partial, (by.x4, by.w_first) + tuple(x.bn_ctx[1:]))
         else:
-            if x.bn_arm is not None:
-                x.bn_coef = x.bn_arm(partial, T)
             ops.conv2d_bnred(dg, dy, w_dg, x.grad, partial, x.bn_ctx)
         x.bn_partial = (partial, T)
     else:

@@ -563,23 +563,6 @@ def bn_finalize(partial, T, C, count, gamma, beta, eps, decay, moving_mean, movi
     return nbytes
 
 
-def bn_finalize_arm(partial, T, C, count, gamma, beta, eps, decay, moving_mean, moving_var, scale, shift,
-                    save_mean, save_invstd, ws):
-    """bn_finalize CHAINED to the convolution that produces `partial` (include/ocr_hip.h: ocr_bn_finalize_arm): call it
-    right before that convolution; nothing is launched here."""
-    L.call("ocr_bn_finalize_arm", ptr(partial), c_int(T), c_int(C), c_double(count), ptr(gamma), ptr(beta),
-           c_float(eps), c_float(decay), ptr(moving_mean), ptr(moving_var), ptr(scale), ptr(shift),
-           ptr(save_mean), ptr(save_invstd), ptr(ws), c_size_t(ws.numel() * ws.element_size()))
-
-
-def bn_bwd_coefficients_arm(partial, T, c, count, scale, save_mean, save_invstd, dgamma, dbeta, coef, stage):
-    """bn_bwd_coefficients chained to the input-gradient convolution whose epilogue sums `partial`."""
-    a, b, cc = coef
-    L.call("ocr_bn_bwd_coefficients_arm", ptr(partial), c_int(T), c_int(c), c_double(count), ptr(scale), ptr(save_mean),
-           ptr(save_invstd), ptr(dgamma), ptr(dbeta), ptr(a), ptr(b), ptr(cc), ptr(stage),
-           c_size_t(stage.numel() * stage.element_size()))
-
-
 def bn_reduce_workspace(T, C):
     return L.call_size("ocr_bn_reduce_workspace", c_int(T), c_int(C))
 
