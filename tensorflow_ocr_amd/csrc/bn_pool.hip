@@ -101,8 +101,6 @@ __device__ __forceinline__ void bn_fin_apply<BnBwdFinC>(const BnBwdFinC& f, int 
 // 10.7; 400 x 1024: 13.9 | 9.9 | 9.0 (one block per channel group: 8.7).  So: up to 1024 rows one block per channel
 // group finalises directly; beyond that T / 16 rows per block, at least 256.
 static inline int red_rows(int T) {
-  static const int forced = [] { const char* e = getenv("OCR_BN_ROWS"); return e ? atoi(e) : 0; }();   // dev sweep
-  if (forced > 0) return forced;
   if (T <= 1024) return (T + 63) / 64 * 64;
   int rows = ((T + 15) / 16 + 31) / 32 * 32;
   if (rows < 256) rows = 256;

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(
 // page.  Same epilogue (and batch-norm statistics per 256-pixel tile) as the kernel above.
 __device__ const u32x4 ocr_conv_zero_page[4] = {};
 
-template <int BN, int WCO, bool EPI_LOADS, int NBUF = 2>
+template <int BN, int WCO, bool EPI_LOADS>
 __global__ __launch_bounds__(512) void conv_pw_kernel(
     ConvP p, const half_t* __restrict__ x, const half_t* __restrict__ w,
     const float* __restrict__ bias, half_t* __restrict__ y, float* __restrict__ stats) {
@@ -462,21 +462,15 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
     }
   };
 
-  if (NBUF == 2) dma_stage(0, 0);
+  dma_stage(0, 0);
   int buf = 0;
   for (int kc = 0; kc < nk; ++kc) {
-    if (NBUF == 1) {
-      // ONE stage buffer (48 KB with 128-cout tiles: two workgroups per CU — the other one's MFMAs and stores run under
-      // this one's fetch): the previous stage's readers are done, fetch, wait
-      if (kc > 0) __syncthreads();
-      dma_stage(kc, 0);
-    }
     // after this barrier: stage kc has landed (the explicit vmcnt(0): hipcc does not count an LDS-DMA among the accesses
     // a workgroup barrier waits for — see conv_igemm_kernel), and stage kc-1's readers are done, so the other buffer
     // may be overwritten
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (NBUF == 2 && kc + 1 < nk) dma_stage(kc + 1, buf ^ 1);
+    if (kc + 1 < nk) dma_stage(kc + 1, buf ^ 1);
     const char* ab = smem + buf * STAGE + a_lane;
     const char* bb = smem + buf * STAGE + ABYTES + b_lane;
 #pragma unroll
@@ -499,7 +493,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(
             acc[i][t0 + t] = OCR_MFMA_16x16x32(a[i], b[t], acc[i][t0 + t], 0, 0, 0);
       }
     }
-    if (NBUF == 2) buf ^= 1;
+    buf ^= 1;
   }
 
   // epilogue on the flat tile: "row" r of the 8x32 layout = pixels px0 + 32r .. +31
@@ -2122,23 +2116,20 @@ __global__ __launch_bounds__(512) void conv_c64_persist_kernel(
   }
 }
 
-static bool pw_xcd_swizzle() {
-  static const int on = [] { const char* e = getenv("OCR_XCD_PW"); return e ? atoi(e) : 1; }();
-  return on != 0;
-}
+static bool pw_xcd_swizzle() { return true; }
 
-template <int BN, int WCO, int NBUF = 2>
+template <int BN, int WCO>
 int launch_pw(const ConvP& p, const void* x, const void* w, const void* bias, void* y, void* stats,
               hipStream_t st) {
   // one K stage (cin = 64): nothing to double-buffer
-  const size_t main_bytes = (p.cin == 64 || NBUF == 1 ? 1 : 2) * ((size_t)BN * 128 + 256 * 128);
+  const size_t main_bytes = (p.cin == 64 ? 1 : 2) * ((size_t)BN * 128 + 256 * 128);
   const bool epi_loads = (p.flags & OCR_CONV_ACCUM_F16) != 0 || p.br.y != nullptr;
   // the store-only epilogue takes a 256-cout tile in two halves, the one with global operands in one piece
   const size_t epi_bytes = conv_epilogue_lds(epi_loads ? BN : (BN > 128 ? 128 : BN), 512);
   const size_t lds = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   // two instantiations: the epilogue with global operands (ACCUM / BN-backward / tail) batches its loads
   // ahead of its stores (conv_epilogue.h) and needs ~40 more registers than the store-only one
-  auto kern = epi_loads ? conv_pw_kernel<BN, WCO, true, NBUF> : conv_pw_kernel<BN, WCO, false, NBUF>;
+  auto kern = epi_loads ? conv_pw_kernel<BN, WCO, true> : conv_pw_kernel<BN, WCO, false>;
   static bool configured[2] = {false, false};
   if (!configured[epi_loads]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2198,14 +2189,11 @@ template <int BN, int CK, int WCO, bool M16, int TH, int NW = 2>
 int launch_t(const ConvP& p, const void* x, const void* w, const void* bias, void* y,
              void* stats, hipStream_t st) {
   if constexpr (NW == 2 && BN == 256 && M16 && TH == 8) {
-    // dev sweep (OCR_IGEMM_RING=3|4): a deeper weight-slot ring for the 256-cout tiles, the slice requested two or three taps
-    // ahead.  Measured on fc6 (144 tap steps of 32 MFMAs per tile) and the strided ResNet convolutions: headline 19.85 ->
-    // 19.96 ms, ResNet 39.31 -> 39.22 — the tap step's cost is not the slice's fetch; default 2.
-    static const int ring = [] { const char* e = getenv("OCR_IGEMM_RING"); return e ? atoi(e) : 3; }();
+    // a three-slot weight ring for the 256-cout tiles, the slice requested two taps ahead (a four-slot ring was measured
+    // too, on fc6 — 144 tap steps of 32 MFMAs per tile — and the strided ResNet convolutions: headline 19.85 -> 19.96 ms,
+    // ResNet 39.31 -> 39.22: the tap step's cost is not the slice's fetch)
     const int taps = p.kh * p.kw;
-    if (ring >= 4 && taps >= 4 && (size_t)p.halo_bytes + 4 * BN * conv_wrs(CK) <= 160 * 1024)
-      return launch_t<BN, CK, WCO, M16, TH, 4>(p, x, w, bias, y, stats, st);
-    if (ring >= 3 && taps >= 3 && (size_t)p.halo_bytes + 3 * BN * conv_wrs(CK) <= 160 * 1024)
+    if (taps >= 3 && (size_t)p.halo_bytes + 3 * BN * conv_wrs(CK) <= 160 * 1024)
       return launch_t<BN, CK, WCO, M16, TH, 3>(p, x, w, bias, y, stats, st);
   }
   size_t main_bytes = (size_t)p.halo_bytes + NW * BN * conv_wrs(CK);
@@ -2224,9 +2212,8 @@ int launch_t(const ConvP& p, const void* x, const void* w, const void* bias, voi
   }
   const int m_tiles = p.n * p.tiles_x * p.tiles_y;
   dim3 grid((unsigned)(m_tiles * p.n_tiles));
-  static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 3; }();
   ConvP q = p;
-  q.xcd_swizzle = (swz & 1) && grid.x % 8 == 0;
+  q.xcd_swizzle = grid.x % 8 == 0;      // XCD-aware order: A/B -0.04 ms on the headline step (profiles/r06_ab_xcd_swizzle.txt)
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, q,
                      static_cast<const half_t*>(x), static_cast<const half_t*>(w),
                      static_cast<const float*>(bias), static_cast<half_t*>(y),
@@ -2261,8 +2248,6 @@ static int c64_per(const ConvP& p) {
 // the epilogue mode of the wave-private-epilogue kernels, a compile-time constant in the kernel (see
 // conv3x3_w4_kernel): anything unusual takes the generic instantiation (0), which reads the flags at run time
 static int epi_mode(const ConvP& p) {
-  static const int force_generic = [] { const char* e = getenv("OCR_W4_GENERIC_EPI"); return e ? atoi(e) : 0; }();
-  if (force_generic) return 0;
   const bool br = p.br.y != nullptr;
   const int fl = p.flags;
   if (p.br.first_x4 != nullptr) return p.br.first_s1 != nullptr ? 7 : 6;      // (conv_c64_persist_kernel only: the entry point checks the variant)
@@ -2324,9 +2309,8 @@ static int launch_w4(const ConvP& p, const void* x, const void* w, const void* b
   }
   const int m_tiles = p.n * p.tiles_x * p.tiles_y;
   dim3 grid((unsigned)(m_tiles * p.n_tiles));
-  static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 3; }();
   ConvP q = p;
-  q.xcd_swizzle = (swz & 1) && grid.x % 8 == 0;
+  q.xcd_swizzle = grid.x % 8 == 0;      // XCD-aware order: A/B -0.04 ms on the headline step (profiles/r06_ab_xcd_swizzle.txt)
   hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)W4_LDS, st, q, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats));
@@ -2370,12 +2354,8 @@ static int launch_w4s(const ConvP& p0, const void* x, const void* w, const void*
   p.n_tiles = p.cout / BN;
   const int m_tiles = p.n * p.tiles_x * p.tiles_y;
   dim3 grid((unsigned)(m_tiles * p.n_tiles));
-  static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 3; }();
-  p.xcd_swizzle = (swz & 1) && grid.x % 8 == 0;
-  // OCR_W4S_SOLO=1 (measurement switch): ask for the whole LDS, so that ONE workgroup fits a CU — what a wave of this
-  // kernel does without a partner on its SIMD (scripts/clock_diag.py)
-  static const int solo = [] { const char* e = getenv("OCR_W4S_SOLO"); return e ? atoi(e) : 0; }();
-  hipLaunchKernelGGL(kern, grid, dim3(256), solo ? (size_t)(160 * 1024) : (size_t)w4s_lds(BN), st, p, static_cast<const half_t*>(x),
+  p.xcd_swizzle = grid.x % 8 == 0;
+  hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)w4s_lds(BN), st, p, static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), static_cast<const float*>(bias), static_cast<half_t*>(y),
                      static_cast<float*>(stats));
   return ocr_launch_status();
@@ -2415,17 +2395,14 @@ int fill_params(const ocr_conv_desc* d, ConvP* p, TileCfg* cfg) {
   p->pt = d->pad_top; p->pl = d->pad_left; p->flip = d->flip_taps; p->flags = d->flags;
   // MFMA shape: on random data the chip holds a higher clock on 16x16x32 than on 32x32x16 at equal
   // cycles per FLOP (MI355X_MICROARCH.md "DVFS give-back" item 7; measured here +3..5 % on the 3x3
-  // layers, -20 % on the 1x1 fc7 whose per-tap loop is too short).  OCR_CONV_MFMA=16|32 forces one.
-  static const int force = [] { const char* e = getenv("OCR_CONV_MFMA"); return e ? atoi(e) : 0; }();
-  static const int tall = [] { const char* e = getenv("OCR_CONV_TALL"); return e ? atoi(e) : 1; }();
-  p->m16 = force == 16 ? 1 : force == 32 ? 0 : (d->kh * d->kw > 1);
+  // layers, -20 % on the 1x1 fc7 whose per-tap loop is too short).
+  p->m16 = d->kh * d->kw > 1;
   const int c64 = d->cin % 64 == 0;
   TileCfg cand[6];
   int nc = 0;
-  static const int max_bn = [] { const char* e = getenv("OCR_CONV_BN"); return e ? atoi(e) : 256; }();
-  if (d->cout % 256 == 0 && max_bn >= 256) { if (c64) cand[nc++] = {256, 64, 8}; cand[nc++] = {256, 32, 8}; }
+  if (d->cout % 256 == 0) { if (c64) cand[nc++] = {256, 64, 8}; cand[nc++] = {256, 32, 8}; }
   if (d->cout % 128 == 0) {
-    if (tall && d->oh > 8) { if (c64) cand[nc++] = {128, 64, 16}; cand[nc++] = {128, 32, 16}; }
+    if (d->oh > 8) { if (c64) cand[nc++] = {128, 64, 16}; cand[nc++] = {128, 32, 16}; }
     if (c64) cand[nc++] = {128, 64, 8};
     cand[nc++] = {128, 32, 8};
   } else if (d->cout % 64 == 0) {
@@ -2511,25 +2488,13 @@ static int dispatch(ConvP& p, TileCfg c, const void* x, const void* w_kc, const 
     // cin = 64 (one K stage, nothing to prefetch under) without global operands in the epilogue: 128-cout tiles
     // need 70 KB of LDS and 118 registers — two workgroups per CU, whose phases overlap (ResNet's 64 -> 256
     // forward convolutions: one 256-cout workgroup per CU exposes its fetch latency on every tile)
-    static const int split = [] { const char* e = getenv("OCR_PW_SPLIT64"); return e ? atoi(e) : 1; }();
     const bool epi_loads = (p.flags & OCR_CONV_ACCUM_F16) != 0 || p.br.y != nullptr;
-    if (split && c.bn == 256 && p.cin == 64 && !epi_loads) {
+    if (c.bn == 256 && p.cin == 64 && !epi_loads) {
       p.n_tiles = p.cout / 128;
       return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
     }
-    // the same split for the epilogue WITH global operands (ResNet stage-1 tails: 64 -> 256 input gradients with four
-    // operand streams): 70 KB of LDS per workgroup -> two per CU, one's operand batches in flight under the other's MFMAs
-    static const int split_epi = [] { const char* e = getenv("OCR_PW_SPLIT64_EPI"); return e ? atoi(e) : 0; }();
-    if (split_epi && c.bn == 256 && p.cin == 64 && epi_loads) {
-      p.n_tiles = p.cout / 128;
-      return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
-    }
-    // dev sweep: 128-cout tiles on ONE stage buffer for store-only launches with up to OCR_PW_SINGLE input channels
-    static const int single = [] { const char* e = getenv("OCR_PW_SINGLE"); return e ? atoi(e) : 0; }();
-    if (single && c.bn >= 128 && !epi_loads && p.cin <= single && p.cin > 64) {
-      p.n_tiles = p.cout / 128;
-      return launch_pw<128, 2, 1>(p, x, w_kc, bias, y, stats, st);
-    }
+    // (the same split for the epilogue WITH global operands — ResNet stage-1 tails, 64 -> 256 input gradients with four
+    // operand streams — and 128-cout tiles on ONE stage buffer for store-only launches were measured too: not faster)
     if (c.bn == 256) return launch_pw<256, 4>(p, x, w_kc, bias, y, stats, st);
     if (c.bn == 128) return launch_pw<128, 2>(p, x, w_kc, bias, y, stats, st);
     return launch_pw<64, 1>(p, x, w_kc, bias, y, stats, st);

@@ -22,6 +22,7 @@
 namespace ocr_detail {   // conv_wgrad_pw.hip: GEMM-tiled path for 1x1 convolutions
 int wgrad_pw_splits(const ocr_conv_desc* d);
 int wgrad_pw_launch(const ocr_conv_desc* d, const void* x, const void* dy, void* slab, hipStream_t st);
+bool wgrad_pw_is_256x256(const ocr_conv_desc* d);     // the 256 x 256-tile instantiation (the one whose register room is tabulated)
 }
 
 namespace {
@@ -784,19 +785,6 @@ int fill(const ocr_conv_desc* d, WgP* p) {
 
 OCR_DIAG_READER(ocr_diag_read_wgrad, ocr_diag_wgrad)
 
-extern "C" size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d) {
-  if (!d) return 0;
-  if (const int s = ocr_detail::wgrad_pw_splits(d))
-    return (size_t)s * d->kh * d->kw * d->cin * d->cout * sizeof(float);
-  Wg2P p2;
-  int cob = 0;
-  if (fill2(d, &p2, &cob) == OCR_OK)
-    return (size_t)p2.splits * (cob == 64 ? 2 : 1) * d->kh * d->kw * d->cin * d->cout * sizeof(float);
-  WgP p;
-  if (fill(d, &p) != OCR_OK) return 0;
-  return (size_t)p.splits * 2 * d->kh * d->kw * d->cin * d->cout * sizeof(float);
-}
-
 template <typename K, typename P>
 static int launch_wg(K kern, const P& p, unsigned grid, size_t lds, const void* x, const void* dy,
                      void* ws, hipStream_t st, unsigned threads = 256) {
@@ -808,6 +796,42 @@ static int launch_wg(K kern, const P& p, unsigned grid, size_t lds, const void* 
   return ocr_launch_status();
 }
 
+// Which kernel family computes the weight gradient of `d`, with its plan — the ONE place this is decided: the launch
+// (wgrad_slabs), the slab count the reduction sums (wgrad_slab_count) and the register room a guest finds beside the
+// kernel (ocr_conv2d_wgrad_guest_room) all read it.
+struct WgradSel {
+  enum Family { NONE, PW, TAP3, TAP2, GENERIC } family = NONE;
+  int splits = 0;       // slabs written
+  int cob = 0;          // TAP3 / TAP2: cout block (64 | 128)
+  Wg2P p2{};            // TAP3 / TAP2
+  WgP p{};              // GENERIC
+};
+static WgradSel wgrad_select(const ocr_conv_desc* d) {
+  WgradSel s;
+  if ((s.splits = ocr_detail::wgrad_pw_splits(d)) > 0) {
+    s.family = WgradSel::PW;
+    return s;
+  }
+  if (fill2(d, &s.p2, &s.cob) == OCR_OK) {
+    static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();   // 0: the wgrad2 family (tests)
+    const bool small = (size_t)d->n * d->h * d->w * d->cin < (1u << 30) && (size_t)d->n * d->oh * d->ow * d->cout < (1u << 30);   // < 2 GiB each
+    const bool use3 = d->kh * d->kw == 9 && v3 && small && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1;
+    s.family = use3 ? WgradSel::TAP3 : WgradSel::TAP2;
+    s.splits = s.p2.splits * (s.cob == 64 && !use3 ? 2 : 1);       // (wgrad2<64> splits K once more inside the workgroup)
+    return s;
+  }
+  if (fill(d, &s.p) == OCR_OK) {
+    s.family = WgradSel::GENERIC;
+    s.splits = s.p.splits * 2;
+  }
+  return s;
+}
+
+extern "C" size_t ocr_conv2d_wgrad_workspace(const ocr_conv_desc* d) {
+  if (!d) return 0;
+  return (size_t)wgrad_select(d).splits * d->kh * d->kw * d->cin * d->cout * sizeof(float);
+}
+
 // The partial slabs [splits][kh][kw][cin][cout] of one weight gradient (every kernel family); *splits_out = their number.
 static int wgrad_slabs(const ocr_conv_desc* d, const void* x, const void* dy, void* workspace, size_t ws_bytes,
                        void* stream, int* splits_out) {
@@ -817,23 +841,20 @@ static int wgrad_slabs(const ocr_conv_desc* d, const void* x, const void* dy, vo
   const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntaps = d->kh * d->kw;
-  int splits = 0, rc;
-  Wg2P p2;
-  int cob = 0;
-  if ((splits = ocr_detail::wgrad_pw_splits(d)) > 0) {
-    if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
+  WgradSel sel = wgrad_select(d);
+  if (sel.family == WgradSel::NONE) return OCR_ERR_UNSUPPORTED;
+  const int splits = sel.splits;
+  if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
+  int rc;
+  if (sel.family == WgradSel::PW) {
     rc = ocr_detail::wgrad_pw_launch(d, x, dy, workspace, st);
-  } else if (fill2(d, &p2, &cob) == OCR_OK) {
-    static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();
-    const bool small = (size_t)d->n * d->h * d->w * d->cin < (1u << 30) && (size_t)d->n * d->oh * d->ow * d->cout < (1u << 30);   // < 2 GiB each
-    const bool use3 = ntaps == 9 && v3 && small && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1;
-    splits = p2.splits * (cob == 64 && !use3 ? 2 : 1);       // (wgrad2<64> splits K once more inside the workgroup)
-    if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
+  } else if (sel.family == WgradSel::TAP3 || sel.family == WgradSel::TAP2) {
+    Wg2P& p2 = sel.p2;
+    const int cob = sel.cob;
     const size_t lds = 2 * ((size_t)p2.HT * p2.WT * X2STR + 128 * (cob * 2 + 32));
     const unsigned grid = (unsigned)(p2.splits * p2.nci * p2.nco);
-    static const int swz = [] { const char* e = getenv("OCR_XCD_SWIZZLE"); return e ? atoi(e) : 2; }();
-    p2.xcd_swizzle = (swz & 2) && grid % 8 == 0;
-    if (use3)
+    p2.xcd_swizzle = grid % 8 == 0;           // XCD-aware workgroup order (conv_igemm.hip)
+    if (sel.family == WgradSel::TAP3)
       rc = cob == 128 ? launch_wg(wgrad3_kernel<9, 128>, p2, grid, lds, x, dy, workspace, st, 256)
                       : launch_wg(wgrad3_kernel<9, 64>, p2, grid, lds, x, dy, workspace, st, 256);
     else if (cob == 128)
@@ -843,11 +864,7 @@ static int wgrad_slabs(const ocr_conv_desc* d, const void* x, const void* dy, vo
       rc = ntaps == 1 ? launch_wg(wgrad2_kernel<64, 1>, p2, grid, lds, x, dy, workspace, st, 512)
                       : launch_wg(wgrad2_kernel<64, 9>, p2, grid, lds, x, dy, workspace, st, 512);
   } else {
-    WgP p;
-    rc = fill(d, &p);
-    if (rc != OCR_OK) return rc;
-    splits = p.splits * 2;
-    if (ws_bytes < (size_t)splits * elems * sizeof(float)) return OCR_ERR_WORKSPACE;
+    const WgP& p = sel.p;
     const size_t lds = (size_t)p.HT * p.WT * XSTR + 256 * DSTR;
     const unsigned grid = (unsigned)(p.splits * p.nci * p.nco);
     rc = ntaps == 1 ? launch_wg(wgrad_kernel<1>, p, grid, lds, x, dy, workspace, st, 512)
@@ -880,20 +897,7 @@ extern "C" int ocr_conv2d_wgrad_slabs_f16(const ocr_conv_desc* d, const void* x,
 }
 
 // the number of slabs wgrad_slabs writes for `d` (the same selection, nothing launched); <= 0: unsupported
-static int wgrad_slab_count(const ocr_conv_desc* d) {
-  if (const int s = ocr_detail::wgrad_pw_splits(d)) return s;
-  Wg2P p2;
-  int cob = 0;
-  if (fill2(d, &p2, &cob) == OCR_OK) {
-    static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();
-    const bool small = (size_t)d->n * d->h * d->w * d->cin < (1u << 30) && (size_t)d->n * d->oh * d->ow * d->cout < (1u << 30);
-    const bool use3 = d->kh * d->kw == 9 && v3 && small && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1;
-    return p2.splits * (cob == 64 && !use3 ? 2 : 1);
-  }
-  WgP p;
-  if (fill(d, &p) != OCR_OK) return 0;
-  return p.splits * 2;
-}
+static int wgrad_slab_count(const ocr_conv_desc* d) { return wgrad_select(d).splits; }
 
 // Registers per lane a SIMD has LEFT beside the resident workgroup(s) of the kernel ocr_conv2d_wgrad_slabs_f16 selects for
 // `d` — what a guest wave may use (csrc/guest_bn.hip needs 56) — or 0 where the kernel fills the file / is not tabulated.
@@ -904,16 +908,10 @@ static int wgrad_slab_count(const ocr_conv_desc* d) {
 // tests/test_host_cpu.py::test_guest_kernels_fit_beside_the_weight_gradient re-derives the first from the compiler.
 extern "C" int ocr_conv2d_wgrad_guest_room(const ocr_conv_desc* d) {
   if (!d || d->n <= 0 || d->h <= 0 || d->w <= 0 || d->oh <= 0 || d->ow <= 0) return 0;
-  if (ocr_detail::wgrad_pw_splits(d) > 0)
-    return (d->cin % 256 == 0 && d->cout % 256 == 0 && !getenv("OCR_WGRAD_PW_TILE") && !getenv("OCR_WGRAD_PW_COB")) ? 80 : 0;
-  Wg2P p2;
-  int cob = 0;
-  if (fill2(d, &p2, &cob) != OCR_OK) return 0;
-  static const int v3 = [] { const char* e = getenv("OCR_WGRAD3"); return e ? atoi(e) : 1; }();
-  const bool small = (size_t)d->n * d->h * d->w * d->cin < (1u << 30) && (size_t)d->n * d->oh * d->ow * d->cout < (1u << 30);
-  const bool use3 = d->kh * d->kw == 9 && v3 && small && d->cin % 64 == 0 && d->kw == 3 && d->stride == 1 && d->dilation == 1;
-  if (!use3) return 0;
-  return cob == 128 ? 56 : 248;
+  const WgradSel sel = wgrad_select(d);
+  if (sel.family == WgradSel::PW) return ocr_detail::wgrad_pw_is_256x256(d) ? 80 : 0;
+  if (sel.family != WgradSel::TAP3) return 0;
+  return sel.cob == 128 ? 56 : 248;
 }
 
 extern "C" int ocr_conv2d_wgrad_reduce_f32(const ocr_conv_desc* d, const void* workspace, void* dw, void* stream) {

@@ -192,12 +192,7 @@ bool pw_plan(const ocr_conv_desc* d, PwP* p, PwCfg* c) {
   if (!(d->kh * d->kw == 1 || (d->dilation > 1 && d->kh * d->kw <= 9))) return false;
   c->cib = d->cin % 256 == 0 ? 256 : d->cin % 128 == 0 ? 128 : 64;
   c->cob = d->cout % 256 == 0 ? 256 : d->cout % 128 == 0 ? 128 : 64;
-  static const int max_tile = [] { const char* e = getenv("OCR_WGRAD_PW_TILE"); return e ? atoi(e) : 256; }();   // dev sweep
-  static const int wgs = [] { const char* e = getenv("OCR_WGRAD_PW_WGS"); return e ? atoi(e) : 256; }();
-  static const int max_cob = [] { const char* e = getenv("OCR_WGRAD_PW_COB"); return e ? atoi(e) : 256; }();
-  if (c->cib > max_tile) c->cib = max_tile;
-  if (c->cob > max_tile) c->cob = max_tile;
-  if (c->cob > max_cob) c->cob = max_cob;
+  constexpr int wgs = 256;                       // one resident workgroup per CU
   p->n = d->n; p->h = d->h; p->w = d->w; p->cin = d->cin;
   p->oh = d->oh; p->ow = d->ow; p->cout = d->cout;
   p->stride = d->stride; p->pt = d->pad_top; p->pl = d->pad_left;
@@ -230,9 +225,8 @@ int pw_launch(const PwP& p, const void* x, const void* dy, void* slab, hipStream
     configured = true;
   }
   PwP q = p;
-  static const int swz = [] { const char* e = getenv("OCR_XCD_PW"); return e ? atoi(e) : 1; }();
   const unsigned grid = (unsigned)(p.splits * p.nci * p.nco * p.kh * p.kw);
-  q.xcd_swizzle = swz && p.nci * p.nco * p.kh * p.kw > 1 && grid % 8 == 0;
+  q.xcd_swizzle = p.nci * p.nco * p.kh * p.kw > 1 && grid % 8 == 0;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, q,
                      static_cast<const half_t*>(x), static_cast<const half_t*>(dy), static_cast<float*>(slab));
   return ocr_launch_status();
@@ -247,6 +241,12 @@ int wgrad_pw_splits(const ocr_conv_desc* d) {
   PwP p;
   PwCfg c;
   return pw_plan(d, &p, &c) ? p.splits : 0;
+}
+
+bool wgrad_pw_is_256x256(const ocr_conv_desc* d) {
+  PwP p;
+  PwCfg c;
+  return pw_plan(d, &p, &c) && c.cib == 256 && c.cob == 256;
 }
 
 int wgrad_pw_launch(const ocr_conv_desc* d, const void* x, const void* dy, void* slab, hipStream_t st) {

@@ -40,12 +40,8 @@ __device__ __forceinline__ void st8(__amdgpu_buffer_rsrc_t r, unsigned voff, uns
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, kGuestAuxSt);
 }
 
-// OCR_GUEST_PRIO=1 (measurement switch): the guest's waves at s_setprio 3 — they issue a handful of instructions per
-// hundred of the host's and are otherwise served after the older (host) wave of their SIMD.
-static int guest_prio() {
-  static const int v = [] { const char* e = getenv("OCR_GUEST_PRIO"); return e ? atoi(e) : 0; }();
-  return v;
-}
+// (The guest's waves at s_setprio 3 were measured — they issue a handful of instructions per hundred of the host's and are
+// otherwise served after the older, host, wave of their SIMD: no difference, removed.)
 
 // dy = A*dz + B*y + C, dz = relu ? da * [fma(y, A, S) > tie] : da.  Thread = one 4-channel chunk (fixed for the
 // thread's lifetime: its coefficients stay in registers) x a strided set of pixels, U of them in flight.
@@ -55,8 +51,7 @@ template <bool RELU, int U>
 __global__ __launch_bounds__(256) void bn_apply_affine_kernel(
     const half_t* __restrict__ y, const half_t* __restrict__ da, const float* __restrict__ cA,
     const float* __restrict__ cS, const float* __restrict__ cB, const float* __restrict__ cC, unsigned units,
-    int c, half_t* __restrict__ dy, int prio) {
-  if (prio) __builtin_amdgcn_s_setprio(3);
+    int c, half_t* __restrict__ dy) {
   const int chunks = c >> 2, lanes = 256 / chunks;
   const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
   const size_t bytes = (size_t)units * c * 2;
@@ -105,8 +100,7 @@ template <bool RELU>
 __global__ __launch_bounds__(256) void bn_pool_apply_affine_kernel(
     const half_t* __restrict__ y, const half_t* __restrict__ da_pool, const unsigned char* __restrict__ argmax,
     const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC, int n, int h, int w,
-    int c, half_t* __restrict__ dy, int prio) {
-  if (prio) __builtin_amdgcn_s_setprio(3);
+    int c, half_t* __restrict__ dy) {
   const int chunks = c >> 2, lanes = 256 / chunks;
   const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
   const int oh = h >> 1, ow = w >> 1;
@@ -167,9 +161,7 @@ template <bool RELU>
 __global__ __launch_bounds__(256) void bn_poolfull_apply_affine_kernel(
     const half_t* __restrict__ y, const half_t* __restrict__ da_full, const half_t* __restrict__ da_pool,
     const unsigned char* __restrict__ argmax, const float* __restrict__ cA, const float* __restrict__ cS,
-    const float* __restrict__ cB, const float* __restrict__ cC, int n, int h, int w, int c, half_t* __restrict__ dy,
-    int prio) {
-  if (prio) __builtin_amdgcn_s_setprio(3);
+    const float* __restrict__ cB, const float* __restrict__ cC, int n, int h, int w, int c, half_t* __restrict__ dy) {
   const int chunks = c >> 2, lanes = 256 / chunks;
   const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
   const int oh = h >> 1, ow = w >> 1;
@@ -227,8 +219,7 @@ template <bool RELU, int U>
 __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(
     const half_t* __restrict__ y, const half_t* __restrict__ da, const float* __restrict__ cA,
     const float* __restrict__ cS, const float* __restrict__ cMu, const float* __restrict__ cIs, unsigned units, int c,
-    float* __restrict__ partial, int prio) {
-  if (prio) __builtin_amdgcn_s_setprio(3);
+    float* __restrict__ partial) {
   const int chunks = c >> 2, lanes = 256 / chunks;
   const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
   const size_t bytes = (size_t)units * c * 2;
@@ -289,8 +280,7 @@ __global__ __launch_bounds__(256) void bn_poolfull_reduce_rows_kernel(
     const half_t* __restrict__ y, const half_t* __restrict__ da_full, const half_t* __restrict__ da_pool,
     const unsigned char* __restrict__ argmax, const float* __restrict__ cA, const float* __restrict__ cS,
     const float* __restrict__ cMu, const float* __restrict__ cIs, int n, int h, int w, int c,
-    float* __restrict__ partial, int prio) {
-  if (prio) __builtin_amdgcn_s_setprio(3);
+    float* __restrict__ partial) {
   const int chunks = c >> 2, lanes = 256 / chunks;
   const int ch = threadIdx.x % chunks, ul = threadIdx.x / chunks;
   const int oh = h >> 1, ow = w >> 1;
@@ -361,8 +351,7 @@ bool pow2g(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // otherwise 4 per CU, which is what the pass needs to reach the HBM rate alone
 unsigned guest_grid(size_t units, size_t per_wg, int max_workgroups) {
   size_t b = (units + per_wg - 1) / per_wg;
-  static const unsigned cap = [] { const char* e = getenv("OCR_GUEST_GRID"); return e ? (unsigned)atoi(e) : 1024u; }();
-  const size_t lim = max_workgroups > 0 ? (size_t)max_workgroups : (size_t)cap;
+  const size_t lim = max_workgroups > 0 ? (size_t)max_workgroups : (size_t)1024;
   if (b > lim) b = lim;
   return (unsigned)(b < 1 ? 1 : b);
 }
@@ -387,12 +376,12 @@ extern "C" int ocr_bn_relu_bwd_apply_affine_f16(const void* y, const void* da, c
     hipLaunchKernelGGL((bn_apply_affine_kernel<true, U>), dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(y),
                        static_cast<const half_t*>(da), static_cast<const float*>(scale), static_cast<const float*>(shift),
                        static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), (unsigned)units, c,
-                       static_cast<half_t*>(dy), guest_prio());
+                       static_cast<half_t*>(dy));
   else
     hipLaunchKernelGGL((bn_apply_affine_kernel<false, U>), dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(y),
                        static_cast<const half_t*>(da), static_cast<const float*>(scale), static_cast<const float*>(shift),
                        static_cast<const float*>(coef_b), static_cast<const float*>(coef_c), (unsigned)units, c,
-                       static_cast<half_t*>(dy), guest_prio());
+                       static_cast<half_t*>(dy));
   return ocr_launch_status();
 }
 
@@ -413,12 +402,12 @@ extern "C" int ocr_bn_relu_pool_bwd_idx_apply_affine_f16(const void* y, const vo
     hipLaunchKernelGGL(bn_pool_apply_affine_kernel<true>, dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(y),
                        static_cast<const half_t*>(da_pool), static_cast<const unsigned char*>(argmax_u8),
                        static_cast<const float*>(coef_a), static_cast<const float*>(coef_b),
-                       static_cast<const float*>(coef_c), n, h, w, c, static_cast<half_t*>(dy), guest_prio());
+                       static_cast<const float*>(coef_c), n, h, w, c, static_cast<half_t*>(dy));
   else
     hipLaunchKernelGGL(bn_pool_apply_affine_kernel<false>, dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(y),
                        static_cast<const half_t*>(da_pool), static_cast<const unsigned char*>(argmax_u8),
                        static_cast<const float*>(coef_a), static_cast<const float*>(coef_b),
-                       static_cast<const float*>(coef_c), n, h, w, c, static_cast<half_t*>(dy), guest_prio());
+                       static_cast<const float*>(coef_c), n, h, w, c, static_cast<half_t*>(dy));
   return ocr_launch_status();
 }
 
@@ -440,7 +429,7 @@ extern "C" int ocr_bn_relu_poolfull_bwd_apply_affine_f16(const void* y, const vo
                      static_cast<const half_t*>(da_full), static_cast<const half_t*>(da_pool),
                      static_cast<const unsigned char*>(argmax_u8), static_cast<const float*>(scale),
                      static_cast<const float*>(shift), static_cast<const float*>(coef_b), static_cast<const float*>(coef_c),
-                     n, h, w, c, static_cast<half_t*>(dy), guest_prio());
+                     n, h, w, c, static_cast<half_t*>(dy));
   return ocr_launch_status();
 }
 
@@ -484,12 +473,12 @@ extern "C" int ocr_bn_relu_bwd_reduce_rows_f16(const void* y, const void* da_ful
   if (pooled)
     hipLaunchKernelGGL(bn_poolfull_reduce_rows_kernel<true>, dim3(grid), dim3(256), 0, st, yp, gf,
                        static_cast<const half_t*>(da_pool), static_cast<const unsigned char*>(argmax_u8), sc, sh, mu, is,
-                       n, h, w, c, out, guest_prio());
+                       n, h, w, c, out);
   else if (relu)
     hipLaunchKernelGGL((bn_reduce_rows_kernel<true, 4>), dim3(grid), dim3(256), 0, st, yp, gf, sc, sh, mu, is,
-                       (unsigned)((size_t)n * h * w), c, out, guest_prio());
+                       (unsigned)((size_t)n * h * w), c, out);
   else
     hipLaunchKernelGGL((bn_reduce_rows_kernel<false, 4>), dim3(grid), dim3(256), 0, st, yp, gf, sc, sh, mu, is,
-                       (unsigned)((size_t)n * h * w), c, out, guest_prio());
+                       (unsigned)((size_t)n * h * w), c, out);
   return ocr_launch_status();
 }

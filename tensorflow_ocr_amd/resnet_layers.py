@@ -168,7 +168,7 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
             else:
                 ops.conv2d_pw_bnbwd_tail(dg, dz_f, ybn_f, coef_f, relu_shift, dy, w_dg, x.grad)
             dd = ops.ConvDesc(d.n, d.h, d.w, d.cin, d.oh, d.ow, d.cout, 1, 1, 1, 1, 0, 0, 0, 0)
-            ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad, alloc=_slab_alloc(g))
+            ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad)
             return
         if strided and not s2d:
             dy_full = g.empty(y_full.shape)
@@ -179,10 +179,10 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
         def weight_gradient():
             if s2d:
                 dw22 = g.empty((2, 2, 4 * cin, cout), F32)
-                ops.conv2d_wgrad(dd, x_in, dy, dw22, g.ws_wgrad, alloc=_slab_alloc(g))
+                ops.conv2d_wgrad(dd, x_in, dy, dw22, g.ws_wgrad)
                 ops.weights_s2d_grad(dw22, wv.grad)
             else:
-                ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad, alloc=_slab_alloc(g))
+                ops.conv2d_wgrad(dd, x_in, dy, wv.grad, g.ws_wgrad)
         def input_gradient():
             pt = d.dilation * (d.kh - 1) - d.pad_top
             pl = d.dilation * (d.kw - 1) - d.pad_left
@@ -228,15 +228,9 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
                 x.bn_partial = (partial, Tm)
             else:
                 ops.conv2d(dg, dy, w_dg, x.grad, None, None)
-        if ops.GUEST_BN and GUEST_RESNET and x.requires_grad:
-            # input gradient FIRST (layers._conv_backward): the weight gradient is held back by the recorded step and runs
-            # as the host of a later batch-norm apply pass (train.schedule_guests)
+        weight_gradient()
+        if x.requires_grad:
             input_gradient()
-            weight_gradient()
-        else:
-            weight_gradient()
-            if x.requires_grad:
-                input_gradient()
 
     def can_fuse_bwd(wide=False):
         """The fused form of `backward_from`: this is a stride-1 1x1 convolution the pointwise kernel takes.  Default: its
@@ -257,16 +251,9 @@ def conv_bn_raw(g, x, cout, k, scope, *, stride=1, rate=1, is_training=True, wei
     return c
 
 
-# Guests beside held-back weight gradients (layers.conv2d / train.schedule_guests) for THIS net: measured slower at 64 x 640^2
-# (39.13-39.18 ms/step against 38.77 without, 38.98 with the split weight gradients but one stream): its apply passes are
-# 47 us each — a fork + join costs the main queue ~25 us — and its hosts are the HBM-hungry pointwise weight gradients.
-# Off; the switch keeps the path under test.
-GUEST_RESNET = __import__("os").environ.get("OCR_GUEST_RESNET", "0") == "1"
-
-
-def _slab_alloc(g):
-    """A weight gradient's own slab buffer (ops.conv2d_wgrad: the split form the recorded step can hold back)."""
-    return (lambda nb: g.empty((nb,), torch.uint8)) if GUEST_RESNET else None
+# (Guests beside held-back weight gradients — layers.conv2d / train.schedule_guests — were measured for THIS net too and
+# are not used: 39.13-39.18 ms/step at 64 x 640^2 against 38.77 without; its apply passes are 47 us each, a fork + join
+# costs the main queue ~25 us, and its hosts are the HBM-hungry pointwise weight gradients.)
 
 
 def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_training=True, owner=None, defer=False):
@@ -308,16 +295,8 @@ def conv_bn_act(g, x, cout, k, scope, *, stride=1, rate=1, relu=True, is_trainin
             return
         if a.bn_partial is not None:
             part_f, T_f = a.bn_partial
-            if GUEST_RESNET and ops.guest_apply_ok(c.y.shape):
-                # the apply pass as a guest beside held-back weight gradients (layers.conv2d's backward)
-                n_, h_, w_, c_ = c.y.shape
-                coef = (g.empty((c_,), F32), g.empty((c_,), F32), g.empty((c_,), F32))
-                ops.bn_bwd_coefficients_pre(part_f, T_f, c_, float(n_) * h_ * w_, c.scale, c.mean, c.invstd, c.gamma.grad,
-                                            c.beta.grad, coef, ws)
-                ops.bn_relu_bwd_apply_affine(c.y, a.grad, c.scale, c.shift, coef[1], coef[2], relu, dy)
-            else:
-                ops.bn_relu_bwd_apply(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, relu, part_f, T_f,
-                                      c.gamma.grad, c.beta.grad, dy, ws)
+            ops.bn_relu_bwd_apply(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, relu, part_f, T_f,
+                                  c.gamma.grad, c.beta.grad, dy, ws)
             a.bn_partial = None
         else:
             ops.bn_relu_bwd(c.y, c.scale, c.shift, c.mean, c.invstd, a.grad, None, relu, 0, c.gamma.grad,
