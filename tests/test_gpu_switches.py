@@ -5,8 +5,8 @@ The host layers keep alternative formulations of the same arithmetic behind modu
 fused kernels replaced: they are what the fused forms are A/B-ed and debugged against) and the library keeps the general
 kernel families behind the special ones (OCR_CONV_W4=0 ... : the instantiations other shapes take anyway).  Each flag is
 flipped here on a small training run of the net it belongs to; the run must agree with the default configuration — same
-loss trajectory within what the 16-bit rounding of one differently-ordered pass grows to over four or five optimiser steps
-of a net that learns its batch by heart (5e-2; measured 0 .. 2.1e-2: most alternates are bit-identical or differ in the
+loss trajectory within what the 16-bit rounding of one differently-ordered pass grows to over three optimiser steps
+of a net that learns its batch by heart (2e-2; measured 0 .. 3e-3, and 6e-2 by the fifth step: most alternates are bit-identical or differ in the
 last f16 digit of a few activations) and the same accumulated parameter update (cosine > 0.93, measured 0.95 .. 1: Adam's
 first steps are sign-like, a last-digit difference flips the tiniest gradients).  The exact equivalences are held kernel
 by kernel in test_gpu_conv_abi.py, test_gpu_layers.py, test_gpu_resnet.py; this file keeps the alternates ALIVE.
@@ -28,7 +28,7 @@ SMALL = [("block1", [(128, 64, 1), (128, 64, 2)]), ("block2", [(256, 64, 1), (25
          ("block3", [(256, 128, 1), (256, 128, 2)]), ("block4", [(512, 128, 1)])]
 
 
-def _run_vgg(device, steps=5, replay=True):
+def _run_vgg(device, steps=3, replay=True):
     from tensorflow_ocr_amd import synthetic
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.nets import model_vgg_16 as M
@@ -46,7 +46,7 @@ def _run_vgg(device, steps=5, replay=True):
     return losses, g.store.flat - p0
 
 
-def _run_pixellink(device, steps=5):
+def _run_pixellink(device, steps=3):
     from tensorflow_ocr_amd import synthetic
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.nets import pixellink
@@ -64,7 +64,7 @@ def _run_pixellink(device, steps=5):
     return losses, g.store.flat - p0
 
 
-def _run_east(device, steps=4):
+def _run_east(device, steps=3):
     from tensorflow_ocr_amd import synthetic
     from tensorflow_ocr_amd.graph import Graph
     from tensorflow_ocr_amd.nets import model_vgg_16 as M
@@ -96,7 +96,7 @@ def _agree(got, ref, what):
     lr, pr = ref
     assert all(np.isfinite(lg)) and bool(torch.isfinite(pg).all()), what
     for a, b in zip(lg, lr):
-        assert abs(a - b) <= 5e-2 * max(1.0, abs(b)), (what, lg, lr)
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (what, lg, lr)
     # the parameters moved, and in the same direction (the accumulated update of the run, per run from the same start)
     assert float(pg.abs().max()) > 0
     cos = float((pg.double() @ pr.double()) / (pg.double().norm() * pr.double().norm()))
