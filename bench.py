@@ -80,6 +80,8 @@ CONFIG_LEGS = (
     # 128 synthetic JPEGs (20 MB) cycled: every timed read is served by the page cache — the leg measures decode + parse +
     # upload + resize / label kernels, NOT storage
     ("pipeline_train_vgg16_512_b32_fed_from_files_page_cached", "pipeline_train", {}, 1),
+    # the precision that meets north_star's "score maps within 1e-3": f32 on the matrix cores, inference forward
+    ("f32_inference_forward_model_vgg_512_pixellink_1024", "f32_forward", {}, 1),
 )
 
 
