@@ -11,6 +11,7 @@ the implicit-GEMM conv, achieved TFLOP/s from HIP-event timing of every launch i
 steps) and, at N=1, `cpu_baseline` (the CPU oracle's train step on the host cores; baseline only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -341,10 +342,19 @@ def main():
     # backward on the compute stream is marked with an event, so `backward_stretch_ms` is what the stand-in costs the
     # conv workgroups it shares the chip with and `step_ms_with - step_ms_without` what stays exposed.
     if comm is not None and red is not None and red.active and red.mode == "abi" and red.proxy is not None and probe_only:
-        arms = (("without", False, True), ("overlapped", True, True), ("after_backward", True, False))
-        res = {k: [[], []] for k, _, _ in arms}
+        # the fat arms (round 6): the same stand-in with ~128 VGPRs + 64 KB of LDS per workgroup on 32 workgroups — with the
+        # 18-register one they bracket what a real ring's kernels cost the step (ocr_comm_proxy_set_footprint)
+        from tensorflow_ocr_amd import _lib as _L
+        # "at_fork" arms (item 7c): a completed bucket's stand-in is issued at the NEXT fork of the recorded step, beside held-back
+        # weight gradients, instead of right behind the join (train.schedule_guests(xchg_at_fork=True))
+        arms = (("without", False, True, 0, False), ("overlapped", True, True, 0, False), ("after_backward", True, False, 0, False),
+                ("overlapped_fat", True, True, 1, False), ("after_backward_fat", True, False, 1, False),
+                ("overlapped_at_fork", True, True, 0, True), ("overlapped_fat_at_fork", True, True, 1, True))
+        res = {a[0]: [[], []] for a in arms}
         for rnd in range(2):
-            for arm, with_proxy, overlap in arms:
+            for arm, with_proxy, overlap, fat, at_fork in arms:
+                _L.call("ocr_comm_proxy_set_footprint", ctypes.c_int(fat), ctypes.c_int(32 if fat else 0))
+                step.reschedule(xchg_at_fork=at_fork)
                 red.enabled, red.use_proxy, red.overlap = with_proxy, with_proxy, overlap
                 step.backward_end_event = None
                 step(*batch)
@@ -359,6 +369,8 @@ def main():
                 res[arm][0].append((time.perf_counter() - t1) / args.steps * 1e3)
                 res[arm][1].append(float(np.median([e0.elapsed_time(e1) for e0, e1 in evs])))
         stats = red.proxy_stats.cpu().numpy()
+        _L.call("ocr_comm_proxy_set_footprint", ctypes.c_int(0), ctypes.c_int(0))
+        step.reschedule()
         red.enabled, red.use_proxy, red.overlap = False, False, True
         step.backward_end_event = None
         nb = len(red.buckets)
@@ -380,6 +392,19 @@ def main():
             "proxy_launches": int(stats[4]), "rounds": "three arms interleaved twice, best of 2 per arm",
             "reading": "overlapped: the buckets' stand-ins run under backward (dist.GradientAllReduce(overlap=True)); "
                        "after_backward: all of them between backward and the optimiser (overlap=False); DESIGN.md 3.4"}
+        comm["proxy_fat"] = {
+            "kernel": "the same stand-in at ~128 VGPRs + 64 KB of LDS per workgroup, 32 workgroups (RCCL-like footprint)",
+            "step_ms_with": round(best["overlapped_fat"][0], 3), "step_ms_with_after_backward": round(best["after_backward_fat"][0], 3),
+            "backward_stretch_ms": round(best["overlapped_fat"][1] - best["without"][1], 3),
+            "exposed_ms_overlapped": round(best["overlapped_fat"][0] - best["without"][0], 3),
+            "exposed_ms_after_backward": round(best["after_backward_fat"][0] - best["without"][0], 3)}
+        comm["proxy_at_fork"] = {
+            "what": "the buckets' stand-ins issued at the next fork of the recorded step (train.schedule_guests(xchg_at_fork=True)) "
+                    "instead of right behind the join: beside held-back weight gradients, the only kernels they can share a CU with",
+            "exposed_ms_overlapped": round(best["overlapped_at_fork"][0] - best["without"][0], 3),
+            "backward_stretch_ms": round(best["overlapped_at_fork"][1] - best["without"][1], 3),
+            "exposed_ms_overlapped_fat": round(best["overlapped_fat_at_fork"][0] - best["without"][0], 3),
+            "backward_stretch_ms_fat": round(best["overlapped_fat_at_fork"][1] - best["without"][1], 3)}
         # the placement this build ships and what each placement projects to at 8 ranks, from THIS run's
         # numbers (a projection from a one-GPU stand-in paced at one xGMI link: RCCL with more than one rank has never run here)
         pr = comm["proxy"]
@@ -392,6 +417,12 @@ def main():
                                           "after_backward": round(w0 + pr["exposed_ms_after_backward"], 3)},
             "projected_scaling_of_8": {"under_backward": round(8.0 * w0 / (w0 + pr["exposed_ms_overlapped"]), 2),
                                        "after_backward": round(8.0 * w0 / (w0 + pr["exposed_ms_after_backward"]), 2)},
+            # the bracket: the 18-register stand-in is the optimistic end, the RCCL-like footprint the other
+            "projected_scaling_of_8_bracket": {
+                "under_backward": [round(8.0 * w0 / (w0 + max(comm["proxy_fat"]["exposed_ms_overlapped"], 0.0)), 2),
+                                   round(8.0 * w0 / (w0 + max(pr["exposed_ms_overlapped"], 0.0)), 2)],
+                "after_backward": [round(8.0 * w0 / (w0 + max(comm["proxy_fat"]["exposed_ms_after_backward"], 0.0)), 2),
+                                   round(8.0 * w0 / (w0 + max(pr["exposed_ms_after_backward"], 0.0)), 2)]},
             "why_the_stand_in_is_not_hidden": "its workgroups (18 registers) are placed beside the weight gradients and the 64-channel "
                                               "kernel, but a 512-register input-gradient wave cannot share a CU with them: those launches "
                                               "run one round longer (profiles/r05_coresidency_probe.json; DESIGN.md 3.5a)"}

@@ -26,7 +26,7 @@ extern "C" {
  * ocr_conv2d_bnred_f16, ocr_conv2d_bnred_tail_f16, ocr_bn_add_relu_f16, ocr_bn_relu_pool_idx_f16; round 4: the
  * batched head entry points and the seed-rank argument of ocr_link_cc_directed; round 5: the guest kernels).  The Python host refuses a
  * library whose ocr_abi_version() differs from the value it was written against (_lib.ABI_VERSION). */
-#define OCR_ABI_VERSION 6
+#define OCR_ABI_VERSION 7
 
 enum {
   OCR_OK = 0,
@@ -915,6 +915,11 @@ int ocr_stream_wait_event(void* stream, void* event);
  * workgroups it shares the chip with).  stats_u64x8 (device; set ONCE by the caller to {~0, 0, 0, 0, 0, 0, 0, 0}; may be NULL): [3] += busy
  * ticks (100 MHz) of every launch, [4] += 1. */
 int ocr_comm_proxy(void* buf, size_t bytes, int workgroups, float link_gbps, void* stats_u64x8, void* stream);
+/* Footprint of the stand-in for the ocr_comm_proxy launches that follow (process-wide; a recorded step replays its calls
+ * unchanged): fat = 0: 18 registers, no LDS (the default); fat = 1: ~128 VGPRs and 64 KB of LDS per workgroup, the order of
+ * RCCL's generic all-reduce kernels — the two bracket what a real ring's device side costs the kernels it shares the chip
+ * with.  workgroups > 0 overrides the launch's own count (RCCL runs 16-32 channels); 0 keeps it. */
+int ocr_comm_proxy_set_footprint(int fat, int workgroups);
 
 #ifdef __cplusplus
 }

@@ -39,7 +39,7 @@ class SoftmaxLossDesc(ctypes.Structure):
 _lib = None
 # the value of OCR_ABI_VERSION (include/ocr_hip.h) this host layer was written against: a library built from
 # other sources would take its pointers shifted by a slot and write wildly instead of returning an OCR_ERR
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def load():

@@ -177,10 +177,23 @@ extern "C" int ocr_stream_wait_event(void* stream, void* event) {
 // the recorded step launches ocr_allreduce_bucket, with the same event ordering.  stats (8 x u64, device, set by
 // the caller once to {~0, 0, ...}): [3] accumulates the busy time of every launch (last workgroup's end - first workgroup's start,
 // 100 MHz ticks), [4] counts launches; [0..2] are per-launch scratch that resets itself.
+// Round 6: the stand-in's own footprint decides what it can share a CU with — 18 registers sit beside
+// anything that leaves 24 free, RCCL's kernels do not.  FAT = the same walk with ~128 VGPRs and 64 KB of LDS per
+// workgroup (the order of RCCL's generic all-reduce kernels: unrolled 16-byte loads in flight per lane, a staging
+// buffer per channel), so the two arms BRACKET what a real ring's device side costs the step (bench.py: exchange.proxy /
+// exchange.proxy_fat).  ocr_comm_proxy_set_footprint selects the variant (and optionally the workgroup count) for the
+// launches that follow — the recorded step's ocr_comm_proxy calls are replayed unchanged.
 namespace {
 constexpr size_t kProxyChunk = 256 << 10;
+int g_proxy_fat = 0, g_proxy_wgs = 0;
+template <bool FAT>
 __global__ __launch_bounds__(256) void comm_proxy_kernel(uint4* __restrict__ buf, size_t bytes, unsigned long long ticks_per_chunk,
                                                          unsigned long long* __restrict__ stats) {
+  if (FAT) {
+    extern __shared__ unsigned fat_lds[];
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");            // the allocation reaches 128 VGPRs
+    fat_lds[threadIdx.x] = threadIdx.x;                       // (the 64 KB are requested at launch; keep the segment live)
+  }
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   const size_t nchunks = (bytes + kProxyChunk - 1) / kProxyChunk;
   for (size_t k = blockIdx.x; k < nchunks; k += gridDim.x) {
@@ -216,7 +229,26 @@ extern "C" int ocr_comm_proxy(void* buf, size_t bytes, int workgroups, float lin
   if (!buf || bytes < 16 || workgroups < 1 || workgroups > 256 || !(link_gbps > 0.f) || ((uintptr_t)buf & 15)) return OCR_ERR_INVALID_ARG;
   const double sec_per_chunk = 2.0 * (double)kProxyChunk / ((double)link_gbps * 1e9);
   const unsigned long long ticks = (unsigned long long)(sec_per_chunk * 1e8 + 0.5);              // s_memrealtime: 100 MHz
-  hipLaunchKernelGGL(comm_proxy_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<uint4*>(buf), bytes, ticks, static_cast<unsigned long long*>(stats_u64x8));
+  if (g_proxy_wgs > 0) workgroups = g_proxy_wgs;
+  if (g_proxy_fat)
+    hipLaunchKernelGGL(comm_proxy_kernel<true>, dim3(workgroups), dim3(256), 64 * 1024, static_cast<hipStream_t>(stream),
+                       static_cast<uint4*>(buf), bytes, ticks, static_cast<unsigned long long*>(stats_u64x8));
+  else
+    hipLaunchKernelGGL(comm_proxy_kernel<false>, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uint4*>(buf), bytes, ticks, static_cast<unsigned long long*>(stats_u64x8));
   return ocr_launch_status();
+}
+
+extern "C" int ocr_comm_proxy_set_footprint(int fat, int workgroups) {
+  if (workgroups < 0 || workgroups > 256) return OCR_ERR_INVALID_ARG;
+  static bool configured = false;
+  if (fat && !configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(comm_proxy_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            64 * 1024) != hipSuccess)
+      return OCR_ERR_HIP;
+    configured = true;
+  }
+  g_proxy_fat = fat ? 1 : 0;
+  g_proxy_wgs = workgroups;
+  return OCR_OK;
 }

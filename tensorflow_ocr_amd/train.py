@@ -191,9 +191,15 @@ USE_GUESTS = __import__("os").environ.get("OCR_GUEST_STREAM", "1") == "1"
 GUEST_COVER = float(__import__("os").environ.get("OCR_GUEST_COVER", "2.1"))
 GUEST_PAIRED_GRID = int(__import__("os").environ.get("OCR_GUEST_PAIRED_GRID", "256"))
 GUEST_MIN_US = float(__import__("os").environ.get("OCR_GUEST_MIN_US", "40"))
+# a completed bucket's exchange entries at the NEXT fork instead of right behind the join that followed its last weight
+# gradient: the comm kernel then starts beside held-back weight gradients (456 of 512 registers: the
+# only kernels of the step it can share a CU with) instead of beside the next input-gradient launch (512: it cannot).
+# Measured with the one-GPU stand-ins (bench.py exchange.proxy_at_fork): 1.34 -> 1.23 ms of the stand-in's 1.10-1.19 ms
+# exposed per step, either footprint; on.  (Issuing an exchange entry later than recorded is always correct.)
+XCHG_AT_FORK = __import__("os").environ.get("OCR_XCHG_AT_FORK", "1") == "1"
 
 
-def schedule_guests(entries, cover=None, min_us=None):
+def schedule_guests(entries, cover=None, min_us=None, xchg_at_fork=None):
     """Run the HBM-bound batch-norm backward passes of the recorded step as GUESTS beside its weight gradients
     (csrc/guest_bn.hip; measured rates: profiles/r05_guest_pairs.json).
 
@@ -216,7 +222,9 @@ def schedule_guests(entries, cover=None, min_us=None):
     point."""
     cover = GUEST_COVER if cover is None else cover
     min_us = GUEST_MIN_US if min_us is None else min_us
+    xchg_at_fork = XCHG_AT_FORK if xchg_at_fork is None else xchg_at_fork
     out, pending, i, n = [], [], 0, len(entries)
+    deferred = []                # exchange entries of hosts already run, waiting for the next fork (xchg_at_fork)
 
     def tag(e):
         return e[4] if (e[0] == "c" and e[4] is not None) else (None,)
@@ -236,6 +244,8 @@ def schedule_guests(entries, cover=None, min_us=None):
         return False
 
     def flush():
+        out.extend(deferred)         # (recorded before anything still pending: their buckets are complete)
+        del deferred[:]
         for head, tail, _ in pending:
             out.append(head)
             out.extend(tail)
@@ -248,6 +258,8 @@ def schedule_guests(entries, cover=None, min_us=None):
             i += 1
             continue
         if t[0] == "side" and not guest_ahead(i):
+            out.extend(deferred)             # (no fork will come for them either)
+            del deferred[:]
             out.append(e)                    # no guest left to host (a net without batch norm: every call stays in place,
             i += 1                           # and the exchange sees its buckets as early as it was recorded)
             continue
@@ -289,6 +301,8 @@ def schedule_guests(entries, cover=None, min_us=None):
                     if len(e[2]) >= 2 and t[-1] != "as_is":
                         g[2] = tuple(e[2][:-2]) + (__import__("ctypes").c_int(GUEST_PAIRED_GRID),) + (e[2][-1],)
                     out.append(["fork"])
+                    out.extend(deferred)          # the exchange of buckets completed by EARLIER hosts starts with these hosts
+                    del deferred[:]
                     out.append(g)
                     hosts = [pending[k] for k in take]
                     for k in reversed(take):
@@ -297,7 +311,8 @@ def schedule_guests(entries, cover=None, min_us=None):
                         out.append(head)
                     out.append(["join"])
                     for _, tail, _ in hosts:
-                        out.extend(tail)
+                        for te in tail:
+                            (deferred if (xchg_at_fork and tag(te)[0] == "xchg") else out).append(te)
                     i += 1
                     continue
             out.append(e)
@@ -415,12 +430,18 @@ class TrainStep:
             rec.py(lambda: self.opt.apply_gradients(self.reducer.grad_scale))
             rec.entries[-1].append("opt")
             rec.py(self._repack)
+            self.recorded = rec.entries                       # (kept: reschedule() derives another plan from the same recording)
             self.plan = schedule_guests(rec.entries) if USE_GUESTS else rec.entries
             self.static_batch = list(batch)
             self.keepalive, g.keepalive = g.keepalive, None
             g.reset_tape()
         self.loss = loss
         return loss
+
+    def reschedule(self, **kw):
+        """Another guest / exchange placement of the SAME recorded step (schedule_guests keywords): bench.py's A/B arms."""
+        if self.plan is not None and USE_GUESTS:
+            self.plan = schedule_guests(self.recorded, **kw)
 
     def _repack(self):
         """Batched re-pack of the [tap][cout][cin] / [tap][cin][cout] operand copies from the f32 masters, stamped

@@ -634,7 +634,7 @@ def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
             c("coef3", ("pre",)), c("apply3", ("guest", 0.25 * G)), c("dgrad3"), c("wgrad3", ("side", W)), c("wgrad3b", ("side", 5 * W)),
             c("dgrad2"), c("wgrad2", ("side", W)),
             c("xl", ("xchg", "rccl", "late")), c("xf", ("xchg", "finish")), ["py", None, "opt"]]
-    out = schedule_guests(plan, cover=2.0, min_us=0)
+    out = schedule_guests(plan, cover=2.0, min_us=0, xchg_at_fork=False)
     names = [e[3] if e[0] == "c" else e[0] for e in out]
     assert names == ["apply5", "dgrad5",
                      "coef4", "fork", "apply4", "wgrad5", "join", "red5", "s2d5", "x5a", "x5b",   # one host is all there is
@@ -646,29 +646,29 @@ def test_schedule_guests_holds_weight_gradients_back_and_spends_them_as_hosts():
     # a long guest takes several hosts along, skips one that would overshoot, and leaves the rest held back
     plan2 = [c("w0", ("side", W)), c("big", ("side", 4 * W)), c("w1", ("side", W)), c("w2", ("side", W)), c("w3", ("side", W)),
              c("coef", ("pre",)), c("apply", ("guest", 1.4 * G)), c("dgrad"), ["py", None]]
-    names2 = [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan2, cover=2.0, min_us=0)]
+    names2 = [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan2, cover=2.0, min_us=0, xchg_at_fork=False)]
     assert names2 == ["coef", "fork", "apply", "w0", "w1", "w2", "join", "dgrad", "big", "w3", "py"]
     # a host far larger than the guest needs is not spent on it
     plan3 = [c("huge", ("side", 10 * W)), c("coef", ("pre",)), c("apply", ("guest", 0.2 * G)), c("dgrad"), ["py", None]]
-    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan3, cover=2.0, min_us=0)] == ["coef", "apply", "dgrad", "huge", "py"]
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan3, cover=2.0, min_us=0, xchg_at_fork=False)] == ["coef", "apply", "dgrad", "huge", "py"]
     # a host whose weight gradient completed an exchange bucket never overtakes an older held-back weight gradient (the
     # bucket's all-reduce reads both): the small one stays behind the big one it was recorded after
     plan6 = [c("big", ("side", 4 * W)), c("small", ("side", W)), c("xs", ("xchg", "rccl", "early")), c("coef", ("pre",)),
              c("apply", ("guest", 0.5 * G)), c("dgrad"), ["py", None]]
-    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan6, cover=2.0, min_us=0)] == [
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan6, cover=2.0, min_us=0, xchg_at_fork=False)] == [
         "coef", "apply", "dgrad", "big", "small", "xs", "py"]
     plan7 = [c("big", ("side", 4 * W)), c("small", ("side", W)), c("coef", ("pre",)), c("apply", ("guest", 0.5 * G)), c("dgrad"), ["py", None]]
-    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan7, cover=2.0, min_us=0)] == [
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan7, cover=2.0, min_us=0, xchg_at_fork=False)] == [
         "coef", "fork", "apply", "small", "join", "dgrad", "big", "py"]
     # no guest ahead: nothing is held back (a net without batch norm keeps its recorded order, exchange entries included)
     plan5 = [c("dgrad"), c("w0", ("side", W)), c("r0", ("reduce",)), c("x0", ("xchg", None, "early")), c("dgrad1"), c("w1", ("side", W)),
              c("xf", ("xchg", "finish")), ["py", None]]
-    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan5, cover=2.0, min_us=0)] == [
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan5, cover=2.0, min_us=0, xchg_at_fork=False)] == [
         "dgrad", "w0", "r0", "x0", "dgrad1", "w1", "xf", "py"]
     # a guest shorter than a fork + join costs is left alone; a weight gradient that cannot host stays where it was recorded
     plan4 = [c("w0", ("side", W)), c("fat", ("side",)), c("redf", ("reduce",)), c("coef", ("pre",)), c("apply", ("guest", 0.3 * G)),
              c("dgrad"), ["py", None]]
-    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan4, cover=2.0, min_us=40)] == [
+    assert [e[3] if e[0] == "c" else e[0] for e in schedule_guests(plan4, cover=2.0, min_us=40, xchg_at_fork=False)] == [
         "coef", "apply", "dgrad", "w0", "fat", "redf", "py"]
 
 
@@ -685,6 +685,10 @@ def test_schedule_guests_never_fires_a_bucket_before_its_held_back_weight_gradie
     W, G = 1.3e9 * 100, 5.0e6 * 100
 
     def check(plan, **kw):
+        check1(plan, xchg_at_fork=True, **kw)
+        return check1(plan, xchg_at_fork=False, **kw)
+
+    def check1(plan, **kw):
         out = schedule_guests(plan, **kw)
         names = [e[3] if e[0] == "c" else e[0] for e in out]
         rec = [e[3] if e[0] == "c" else e[0] for e in plan]
@@ -718,6 +722,30 @@ def test_schedule_guests_never_fires_a_bucket_before_its_held_back_weight_gradie
             c("xf", ("xchg", "finish")), ["py", None]]
     names = check(plan, cover=1.0, min_us=0)
     assert names[:6] == ["coef4", "fork", "apply4", "w5", "join", "red5"]
+
+
+def test_schedule_guests_exchange_at_the_next_fork():
+    """xchg_at_fork: a paired host's exchange entries wait for the NEXT fork (they start beside that fork's hosts) or for
+    the first entry that needs the gradients; nothing is lost, weight gradients still precede their bucket's exchange."""
+    from tensorflow_ocr_amd.train import schedule_guests
+
+    def c(name, tag=None):
+        return ["c", None, (), name, tag]
+    W, G = 1.3e9 * 100, 5.0e6 * 100
+    plan = [c("w5", ("side", W)), c("red5", ("reduce",)), c("x5", ("xchg", "rccl", "early")),
+            c("coef4", ("pre",)), c("apply4", ("guest", G)), c("dgrad4"),
+            c("w4", ("side", W)), c("red4", ("reduce",)), c("x4", ("xchg", "rccl", "early")),
+            c("coef3", ("pre",)), c("apply3", ("guest", G)), c("dgrad3"),
+            c("w3", ("side", W)), c("red3", ("reduce",)),
+            c("xf", ("xchg", "finish")), ["py", None, "opt"]]
+    names = lambda p: [e[3] if e[0] == "c" else e[0] for e in p]
+    base = names(schedule_guests(plan, cover=1.0, min_us=0, xchg_at_fork=False))
+    assert base == ["coef4", "fork", "apply4", "w5", "join", "red5", "x5", "dgrad4",
+                    "coef3", "fork", "apply3", "w4", "join", "red4", "x4", "dgrad3", "w3", "red3", "xf", "py"]
+    at_fork = names(schedule_guests(plan, cover=1.0, min_us=0, xchg_at_fork=True))
+    assert at_fork == ["coef4", "fork", "apply4", "w5", "join", "red5", "dgrad4",
+                       "coef3", "fork", "x5", "apply3", "w4", "join", "red4", "dgrad3", "x4", "w3", "red3", "xf", "py"]      # (x4: no fork left)
+    assert sorted(at_fork) == sorted(base)
 
 
 def test_decode_slab_is_reserved_not_sparse(tmp_path):
