@@ -197,9 +197,13 @@ GUEST_MIN_US = float(__import__("os").environ.get("OCR_GUEST_MIN_US", "40"))
 # Measured with the one-GPU stand-ins (bench.py exchange.proxy_at_fork): 1.34 -> 1.23 ms of the stand-in's 1.10-1.19 ms
 # exposed per step, either footprint; on.  (Issuing an exchange entry later than recorded is always correct.)
 XCHG_AT_FORK = __import__("os").environ.get("OCR_XCHG_AT_FORK", "1") == "1"
+# hosts shared out with the guests still to come in view (round 6): the greedy choice covered conv2_1's apply pass with two
+# weight gradients (791 us for a 577 us pass) and left conv1_2's pooled pass — the last and largest — 306 us of host for 585,
+# 0.28 ms exposed on the critical path (profiles/r05_guest_pairs_trace.txt).  0: the round-5 greedy choice (A/B).
+GUEST_BALANCE = __import__("os").environ.get("OCR_GUEST_BALANCE", "1") == "1"
 
 
-def schedule_guests(entries, cover=None, min_us=None, xchg_at_fork=None):
+def schedule_guests(entries, cover=None, min_us=None, xchg_at_fork=None, balance=None):
     """Run the HBM-bound batch-norm backward passes of the recorded step as GUESTS beside its weight gradients
     (csrc/guest_bn.hip; measured rates: profiles/r05_guest_pairs.json).
 
@@ -223,6 +227,7 @@ def schedule_guests(entries, cover=None, min_us=None, xchg_at_fork=None):
     cover = GUEST_COVER if cover is None else cover
     min_us = GUEST_MIN_US if min_us is None else min_us
     xchg_at_fork = XCHG_AT_FORK if xchg_at_fork is None else xchg_at_fork
+    balance = GUEST_BALANCE if balance is None else balance
     out, pending, i, n = [], [], 0, len(entries)
     deferred = []                # exchange entries of hosts already run, waiting for the next fork (xchg_at_fork)
 
@@ -242,6 +247,24 @@ def schedule_guests(entries, cover=None, min_us=None, xchg_at_fork=None):
             if eq[0] != "c" or (tq[0] == "xchg" and not travels(eq)):
                 return False
         return False
+
+    def outlook(i0):
+        """(what the guests from entry i0 on want of hosts, us; what the weight gradients recorded behind i0 and in front of
+        the last of those guests will supply, us)"""
+        last = None
+        for q in range(i0, n):
+            tq = tag(entries[q])
+            if tq[0] == "guest" and len(tq) > 1 and tq[1] / 5.0e6 >= min_us:
+                last = q
+        want = supply = 0.0
+        if last is not None:
+            for q in range(i0, last + 1):
+                tq = tag(entries[q])
+                if tq[0] == "guest" and len(tq) > 1 and tq[1] / 5.0e6 >= min_us:
+                    want += cover * tq[1] / 5.0e6
+                elif tq[0] == "side" and len(tq) >= 2 and q > i0:
+                    supply += tq[1] / 1.3e9
+        return want, supply
 
     def flush():
         out.extend(deferred)         # (recorded before anything still pending: their buckets are complete)
@@ -281,14 +304,36 @@ def schedule_guests(entries, cover=None, min_us=None, xchg_at_fork=None):
                 def closes_bucket(k):
                     return any(tag(x)[0] == "xchg" for x in pending[k][1])
                 take, acc, skipped = [], 0.0, False
-                for k, (_, _, us) in enumerate(pending):                  # oldest first, no large overshoot
-                    if acc >= 0.85 * need:
-                        break
-                    if acc + us <= 1.3 * need and not (skipped and closes_bucket(k)):
-                        take.append(k)
-                        acc += us
-                    else:
-                        skipped = True
+                if balance and len(pending) <= 12:
+                    # what is exposed of a guest is what its hosts do not cover, and every host a guest can use the later
+                    # guests can use too: when the guests still to come want more than all hosts can give, each gets its
+                    # SHARE (target), and the subset of the pending hosts whose sum is closest to the target goes — a miss
+                    # either way costs a guest (this one or a later one) the same; with hosts to spare, covering counts
+                    want, supply = outlook(i)
+                    have = sum(us for _, _, us in pending) + supply
+                    scarce = have < want
+                    target = need * have / want if scarce else need
+                    best = None
+                    for m in range(1, 1 << len(pending)):
+                        ks = [k for k in range(len(pending)) if m >> k & 1]
+                        if any(closes_bucket(k) and any(j not in ks for j in range(k)) for k in ks):
+                            continue
+                        tot = sum(pending[k][2] for k in ks)
+                        miss = abs(tot - target) if scarce else (2.0 * (target - tot) if tot < target else 0.25 * (tot - target))
+                        key = (miss, len(ks), ks)
+                        if best is None or key < best[0]:
+                            best = (key, ks, tot)
+                    if best is not None and best[2] <= 3.0 * need:
+                        take, acc = best[1], best[2]
+                else:
+                    for k, (_, _, us) in enumerate(pending):                  # oldest first, no large overshoot
+                        if acc >= 0.85 * need:
+                            break
+                        if acc + us <= 1.3 * need and not (skipped and closes_bucket(k)):
+                            take.append(k)
+                            acc += us
+                        else:
+                            skipped = True
                 if not take:
                     ok = [q for q in range(len(pending)) if q == 0 or not closes_bucket(q)]
                     k = min(ok, key=lambda q: pending[q][2])

@@ -107,7 +107,8 @@ VGG_FLAGS = [("layers", "FUSE_BN_REDUCE", False), ("layers", "FUSE_BN_POOL_REDUC
              ("layers", "FIRST_DROP_Y", False), ("layers", "FIRST_MOMENTS", False), ("layers", "FIRST_WGRAD_RECOMPUTE", True),
              ("layers", "GUEST_REDUCE", False), ("layers", "FUSE_FIRST_WGRAD", False), ("layers", "FIRST_WGRAD_SUMS", False),
              ("layers", "FUSE_BN_W4_MAXHW", 0), ("ops", "GUEST_BN", False), ("train", "USE_GUESTS", False),
-             ("train", "GUEST_MIN_US", 0.0), ("train", "GUEST_COVER", 1.0), ("train", "GUEST_PAIRED_GRID", 64)]
+             ("train", "GUEST_MIN_US", 0.0), ("train", "GUEST_COVER", 1.0), ("train", "GUEST_PAIRED_GRID", 64),
+             ("train", "GUEST_BALANCE", False), ("train", "XCHG_AT_FORK", False)]
 
 
 @pytest.mark.parametrize("mod,flag,value", VGG_FLAGS)

@@ -724,6 +724,34 @@ def test_schedule_guests_never_fires_a_bucket_before_its_held_back_weight_gradie
     assert names[:6] == ["coef4", "fork", "apply4", "w5", "join", "red5"]
 
 
+def test_schedule_guests_shares_hosts_out_when_the_guests_to_come_want_more_than_there_is():
+    """Round 6 (train.GUEST_BALANCE): the greedy choice gave conv2_1's apply pass two weight gradients (260 + 525 us for a
+    pass that wants 676) and left the last, largest pass 306 us for the 1 071 it wants.  With the guests still to come in
+    view each gets its share: the first takes the ONE host closest to its share, the last gets the other two.  With hosts
+    to spare the choice covers the guest (no deficit) with the smallest excess."""
+    from tensorflow_ocr_amd.train import schedule_guests
+
+    def c(name, tag=None):
+        return ["c", None, (), name, tag]
+    us = lambda t: 1.3e9 * t                 # a weight gradient estimated at t us
+    al = lambda t: 5.0e6 * t                 # a guest that takes t us alone
+    plan = [c("wA", ("side", us(260))), c("wB", ("side", us(525))),
+            c("coef9", ("pre",)), c("g9", ("guest", al(322))), c("dgrad9"),
+            c("wC", ("side", us(306))),
+            c("coef10", ("pre",)), c("g10", ("guest", al(510))), c("dgrad10"),
+            c("wD", ("side", us(537))), ["py", None, "opt"]]
+    names = lambda p: [e[3] if e[0] == "c" else e[0] for e in p]
+    greedy = names(schedule_guests(plan, cover=2.1, min_us=40, balance=False))
+    assert greedy == ["coef9", "fork", "g9", "wA", "wB", "join", "dgrad9", "coef10", "fork", "g10", "wC", "join", "dgrad10", "wD", "py"]
+    shared = names(schedule_guests(plan, cover=2.1, min_us=40, balance=True))
+    assert shared == ["coef9", "fork", "g9", "wB", "join", "dgrad9", "coef10", "fork", "g10", "wA", "wC", "join", "dgrad10", "wD", "py"]
+    # hosts to spare: cover, with the smallest excess (the 700 us host stays for nobody in particular)
+    plan2 = [c("w1", ("side", us(700))), c("w2", ("side", us(150))), c("w3", ("side", us(120))),
+             c("coef", ("pre",)), c("g", ("guest", al(100))), c("dgrad"), ["py", None, "opt"]]
+    assert names(schedule_guests(plan2, cover=2.1, min_us=40, balance=True)) == [
+        "coef", "fork", "g", "w2", "w3", "join", "dgrad", "w1", "py"]
+
+
 def test_schedule_guests_exchange_at_the_next_fork():
     """xchg_at_fork: a paired host's exchange entries wait for the NEXT fork (they start beside that fork's hosts) or for
     the first entry that needs the gradients; nothing is lost, weight gradients still precede their bucket's exchange."""
