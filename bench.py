@@ -161,7 +161,7 @@ def counters_from_profiles(dom):
     return vals, src
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def main():
@@ -425,7 +425,7 @@ def main():
                                    round(8.0 * w0 / (w0 + max(pr["exposed_ms_after_backward"], 0.0)), 2)]},
             "why_the_stand_in_is_not_hidden": "its workgroups (18 registers) are placed beside the weight gradients and the 64-channel "
                                               "kernel, but a 512-register input-gradient wave cannot share a CU with them: those launches "
-                                              "run one round longer (profiles/r05_coresidency_probe.json; DESIGN.md 3.5a)"}
+                                              "run one round longer (profiles/r06_coresidency_probe.json; DESIGN.md 3.5a)"}
     # dominant kernel: the conv_igemm instantiation with the most accumulated time
     per, fwd = {}, {}
     for variant, flops, phase, e0, e1 in timing:

@@ -393,6 +393,12 @@ def test_bench_default_single_gpu_line_reports_the_exchange(device):
     ex = out["exchange"]
     assert ex["mode"] == "abi" and ex["rccl_ranks"] == 1 and sum(ex["bucket_bytes"]) == ex["grad_bytes"]
     assert "comm_exposed_ms" in ex and "ms_per_step_with_exchange" in ex and ex["in_timed_region"] is False
+    # round 6: the stand-in at both footprints (ocr_comm_proxy_set_footprint) and with the buckets issued at the next fork
+    # (train.schedule_guests(xchg_at_fork=True)); the plan's projection is a bracket over the two footprints
+    assert {"backward_stretch_ms", "exposed_ms_overlapped", "exposed_ms_after_backward"} <= set(ex["proxy_fat"])
+    assert {"exposed_ms_overlapped", "exposed_ms_overlapped_fat"} <= set(ex["proxy_at_fork"])
+    br = ex["plan"]["projected_scaling_of_8_bracket"]
+    assert all(0 < lo <= 8.0 and 0 < hi <= 8.0 for lo, hi in (br["under_backward"], br["after_backward"]))
     rf = out["roofline"]
     assert set(rf["counters_from"]["files"]) == {"traffic", "mfma_busy", "clock_ghz"}
     for f, v in rf["counters_from"]["files"].items():      # a counter is reported only with current provenance
