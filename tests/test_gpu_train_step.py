@@ -303,6 +303,23 @@ else:
     assert red.mode == "abi" and red.comm.size() == 1
     nb = len(red.buckets)
     assert n_x == 5 * nb and names.count("ocr_allreduce_bucket") == nb and n_py == 2, (n_x, n_py, names)
+    # ADVICE r5 (high), on the REAL recorded step: no exchange entry of the scheduled plan runs before a weight-gradient
+    # launch (slab kernel, slab sum, conv1_1's sums form) that was recorded in front of it — at this size every guest is below
+    # the pairing threshold, i.e. the advisor's case: all weight gradients held back, bucket 0 completed by an in-place launch.
+    # Checked for every placement of the scheduler (exchange at the fork or behind the join, balanced or greedy hosts)
+    from tensorflow_ocr_amd.train import schedule_guests
+    rec = s1.recorded
+    is_x = lambda e: e[0] == "c" and e[4] is not None and e[4][0] == "xchg"
+    is_w = lambda e: e[0] == "c" and ((e[4] is not None and e[4][0] in ("side", "reduce")) or "wgrad" in e[3])
+    assert sum(map(is_w, rec)) >= 20 and sum(map(is_x, rec)) == 5 * nb
+    for kw in (dict(), dict(xchg_at_fork=False), dict(balance=False), dict(min_us=0.0), dict(min_us=0.0, xchg_at_fork=False)):
+        pos = {id(e): i for i, e in enumerate(schedule_guests(rec, **kw))}
+        seen_w = []
+        for e in rec:
+            if is_w(e):
+                seen_w.append(e)
+            elif is_x(e):
+                assert all(pos[id(w)] < pos[id(e)] for w in seen_w), (kw, e[3], e[4])
     # bench.py's A/B switch: with the exchange disabled the replay skips those entries and still trains
     red.enabled = False
     s1(*b1); s0(*b0)
